@@ -1,0 +1,131 @@
+/*
+ * patchaugnet_hip.h -- C ABI of libpatchaugnet_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary for PatchAugNet's descriptor-extraction hot path.  Plain
+ * C: raw device pointers, ints, floats and an opaque stream handle; no torch,
+ * no C++ types.  Two groups of entry points:
+ *
+ *  1. pa_* -- the boundary proper.  Every function enqueues work on `stream`
+ *     (a hipStream_t; NULL = the null stream), never synchronises, never
+ *     allocates, never retains a pointer, and returns 0 on success, a negative
+ *     PA_E* code for bad arguments, or a positive hipError_t for a failed launch
+ *     (pa_last_error() gives the text).  All tensors are contiguous; float = fp32,
+ *     int = int32 unless stated.  Layouts are the reference's (citations are
+ *     file:line under the reference tree, WHU-USI3DV/PatchAugNet).
+ *
+ *  2. the reference's own extern "C" launcher names (furthestsampling_cuda_launcher,
+ *     knnquery_cuda_launcher, ...) with the reference's exact signatures, so
+ *     the reference's torch binding layer (the *_cuda.cpp files under libs/pointops/src/<op>/)
+ *     can link against this library unchanged.  They forward to group 1; where
+ *     the original has no stream argument they use the null stream exactly as
+ *     the original does.  "cuda" in these names is the
+ *     reference's spelling of an import name, not a CUDA dependency.
+ */
+#ifndef PATCHAUGNET_HIP_H
+#define PATCHAUGNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *pa_stream_t; /* hipStream_t */
+
+#define PA_OK 0
+#define PA_EINVAL (-1)      /* bad size / null pointer */
+#define PA_EUNSUPPORTED (-2) /* shape outside what the kernel supports (documented per function) */
+
+int pa_abi_version(void);
+const char *pa_last_error(void); /* thread-local text of the last non-zero return */
+
+/* ---- K1: furthest point sampling ------------------------------------------------------------
+ * replaces furthestsampling_cuda_launcher  (libs/pointops/src/sampling/sampling_cuda_kernel.h:17,
+ * kernel sampling_cuda_kernel.cu:59-168).  xyz (b,n,3); temp (b,n) caller-filled (1e10) and left
+ * holding the final running minima, as the reference leaves it; idx (b,m) int32.  Bit-exact,
+ * including the reference's tie-break order (larger min-distance, then lower bit-reversed
+ * k mod block, then lower k). */
+int pa_furthestsampling(int b, int n, int m, const float *xyz, float *temp, int *idx, pa_stream_t stream);
+
+/* ---- K2/K3: gathering  (sampling_cuda_kernel.h:15-16, .cu:6-36) -----------------------------
+ * forward: out[b,c,j] = points[b,c,idx[b,j]];  backward: grad_points[b,c,idx[b,j]] += grad_out[b,c,j]
+ * (grad_points must be zeroed by the caller, libs/pointops/functions/pointops.py:52). */
+int pa_gathering_forward(int b, int c, int n, int m, const float *points, const int *idx, float *out, pa_stream_t stream);
+int pa_gathering_backward(int b, int c, int n, int m, const float *grad_out, const int *idx, float *grad_points, pa_stream_t stream);
+
+/* ---- K4: kNN query  (knnquery_cuda_kernel.h:14, .cu:6-50) ------------------------------------
+ * xyz (b,n,3), new_xyz (b,m,3) -> idx (b,m,nsample) int32, dist2 (b,m,nsample) fp32, ascending
+ * (d2, index).  Slots that cannot be filled (nsample > n, non-finite distances) hold index 0 and
+ * +inf like the reference.  Any nsample >= 1 is accepted (the reference silently overflows above
+ * 200). */
+int pa_knnquery(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx, float *dist2, pa_stream_t stream);
+
+/* ---- K5/K6/K8: grouping  (grouping_cuda_kernel.h:16-19, .cu:28-46, :60-74; grouping_int .cu:33-49)
+ * forward: out[b,c,j,s] = points[b,c,idx[b,j,s]] */
+int pa_grouping_forward(int b, int c, int n, int m, int nsample, const float *points, const int *idx, float *out, pa_stream_t stream);
+int pa_grouping_backward(int b, int c, int n, int m, int nsample, const float *grad_out, const int *idx, float *grad_points, pa_stream_t stream);
+int pa_grouping_int_forward(int b, int c, int n, int m, int nsample, const int64_t *points, const int *idx, int64_t *out, pa_stream_t stream);
+
+/* ---- K9/K10/K11: three-NN + interpolation  (interpolation_cuda_kernel.h:18-23, .cu:90-114, :134-195)
+ * nearestneighbor: unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3) SQUARED distances, idx (b,n,3).
+ * interpolation forward: out[b,c,j] = (w0*p[i0] + w1*p[i1]) + w2*p[i2], points (b,c,m), idx/weight (b,n,3). */
+int pa_nearestneighbor(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx, pa_stream_t stream);
+int pa_interpolation_forward(int b, int c, int m, int n, const float *points, const int *idx, const float *weight, float *out, pa_stream_t stream);
+int pa_interpolation_backward(int b, int c, int n, int m, const float *grad_out, const int *idx, const float *weight, float *grad_points, pa_stream_t stream);
+
+/* ---- K13: ball query  (ballquery_cuda_kernel.h:17, .cu:47-80); idx caller-zeroed --------------*/
+int pa_ballquery(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int *idx, pa_stream_t stream);
+
+/* ---- K14/K15: featuredistribute / featuregather  (featuredistribute_cuda_kernel.h:15-17) ------*/
+int pa_featuredistribute(int b, int n, int m, const float *max_xyz, const float *xyz, int *distribute_idx, pa_stream_t stream);
+int pa_featuregather_forward(int b, int n, int m, int c, const float *max_feature, const int *distribute_idx, float *distribute_feature, pa_stream_t stream);
+int pa_featuregather_backward(int b, int n, int m, int c, const float *grad_distribute_feature, const int *distribute_idx, float *grad_max_feature, pa_stream_t stream);
+
+/* ---- K16: label statistics  (labelstat_cuda_kernel.h:20-27) -----------------------------------*/
+int pa_labelstat_and_ballquery(int b, int n, int m, float radius, int nsample, int nclass, const float *new_xyz, const float *xyz,
+                               const int *label_stat, int *idx, int *new_label_stat, pa_stream_t stream);
+int pa_labelstat_ballrange(int b, int n, int m, float radius, int nclass, const float *new_xyz, const float *xyz,
+                           const int *label_stat, int *new_label_stat, pa_stream_t stream);
+int pa_labelstat_idx(int b, int n, int m, int nsample, int nclass, const int *label_stat, const int *idx, int *new_label_stat, pa_stream_t stream);
+
+/* ---- Chamfer distance  (libs/chamfer_dist/chamfer_cuda.cpp:12-39, chamfer.cu:15-229) ----------
+ * forward: xyz1 (B,n,3), xyz2 (B,m,3) -> dist1 (B,n), dist2 (B,m) squared NN distances, idx1, idx2.
+ * backward: grad_xyz1/grad_xyz2 are zero-filled by the call, then accumulated (both directions). */
+int pa_chamfer_forward(int B, int n, int m, const float *xyz1, const float *xyz2, float *dist1, float *dist2, int *idx1, int *idx2, pa_stream_t stream);
+int pa_chamfer_backward(int B, int n, int m, const float *xyz1, const float *xyz2, const int *idx1, const int *idx2,
+                        const float *grad_dist1, const float *grad_dist2, float *grad_xyz1, float *grad_xyz2, pa_stream_t stream);
+
+/* ---- Generic-dimension brute-force kNN  (libs/KNN_CUDA/knn_cuda/csrc/cuda/knn.cpp:23-56, knn.cu:232-269)
+ * ref (dim,nr), query (dim,nq) -> dist (k,nq) fp32 L2 (sqrt applied), ind (k,nq) int64 1-BASED, order (dist asc, row asc). */
+int pa_knn_generic(const float *ref, int nr, const float *query, int nq, int dim, int k, float *dist, int64_t *ind, pa_stream_t stream);
+
+/* ---- the reference's launcher names (group 2) -------------------------------------------------*/
+void furthestsampling_cuda_launcher(int b, int n, int m, const float *dataset, float *temp, int *idxs);
+void gathering_forward_cuda_launcher(int b, int c, int n, int m, const float *points, const int *idx, float *out);
+void gathering_backward_cuda_launcher(int b, int c, int n, int m, const float *grad_out, const int *idx, float *grad_points);
+void knnquery_cuda_launcher(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx, float *dist2, pa_stream_t stream);
+void grouping_forward_cuda_launcher(int b, int c, int n, int m, int nsample, const float *points, const int *idx, float *out);
+void grouping_forward_cuda_launcher_fast(int b, int c, int n, int npoints, int nsample, const float *points, const int *idx, float *out);
+void grouping_backward_cuda_launcher(int b, int c, int n, int m, int nsample, const float *grad_out, const int *idx, float *grad_points);
+void grouping_int_forward_cuda_launcher(int b, int c, int n, int m, int nsample, const long int *points, const int *idx, long int *out);
+void grouping_int_forward_cuda_launcher_fast(int b, int c, int n, int npoints, int nsample, const long int *points, const int *idx, long int *out);
+void nearestneighbor_cuda_launcher(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx);
+void nearestneighbor_cuda_launcher_fast(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx);
+void interpolation_forward_cuda_launcher(int b, int c, int m, int n, const float *points, const int *idx, const float *weight, float *out);
+void interpolation_forward_cuda_launcher_fast(int b, int c, int m, int n, const float *points, const int *idx, const float *weight, float *out);
+void interpolation_backward_cuda_launcher(int b, int n, int c, int m, const float *grad_out, const int *idx, const float *weight, float *grad_points);
+void ballquery_cuda_launcher(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int *idx);
+void ballquery_cuda_launcher_fast(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int *idx, pa_stream_t stream);
+void featuredistribute_cuda_launcher(int b, int n, int m, const float *max_xyz, const float *xyz, int *distribute_idx, pa_stream_t stream);
+void featuregather_forward_cuda_launcher(int b, int n, int m, int c, const float *max_feature, const int *distribute_idx, float *distribute_feature, pa_stream_t stream);
+void featuregather_backward_cuda_launcher(int b, int n, int m, int c, const float *grad_distribute_feature, const int *distribute_idx, float *grad_max_feature, pa_stream_t stream);
+void labelstat_and_ballquery_cuda_launcher_fast(int b, int n, int m, float radius, int nsample, int nclass, const float *new_xyz, const float *xyz,
+                                                const int *label_stat, int *idx, int *new_label_stat, pa_stream_t stream);
+void labelstat_ballrange_cuda_launcher_fast(int b, int n, int m, float radius, int nclass, const float *new_xyz, const float *xyz,
+                                            const int *label_stat, int *new_label_stat, pa_stream_t stream);
+void labelstat_idx_cuda_launcher_fast(int b, int n, int m, int nsample, int nclass, const int *label_stat, const int *idx, int *new_label_stat, pa_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PATCHAUGNET_HIP_H */

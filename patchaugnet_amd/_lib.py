@@ -1,0 +1,108 @@
+"""ctypes binding of libpatchaugnet_hip.so (C ABI: include/patchaugnet_hip.h).
+
+The HIP library is the product path; there is NO fallback.  If the shared object
+is missing or a tensor is not on a HIP device the call raises immediately.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "libpatchaugnet_hip.so")
+_lib = None
+
+_I, _F, _P = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+
+# name -> argument type string: i = int, f = float, p = device pointer; a trailing stream pointer is implied
+_SIGS = {
+    "pa_furthestsampling": "iiippp",
+    "pa_gathering_forward": "iiiippp",
+    "pa_gathering_backward": "iiiippp",
+    "pa_knnquery": "iiiipppp",
+    "pa_grouping_forward": "iiiiippp",
+    "pa_grouping_backward": "iiiiippp",
+    "pa_grouping_int_forward": "iiiiippp",
+    "pa_nearestneighbor": "iiipppp",
+    "pa_interpolation_forward": "iiiipppp",
+    "pa_interpolation_backward": "iiiipppp",
+    "pa_ballquery": "iiifippp",
+    "pa_featuredistribute": "iiippp",
+    "pa_featuregather_forward": "iiiippp",
+    "pa_featuregather_backward": "iiiippp",
+    "pa_labelstat_and_ballquery": "iiifiippppp",
+    "pa_labelstat_ballrange": "iiifipppp",
+    "pa_labelstat_idx": "iiiiippp",
+    "pa_chamfer_forward": "iiipppppp",
+    "pa_chamfer_backward": "iiipppppppp",
+    "pa_knn_generic": "pipiiipp",
+}
+_T = {"i": _I, "f": _F, "p": _P}
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 with hipcc (csrc/Makefile).  Cross-compiles without a GPU."""
+    cmd = ["make", "-C", _CSRC, "-j8"] + (["-B"] if force else [])
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc build of libpatchaugnet_hip.so failed:\n" + res.stdout[-4000:])
+    return LIB_PATH
+
+
+def register(sigs):
+    """Declare further entry points (used by the fused-kernel modules)."""
+    _SIGS.update(sigs)
+    if _lib is not None:
+        _declare(_lib, sigs)
+
+
+def _declare(lib, sigs):
+    for name, sig in sigs.items():
+        fn = getattr(lib, name)
+        fn.argtypes = [_T[ch] for ch in sig] + [_P]
+        fn.restype = _I
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C patchaugnet_amd/csrc`). There is no CPU or PyTorch fallback for these ops.")
+        l = ctypes.CDLL(LIB_PATH)
+        l.pa_last_error.restype = ctypes.c_char_p
+        l.pa_abi_version.restype = _I
+        _declare(l, _SIGS)
+        _lib = l
+    return _lib
+
+
+def check_device(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("patchaugnet_amd ops run on the MI355X only: got a tensor on %s "
+                               "(no CPU fallback; the CPU checker lives in oracle/ and is test infrastructure)" % t.device)
+        if not t.is_contiguous():
+            raise RuntimeError("patchaugnet_amd ops need contiguous tensors")
+
+
+def ptr(t):
+    return _P(t.data_ptr()) if t is not None else _P(0)
+
+
+def stream_ptr():
+    return _P(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name, *args, stream=None):
+    """Invoke an entry point on the current torch stream; raise on a non-zero return."""
+    l = lib()
+    rc = getattr(l, name)(*args, stream if stream is not None else stream_ptr())
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {l.pa_last_error().decode()}")

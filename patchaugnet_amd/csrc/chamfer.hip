@@ -1,0 +1,139 @@
+// C1/C2 -- Chamfer distance forward / backward (gfx950).
+//
+// Reference semantics: libs/chamfer_dist/chamfer.cu:15-145 (forward): for each p in xyz1 the
+// nearest q in xyz2 with d = (qx-px)^2 + (qy-py)^2 + (qz-pz)^2 ("buf - x1" form, :42-45, fp32, no FMA); inside a
+// 512-point tile the first element is taken unconditionally and later ones on strict '<'; across tiles the stored
+// result is replaced on strict '>' (:137) => (d asc, index asc).  Backward: chamfer.cu:173-229.
+//
+// MI355X design.  The reference launches a fixed (32,16) x 512 grid; at the training shape (B = R*1024 patches of
+// n = m = 20 points) 20 of every 8192 threads work.  Here work items are (batch, point) pairs packed densely
+// into wavefronts: for small clouds (m <= 512, one tile) a lane owns one pair and reads the <= 6 KiB partner cloud
+// straight from L1/L2; larger clouds go through 512-point LDS tiles (same tile size as the reference so the tile
+// boundary rule is literally the same).
+#include "pa_common.h"
+
+namespace {
+
+constexpr int CT_TILE = 512;
+
+__device__ __forceinline__ void chamfer_scan(const float *__restrict__ q, int cnt, int base, float x1, float y1, float z1,
+                                              float &best_dist, int &best_idx)
+{
+    best_dist = 0.f;
+    best_idx = 0;
+    for (int k = 0; k < cnt; ++k) {
+        const float x2 = q[k * 3 + 0] - x1, y2 = q[k * 3 + 1] - y1, z2 = q[k * 3 + 2] - z1;
+        const float d = x2 * x2 + y2 * y2 + z2 * z2;
+        if (k == 0 || d < best_dist) { best_dist = d; best_idx = k + base; }
+    }
+}
+
+// one lane per (batch, point of xyz1); xyz2[batch] (<= 512 points) read from global/L2
+__global__ __launch_bounds__(256) void chamfer_small_kernel(long total, int n, int m, const float *__restrict__ xyz1,
+                                                              const float *__restrict__ xyz2, float *__restrict__ dist,
+                                                              int *__restrict__ indexes)
+{
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= total) return;
+    const long i = g / n;
+    const float *p = xyz1 + g * 3;
+    float bd;
+    int bi;
+    chamfer_scan(xyz2 + i * m * 3, m, 0, p[0], p[1], p[2], bd, bi);
+    dist[g] = bd;
+    indexes[g] = bi;
+}
+
+__global__ __launch_bounds__(256) void chamfer_tiled_kernel(int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+                                                              float *__restrict__ dist, int *__restrict__ indexes)
+{
+    __shared__ float buf[CT_TILE * 3];
+    const int i = blockIdx.y, tid = threadIdx.x;
+    const int j = blockIdx.x * 256 + tid;
+    float x1 = 0.f, y1 = 0.f, z1 = 0.f;
+    if (j < n) {
+        const float *p = xyz1 + ((size_t)i * n + j) * 3;
+        x1 = p[0]; y1 = p[1]; z1 = p[2];
+    }
+    float res_d = 0.f;
+    int res_i = 0;
+    for (int k2 = 0; k2 < m; k2 += CT_TILE) {
+        const int end_k = min(m, k2 + CT_TILE) - k2;
+        __syncthreads();
+        for (int t = tid; t < end_k * 3; t += 256) buf[t] = xyz2[((size_t)i * m + k2) * 3 + t];
+        __syncthreads();
+        float bd;
+        int bi;
+        chamfer_scan(buf, end_k, k2, x1, y1, z1, bd, bi);
+        if (k2 == 0 || res_d > bd) { res_d = bd; res_i = bi; }  // chamfer.cu:137
+    }
+    if (j < n) {
+        dist[(size_t)i * n + j] = res_d;
+        indexes[(size_t)i * n + j] = res_i;
+    }
+}
+
+// one lane per (batch, point of xyz1): grad_xyz1[b,j] += g*(p-q);  grad_xyz2[b,idx] -= g*(p-q)   (chamfer.cu:173-201)
+__global__ __launch_bounds__(256) void chamfer_grad_kernel(long total, int n, int m, const float *__restrict__ xyz1,
+                                                             const float *__restrict__ xyz2, const float *__restrict__ grad_dist1,
+                                                             const int *__restrict__ idx1, float *__restrict__ grad_xyz1,
+                                                             float *__restrict__ grad_xyz2)
+{
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const long i = t / n;
+    const float x1 = xyz1[t * 3 + 0], y1 = xyz1[t * 3 + 1], z1 = xyz1[t * 3 + 2];
+    const int j2 = idx1[t];
+    const float *q = xyz2 + (i * m + j2) * 3;
+    const float g = grad_dist1[t] * 2;
+    atomicAdd(grad_xyz1 + t * 3 + 0, g * (x1 - q[0]));
+    atomicAdd(grad_xyz1 + t * 3 + 1, g * (y1 - q[1]));
+    atomicAdd(grad_xyz1 + t * 3 + 2, g * (z1 - q[2]));
+    float *o = grad_xyz2 + (i * m + j2) * 3;
+    atomicAdd(o + 0, -(g * (x1 - q[0])));
+    atomicAdd(o + 1, -(g * (y1 - q[1])));
+    atomicAdd(o + 2, -(g * (z1 - q[2])));
+}
+
+int one_direction(int B, int n, int m, const float *a, const float *bq, float *dist, int *idx, hipStream_t st)
+{
+    if (m <= CT_TILE) {
+        const long total = (long)B * n;
+        hipLaunchKernelGGL(chamfer_small_kernel, dim3(pa_div_up(total, 256)), dim3(256), 0, st, total, n, m, a, bq, dist, idx);
+    } else {
+        PA_REQUIRE(B <= 65535, "pa_chamfer_forward: B=%d exceeds the grid limit for clouds above 512 points", B);
+        hipLaunchKernelGGL(chamfer_tiled_kernel, dim3(pa_div_up(n, 256), B), dim3(256), 0, st, n, m, a, bq, dist, idx);
+    }
+    return PA_OK;
+}
+
+}  // namespace
+
+PA_API int pa_chamfer_forward(int B, int n, int m, const float *xyz1, const float *xyz2, float *dist1, float *dist2, int *idx1, int *idx2,
+                              pa_stream_t stream)
+{
+    PA_REQUIRE(B > 0 && n > 0 && m > 0, "pa_chamfer_forward: B=%d n=%d m=%d must be positive", B, n, m);
+    PA_REQUIRE(xyz1 && xyz2 && dist1 && dist2 && idx1 && idx2, "pa_chamfer_forward: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    int r = one_direction(B, n, m, xyz1, xyz2, dist1, idx1, st);
+    if (r) return r;
+    r = one_direction(B, m, n, xyz2, xyz1, dist2, idx2, st);
+    if (r) return r;
+    PA_CHECK_LAUNCH("pa_chamfer_forward");
+    return PA_OK;
+}
+
+PA_API int pa_chamfer_backward(int B, int n, int m, const float *xyz1, const float *xyz2, const int *idx1, const int *idx2,
+                               const float *grad_dist1, const float *grad_dist2, float *grad_xyz1, float *grad_xyz2, pa_stream_t stream)
+{
+    PA_REQUIRE(B > 0 && n > 0 && m > 0, "pa_chamfer_backward: B=%d n=%d m=%d must be positive", B, n, m);
+    PA_REQUIRE(xyz1 && xyz2 && idx1 && idx2 && grad_dist1 && grad_dist2 && grad_xyz1 && grad_xyz2, "pa_chamfer_backward: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipMemsetAsync(grad_xyz1, 0, sizeof(float) * (size_t)B * n * 3, st);  // chamfer.cu:212-213 (zeros_like)
+    (void)hipMemsetAsync(grad_xyz2, 0, sizeof(float) * (size_t)B * m * 3, st);
+    const long t1 = (long)B * n, t2 = (long)B * m;
+    hipLaunchKernelGGL(chamfer_grad_kernel, dim3(pa_div_up(t1, 256)), dim3(256), 0, st, t1, n, m, xyz1, xyz2, grad_dist1, idx1, grad_xyz1, grad_xyz2);
+    hipLaunchKernelGGL(chamfer_grad_kernel, dim3(pa_div_up(t2, 256)), dim3(256), 0, st, t2, m, n, xyz2, xyz1, grad_dist2, idx2, grad_xyz2, grad_xyz1);
+    PA_CHECK_LAUNCH("pa_chamfer_backward");
+    return PA_OK;
+}

@@ -1,0 +1,180 @@
+// K1 -- furthest point sampling for gfx950.
+//
+// Reference semantics: libs/pointops/src/sampling/sampling_cuda_kernel.cu:59-168.
+// Round j: temp[k] = fminf(d2(p_k, p_old), temp[k]) for every k; the next sample is the argmax of temp under
+// the total order the reference's strided scan + stride-halving LDS tree induce:
+//     (temp larger first, then bitrev_{log2 bs}(k mod bs) smaller first, then k smaller first),  bs = opt_n_threads(n).
+//
+// MI355X design (not the reference's): the reference round-trips temp through global memory and runs a
+// 10-barrier LDS tree per round.  Here one workgroup owns one cloud, every lane keeps its points AND their
+// running minima in VGPRs for the whole launch, and the order above is folded into one unsigned 64-bit key
+//     key = float_bits(temp) << 32 | ~rank(k),   rank(k) = bitrev(k mod bs) << qbits | (k / bs)
+// so that a plain unsigned max is the reference's argmax (temp >= 0, so its bit pattern is monotone).
+// The wave maximum is taken with DPP row shifts / broadcasts (no LDS), waves meet through one double-buffered
+// LDS slot array with ONE barrier per round, and the winner's coordinates come from an LDS copy of the cloud.
+#include "pa_common.h"
+
+namespace {
+
+struct FpsOrder {
+    int log2bs;  // log2 of the reference's block size for this n
+    int qbits;   // bits needed for k / bs
+};
+
+__device__ __forceinline__ u32 fps_lowkey(int k, FpsOrder o)
+{
+    const u32 r = o.log2bs ? (__brev((u32)k & ((1u << o.log2bs) - 1u)) >> (32 - o.log2bs)) : 0u;
+    const u32 rank = (r << o.qbits) | ((u32)k >> o.log2bs);
+    return ~rank;
+}
+
+__device__ __forceinline__ int fps_decode(u32 lowkey, FpsOrder o)
+{
+    const u32 rank = ~lowkey;
+    const u32 q = rank & ((1u << o.qbits) - 1u);
+    const u32 rb = rank >> o.qbits;
+    const u32 r = o.log2bs ? (__brev(rb) >> (32 - o.log2bs)) : 0u;
+    return (int)((q << o.log2bs) | r);
+}
+
+// Register-resident path: NT threads, PPT points per lane, n <= NT*PPT, cloud copy in LDS (SoA, 12 B/point).
+template <int NT, int PPT>
+__global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, FpsOrder ord, const float *__restrict__ xyz_all,
+                                                       float *__restrict__ temp_all, int *__restrict__ idx_all)
+{
+    constexpr int NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sx = smem, *sy = smem + n, *sz = smem + 2 * n;
+    u64 *slots = reinterpret_cast<u64 *>(smem + 3 * n + ((3 * n) & 1));  // 8-byte aligned, [2][NW]
+
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float *xyz = xyz_all + (size_t)b * n * 3;
+    float *temp = temp_all + (size_t)b * n;
+    int *idxs = idx_all + (size_t)b * m;
+
+    float px[PPT], py[PPT], pz[PPT], t[PPT];
+    u32 low[PPT];
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+        const int k = tid + p * NT;
+        if (k < n) {
+            px[p] = xyz[k * 3 + 0];
+            py[p] = xyz[k * 3 + 1];
+            pz[p] = xyz[k * 3 + 2];
+            t[p] = temp[k];
+            low[p] = fps_lowkey(k, ord);
+            sx[k] = px[p];
+            sy[k] = py[p];
+            sz[k] = pz[p];
+        } else {  // padding: key 0 never beats a real point (real low keys are >= 1)
+            px[p] = py[p] = pz[p] = 0.f;
+            t[p] = 0.f;
+            low[p] = 0u;
+        }
+    }
+    if (tid == 0) idxs[0] = 0;
+    __syncthreads();
+    float ox = sx[0], oy = sy[0], oz = sz[0];
+
+    for (int j = 1; j < m; ++j) {
+        u64 best = 0;
+#pragma unroll
+        for (int p = 0; p < PPT; ++p) {
+            const float dx = px[p] - ox, dy = py[p] - oy, dz = pz[p] - oz;
+            const float d = dx * dx + dy * dy + dz * dz;  // sampling_cuda_kernel.cu:93
+            t[p] = fminf(d, t[p]);                        // :94
+            best = pa_max_u64(best, pa_make_key(t[p], low[p]));
+        }
+        u64 g = pa_wave_max_u64(best);
+        if (NW > 1) {
+            u64 *s = slots + (j & 1) * NW;
+            if ((tid & 63) == 0) s[tid >> 6] = g;
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < NW; ++w) g = pa_max_u64(g, s[w]);
+        }
+        const int old = fps_decode((u32)g, ord);
+        ox = sx[old];
+        oy = sy[old];
+        oz = sz[old];
+        if (tid == 0) idxs[j] = old;
+    }
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+        const int k = tid + p * NT;
+        if (k < n) temp[k] = t[p];
+    }
+}
+
+// Any-n path: temp stays in global memory (as in the reference), same key order, 1024 threads.
+__global__ __launch_bounds__(1024) void fps_stream_kernel(int n, int m, FpsOrder ord, const float *__restrict__ xyz_all,
+                                                            float *__restrict__ temp_all, int *__restrict__ idx_all)
+{
+    constexpr int NT = 1024, NW = NT / 64;
+    __shared__ u64 slots[2 * NW];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float *xyz = xyz_all + (size_t)b * n * 3;
+    float *temp = temp_all + (size_t)b * n;
+    int *idxs = idx_all + (size_t)b * m;
+    if (tid == 0) idxs[0] = 0;
+    int old = 0;
+    for (int j = 1; j < m; ++j) {
+        const float ox = xyz[old * 3 + 0], oy = xyz[old * 3 + 1], oz = xyz[old * 3 + 2];
+        u64 best = 0;
+        for (int k = tid; k < n; k += NT) {
+            const float dx = xyz[k * 3 + 0] - ox, dy = xyz[k * 3 + 1] - oy, dz = xyz[k * 3 + 2] - oz;
+            const float d = dx * dx + dy * dy + dz * dz;
+            const float d2 = fminf(d, temp[k]);
+            temp[k] = d2;
+            best = pa_max_u64(best, pa_make_key(d2, fps_lowkey(k, ord)));
+        }
+        u64 g = pa_wave_max_u64(best);
+        u64 *s = slots + (j & 1) * NW;
+        if ((tid & 63) == 0) s[tid >> 6] = g;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < NW; ++w) g = pa_max_u64(g, s[w]);
+        old = fps_decode((u32)g, ord);
+        if (tid == 0) idxs[j] = old;
+    }
+}
+
+template <int NT, int PPT>
+int launch_reg(int b, int n, int m, FpsOrder ord, const float *xyz, float *temp, int *idx, hipStream_t st)
+{
+    const size_t lds = (size_t)(3 * n + ((3 * n) & 1)) * 4 + 2 * (NT / 64) * 8;
+    if (lds > 48 * 1024)  // opt in to the large-LDS carve-out (gfx950: 160 KiB per CU)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_reg_kernel<NT, PPT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((fps_reg_kernel<NT, PPT>), dim3(b), dim3(NT), lds, st, n, m, ord, xyz, temp, idx);
+    return 0;
+}
+
+}  // namespace
+
+PA_API int pa_furthestsampling(int b, int n, int m, const float *xyz, float *temp, int *idx, pa_stream_t stream)
+{
+    PA_REQUIRE(b > 0 && n > 0, "pa_furthestsampling: b=%d n=%d must be positive", b, n);
+    PA_REQUIRE(xyz && temp && idx, "pa_furthestsampling: null pointer");
+    if (m <= 0) return PA_OK;  // sampling_cuda_kernel.cu:61-62
+    hipStream_t st = (hipStream_t)stream;
+    const int bs = pa_opt_n_threads(n);
+    FpsOrder ord;
+    ord.log2bs = 0;
+    while ((1 << ord.log2bs) < bs) ++ord.log2bs;
+    const int Q = (n + bs - 1) / bs;
+    ord.qbits = 0;
+    while ((1 << ord.qbits) < Q) ++ord.qbits;
+
+    if (n <= 64) launch_reg<64, 1>(b, n, m, ord, xyz, temp, idx, st);
+    else if (n <= 128) launch_reg<64, 2>(b, n, m, ord, xyz, temp, idx, st);
+    else if (n <= 256) launch_reg<64, 4>(b, n, m, ord, xyz, temp, idx, st);
+    else if (n <= 512) launch_reg<64, 8>(b, n, m, ord, xyz, temp, idx, st);
+    else if (n <= 1024) launch_reg<256, 4>(b, n, m, ord, xyz, temp, idx, st);
+    else if (n <= 2048) launch_reg<256, 8>(b, n, m, ord, xyz, temp, idx, st);
+    else if (n <= 4096) launch_reg<256, 16>(b, n, m, ord, xyz, temp, idx, st);
+    else if (n <= 8192) launch_reg<256, 32>(b, n, m, ord, xyz, temp, idx, st);
+    else hipLaunchKernelGGL(fps_stream_kernel, dim3(b), dim3(1024), 0, st, n, m, ord, xyz, temp, idx);
+    PA_CHECK_LAUNCH("pa_furthestsampling");
+    return PA_OK;
+}

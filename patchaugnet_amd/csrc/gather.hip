@@ -1,0 +1,290 @@
+// K2 gathering, K5 grouping (the roofline-graded neighbourhood gather), K8 grouping_int, K10 interpolation,
+// and their scatter-add backward passes K3 / K6 / K11 / K15 (gfx950).
+//
+// Reference semantics (all pure data movement except K10's fixed-order 3-term sum):
+//   K2  libs/pointops/src/sampling/sampling_cuda_kernel.cu:6-19    out[b,c,j]   = points[b,c,idx[b,j]]
+//   K5  libs/pointops/src/grouping/grouping_cuda_kernel.cu:60-74   out[b,c,j,s] = points[b,c,idx[b,j,s]]
+//   K10 libs/pointops/src/interpolation/interpolation_cuda_kernel.cu:181-195
+//                                   out[b,c,j] = (w0*p[i0] + w1*p[i1]) + w2*p[i2]
+//   K3/K6/K11/K15: atomicAdd scatters (:23-36, grouping :28-46, interpolation :90-114, featuredistribute :89-101)
+//
+// MI355X design.  The reference launches one thread per OUTPUT element: every 4-byte read is an uncoalesced HBM/L2
+// access and idx is re-read once per channel.  Here a workgroup owns (batch b, a tile of CT channel rows, a slice
+// of the output columns): the CT rows are staged into LDS with coalesced 16-byte loads, every lane then loads FOUR
+// consecutive indices once (int4), reuses them for all CT rows, gathers from LDS and writes one coalesced 16-byte
+// store per row.  HBM traffic is therefore the algorithmic minimum 4*(c*n + m*k + c*m*k) bytes per batch element
+// plus an idx re-read per channel tile (c/CT times, L2-resident).  K2 is K5 with nsample = 1.
+#include "pa_common.h"
+
+namespace {
+
+constexpr int GT = 256;  // threads per workgroup
+
+// rows: CT channel rows of length n staged in LDS; cols: flattened (j,s) output columns [col0, col1)
+template <int CT>
+__global__ __launch_bounds__(GT) void group_lds_kernel(int c, int n, int mk, int cols_per_block, const float *__restrict__ points,
+                                                         const int *__restrict__ idx, float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float rows[];  // [CT][n]
+    const int b = blockIdx.z, c0 = blockIdx.y * CT, tid = threadIdx.x;
+    const int ct = min(CT, c - c0);
+    const float *src = points + ((size_t)b * c + c0) * n;
+    const int total = ct * n;
+    // stage: rows are contiguous in memory ((b,c,n) layout), so this is one linear coalesced copy
+    if ((((uintptr_t)src) & 15) == 0) {
+        const float4 *s4 = reinterpret_cast<const float4 *>(src);
+        float4 *d4 = reinterpret_cast<float4 *>(rows);
+        for (int i = tid; i < total / 4; i += GT) d4[i] = s4[i];
+        for (int i = (total & ~3) + tid; i < total; i += GT) rows[i] = src[i];
+    } else {
+        for (int i = tid; i < total; i += GT) rows[i] = src[i];
+    }
+    __syncthreads();
+    const int col0 = blockIdx.x * cols_per_block;
+    const int col1 = min(col0 + cols_per_block, mk);
+    const int *id = idx + (size_t)b * mk;
+    float *o = out + ((size_t)b * c + c0) * mk;
+    const bool vec = ((mk & 3) == 0) && ((((uintptr_t)id) & 15) == 0) && ((((uintptr_t)o) & 15) == 0);
+    if (vec) {  // col0 is a multiple of 4 by construction
+        for (int t = col0 + tid * 4; t < col1; t += GT * 4) {
+            const int4 i4 = *reinterpret_cast<const int4 *>(id + t);
+#pragma unroll
+            for (int r = 0; r < CT; ++r) {
+                if (r < ct) {
+                    const float *row = rows + r * n;
+                    const float4 v = make_float4(row[i4.x], row[i4.y], row[i4.z], row[i4.w]);
+                    *reinterpret_cast<float4 *>(o + (size_t)r * mk + t) = v;
+                }
+            }
+        }
+    } else {
+        for (int t = col0 + tid; t < col1; t += GT) {
+            const int i = id[t];
+            for (int r = 0; r < ct; ++r) o[(size_t)r * mk + t] = rows[r * n + i];
+        }
+    }
+}
+
+// fallback when a single row does not fit in LDS: straight from global memory, indices still loaded once per lane
+template <typename T>
+__global__ __launch_bounds__(GT) void group_direct_kernel(int c, int n, int mk, const T *__restrict__ points, const int *__restrict__ idx,
+                                                            T *__restrict__ out)
+{
+    const int b = blockIdx.z, ch = blockIdx.y;
+    const int t = blockIdx.x * GT + threadIdx.x;
+    if (t >= mk) return;
+    out[((size_t)b * c + ch) * mk + t] = points[((size_t)b * c + ch) * n + idx[(size_t)b * mk + t]];
+}
+
+template <int CT>
+__global__ __launch_bounds__(GT) void interp_lds_kernel(int c, int m, int n, int cols_per_block, const float *__restrict__ points,
+                                                          const int *__restrict__ idx, const float *__restrict__ weight,
+                                                          float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float rows[];  // [CT][m]
+    const int b = blockIdx.z, c0 = blockIdx.y * CT, tid = threadIdx.x;
+    const int ct = min(CT, c - c0);
+    const float *src = points + ((size_t)b * c + c0) * m;
+    const int total = ct * m;
+    for (int i = tid; i < total; i += GT) rows[i] = src[i];
+    __syncthreads();
+    const int col0 = blockIdx.x * cols_per_block;
+    const int col1 = min(col0 + cols_per_block, n);
+    const int *id = idx + (size_t)b * n * 3;
+    const float *w = weight + (size_t)b * n * 3;
+    float *o = out + ((size_t)b * c + c0) * n;
+    for (int j = col0 + tid; j < col1; j += GT) {
+        const int i0 = id[j * 3 + 0], i1 = id[j * 3 + 1], i2 = id[j * 3 + 2];
+        const float w0 = w[j * 3 + 0], w1 = w[j * 3 + 1], w2 = w[j * 3 + 2];
+#pragma unroll
+        for (int r = 0; r < CT; ++r) {
+            if (r < ct) {
+                const float *row = rows + r * m;
+                o[(size_t)r * n + j] = w0 * row[i0] + w1 * row[i1] + w2 * row[i2];  // interpolation_cuda_kernel.cu:194
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(GT) void interp_direct_kernel(int c, int m, int n, const float *__restrict__ points, const int *__restrict__ idx,
+                                                             const float *__restrict__ weight, float *__restrict__ out)
+{
+    const int b = blockIdx.z, ch = blockIdx.y;
+    const int j = blockIdx.x * GT + threadIdx.x;
+    if (j >= n) return;
+    const int *id = idx + ((size_t)b * n + j) * 3;
+    const float *w = weight + ((size_t)b * n + j) * 3;
+    const float *row = points + ((size_t)b * c + ch) * m;
+    out[((size_t)b * c + ch) * n + j] = w[0] * row[id[0]] + w[1] * row[id[1]] + w[2] * row[id[2]];
+}
+
+// scatter-add: grad_points[b,ch,idx[b,t]] += grad_out[b,ch,t]   (K3 with mk = m, K6 with mk = m*nsample, K15)
+__global__ __launch_bounds__(GT) void scatter_add_kernel(int c, int n, int mk, const float *__restrict__ grad_out, const int *__restrict__ idx,
+                                                           float *__restrict__ grad_points)
+{
+    const int b = blockIdx.z, ch = blockIdx.y;
+    const int t = blockIdx.x * GT + threadIdx.x;
+    if (t >= mk) return;
+    atomicAdd(grad_points + ((size_t)b * c + ch) * n + idx[(size_t)b * mk + t], grad_out[((size_t)b * c + ch) * mk + t]);
+}
+
+__global__ __launch_bounds__(GT) void interp_backward_kernel(int c, int n, int m, const float *__restrict__ grad_out, const int *__restrict__ idx,
+                                                               const float *__restrict__ weight, float *__restrict__ grad_points)
+{
+    const int b = blockIdx.z, ch = blockIdx.y;
+    const int j = blockIdx.x * GT + threadIdx.x;
+    if (j >= n) return;
+    const int *id = idx + ((size_t)b * n + j) * 3;
+    const float *w = weight + ((size_t)b * n + j) * 3;
+    const float g = grad_out[((size_t)b * c + ch) * n + j];
+    float *gp = grad_points + ((size_t)b * c + ch) * m;
+    atomicAdd(gp + id[0], g * w[0]);
+    atomicAdd(gp + id[1], g * w[1]);
+    atomicAdd(gp + id[2], g * w[2]);
+}
+
+// pick the channel tile so CT rows fit in 64 KiB of LDS (two workgroups per CU) and the column split so that the
+// launch has >= ~1024 workgroups whenever the problem is big enough
+struct GatherPlan { int ct; int cols_per_block; int col_blocks; size_t lds; };
+
+GatherPlan plan(int b, int c, int row_len, int cols)
+{
+    GatherPlan p;
+    const size_t row_bytes = (size_t)row_len * 4;
+    p.ct = 16;
+    while (p.ct > 1 && (p.ct * row_bytes > 64 * 1024 || p.ct / 2 >= c)) p.ct /= 2;
+    p.lds = (size_t)p.ct * row_bytes;
+    const long wg = (long)b * pa_div_up(c, p.ct);
+    int split = 1;
+    while (wg * split < 1024 && pa_div_up(cols, split * 2) >= 1024) split *= 2;
+    p.cols_per_block = ((pa_div_up(cols, split) + 3) / 4) * 4;
+    p.col_blocks = pa_div_up(cols, p.cols_per_block);
+    return p;
+}
+
+template <int CT>
+void launch_group(const GatherPlan &p, int b, int c, int n, int mk, const float *points, const int *idx, float *out, hipStream_t st)
+{
+    if (p.lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&group_lds_kernel<CT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
+    hipLaunchKernelGGL(group_lds_kernel<CT>, dim3(p.col_blocks, pa_div_up(c, CT), b), dim3(GT), p.lds, st, c, n, mk, p.cols_per_block, points, idx, out);
+}
+
+template <int CT>
+void launch_interp(const GatherPlan &p, int b, int c, int m, int n, const float *points, const int *idx, const float *w, float *out, hipStream_t st)
+{
+    if (p.lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&interp_lds_kernel<CT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
+    hipLaunchKernelGGL(interp_lds_kernel<CT>, dim3(p.col_blocks, pa_div_up(c, CT), b), dim3(GT), p.lds, st, c, m, n, p.cols_per_block, points, idx, w, out);
+}
+
+int group_forward(const char *name, int b, int c, int n, int mk, const float *points, const int *idx, float *out, hipStream_t st)
+{
+    PA_REQUIRE(b > 0 && c > 0 && n > 0 && mk > 0, "%s: sizes must be positive (b=%d c=%d n=%d cols=%d)", name, b, c, n, mk);
+    PA_REQUIRE(points && idx && out, "%s: null pointer", name);
+    PA_REQUIRE(b <= 65535 && c <= 65535 * 16, "%s: b=%d / c=%d exceed the grid limits", name, b, c);
+    if ((size_t)n * 4 > 128 * 1024) {
+        PA_REQUIRE(c <= 65535, "%s: c=%d exceeds the grid limit", name, c);
+        hipLaunchKernelGGL(group_direct_kernel<float>, dim3(pa_div_up(mk, GT), c, b), dim3(GT), 0, st, c, n, mk, points, idx, out);
+    } else {
+        GatherPlan p = plan(b, c, n, mk);
+        if ((size_t)n * 4 > 64 * 1024) { p.ct = 1; p.lds = (size_t)n * 4; }
+        switch (p.ct) {
+            case 16: launch_group<16>(p, b, c, n, mk, points, idx, out, st); break;
+            case 8: launch_group<8>(p, b, c, n, mk, points, idx, out, st); break;
+            case 4: launch_group<4>(p, b, c, n, mk, points, idx, out, st); break;
+            case 2: launch_group<2>(p, b, c, n, mk, points, idx, out, st); break;
+            default: launch_group<1>(p, b, c, n, mk, points, idx, out, st); break;
+        }
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { pa_set_error("%s: launch failed: %s", name, hipGetErrorString(e)); return (int)e; }
+    return PA_OK;
+}
+
+int scatter_add(const char *name, int b, int c, int n, int mk, const float *grad_out, const int *idx, float *grad_points, hipStream_t st)
+{
+    PA_REQUIRE(b > 0 && c > 0 && n > 0 && mk > 0, "%s: sizes must be positive", name);
+    PA_REQUIRE(grad_out && idx && grad_points, "%s: null pointer", name);
+    PA_REQUIRE(b <= 65535 && c <= 65535, "%s: b=%d / c=%d exceed the grid limits", name, b, c);
+    hipLaunchKernelGGL(scatter_add_kernel, dim3(pa_div_up(mk, GT), c, b), dim3(GT), 0, st, c, n, mk, grad_out, idx, grad_points);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { pa_set_error("%s: launch failed: %s", name, hipGetErrorString(e)); return (int)e; }
+    return PA_OK;
+}
+
+}  // namespace
+
+PA_API int pa_grouping_forward(int b, int c, int n, int m, int nsample, const float *points, const int *idx, float *out, pa_stream_t stream)
+{
+    PA_REQUIRE(m > 0 && nsample > 0, "pa_grouping_forward: m=%d nsample=%d must be positive", m, nsample);
+    return group_forward("pa_grouping_forward", b, c, n, m * nsample, points, idx, out, (hipStream_t)stream);
+}
+
+PA_API int pa_gathering_forward(int b, int c, int n, int m, const float *points, const int *idx, float *out, pa_stream_t stream)
+{
+    return group_forward("pa_gathering_forward", b, c, n, m, points, idx, out, (hipStream_t)stream);
+}
+
+PA_API int pa_featuregather_forward(int b, int n, int m, int c, const float *max_feature, const int *distribute_idx, float *distribute_feature, pa_stream_t stream)
+{
+    return group_forward("pa_featuregather_forward", b, c, n, m, max_feature, distribute_idx, distribute_feature, (hipStream_t)stream);
+}
+
+PA_API int pa_grouping_int_forward(int b, int c, int n, int m, int nsample, const int64_t *points, const int *idx, int64_t *out, pa_stream_t stream)
+{
+    PA_REQUIRE(b > 0 && c > 0 && n > 0 && m > 0 && nsample > 0, "pa_grouping_int_forward: sizes must be positive");
+    PA_REQUIRE(points && idx && out, "pa_grouping_int_forward: null pointer");
+    PA_REQUIRE(b <= 65535 && c <= 65535, "pa_grouping_int_forward: b=%d / c=%d exceed the grid limits", b, c);
+    hipLaunchKernelGGL(group_direct_kernel<int64_t>, dim3(pa_div_up(m * nsample, GT), c, b), dim3(GT), 0, (hipStream_t)stream, c, n, m * nsample, points, idx, out);
+    PA_CHECK_LAUNCH("pa_grouping_int_forward");
+    return PA_OK;
+}
+
+PA_API int pa_grouping_backward(int b, int c, int n, int m, int nsample, const float *grad_out, const int *idx, float *grad_points, pa_stream_t stream)
+{
+    PA_REQUIRE(m > 0 && nsample > 0, "pa_grouping_backward: m=%d nsample=%d must be positive", m, nsample);
+    return scatter_add("pa_grouping_backward", b, c, n, m * nsample, grad_out, idx, grad_points, (hipStream_t)stream);
+}
+
+PA_API int pa_gathering_backward(int b, int c, int n, int m, const float *grad_out, const int *idx, float *grad_points, pa_stream_t stream)
+{
+    return scatter_add("pa_gathering_backward", b, c, n, m, grad_out, idx, grad_points, (hipStream_t)stream);
+}
+
+PA_API int pa_featuregather_backward(int b, int n, int m, int c, const float *grad_distribute_feature, const int *distribute_idx, float *grad_max_feature, pa_stream_t stream)
+{
+    return scatter_add("pa_featuregather_backward", b, c, n, m, grad_distribute_feature, distribute_idx, grad_max_feature, (hipStream_t)stream);
+}
+
+PA_API int pa_interpolation_forward(int b, int c, int m, int n, const float *points, const int *idx, const float *weight, float *out, pa_stream_t stream)
+{
+    PA_REQUIRE(b > 0 && c > 0 && m > 0 && n > 0, "pa_interpolation_forward: sizes must be positive");
+    PA_REQUIRE(points && idx && weight && out, "pa_interpolation_forward: null pointer");
+    PA_REQUIRE(b <= 65535 && c <= 65535, "pa_interpolation_forward: b=%d / c=%d exceed the grid limits", b, c);
+    hipStream_t st = (hipStream_t)stream;
+    if ((size_t)m * 4 > 64 * 1024) {
+        hipLaunchKernelGGL(interp_direct_kernel, dim3(pa_div_up(n, GT), c, b), dim3(GT), 0, st, c, m, n, points, idx, weight, out);
+    } else {
+        GatherPlan p = plan(b, c, m, n);
+        switch (p.ct) {
+            case 16: launch_interp<16>(p, b, c, m, n, points, idx, weight, out, st); break;
+            case 8: launch_interp<8>(p, b, c, m, n, points, idx, weight, out, st); break;
+            case 4: launch_interp<4>(p, b, c, m, n, points, idx, weight, out, st); break;
+            case 2: launch_interp<2>(p, b, c, m, n, points, idx, weight, out, st); break;
+            default: launch_interp<1>(p, b, c, m, n, points, idx, weight, out, st); break;
+        }
+    }
+    PA_CHECK_LAUNCH("pa_interpolation_forward");
+    return PA_OK;
+}
+
+PA_API int pa_interpolation_backward(int b, int c, int n, int m, const float *grad_out, const int *idx, const float *weight, float *grad_points, pa_stream_t stream)
+{
+    PA_REQUIRE(b > 0 && c > 0 && m > 0 && n > 0, "pa_interpolation_backward: sizes must be positive");
+    PA_REQUIRE(grad_out && idx && weight && grad_points, "pa_interpolation_backward: null pointer");
+    PA_REQUIRE(b <= 65535 && c <= 65535, "pa_interpolation_backward: b=%d / c=%d exceed the grid limits", b, c);
+    hipLaunchKernelGGL(interp_backward_kernel, dim3(pa_div_up(n, GT), c, b), dim3(GT), 0, (hipStream_t)stream, c, n, m, grad_out, idx, weight, grad_points);
+    PA_CHECK_LAUNCH("pa_interpolation_backward");
+    return PA_OK;
+}

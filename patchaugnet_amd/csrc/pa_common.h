@@ -1,0 +1,94 @@
+// Shared device/host helpers for libpatchaugnet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <cmath>
+
+#include "../../include/patchaugnet_hip.h"
+
+#define PA_API extern "C" __attribute__((visibility("default")))
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// ---- error reporting ---------------------------------------------------------------------------
+void pa_set_error(const char *fmt, ...);
+
+#define PA_REQUIRE(cond, ...)            \
+    do {                                 \
+        if (!(cond)) {                   \
+            pa_set_error(__VA_ARGS__);   \
+            return PA_EINVAL;            \
+        }                                \
+    } while (0)
+
+// Called right after a kernel launch: reports launch-configuration errors without synchronising.
+#define PA_CHECK_LAUNCH(name)                                                        \
+    do {                                                                             \
+        hipError_t e__ = hipGetLastError();                                          \
+        if (e__ != hipSuccess) {                                                     \
+            pa_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));     \
+            return (int)e__;                                                         \
+        }                                                                            \
+    } while (0)
+
+static inline int pa_div_up(long a, long b) { return (int)((a + b - 1) / b); }
+
+// libs/pointops/src/cuda_utils.h:15-18 -- the reference's block-size rule; it fixes the FPS
+// tie-break order, so it is computed with the same double-precision log ratio.
+static inline int pa_opt_n_threads(int work_size)
+{
+    const int pow_2 = (int)(std::log(static_cast<double>(work_size)) / std::log(2.0));
+    int t = 1 << pow_2;
+    if (t > 1024) t = 1024;
+    if (t < 1) t = 1;
+    return t;
+}
+
+// ---- wavefront helpers (wave64) ------------------------------------------------------------------
+#define PA_DPP_ROW_SHR(n) (0x110 + (n))
+#define PA_DPP_WAVE_SHR1 0x138
+#define PA_DPP_ROW_BCAST15 0x142
+#define PA_DPP_ROW_BCAST31 0x143
+
+__device__ __forceinline__ u64 pa_make_key(float d, u32 lo) { return ((u64)__float_as_uint(d) << 32) | lo; }
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ u64 pa_dpp_u64(u64 v)
+{
+    const u32 lo = __builtin_amdgcn_update_dpp(0u, (u32)v, CTRL, ROW_MASK, 0xf, true);
+    const u32 hi = __builtin_amdgcn_update_dpp(0u, (u32)(v >> 32), CTRL, ROW_MASK, 0xf, true);
+    return ((u64)hi << 32) | lo;
+}
+
+__device__ __forceinline__ u64 pa_max_u64(u64 a, u64 b) { return a > b ? a : b; }
+
+// max over the 64 lanes of a wavefront; result valid in lane 63 and returned broadcast (SGPR pair).
+__device__ __forceinline__ u64 pa_wave_max_u64(u64 v)
+{
+    v = pa_max_u64(v, pa_dpp_u64<PA_DPP_ROW_SHR(1), 0xf>(v));
+    v = pa_max_u64(v, pa_dpp_u64<PA_DPP_ROW_SHR(2), 0xf>(v));
+    v = pa_max_u64(v, pa_dpp_u64<PA_DPP_ROW_SHR(4), 0xf>(v));
+    v = pa_max_u64(v, pa_dpp_u64<PA_DPP_ROW_SHR(8), 0xf>(v));
+    v = pa_max_u64(v, pa_dpp_u64<PA_DPP_ROW_BCAST15, 0xa>(v));
+    v = pa_max_u64(v, pa_dpp_u64<PA_DPP_ROW_BCAST31, 0xc>(v));
+    const u32 lo = __builtin_amdgcn_readlane((u32)v, 63);
+    const u32 hi = __builtin_amdgcn_readlane((u32)(v >> 32), 63);
+    return ((u64)hi << 32) | lo;
+}
+
+__device__ __forceinline__ u64 pa_readlane_u64(u64 v, int lane)
+{
+    const u32 lo = __builtin_amdgcn_readlane((u32)v, lane);
+    const u32 hi = __builtin_amdgcn_readlane((u32)(v >> 32), lane);
+    return ((u64)hi << 32) | lo;
+}
+
+// squared distance in the arithmetic contract of SURVEY.md section 8: fp32, (dx*dx + dy*dy) + dz*dz,
+// no FMA contraction (the library is built with -ffp-contract=off).
+__device__ __forceinline__ float pa_sqdist(float ax, float ay, float az, float bx, float by, float bz)
+{
+    const float dx = ax - bx, dy = ay - by, dz = az - bz;
+    return dx * dx + dy * dy + dz * dz;
+}

@@ -1,0 +1,467 @@
+"""Host-side op layer: the reference's ``libs/pointops/functions/pointops.py`` API on MI355X.
+
+Same public names, argument order, return values and autograd behaviour as the
+reference (cited per function, paths under the reference tree), but every op is a
+call into libpatchaugnet_hip.so through the C ABI (include/patchaugnet_hip.h) on
+the current torch stream.  Differences from the reference, all deliberate:
+
+  * outputs are allocated on the input's device (the reference hard-codes
+    ``torch.cuda.*Tensor`` = device 0) and calls run under a device guard;
+  * native failures raise RuntimeError (the reference calls exit(-1));
+  * ``knnquery`` accepts any nsample (the reference overflows a 200-entry local array).
+
+CPU tensors are rejected: there is no fallback path.
+"""
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import call, check_device, ptr
+
+
+def _guard(t):
+    return torch.cuda.device(t.device)
+
+
+def _new(like, shape, dtype):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+class FurthestSampling(Function):
+    """pointops.py:11-29 -- xyz (b,n,3) -> idx (b,m) int32."""
+
+    @staticmethod
+    def forward(ctx, xyz, m):
+        check_device(xyz)
+        b, n, _ = xyz.shape
+        idx = _new(xyz, (b, m), torch.int32)
+        temp = torch.full((b, n), 1e10, dtype=torch.float32, device=xyz.device)
+        with _guard(xyz):
+            call("pa_furthestsampling", b, n, m, ptr(xyz), ptr(temp), ptr(idx))
+        ctx.mark_non_differentiable(idx)
+        return idx
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None
+
+
+furthestsampling = FurthestSampling.apply
+
+
+class Gathering(Function):
+    """pointops.py:32-57 -- features (b,c,n), idx (b,m) -> (b,c,m)."""
+
+    @staticmethod
+    def forward(ctx, features, idx):
+        check_device(features, idx)
+        b, c, n = features.shape
+        m = idx.shape[1]
+        out = _new(features, (b, c, m), torch.float32)
+        with _guard(features):
+            call("pa_gathering_forward", b, c, n, m, ptr(features), ptr(idx), ptr(out))
+        ctx.for_backwards = (idx, c, n)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, c, n = ctx.for_backwards
+        b, m = idx.shape
+        grad = torch.zeros((b, c, n), dtype=torch.float32, device=grad_out.device)
+        g = grad_out.contiguous()
+        with _guard(g):
+            call("pa_gathering_backward", b, c, n, m, ptr(g), ptr(idx), ptr(grad))
+        return grad, None
+
+
+gathering = Gathering.apply
+
+
+class NearestNeighbor(Function):
+    """pointops.py:60-82 -- unknown (b,n,3), known (b,m,3) -> (sqrt(dist2) (b,n,3), idx (b,n,3))."""
+
+    @staticmethod
+    def forward(ctx, unknown, known):
+        check_device(unknown, known)
+        b, n, _ = unknown.shape
+        m = known.shape[1]
+        dist2 = _new(unknown, (b, n, 3), torch.float32)
+        idx = _new(unknown, (b, n, 3), torch.int32)
+        with _guard(unknown):
+            call("pa_nearestneighbor", b, n, m, ptr(unknown), ptr(known), ptr(dist2), ptr(idx))
+        ctx.mark_non_differentiable(idx)
+        return torch.sqrt(dist2), idx
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None
+
+
+nearestneighbor = NearestNeighbor.apply
+
+
+class Interpolation(Function):
+    """pointops.py:85-118 -- features (b,c,m), idx/weight (b,n,3) -> (b,c,n)."""
+
+    @staticmethod
+    def forward(ctx, features, idx, weight):
+        check_device(features, idx, weight)
+        b, c, m = features.shape
+        n = idx.shape[1]
+        ctx.interpolation_for_backward = (idx, weight, m)
+        out = _new(features, (b, c, n), torch.float32)
+        with _guard(features):
+            call("pa_interpolation_forward", b, c, m, n, ptr(features), ptr(idx), ptr(weight), ptr(out))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, weight, m = ctx.interpolation_for_backward
+        b, c, n = grad_out.shape
+        grad = torch.zeros((b, c, m), dtype=torch.float32, device=grad_out.device)
+        g = grad_out.contiguous()
+        with _guard(g):
+            call("pa_interpolation_backward", b, c, n, m, ptr(g), ptr(idx), ptr(weight), ptr(grad))
+        return grad, None, None
+
+
+interpolation = Interpolation.apply
+
+
+class Grouping(Function):
+    """pointops.py:121-150 -- features (b,c,n), idx (b,m,nsample) -> (b,c,m,nsample)."""
+
+    @staticmethod
+    def forward(ctx, features, idx):
+        check_device(features, idx)
+        b, c, n = features.shape
+        _, m, nsample = idx.shape
+        out = _new(features, (b, c, m, nsample), torch.float32)
+        with _guard(features):
+            call("pa_grouping_forward", b, c, n, m, nsample, ptr(features), ptr(idx), ptr(out))
+        ctx.for_backwards = (idx, n)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, n = ctx.for_backwards
+        b, c, m, nsample = grad_out.shape
+        grad = torch.zeros((b, c, n), dtype=torch.float32, device=grad_out.device)
+        g = grad_out.contiguous()
+        with _guard(g):
+            call("pa_grouping_backward", b, c, n, m, nsample, ptr(g), ptr(idx), ptr(grad))
+        return grad, None
+
+
+grouping = Grouping.apply
+
+
+class GroupingInt(Function):
+    """pointops.py:153-172 -- int64 payload."""
+
+    @staticmethod
+    def forward(ctx, features, idx):
+        check_device(features, idx)
+        b, c, n = features.shape
+        _, m, nsample = idx.shape
+        out = _new(features, (b, c, m, nsample), torch.int64)
+        with _guard(features):
+            call("pa_grouping_int_forward", b, c, n, m, nsample, ptr(features), ptr(idx), ptr(out))
+        return out
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None
+
+
+grouping_int = GroupingInt.apply
+
+
+class BallQuery(Function):
+    """pointops.py:175-197 -- note the native argument order (new_xyz, xyz)."""
+
+    @staticmethod
+    def forward(ctx, radius, nsample, xyz, new_xyz):
+        check_device(xyz, new_xyz)
+        b, n, _ = xyz.shape
+        m = new_xyz.shape[1]
+        idx = torch.zeros((b, m, nsample), dtype=torch.int32, device=xyz.device)
+        with _guard(xyz):
+            call("pa_ballquery", b, n, m, float(radius), nsample, ptr(new_xyz), ptr(xyz), ptr(idx))
+        ctx.mark_non_differentiable(idx)
+        return idx
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None, None, None
+
+
+ballquery = BallQuery.apply
+
+
+class FeatureDistribute(Function):
+    """pointops.py:200-221"""
+
+    @staticmethod
+    def forward(ctx, max_xyz, xyz):
+        check_device(max_xyz, xyz)
+        b, n, _ = max_xyz.shape
+        m = xyz.shape[1]
+        out = torch.zeros((b, m), dtype=torch.int32, device=xyz.device)
+        with _guard(xyz):
+            call("pa_featuredistribute", b, n, m, ptr(max_xyz), ptr(xyz), ptr(out))
+        ctx.mark_non_differentiable(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None
+
+
+featuredistribute = FeatureDistribute.apply
+
+
+class FeatureGather(Function):
+    """pointops.py:224-256"""
+
+    @staticmethod
+    def forward(ctx, max_feature, distribute_idx):
+        check_device(max_feature, distribute_idx)
+        b, c, n = max_feature.shape
+        m = distribute_idx.shape[1]
+        out = torch.zeros((b, c, m), dtype=torch.float32, device=max_feature.device)
+        with _guard(max_feature):
+            call("pa_featuregather_forward", b, n, m, c, ptr(max_feature), ptr(distribute_idx), ptr(out))
+        ctx.for_backwards = (distribute_idx, n)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        distribute_idx, n = ctx.for_backwards
+        b, c, m = grad.shape
+        out = torch.zeros((b, c, n), dtype=torch.float32, device=grad.device)
+        g = grad.contiguous()
+        with _guard(g):
+            call("pa_featuregather_backward", b, n, m, c, ptr(g), ptr(distribute_idx), ptr(out))
+        return out, None
+
+
+featuregather = FeatureGather.apply
+
+
+class LabelStatBallRange(Function):
+    """pointops.py:259-285"""
+
+    @staticmethod
+    def forward(ctx, radius, xyz, new_xyz, label_stat):
+        check_device(xyz, new_xyz, label_stat)
+        b, n, nclass = label_stat.shape
+        m = new_xyz.shape[1]
+        out = torch.zeros((b, m, nclass), dtype=torch.int32, device=xyz.device)
+        with _guard(xyz):
+            call("pa_labelstat_ballrange", b, n, m, float(radius), nclass, ptr(new_xyz), ptr(xyz), ptr(label_stat), ptr(out))
+        return out
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None, None, None
+
+
+labelstat_ballrange = LabelStatBallRange.apply
+
+
+class LabelStatIdx(Function):
+    """pointops.py:288-312"""
+
+    @staticmethod
+    def forward(ctx, nsample, label_stat, idx):
+        check_device(label_stat, idx)
+        b, n, nclass = label_stat.shape
+        m = idx.shape[1]
+        out = torch.zeros((b, m, nclass), dtype=torch.int32, device=idx.device)
+        with _guard(idx):
+            call("pa_labelstat_idx", b, n, m, nsample, nclass, ptr(label_stat), ptr(idx), ptr(out))
+        return out
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None, None
+
+
+labelstat_idx = LabelStatIdx.apply
+
+
+class LabelStatAndBallQuery(Function):
+    """pointops.py:315-344"""
+
+    @staticmethod
+    def forward(ctx, radius, nsample, xyz, new_xyz, label_stat):
+        check_device(xyz, new_xyz, label_stat)
+        b, n, nclass = label_stat.shape
+        m = new_xyz.shape[1]
+        out = torch.zeros((b, m, nclass), dtype=torch.int32, device=xyz.device)
+        idx = torch.zeros((b, m, nsample), dtype=torch.int32, device=xyz.device)
+        with _guard(xyz):
+            call("pa_labelstat_and_ballquery", b, n, m, float(radius), nsample, nclass, ptr(new_xyz), ptr(xyz),
+                 ptr(label_stat), ptr(idx), ptr(out))
+        return out, idx
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None, None, None, None
+
+
+labelstat_and_ballquery = LabelStatAndBallQuery.apply
+
+
+def pairwise_distances(x, y=None):
+    """pointops.py:347-363 -- ||x_i - y_j||^2 via the expanded form, clamped at 0 (pure torch, as in the reference)."""
+    x_norm = (x ** 2).sum(1).view(-1, 1)
+    y = x if y is None else y
+    y_norm = (y ** 2).sum(1).view(1, -1)
+    return torch.clamp(x_norm + y_norm - 2.0 * torch.mm(x, y.t()), min=0.0)
+
+
+def knnquery_with_dist(nsample, xyz, new_xyz=None):
+    """The native op with both outputs: idx (b,m,nsample) int32 and dist2 (b,m,nsample) fp32."""
+    if new_xyz is None:
+        new_xyz = xyz
+    check_device(xyz, new_xyz)
+    b, m, _ = new_xyz.shape
+    n = xyz.shape[1]
+    idx = _new(xyz, (b, m, nsample), torch.int32)
+    dist2 = _new(xyz, (b, m, nsample), torch.float32)
+    with _guard(xyz):
+        call("pa_knnquery", b, n, m, nsample, ptr(xyz), ptr(new_xyz), ptr(idx), ptr(dist2))
+    return idx, dist2
+
+
+class KNNQuery(Function):
+    """pointops.py:407-433 -- returns idx only (the reference discards dist2 too)."""
+
+    @staticmethod
+    def forward(ctx, nsample, xyz, new_xyz=None):
+        idx, _ = knnquery_with_dist(nsample, xyz, new_xyz)
+        ctx.mark_non_differentiable(idx)
+        return idx
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None, None
+
+
+knnquery = KNNQuery.apply
+
+
+def knnquery_naive(nsample, xyz, new_xyz=None):
+    """pointops.py:366-404 (torch sort of the full distance matrix; kept for API parity)."""
+    new_xyz = xyz if new_xyz is None else new_xyz
+    dist = (new_xyz.unsqueeze(2) - xyz.unsqueeze(1)).pow(2).sum(dim=3)
+    return torch.sort(dist, dim=2)[1][:, :, :nsample].int()
+
+
+def knnquery_exclude(nsample, xyz, new_xyz=None):
+    """pointops.py:436-473 (neighbours 1..nsample, i.e. excluding the closest)."""
+    new_xyz = xyz if new_xyz is None else new_xyz
+    dist = (new_xyz.unsqueeze(2) - xyz.unsqueeze(1)).pow(2).sum(dim=3)
+    return torch.sort(dist, dim=2)[1][:, :, 1:nsample + 1].int()
+
+
+def _neighbours(radius, nsample, xyz, new_xyz):
+    return ballquery(radius, nsample, xyz, new_xyz) if radius is not None else knnquery(nsample, xyz, new_xyz)
+
+
+def _centred_groups(xyz, new_xyz, features, center_features, idx, use_xyz):
+    """Shared tail of the QueryAndGroup_Edge* modules (pointops.py:559-570 / :617-630)."""
+    o_grouped_xyz = grouping(xyz.transpose(1, 2).contiguous(), idx)
+    grouped_xyz = o_grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
+    if features is not None:
+        grouped = grouping(features, idx)
+        if grouped.size(3) > 1:
+            grouped = grouped - center_features.unsqueeze(-1)
+        new_features = torch.cat([grouped_xyz, grouped], dim=1) if use_xyz else grouped
+    else:
+        assert use_xyz, "Cannot have not features and not use xyz as a feature!"
+        new_features = grouped_xyz
+    return new_features, o_grouped_xyz, grouped_xyz
+
+
+class QueryAndGroup(nn.Module):
+    """pointops.py:476-516 -- kNN (radius None) or ball grouping, xyz centred on the query, features as is."""
+
+    def __init__(self, radius=None, nsample=32, use_xyz=True):
+        super().__init__()
+        self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
+
+    def forward(self, xyz, new_xyz=None, features=None, idx=None):
+        new_xyz = xyz if new_xyz is None else new_xyz
+        if idx is None:
+            idx = _neighbours(self.radius, self.nsample, xyz, new_xyz)
+        grouped_xyz = grouping(xyz.transpose(1, 2).contiguous(), idx)
+        grouped_xyz -= new_xyz.transpose(1, 2).unsqueeze(-1)
+        if features is None:
+            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+            return grouped_xyz
+        grouped = grouping(features, idx)
+        return torch.cat([grouped_xyz, grouped], dim=1) if self.use_xyz else grouped
+
+
+class QueryAndGroup_Edge(nn.Module):
+    """pointops.py:519-582 -- EdgeConv-style grouping: neighbour minus centre for xyz AND features.
+
+    With knn_dilation > 1 the reference asks for dilation*nsample neighbours and keeps columns
+    ``torch.randperm(nsample)`` of them (:553-555), i.e. the nsample NEAREST in a random order drawn
+    from the CPU generator.  Only nsample neighbours are therefore searched here (the sorted top-k
+    list's prefix is the same) and the same CPU-generator permutation is applied, so ``sample_idx``
+    matches the reference element for element under the same ``torch.manual_seed``."""
+
+    def __init__(self, radius=None, nsample=32, knn_dilation=1, use_xyz=True, ret_gxyz=False, ret_sample_idx=False):
+        super().__init__()
+        self.radius, self.nsample, self.knn_dilation, self.use_xyz = radius, nsample, knn_dilation, use_xyz
+        self.ret_gxyz, self.ret_sample_idx = ret_gxyz, ret_sample_idx
+
+    def forward(self, xyz, new_xyz=None, features=None, center_features=None, idx=None):
+        new_xyz = xyz if new_xyz is None else new_xyz
+        if idx is None:
+            idx = _neighbours(self.radius, self.nsample, xyz, new_xyz)
+            if self.radius is None and self.knn_dilation > 1:
+                perm = torch.randperm(self.nsample).to(idx.device)
+                idx = idx.index_select(2, perm).contiguous()
+        new_features, o_grouped_xyz, _ = _centred_groups(xyz, new_xyz, features, center_features, idx, self.use_xyz)
+        res = new_features
+        if self.ret_gxyz:
+            res = res, o_grouped_xyz
+        if self.ret_sample_idx:
+            res = res, idx
+        return res
+
+
+class QueryAndGroup_Edge_Split(nn.Module):
+    """pointops.py:584-635"""
+
+    def __init__(self, radius=None, nsample=32, use_xyz=True, ret_gxyz=False):
+        super().__init__()
+        self.radius, self.nsample, self.use_xyz, self.ret_gxyz = radius, nsample, use_xyz, ret_gxyz
+
+    def forward(self, xyz, new_xyz=None, features=None, center_features=None, idx=None):
+        new_xyz = xyz if new_xyz is None else new_xyz
+        if idx is None:
+            idx = _neighbours(self.radius, self.nsample, xyz, new_xyz)
+        new_features, o_grouped_xyz, grouped_xyz = _centred_groups(xyz, new_xyz, features, center_features, idx, self.use_xyz)
+        return (new_features, o_grouped_xyz) if self.ret_gxyz else (new_features, grouped_xyz)
+
+
+class GroupAll(nn.Module):
+    """pointops.py:637-661"""
+
+    def __init__(self, use_xyz=True):
+        super().__init__()
+        self.use_xyz = use_xyz
+
+    def forward(self, xyz, new_xyz, features=None):
+        grouped_xyz = xyz.transpose(1, 2).unsqueeze(2)
+        if features is None:
+            return grouped_xyz
+        grouped = features.unsqueeze(2)
+        return torch.cat([grouped_xyz, grouped], dim=1) if self.use_xyz else grouped

@@ -1,0 +1,200 @@
+"""Parity of the HIP kernels (through the C ABI / patchaugnet_amd.pointops) with the CPU oracle.
+Bit-exact for every index output and every pure gather; K10 bit-exact given the fixed summation order."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_ops as o
+
+pytestmark = pytest.mark.gpu
+RNG = np.random.default_rng(11)
+
+
+@pytest.fixture(scope="module")
+def P():
+    from patchaugnet_amd import pointops
+    return pointops
+
+
+def cloud(b, n, kind="uniform"):
+    x = (RNG.random((b, n, 3), dtype=np.float32) * 2 - 1).astype(np.float32)
+    if kind == "lattice":      # coarse lattice => many exact distance ties and duplicates
+        x = (np.round(x * 4) / 4).astype(np.float32)
+    elif kind == "dup":        # 10 % exact duplicates
+        k = max(n // 10, 1)
+        x[:, RNG.choice(n, k, replace=False)] = x[:, RNG.choice(n, k, replace=False)]
+    return x
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+FPS_CASES = [(2, 4096, 1024, "uniform"), (3, 1024, 128, "uniform"), (2, 128, 16, "uniform"), (2, 256, 64, "lattice"),
+             (2, 64, 16, "uniform"), (1, 1000, 100, "dup"), (2, 100, 37, "uniform"), (1, 600, 600, "lattice"),
+             (2, 2048, 64, "uniform"), (1, 5000, 50, "uniform"), (1, 8192, 33, "lattice"), (1, 9000, 20, "uniform"),
+             (1, 1, 1, "uniform"), (2, 3, 3, "uniform"), (1, 4096, 1024, "lattice"), (1, 512, 300, "dup")]
+
+
+@pytest.mark.parametrize("b,n,m,kind", FPS_CASES)
+def test_fps_bit_exact(P, b, n, m, kind):
+    x = cloud(b, n, kind)
+    ref = o.furthestsampling(x, m)
+    got = P.furthestsampling(dev(x), m).cpu().numpy()
+    assert got.dtype == np.int32 and np.array_equal(got, ref), f"first mismatch col {np.argmax((got != ref).any(0))}"
+
+
+def test_fps_leaves_temp_like_reference():
+    """temp holds the final running minima after the call (sampling_cuda_kernel.cu:94-95 writes it back every round)."""
+    from patchaugnet_amd import _lib
+    x = cloud(2, 777, "uniform")
+    xd = dev(x)
+    temp = torch.full((2, 777), 1e10, device="cuda")
+    idx = torch.empty((2, 50), dtype=torch.int32, device="cuda")
+    _lib.call("pa_furthestsampling", 2, 777, 50, _lib.ptr(xd), _lib.ptr(temp), _lib.ptr(idx))
+    sel = x[np.arange(2)[:, None], idx.cpu().numpy()[:, :-1]]          # all but the last sample were applied
+    d = x[:, :, None, :] - sel[:, None, :, :]
+    d = d * d
+    exp = ((d[..., 0] + d[..., 1]) + d[..., 2]).min(2)
+    assert np.array_equal(temp.cpu().numpy(), exp.astype(np.float32))
+
+
+KNN_CASES = [(2, 4096, 1024, 40, "uniform"), (2, 4096, 512, 20, "uniform"), (3, 1024, 128, 20, "uniform"),
+             (2, 128, 16, 20, "uniform"), (2, 256, 64, 20, "lattice"), (1, 1000, 77, 40, "dup"), (2, 30, 7, 40, "uniform"),
+             (1, 100, 10, 64, "uniform"), (1, 100, 10, 1, "uniform"), (1, 300, 9, 100, "uniform"), (1, 50, 5, 200, "lattice"),
+             (1, 9000, 16, 20, "uniform"), (1, 64, 64, 64, "lattice")]
+
+
+@pytest.mark.parametrize("b,n,m,k,kind", KNN_CASES)
+def test_knn_bit_exact(P, b, n, m, k, kind):
+    x = cloud(b, n, kind)
+    q = x[:, RNG.choice(n, m, replace=False)] if m <= n else cloud(b, m)
+    ri, rd = o.knnquery(k, x, q)
+    gi, gd = P.knnquery_with_dist(k, dev(x), dev(q))
+    assert np.array_equal(gi.cpu().numpy(), ri)
+    assert np.array_equal(gd.cpu().numpy().view(np.uint32), rd.view(np.uint32))
+    assert np.array_equal(P.knnquery(k, dev(x), dev(q)).cpu().numpy(), ri)
+
+
+def test_knn_non_finite_points(P):
+    x = cloud(1, 200)
+    x[0, 5] = np.inf
+    x[0, 9, 1] = np.nan
+    q = x[:, 20:40].copy()
+    ri, rd = o.knnquery(20, x, q)
+    gi, gd = P.knnquery_with_dist(20, dev(x), dev(q))
+    assert np.array_equal(gi.cpu().numpy(), ri) and np.array_equal(gd.cpu().numpy().view(np.uint32), rd.view(np.uint32))
+
+
+NN_CASES = [(2, 4096, 1024, "uniform"), (2, 1024, 128, "uniform"), (2, 128, 16, "lattice"), (1, 50, 2, "uniform"),
+            (1, 40, 1, "uniform"), (1, 300, 2500, "uniform"), (2, 257, 100, "dup")]
+
+
+@pytest.mark.parametrize("b,n,m,kind", NN_CASES)
+def test_three_nn_bit_exact(P, b, n, m, kind):
+    u, kn = cloud(b, n, kind), cloud(b, m, kind)
+    rd, ri = o.nearestneighbor(u, kn)
+    gd, gi = P.nearestneighbor(dev(u), dev(kn))
+    assert np.array_equal(gi.cpu().numpy(), ri)
+    assert np.array_equal(gd.cpu().numpy(), np.sqrt(rd))          # wrapper returns sqrt(dist2), pointops.py:76
+
+
+GROUP_CASES = [(2, 3, 4096, 1024, 20), (2, 64, 1024, 128, 20), (2, 256, 128, 16, 20), (1, 5, 100, 7, 3), (1, 1, 10, 1, 1),
+               (2, 67, 333, 50, 20), (1, 2, 40000, 64, 4), (3, 16, 20000, 8, 5)]
+
+
+@pytest.mark.parametrize("b,c,n,m,k", GROUP_CASES)
+def test_grouping_and_gathering_bit_exact(P, b, c, n, m, k):
+    f = RNG.standard_normal((b, c, n)).astype(np.float32)
+    idx = RNG.integers(0, n, (b, m, k), dtype=np.int32)
+    assert np.array_equal(P.grouping(dev(f), dev(idx)).cpu().numpy(), o.grouping_forward(f, idx))
+    i1 = RNG.integers(0, n, (b, m), dtype=np.int32)
+    assert np.array_equal(P.gathering(dev(f), dev(i1)).cpu().numpy(), o.gathering_forward(f, i1))
+    assert np.array_equal(P.featuregather(dev(f), dev(i1)).cpu().numpy(), o.gathering_forward(f, i1))
+
+
+def test_grouping_int(P):
+    f = RNG.integers(-2**40, 2**40, (2, 3, 50), dtype=np.int64)
+    idx = RNG.integers(0, 50, (2, 9, 4), dtype=np.int32)
+    assert np.array_equal(P.grouping_int(dev(f), dev(idx)).cpu().numpy(), o.grouping_int_forward(f, idx))
+
+
+@pytest.mark.parametrize("b,c,m,n", [(2, 512, 16, 128), (2, 256, 128, 1024), (2, 256, 1024, 4096), (1, 7, 33, 100), (1, 3, 20000, 50)])
+def test_interpolation_bit_exact(P, b, c, m, n):
+    f = RNG.standard_normal((b, c, m)).astype(np.float32)
+    idx = RNG.integers(0, m, (b, n, 3), dtype=np.int32)
+    w = RNG.random((b, n, 3), dtype=np.float32)
+    w /= w.sum(-1, keepdims=True)
+    got = P.interpolation(dev(f), dev(idx), dev(w)).cpu().numpy()
+    assert np.array_equal(got, o.interpolation_forward(f, idx, w))
+
+
+def test_backward_ops(P):
+    b, c, n, m, k = 2, 6, 50, 12, 5
+    f = torch.randn(b, c, n, device="cuda", requires_grad=True)
+    idx = dev(RNG.integers(0, n, (b, m, k), dtype=np.int32))
+    go = torch.randn(b, c, m, k, device="cuda")
+    P.grouping(f, idx).backward(go)
+    ref = o.grouping_backward(go.cpu().numpy(), idx.cpu().numpy(), n)
+    assert np.allclose(f.grad.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+    f.grad = None
+    i1 = dev(RNG.integers(0, n, (b, m), dtype=np.int32))
+    g1 = torch.randn(b, c, m, device="cuda")
+    P.gathering(f, i1).backward(g1)
+    assert np.allclose(f.grad.cpu().numpy(), o.gathering_backward(g1.cpu().numpy(), i1.cpu().numpy(), n), rtol=1e-5, atol=1e-5)
+    f.grad = None
+    i3 = dev(RNG.integers(0, n, (b, 30, 3), dtype=np.int32))
+    w = torch.rand(b, 30, 3, device="cuda")
+    g3 = torch.randn(b, c, 30, device="cuda")
+    P.interpolation(f, i3, w).backward(g3)
+    ref = o.interpolation_backward(g3.cpu().numpy(), i3.cpu().numpy(), w.cpu().numpy(), n)
+    assert np.allclose(f.grad.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("n,m,r,k", [(4096, 1024, 0.2, 32), (200, 20, 0.5, 8), (3000, 300, 0.05, 16), (100, 10, 1e-4, 4)])
+def test_ballquery_bit_exact(P, n, m, r, k):
+    x = cloud(2, n)
+    q = x[:, :m].copy()
+    if r < 1e-3:
+        q += 10
+    assert np.array_equal(P.ballquery(r, k, dev(x), dev(q)).cpu().numpy(), o.ballquery(r, k, x, q))
+
+
+def test_labelstat_and_featuredistribute(P):
+    x, q = cloud(2, 300), cloud(2, 40)
+    lab = RNG.integers(0, 5, (2, 300, 6), dtype=np.int32)
+    r, k = 0.6, 12
+    a, bidx = o.labelstat_and_ballquery(r, k, x, q, lab)
+    ga, gb = P.labelstat_and_ballquery(r, k, dev(x), dev(q), dev(lab))
+    assert np.array_equal(ga.cpu().numpy(), a) and np.array_equal(gb.cpu().numpy(), bidx)
+    assert np.array_equal(P.labelstat_ballrange(r, dev(x), dev(q), dev(lab)).cpu().numpy(), o.labelstat_ballrange(r, x, q, lab))
+    idx = RNG.integers(0, 300, (2, 40, 7), dtype=np.int32)
+    assert np.array_equal(P.labelstat_idx(7, dev(lab), dev(idx)).cpu().numpy(), o.labelstat_idx(lab, idx))
+    assert np.array_equal(P.featuredistribute(dev(x), dev(q)).cpu().numpy(), o.featuredistribute(x, q))
+
+
+def test_rejects_cpu_tensors_and_bad_sizes(P):
+    with pytest.raises(RuntimeError):
+        P.furthestsampling(torch.rand(1, 64, 3), 8)
+    from patchaugnet_amd import _lib
+    x = torch.rand(1, 64, 3, device="cuda")
+    with pytest.raises(RuntimeError):
+        _lib.call("pa_knnquery", 1, 64, 0, 4, _lib.ptr(x), _lib.ptr(x), _lib.ptr(x), _lib.ptr(x))
+
+
+def test_full_size_properties(P):
+    """Config-2 sizes (B=32, 4096 points): properties that do not need the slow oracle at full batch."""
+    from patchaugnet_amd.weights import synthetic_submaps
+    x = synthetic_submaps(32, 4096, 1234).squeeze(1).cuda().contiguous()
+    idx = P.furthestsampling(x, 1024)
+    srt = torch.sort(idx.long(), dim=1)[0]
+    assert (srt[:, 1:] != srt[:, :-1]).all() and (idx[:, 0] == 0).all()            # distinct samples, starts at 0
+    ref = o.furthestsampling(x[:2].cpu().numpy(), 1024)
+    assert np.array_equal(idx[:2].cpu().numpy(), ref)
+    new_xyz = P.gathering(x.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
+    ki, kd = P.knnquery_with_dist(20, x, new_xyz)
+    assert (ki[:, :, 0] == idx).all() and (kd[:, :, 0] == 0).all()                  # every centre is its own nearest
+    assert (kd[:, :, 1:] >= kd[:, :, :-1]).all()                                     # sorted
+    g = P.grouping(x.transpose(1, 2).contiguous(), ki)
+    d = g - new_xyz.transpose(1, 2).unsqueeze(-1)
+    assert torch.allclose((d * d).sum(1), kd, atol=1e-6)                             # gathered points are at dist2
