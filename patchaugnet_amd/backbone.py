@@ -1,0 +1,124 @@
+"""PointNet++-style pyramid backbone shared by PatchAugNet and PPT-Net (module path).
+
+Set-abstraction (SA) level  = FPS -> gather centres -> kNN grouping with centre subtraction (EdgeConv style)
+                              -> shared MLP -> max over the neighbourhood [-> grouped self-attention, PPT-Net only];
+feature-propagation (FP)    = 3-NN inverse-distance interpolation -> concat skip features -> shared MLP.
+
+Module trees / parameter names follow ``place_recognition/patch_aug_net/models/patch_aug_net.py:110-363`` and
+``place_recognition/pptnet_origin/models/pptnet.py:65-340`` so reference checkpoints load unchanged.  This is the
+autograd-capable path (training, and the reference-shaped intermediate tensors); evaluation runs the fused HIP
+engine instead (patchaugnet_amd/engine.py), which reads the very same parameters.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import pointops
+from .pt_util import SharedMLP
+
+
+class SALayer(nn.Module):
+    """Grouped self-attention of PPT-Net (pptnet.py:246-282): q and k share one grouped 1x1 conv, so the energy is
+    Y^T Y; row softmax, then column re-normalisation; x + relu(BN(conv(x - x_v @ attn)))."""
+
+    def __init__(self, channels, gp):
+        super().__init__()
+        assert channels % 4 == 0
+        self.gp = gp
+        self.q_conv = nn.Conv1d(channels, channels, 1, bias=False, groups=gp)
+        self.k_conv = nn.Conv1d(channels, channels, 1, bias=False, groups=gp)
+        self.q_conv.weight = self.k_conv.weight          # tied, both names stay in the state-dict (pptnet.py:254)
+        self.v_conv = nn.Conv1d(channels, channels, 1)
+        self.trans_conv = nn.Conv1d(channels, channels, 1)
+        self.after_norm = nn.BatchNorm1d(channels)
+
+    def forward(self, x):
+        bs, ch, n = x.shape
+        y = self.k_conv(x).reshape(bs, self.gp, ch // self.gp, n)
+        energy = torch.matmul(y.permute(0, 1, 3, 2), y).sum(dim=1)
+        attn = torch.softmax(energy, dim=-1)
+        attn = attn / (1e-9 + attn.sum(dim=1, keepdim=True))
+        x_r = torch.matmul(self.v_conv(x), attn)
+        return x + F.relu(self.after_norm(self.trans_conv(x - x_r)))
+
+
+class SAModule(nn.Module):
+    """One set-abstraction level (patch_aug_net.py:195-314 / pptnet.py:137-244)."""
+
+    def __init__(self, *, mlp, npoint, nsample, knn_dilation=1, gp=None, attention=False, radius=None, use_xyz=True):
+        super().__init__()
+        self.npoint = npoint
+        spec = list(mlp)
+        if use_xyz:
+            spec[0] += 3
+        self.groupers = nn.ModuleList([pointops.QueryAndGroup_Edge(radius, nsample, knn_dilation=knn_dilation,
+                                                                   use_xyz=use_xyz, ret_sample_idx=True)])
+        self.mlps = nn.ModuleList([SharedMLP(spec, bn=True)])
+        if attention:
+            self.sas = nn.ModuleList([SALayer(spec[-1], gp)])
+
+    def forward(self, xyz, features):
+        center_idx = pointops.furthestsampling(xyz, self.npoint)
+        new_xyz = pointops.gathering(xyz.transpose(1, 2).contiguous(), center_idx).transpose(1, 2).contiguous()
+        center_features = pointops.gathering(features, center_idx)
+        grouped, sample_idx = self.groupers[0](xyz, new_xyz, features, center_features)
+        y = self.mlps[0](grouped).max(dim=3)[0]
+        if hasattr(self, "sas"):
+            y = self.sas[0](y)
+        return new_xyz, center_idx, sample_idx, y
+
+
+class FPModule(nn.Module):
+    """Feature propagation (patch_aug_net.py:317-363)."""
+
+    def __init__(self, *, mlp):
+        super().__init__()
+        self.mlp = SharedMLP(mlp, bn=True)
+
+    def forward(self, unknown, known, unknown_feats, known_feats):
+        dist, idx = pointops.nearestneighbor(unknown, known)
+        dist_recip = 1.0 / (dist + 1e-8)
+        weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+        x = pointops.interpolation(known_feats, idx, weight)
+        if unknown_feats is not None:
+            x = torch.cat([x, unknown_feats], dim=1)
+        return self.mlp(x.unsqueeze(-1)).squeeze(-1)
+
+
+def origin_indices(l_center_idx, l_sample_idx):
+    """Map level-local centre / neighbour indices back to indices of the input cloud (patch_aug_net.py:169-177)."""
+    c_o, s_o = [l_center_idx[0]], [l_sample_idx[0]]
+    for i in range(1, len(l_center_idx)):
+        c_o.append(torch.gather(c_o[i - 1], -1, l_center_idx[i].long()))
+        s_o.append(torch.gather(c_o[i - 1].unsqueeze(1).expand(-1, l_sample_idx[i].shape[1], -1), -1, l_sample_idx[i].long()))
+    return c_o, s_o
+
+
+class PyramidBackbone(nn.Module):
+    """SA_modules / FP_modules lists.  ``sa_mlps``/``fp_mlps`` are the channel specs; FP_modules[0] is the finest
+    level and the forward pass walks the list backwards, exactly like the reference (patch_aug_net.py:183-187)."""
+
+    def __init__(self, *, sampling, knn, sa_mlps, fp_mlps, knn_dilation=1, gp=8, attention=False, use_origin_pc_in_fp=True):
+        super().__init__()
+        self.use_origin_pc_in_fp = use_origin_pc_in_fp
+        self.SA_modules = nn.ModuleList(SAModule(mlp=m, npoint=s, nsample=k, knn_dilation=knn_dilation, gp=gp, attention=attention)
+                                        for m, s, k in zip(sa_mlps, sampling, knn))
+        self.FP_modules = nn.ModuleList(FPModule(mlp=m) for m in fp_mlps)
+
+    def forward(self, pointcloud):
+        l_xyz, l_feat = [pointcloud], [pointcloud.transpose(1, 2).contiguous()]
+        l_c, l_s = [], []
+        for i, sa in enumerate(self.SA_modules):
+            nx, ci, si, f = sa(l_xyz[i], l_feat[i])
+            l_xyz.append(nx); l_feat.append(f); l_c.append(ci); l_s.append(si)
+        sa_features = list(l_feat[1:])
+        c_o, s_o = origin_indices(l_c, l_s)
+        nfp = len(self.FP_modules)
+        for i in range(-1, -(nfp + 1), -1):
+            skip = l_feat[i - 1]
+            if i == -nfp and not self.use_origin_pc_in_fp:
+                skip = None
+            l_feat[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], skip, l_feat[i])
+        fp = [l_feat[j].unsqueeze(-1) for j in range(nfp - 1, -1, -1)]          # coarse -> fine
+        return {"center_idx_origin": c_o, "sample_idx_origin": s_o, "sa_features": sa_features, "fp_features": fp,
+                "l_xyz": l_xyz}

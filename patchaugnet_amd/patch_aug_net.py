@@ -1,0 +1,105 @@
+"""PatchAugNet: pyramid backbone + pyramid NetVLAD with adaptive feature aggregation + patch decoder.
+
+Model API of ``place_recognition/patch_aug_net/models/patch_aug_net.py:22-107`` and the constructor call of
+``place_recognition/evaluate.py:102-104``:  ``Network(param=cfg, use_a2a_recon=True, use_l2_norm=True)``;
+``forward(x: (B,1,N,3) fp32) -> (desc (B,256), fp_features [(B,256,N_i,1)], center_idx [(B,m_i) int32])``,
+or with ``nn_dict`` the training tuple ``((desc, patch_recon_data), fp_features, center_idx)``.
+State-dict keys equal the reference's (tests/golden/patch_aug_net_state_dict_keys.json).
+
+In ``eval()`` mode under ``torch.no_grad()`` the forward pass runs the fused HIP engine
+(patchaugnet_amd/engine.py); otherwise the autograd-capable module path (patchaugnet_amd/backbone.py).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import loupe as lp
+from . import pointops
+from .backbone import PyramidBackbone
+
+__all__ = ["Network", "PointNetDecoder"]
+
+
+class PointNetDecoder(nn.Module):
+    """pointnet_autoencoder.py:85-111 -- FC 256 -> 1024 -> 1024 -> num_points*3, BN + ReLU, tanh."""
+
+    def __init__(self, embedding_size, output_channels=3, num_points=1024):
+        super().__init__()
+        self.num_points, self.output_channels = num_points, output_channels
+        self.fc1 = nn.Linear(embedding_size, 1024)
+        self.fc2 = nn.Linear(1024, 1024)
+        self.bn1 = nn.BatchNorm1d(1024)
+        self.bn2 = nn.BatchNorm1d(1024)
+        self.fc3 = nn.Linear(1024, num_points * output_channels)
+
+    def forward(self, x):
+        x = F.relu(self.bn1(self.fc1(x)))
+        x = F.relu(self.bn2(self.fc2(x)))
+        return torch.tanh(self.fc3(x)).view(x.shape[0], self.num_points, self.output_channels).contiguous()
+
+
+class Network(nn.Module):
+    def __init__(self, param=None, use_a2a_recon=False, use_l2_norm=False):
+        super().__init__()
+        fs, c = param["FEATURE_SIZE"], 3
+        c_fp = c if param["USE_ORIGIN_PC_IN_FP"] else 0
+        self.backbone = PyramidBackbone(
+            sampling=param["SAMPLING"], knn=param["KNN"], knn_dilation=param["KNN_DILATION"], gp=param["GROUP"],
+            sa_mlps=[[c, 32, 32, 64], [64, 64, 64, 256], [256, 256, 256, 512]],
+            fp_mlps=[[fs[1] + c_fp, 256, 256, fs[0]], [fs[2] + 64, 256, fs[1]], [512 + 256, 256, fs[2]]],
+            use_origin_pc_in_fp=param["USE_ORIGIN_PC_IN_FP"])
+        if param["AGGREGATION"] != "spvlad":
+            raise ValueError("No aggregation algorithm: %r" % (param["AGGREGATION"],))
+        self.aggregation = lp.SpatialPyramidNetVLAD(
+            feature_size=param["FEATURE_SIZE"], max_samples=param["MAX_SAMPLES"], cluster_size=param["CLUSTER_SIZE"],
+            output_dim=param["OUTPUT_DIM"], gating=param["GATING"], aggregation_type=param["AGGREGATION_TYPE"], add_batch_norm=True)
+        self.use_l2_norm, self.use_a2a_recon = use_l2_norm, use_a2a_recon
+        if use_a2a_recon:
+            self.decoder = PointNetDecoder(embedding_size=256, num_points=param["KNN"][0])
+        self.param = dict(param)
+        self._engine = None
+        self.fused_eval = False      # set True once the fused engine covers the model (eval()+no_grad() forwards)
+
+    # ---- fused inference engine (eval + no_grad) ----------------------------------------------------------------
+    def _fused(self, x):
+        from .engine import PatchAugNetEngine
+        if self._engine is None or not self._engine.matches(self, x):
+            self._engine = PatchAugNetEngine(self, x.device)
+        return self._engine.forward(x)
+
+    def train(self, mode=True):
+        self._engine = None            # parameters may change: rebuild folded weights at the next eval forward
+        return super().train(mode)
+
+    def load_state_dict(self, *a, **k):
+        self._engine = None
+        return super().load_state_dict(*a, **k)
+
+    def forward(self, x, nn_dict=None, return_feat=True, use_engine=None):
+        """x: (B, 1, N, 3)."""
+        if use_engine is None:
+            use_engine = self.fused_eval and not self.training and not torch.is_grad_enabled() and nn_dict is None
+        fused = use_engine
+        if fused:
+            desc, fp_features, center_idx = self._fused(x)
+            return (desc, fp_features, center_idx) if return_feat else desc
+        xyz = x.squeeze(1)
+        res = self.backbone(xyz)
+        center_idx, sample_idx, fp_features = res["center_idx_origin"], res["sample_idx_origin"], res["fp_features"]
+        out = self.aggregation(fp_features)
+        if nn_dict is not None:                                   # patch reconstruction branch (:68-104)
+            related = sorted({i for pair in nn_dict for i in pair})
+            origin = pointops.grouping(xyz.transpose(1, 2).contiguous(), sample_idx[0])      # (B, 3, m0, k)
+            data = {"cloud_indices": related, "center_indices": [], "origin_patches": [], "patch_features": [],
+                    "reconstructed_patches": []}
+            for ci in related:
+                feats = fp_features[1][ci].squeeze(-1).transpose(1, 0)                       # (m0, 256)
+                if self.use_l2_norm:
+                    feats = F.normalize(feats)
+                data["center_indices"].append(center_idx[0][ci:ci + 1])
+                data["origin_patches"].append(origin[ci].permute(1, 2, 0))                   # (m0, k, 3)
+                data["patch_features"].append(feats)
+                if self.use_a2a_recon:
+                    data["reconstructed_patches"].append(self.decoder(feats))
+            out = out, data
+        return (out, fp_features, center_idx) if return_feat else out

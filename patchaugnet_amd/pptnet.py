@@ -1,0 +1,38 @@
+"""PPT-Net: pyramid backbone with grouped self-attention + four-scale pyramid NetVLAD.
+
+Model API of ``place_recognition/pptnet_origin/models/pptnet.py:24-62`` as constructed by
+``place_recognition/evaluate.py:91-96``: ``Network(param=cfg, use_normalize=False|True)``;
+``forward(x: (B,1,N,3)) -> (desc (B,256), fp_features, center_idx)``.  State-dict keys equal the reference's
+(tests/golden/pptnet_state_dict_keys.json), including the doubly-saved tied q/k weights.
+"""
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import loupe as lp
+from .backbone import PyramidBackbone
+
+__all__ = ["Network"]
+
+
+class Network(nn.Module):
+    def __init__(self, param=None, use_normalize=True):
+        super().__init__()
+        fs, c = param["FEATURE_SIZE"], 3
+        self.backbone = PyramidBackbone(
+            sampling=param["SAMPLING"], knn=param["KNN"], gp=param["GROUP"], attention=True,
+            sa_mlps=[[c, 32, 32, 64], [64, 64, 64, 128], [128, 128, 128, 256], [256, 256, 256, 512]],
+            fp_mlps=[[fs[1] + c, 256, 256, fs[0]], [fs[2] + 64, 256, fs[1]], [fs[3] + 128, 256, fs[2]], [512 + 256, 256, fs[3]]])
+        if param["AGGREGATION"] != "spvlad":
+            raise ValueError("No aggregation algorithm: %r" % (param["AGGREGATION"],))
+        self.aggregation = lp.SpatialPyramidNetVLAD4(
+            feature_size=param["FEATURE_SIZE"], max_samples=param["MAX_SAMPLES"], cluster_size=param["CLUSTER_SIZE"],
+            output_dim=param["OUTPUT_DIM"], gating=param["GATING"], add_batch_norm=True)
+        self.use_normalize = use_normalize
+
+    def forward(self, x, return_feat=True):
+        res = self.backbone(x.squeeze(1))
+        fp = res["fp_features"]
+        d = self.aggregation(fp[0], fp[1], fp[2], fp[3])
+        if self.use_normalize:
+            d = F.normalize(d)
+        return (d, fp, res["center_idx_origin"]) if return_feat else d

@@ -1,0 +1,88 @@
+"""Host-side checks that need no GPU: the C-ABI library loads, exports every symbol include/patchaugnet_hip.h declares,
+the product package refuses CPU tensors (no silent fallback) and never imports the oracle, state-dict key parity."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    from patchaugnet_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.LIB_PATH
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "patchaugnet_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(?:int|void|const char \*)\s*\*?\s*([a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(libpath):
+    lib = ctypes.CDLL(libpath)
+    names = declared_symbols()
+    assert len(names) >= 40, names
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    lib.pa_abi_version.restype = ctypes.c_int
+    assert lib.pa_abi_version() >= 1
+
+
+def test_bindings_cover_the_pa_entry_points(libpath):
+    from patchaugnet_amd import _lib
+    pa = [n for n in declared_symbols() if n.startswith("pa_") and n not in ("pa_abi_version", "pa_last_error")]
+    assert sorted(pa) == sorted(_lib._SIGS), set(pa) ^ set(_lib._SIGS)
+
+
+def test_argument_validation_without_gpu(libpath):
+    """Bad sizes / null pointers are rejected before any launch, so this runs on a CPU-only box."""
+    from patchaugnet_amd import _lib
+    l = _lib.lib()
+    rc = l.pa_knnquery(1, 0, 4, 4, None, None, None, None, None)
+    assert rc == -1 and b"pa_knnquery" in l.pa_last_error()
+    rc = l.pa_furthestsampling(1, 16, 4, None, None, None, None)
+    assert rc == -1
+
+
+def test_ops_refuse_cpu_tensors():
+    from patchaugnet_amd import pointops
+    x = torch.rand(1, 32, 3)
+    for fn in (lambda: pointops.furthestsampling(x, 4), lambda: pointops.knnquery(4, x, x),
+               lambda: pointops.nearestneighbor(x, x), lambda: pointops.grouping(x.transpose(1, 2).contiguous(), torch.zeros(1, 2, 2, dtype=torch.int32))):
+        with pytest.raises(RuntimeError, match="MI355X"):
+            fn()
+
+
+def test_product_package_never_imports_the_oracle():
+    code = ("import sys; import patchaugnet_amd, patchaugnet_amd.pointops, patchaugnet_amd.patch_aug_net, patchaugnet_amd.pptnet, "
+            "patchaugnet_amd.loupe, patchaugnet_amd.profiling; "
+            "bad=[m for m in sys.modules if m == 'oracle' or m.startswith('oracle.')]; assert not bad, bad")
+    subprocess.check_call([sys.executable, "-c", code], cwd=ROOT)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "patchaugnet_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+
+
+@pytest.mark.parametrize("name", ["patch_aug_net", "pptnet"])
+def test_state_dict_keys_match_the_reference(name):
+    from patchaugnet_amd import configs, patch_aug_net, pptnet
+    if name == "patch_aug_net":
+        m = patch_aug_net.Network(param=configs.patch_aug_net_config(), use_a2a_recon=True, use_l2_norm=True)
+    else:
+        m = pptnet.Network(param=configs.pptnet_config(), use_normalize=False)
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", f"{name}_state_dict_keys.json")))
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    for k, (shape, dt) in ref.items():
+        assert list(sd[k].shape) == shape and str(sd[k].dtype) == dt, k
