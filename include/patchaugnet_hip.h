@@ -99,6 +99,25 @@ int pa_chamfer_backward(int B, int n, int m, const float *xyz1, const float *xyz
  * ref (dim,nr), query (dim,nq) -> dist (k,nq) fp32 L2 (sqrt applied), ind (k,nq) int64 1-BASED, order (dist asc, row asc). */
 int pa_knn_generic(const float *ref, int nr, const float *query, int nq, int dim, int k, float *dist, int64_t *ind, pa_stream_t stream);
 
+/* ---- Fused shared-MLP chains (MFMA, fp32)  -- evaluation-time replacement of the unfused
+ * grouping + subtract + cat (libs/pointops/functions/pointops.py:559-570), SharedMLP = Conv2d 1x1 + BatchNorm2d + ReLU
+ * (utils/model_util/pt_util.py:16-41), max over the neighbourhood (place_recognition/patch_aug_net/models/patch_aug_net.py:236)
+ * and interpolation + cat (patch_aug_net.py:354-359).  Activations are POINT-MAJOR (rows = points, channels contiguous).
+ *   mode 0: rows of x (rows x k0, row stride ldx)
+ *   mode 1: set-abstraction rows [xyz[nbr]-xyz[ctr] (3), feat[nbr]-feat[ctr] (c_feat)], rows = B*m_ctr groups of ns neighbours;
+ *           pooled != 0 writes the max over each group's ns rows (out: groups x n_last), else all groups*ns rows
+ *   mode 2: feature-propagation rows [(w0*f[i0] + w1*f[i1]) + w2*f[i2] (c2), skip (c1)], rows = B*n_unknown
+ * wt[l]: device pointer, K-major (kpad[l] x nout[l]) weights with BatchNorm folded in, rows >= K zero; bias[l]: nout[l] floats.
+ * wt / bias / kpad / nout themselves are HOST arrays of nlayers entries.  Every layer applies ReLU. */
+int pa_mlp_chain(int mode, int pooled, int nlayers, const float *const *wt, const float *const *bias, const int *kpad, const int *nout,
+                 long rows, int k0,
+                 const float *x, int ldx,
+                 const float *xyz, const float *feat, const int *center_idx, const int *nbr_idx, int n_src, int m_ctr, int ns, int c_feat,
+                 const float *known, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2, int c1,
+                 float *out, int ldo, pa_stream_t stream);
+/* out[g][c] = max over s < ns of in[g*ns + s][c]  (rows of c floats) */
+int pa_rowgroup_max(long groups, int ns, int c, const float *in, float *out, pa_stream_t stream);
+
 /* ---- the reference's launcher names (group 2) -------------------------------------------------*/
 void furthestsampling_cuda_launcher(int b, int n, int m, const float *dataset, float *temp, int *idxs);
 void gathering_forward_cuda_launcher(int b, int c, int n, int m, const float *points, const int *idx, float *out);

@@ -37,8 +37,10 @@ _SIGS = {
     "pa_chamfer_forward": "iiipppppp",
     "pa_chamfer_backward": "iiipppppppp",
     "pa_knn_generic": "pipiiipp",
+    "pa_mlp_chain": "iiipppplipippppiiiippppiiiipi",
+    "pa_rowgroup_max": "liipp",
 }
-_T = {"i": _I, "f": _F, "p": _P}
+_T = {"i": _I, "f": _F, "p": _P, "l": ctypes.c_long}
 
 
 def build(force=False, verbose=False):

@@ -1,0 +1,426 @@
+// Fused shared-MLP chains on the MFMA pipe (gfx950): gather/interpolate prologue -> up to 3 x (1x1 conv + folded
+// BatchNorm + ReLU) -> optional max over the neighbourhood, without ever materialising the (B, C, m, k) tensors.
+//
+// Replaces, for evaluation, the reference's unfused sequence
+//   pointops.grouping x2 + subtract + cat   (libs/pointops/functions/pointops.py:559-570)
+//   pt_util.SharedMLP = Conv2d 1x1 (no bias) + BatchNorm2d + ReLU, three separate modules per layer
+//                                            (utils/model_util/pt_util.py:16-41, :98-152)
+//   F.max_pool2d over the k neighbours       (place_recognition/patch_aug_net/models/patch_aug_net.py:236)
+//   pointops.interpolation + cat             (patch_aug_net.py:354-359)
+//
+// Design (MI355X-first):
+//   * activations are POINT-MAJOR (row = point, channels contiguous), so a neighbour gather is one contiguous row;
+//   * one WAVEFRONT owns a tile of R = 16*RT rows end to end: its activation tile lives in a wave-private LDS
+//     region, every layer is computed with v_mfma_f32_16x16x4_f32 (exact fp32, k-ordered fmaf chain) and written
+//     back IN PLACE, so there is not a single workgroup barrier in the kernel;
+//   * weights are BN-folded and stored K-major (Wt[k][n]); the B fragment of lane l is Wt[k0 + l/16][n0 + l%16],
+//     four 64-byte segments straight from L1/L2 into a VGPR, double-buffered one k-step ahead;
+//   * LDS row stride = Kpad + 2 floats: the A-fragment read (row l%16, k = k0 + l/16) then hits 32 distinct banks
+//     per 32-lane group (conflict-free);
+//   * pooled mode orders a wave's rows neighbour-major (row = slot*4 + group): with the 16x16 C/D layout
+//     (col = l%16, row = 4*(l/16) + reg) the four accumulator registers of a lane are the four groups and the
+//     max over neighbours is a plain v_max across row tiles plus two cross-lane steps -- the widest activation
+//     (the last layer's output) never leaves registers.
+#include <string.h>
+
+#include "pa_common.h"
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+struct PaLayer {
+    const float *wt;    // [kpad][n], K-major, rows >= k are zero
+    const float *bias;  // [n]
+    int kpad;           // multiple of 4
+    int n;              // multiple of 16
+};
+
+struct PaChain {
+    int nlayers;
+    PaLayer L[3];
+    long rows;        // plain / FP: number of rows; SA: number of groups (B*m)
+    int k0;           // true number of input channels
+    int lds_stride;   // floats per activation row in LDS (max kpad over layer inputs + 2)
+    int wave_floats;  // floats of LDS per wave (activation tile + prologue scratch)
+    // MODE 0: plain rows
+    const float *x;
+    int ldx;
+    // MODE 1: set-abstraction gather
+    const float *xyz;        // (B, n_src, 3)
+    const float *feat;       // (B, n_src, c_feat) point-major
+    const int *center_idx;   // (B, m_ctr)
+    const int *nbr_idx;      // (B, m_ctr, ns)
+    int n_src, m_ctr, ns, c_feat;
+    // MODE 2: feature-propagation interpolate + skip
+    const float *known;  // (B, m_known, c2) point-major
+    const int *idx3;     // (B, n_unknown, 3)
+    const float *w3;     // (B, n_unknown, 3)
+    const float *skip;   // (B, n_unknown, c1) point-major
+    int n_unknown, m_known, c2, c1;
+    float *out;
+    int ldo;
+};
+
+namespace {
+
+enum { MODE_PLAIN = 0, MODE_SA = 1, MODE_FP = 2 };
+
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// One column chunk (NC tiles of 16 columns starting at tile c0) of one layer for the wave's RT row tiles.
+template <int RT, int NC>
+__device__ __forceinline__ void gemm_chunk(const float *__restrict__ act, int stride, const PaLayer &L, int c0, int lane,
+                                            floatx4 (&acc)[RT][NC])
+{
+    const int ksteps = L.kpad >> 2;
+    const float *wp = L.wt + (size_t)(lane >> 4) * L.n + c0 * 16 + (lane & 15);
+    const float *ap = act + (lane & 15) * stride + (lane >> 4);
+    const size_t wstep = (size_t)4 * L.n;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < NC; ++ct) acc[rt][ct] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    float bn[NC], an[RT];
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) bn[ct] = wp[ct * 16];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) an[rt] = ap[rt * 16 * stride];
+    for (int ks = 0; ks < ksteps; ++ks) {
+        float bc[NC], ac[RT];
+#pragma unroll
+        for (int ct = 0; ct < NC; ++ct) bc[ct] = bn[ct];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) ac[rt] = an[rt];
+        if (ks + 1 < ksteps) {
+            const float *wn = wp + (size_t)(ks + 1) * wstep;
+#pragma unroll
+            for (int ct = 0; ct < NC; ++ct) bn[ct] = wn[ct * 16];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) an[rt] = ap[rt * 16 * stride + (ks + 1) * 4];
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < NC; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[rt], bc[ct], acc[rt][ct], 0, 0, 0);
+    }
+}
+
+// hidden layer: bias + ReLU, written back in place as the next layer's A tile
+template <int RT, int NC>
+__device__ __forceinline__ void store_hidden(float *act, int stride, const PaLayer &L, int c0, int lane, floatx4 (&acc)[RT][NC])
+{
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) {
+        const int col = (c0 + ct) * 16 + (lane & 15);
+        const float bias = L.bias[col];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rt * 16 + (lane >> 4) * 4 + r;
+                act[row * stride + col] = fmaxf(acc[rt][ct][r] + bias, 0.f);
+            }
+    }
+}
+
+// last layer, plain: bias + ReLU to global memory (row-major, ldo)
+template <int RT, int NC>
+__device__ __forceinline__ void store_rows(float *__restrict__ out, int ldo, long row0, long rows, const PaLayer &L, int c0, int lane,
+                                            floatx4 (&acc)[RT][NC])
+{
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) {
+        const int col = (c0 + ct) * 16 + (lane & 15);
+        const float bias = L.bias[col];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long row = row0 + rt * 16 + (lane >> 4) * 4 + r;
+                if (row < rows) out[row * ldo + col] = fmaxf(acc[rt][ct][r] + bias, 0.f);
+            }
+    }
+}
+
+// last layer, pooled: max over the wave's neighbour slots, then bias + ReLU (both monotone, so the order is exact)
+template <int RT, int NC>
+__device__ __forceinline__ void store_pooled(float *__restrict__ out, int ldo, long group0, long groups, const PaLayer &L, int c0, int lane,
+                                              floatx4 (&acc)[RT][NC])
+{
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) {
+        floatx4 m = acc[0][ct];
+#pragma unroll
+        for (int rt = 1; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m[r] = fmaxf(m[r], acc[rt][ct][r]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            m[r] = fmaxf(m[r], __shfl_xor(m[r], 16));
+            m[r] = fmaxf(m[r], __shfl_xor(m[r], 32));
+        }
+        if (lane < 16) {
+            const int col = (c0 + ct) * 16 + lane;
+            const float bias = L.bias[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (group0 + r < groups) out[(group0 + r) * ldo + col] = fmaxf(m[r] + bias, 0.f);
+        }
+    }
+}
+
+template <int RT, int NC, int MODE, bool POOLED>
+__device__ __forceinline__ void run_layer_chunks(float *act, const PaChain &a, int l, long tile, int lane)
+{
+    const PaLayer &L = a.L[l];
+    const int nct = L.n >> 4;
+    const bool last = (l == a.nlayers - 1);
+    for (int c0 = 0; c0 < nct; c0 += NC) {
+        floatx4 acc[RT][NC];
+        gemm_chunk<RT, NC>(act, a.lds_stride, L, c0, lane, acc);
+        if (!last) {
+            lds_fence();  // every A read of this layer has landed before its rows are overwritten (single chunk: host-checked)
+            store_hidden<RT, NC>(act, a.lds_stride, L, c0, lane, acc);
+        } else if (POOLED) {
+            store_pooled<RT, NC>(a.out, a.ldo, tile * 4, a.rows, L, c0, lane, acc);
+        } else {
+            const long total_rows = (MODE == MODE_SA) ? a.rows * a.ns : a.rows;
+            store_rows<RT, NC>(a.out, a.ldo, tile * (RT * 16), total_rows, L, c0, lane, acc);
+        }
+    }
+    lds_fence();
+}
+
+template <int RT, int NCMAX, int MODE, bool POOLED>
+__global__ __launch_bounds__(256) void chain_kernel(PaChain a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int R = RT * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long tile = (long)blockIdx.x * (blockDim.x >> 6) + wave;
+    const long total_rows = (MODE == MODE_SA) ? a.rows * a.ns : a.rows;
+    const long ntiles = POOLED ? (a.rows + 3) / 4 : (total_rows + R - 1) / R;
+    if (tile >= ntiles) return;  // wave-uniform; the kernel has no workgroup barrier
+    float *act = smem + (size_t)wave * a.wave_floats;
+    const int stride = a.lds_stride;
+    const int k0pad = a.L[0].kpad;
+
+    // ---------------------------------------------------------------- prologue: build the A tile of layer 0
+    if (MODE == MODE_PLAIN) {
+        const long row0 = tile * R;
+        for (int q = lane; q < R * k0pad; q += 64) {
+            const int r = q / k0pad, ch = q - r * k0pad;
+            const long row = row0 + r;
+            act[r * stride + ch] = (row < a.rows && ch < a.k0) ? a.x[row * a.ldx + ch] : 0.f;
+        }
+    } else if (MODE == MODE_SA) {
+        int *src = reinterpret_cast<int *>(act + R * stride);  // [R] source point (global row), -1 = padding row
+        int *ctr = src + R;                                    // [R] centre point (global row)
+        for (int r = lane; r < R; r += 64) {
+            long gid;
+            int s;
+            if (POOLED) { gid = tile * 4 + (r & 3); s = r >> 2; if (s >= a.ns) s = 0; }
+            else { const long grow = tile * R + r; gid = grow / a.ns; s = (int)(grow - gid * a.ns); }
+            if (gid < a.rows) {
+                const long b = gid / a.m_ctr;
+                src[r] = (int)(b * a.n_src + a.nbr_idx[gid * a.ns + s]);
+                ctr[r] = (int)(b * a.n_src + a.center_idx[gid]);
+            } else {
+                src[r] = -1;
+                ctr[r] = 0;
+            }
+        }
+        lds_fence();
+        for (int q = lane; q < R * 3; q += 64) {  // centred coordinates -> channels 0..2 (pointops.py:562)
+            const int r = q / 3, t = q - r * 3;
+            const int s = src[r];
+            act[r * stride + t] = s >= 0 ? a.xyz[(size_t)s * 3 + t] - a.xyz[(size_t)ctr[r] * 3 + t] : 0.f;
+        }
+        const int C = a.c_feat;
+        if ((C & 3) == 0) {  // centred features -> channels 3..3+C (pointops.py:567-568), 16-byte loads
+            const int qpr = C >> 2;
+            const float4 *f4 = reinterpret_cast<const float4 *>(a.feat);
+            for (int q = lane; q < R * qpr; q += 64) {
+                const int r = q / qpr, part = q - r * qpr;
+                const int s = src[r];
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (s >= 0) {
+                    const float4 p = f4[(size_t)s * qpr + part], c = f4[(size_t)ctr[r] * qpr + part];
+                    v = make_float4(p.x - c.x, p.y - c.y, p.z - c.z, p.w - c.w);
+                }
+                float *d = act + r * stride + 3 + part * 4;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        } else {
+            for (int q = lane; q < R * C; q += 64) {
+                const int r = q / C, ch = q - r * C;
+                const int s = src[r];
+                act[r * stride + 3 + ch] = s >= 0 ? a.feat[(size_t)s * C + ch] - a.feat[(size_t)ctr[r] * C + ch] : 0.f;
+            }
+        }
+        for (int q = lane; q < R * (k0pad - a.k0); q += 64) {  // zero the K padding
+            const int r = q / (k0pad - a.k0), ch = q - r * (k0pad - a.k0);
+            act[r * stride + a.k0 + ch] = 0.f;
+        }
+    } else {  // MODE_FP
+        int *nb = reinterpret_cast<int *>(act + R * stride);  // [R][3] global rows of the three known neighbours
+        float *wt = reinterpret_cast<float *>(nb + 3 * R);    // [R][3] interpolation weights
+        const long row0 = tile * R;
+        for (int q = lane; q < R * 3; q += 64) {
+            const int r = q / 3;
+            const long p = row0 + r;
+            if (p < a.rows) {
+                const long b = p / a.n_unknown;
+                nb[q] = (int)(b * a.m_known + a.idx3[p * 3 + (q - r * 3)]);
+                wt[q] = a.w3[p * 3 + (q - r * 3)];
+            } else {
+                nb[q] = 0;
+                wt[q] = 0.f;
+            }
+        }
+        lds_fence();
+        const int C2 = a.c2, C1 = a.c1;
+        const int qpr = C2 >> 2;  // host guarantees c2 % 4 == 0
+        const float4 *k4 = reinterpret_cast<const float4 *>(a.known);
+        for (int q = lane; q < R * qpr; q += 64) {
+            const int r = q / qpr, part = q - r * qpr;
+            const float w0 = wt[r * 3 + 0], w1 = wt[r * 3 + 1], w2 = wt[r * 3 + 2];
+            const float4 f0 = k4[(size_t)nb[r * 3 + 0] * qpr + part];
+            const float4 f1 = k4[(size_t)nb[r * 3 + 1] * qpr + part];
+            const float4 f2 = k4[(size_t)nb[r * 3 + 2] * qpr + part];
+            float *d = act + r * stride + part * 4;  // interpolation_cuda_kernel.cu:194: (w0*p0 + w1*p1) + w2*p2
+            d[0] = w0 * f0.x + w1 * f1.x + w2 * f2.x;
+            d[1] = w0 * f0.y + w1 * f1.y + w2 * f2.y;
+            d[2] = w0 * f0.z + w1 * f1.z + w2 * f2.z;
+            d[3] = w0 * f0.w + w1 * f1.w + w2 * f2.w;
+        }
+        const int tail = k0pad - C2;  // skip channels (patch_aug_net.py:359: cat([interpolated, skip])) + zero padding
+        for (int q = lane; q < R * tail; q += 64) {
+            const int r = q / tail, ch = q - r * tail;
+            const long p = row0 + r;
+            act[r * stride + C2 + ch] = (p < a.rows && ch < C1) ? a.skip[p * C1 + ch] : 0.f;
+        }
+    }
+    lds_fence();
+
+    // ---------------------------------------------------------------- layers
+    for (int l = 0; l < a.nlayers; ++l) {
+        const int nct = a.L[l].n >> 4;
+        if (NCMAX >= 16 && nct % 16 == 0) run_layer_chunks<RT, (NCMAX >= 16 ? 16 : NCMAX), MODE, POOLED>(act, a, l, tile, lane);
+        else if (NCMAX >= 8 && nct % 8 == 0) run_layer_chunks<RT, (NCMAX >= 8 ? 8 : NCMAX), MODE, POOLED>(act, a, l, tile, lane);
+        else if (NCMAX >= 4 && nct % 4 == 0) run_layer_chunks<RT, (NCMAX >= 4 ? 4 : NCMAX), MODE, POOLED>(act, a, l, tile, lane);
+        else if (nct % 2 == 0) run_layer_chunks<RT, 2, MODE, POOLED>(act, a, l, tile, lane);
+        else run_layer_chunks<RT, 1, MODE, POOLED>(act, a, l, tile, lane);
+    }
+}
+
+// max over groups of `ns` consecutive rows: out[g][c] = max_s in[g*ns + s][c]   (patch_aug_net.py:236 for the unfused SA level)
+__global__ __launch_bounds__(256) void rowgroup_max_kernel(long groups, int ns, int c, const float *__restrict__ in, float *__restrict__ out)
+{
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= groups * c) return;
+    const long g = t / c;
+    const int ch = (int)(t - g * c);
+    const float *p = in + (g * ns) * c + ch;
+    float m = p[0];
+    for (int s = 1; s < ns; ++s) m = fmaxf(m, p[(size_t)s * c]);
+    out[t] = m;
+}
+
+template <int RT, int NCMAX, int MODE, bool POOLED>
+int launch_chain(const PaChain &a, int waves_per_wg, long ntiles, hipStream_t st)
+{
+    const size_t lds = (size_t)waves_per_wg * a.wave_floats * 4;
+    auto kern = chain_kernel<RT, NCMAX, MODE, POOLED>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(pa_div_up(ntiles, waves_per_wg)), dim3(64 * waves_per_wg), lds, st, a);
+    return 0;
+}
+
+}  // namespace
+
+// Generic entry point.  mode: 0 plain rows, 1 set-abstraction gather, 2 feature-propagation interpolate.
+// wt[l] is K-major (kpad[l] x n[l]) with BN folded in and zero rows beyond the true K; bias[l] has n[l] entries.
+PA_API int pa_mlp_chain(int mode, int pooled, int nlayers, const float *const *wt, const float *const *bias, const int *kpad, const int *nout,
+                        long rows, int k0,
+                        const float *x, int ldx,
+                        const float *xyz, const float *feat, const int *center_idx, const int *nbr_idx, int n_src, int m_ctr, int ns, int c_feat,
+                        const float *known, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2, int c1,
+                        float *out, int ldo, pa_stream_t stream)
+{
+    PA_REQUIRE(nlayers >= 1 && nlayers <= 3, "pa_mlp_chain: nlayers=%d must be 1..3", nlayers);
+    PA_REQUIRE(rows > 0 && k0 > 0 && out, "pa_mlp_chain: rows/k0 must be positive and out non-null");
+    PaChain a;
+    memset(&a, 0, sizeof(a));
+    a.nlayers = nlayers;
+    int kin = k0, maxk = 0;
+    for (int l = 0; l < nlayers; ++l) {
+        PA_REQUIRE(wt[l] && bias[l], "pa_mlp_chain: null weights for layer %d", l);
+        PA_REQUIRE(kpad[l] % 4 == 0 && kpad[l] >= kin && kpad[l] < kin + 4, "pa_mlp_chain: layer %d kpad=%d must be k=%d rounded up to 4", l, kpad[l], kin);
+        PA_REQUIRE(nout[l] % 16 == 0 && nout[l] > 0, "pa_mlp_chain: layer %d n=%d must be a positive multiple of 16", l, nout[l]);
+        a.L[l].wt = wt[l]; a.L[l].bias = bias[l]; a.L[l].kpad = kpad[l]; a.L[l].n = nout[l];
+        if (kpad[l] > maxk) maxk = kpad[l];
+        kin = nout[l];
+    }
+    a.rows = rows; a.k0 = k0; a.lds_stride = maxk + 2;
+    a.x = x; a.ldx = ldx;
+    a.xyz = xyz; a.feat = feat; a.center_idx = center_idx; a.nbr_idx = nbr_idx; a.n_src = n_src; a.m_ctr = m_ctr; a.ns = ns; a.c_feat = c_feat;
+    a.known = known; a.idx3 = idx3; a.w3 = w3; a.skip = skip; a.n_unknown = n_unknown; a.m_known = m_known; a.c2 = c2; a.c1 = c1;
+    a.out = out; a.ldo = ldo;
+    hipStream_t st = (hipStream_t)stream;
+
+    const bool is_pooled = pooled != 0;
+    PA_REQUIRE(!is_pooled || mode == MODE_SA, "pa_mlp_chain: pooled output needs mode 1 (set-abstraction gather)");
+    const int RTv = is_pooled ? (ns + 3) / 4 : 2;
+    const int R = RTv * 16;
+    const int ncmax = is_pooled ? 4 : 16;
+    for (int l = 0; l + 1 < nlayers; ++l)  // hidden layers are written back in place => must be a single column chunk
+        PA_REQUIRE(nout[l] / 16 <= ncmax && ((nout[l] / 16) & (nout[l] / 16 - 1)) == 0,
+                   "pa_mlp_chain: hidden layer %d with n=%d must be 16*2^j <= %d (single column chunk, written back in place)", l, nout[l], ncmax * 16);
+    int scratch = 0;
+    if (mode == MODE_PLAIN) {
+        PA_REQUIRE(x && ldx >= k0, "pa_mlp_chain: plain mode needs x and ldx >= k0");
+    } else if (mode == MODE_SA) {
+        PA_REQUIRE(xyz && feat && center_idx && nbr_idx && n_src > 0 && m_ctr > 0 && ns > 0 && c_feat > 0, "pa_mlp_chain: SA mode arguments");
+        PA_REQUIRE(k0 == 3 + c_feat, "pa_mlp_chain: SA mode k0=%d must be 3 + c_feat=%d", k0, c_feat);
+        PA_REQUIRE(rows % m_ctr == 0, "pa_mlp_chain: SA rows=%ld must be B*m", rows);
+        PA_REQUIRE((rows / m_ctr) * (long)n_src < 2147483647L, "pa_mlp_chain: B*n_src overflows int32 row ids");
+        scratch = 2 * R;
+    } else if (mode == MODE_FP) {
+        PA_REQUIRE(known && idx3 && w3 && n_unknown > 0 && m_known > 0 && c2 > 0 && c1 >= 0 && (c1 == 0 || skip), "pa_mlp_chain: FP mode arguments");
+        PA_REQUIRE(c2 % 4 == 0 && k0 == c2 + c1, "pa_mlp_chain: FP mode needs c2 %% 4 == 0 and k0 == c2 + c1");
+        PA_REQUIRE(rows % n_unknown == 0, "pa_mlp_chain: FP rows=%ld must be B*n", rows);
+        scratch = 6 * R;
+    } else {
+        PA_REQUIRE(false, "pa_mlp_chain: unknown mode %d", mode);
+    }
+    a.wave_floats = ((R * a.lds_stride + scratch + 3) / 4) * 4;
+    const size_t per_wave = (size_t)a.wave_floats * 4;
+    PA_REQUIRE(per_wave <= 156 * 1024, "pa_mlp_chain: one wave tile needs %zu B of LDS (> 156 KiB); reduce K", per_wave);
+    int wpw = 4;
+    while (wpw > 1 && wpw * per_wave > 156 * 1024) wpw >>= 1;
+    const long total_rows = (mode == MODE_SA) ? rows * ns : rows;
+    const long ntiles = is_pooled ? (rows + 3) / 4 : (total_rows + R - 1) / R;
+
+    if (is_pooled) {
+        switch (RTv) {
+            case 4: launch_chain<4, 4, MODE_SA, true>(a, wpw, ntiles, st); break;
+            case 5: launch_chain<5, 4, MODE_SA, true>(a, wpw, ntiles, st); break;
+            case 8: launch_chain<8, 4, MODE_SA, true>(a, wpw, ntiles, st); break;
+            default:
+                pa_set_error("pa_mlp_chain: pooled tiling is built for nsample in (13..16], (17..20], (29..32]; got %d", ns);
+                return PA_EUNSUPPORTED;
+        }
+    } else if (mode == MODE_PLAIN) launch_chain<2, 16, MODE_PLAIN, false>(a, wpw, ntiles, st);
+    else if (mode == MODE_SA) launch_chain<2, 16, MODE_SA, false>(a, wpw, ntiles, st);
+    else launch_chain<2, 16, MODE_FP, false>(a, wpw, ntiles, st);
+    PA_CHECK_LAUNCH("pa_mlp_chain");
+    return PA_OK;
+}
+
+PA_API int pa_rowgroup_max(long groups, int ns, int c, const float *in, float *out, pa_stream_t stream)
+{
+    PA_REQUIRE(groups > 0 && ns > 0 && c > 0 && in && out, "pa_rowgroup_max: bad arguments");
+    hipLaunchKernelGGL(rowgroup_max_kernel, dim3(pa_div_up(groups * c, 256)), dim3(256), 0, (hipStream_t)stream, groups, ns, c, in, out);
+    PA_CHECK_LAUNCH("pa_rowgroup_max");
+    return PA_OK;
+}

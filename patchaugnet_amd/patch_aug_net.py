@@ -58,7 +58,7 @@ class Network(nn.Module):
             self.decoder = PointNetDecoder(embedding_size=256, num_points=param["KNN"][0])
         self.param = dict(param)
         self._engine = None
-        self.fused_eval = False      # set True once the fused engine covers the model (eval()+no_grad() forwards)
+        self.fused_eval = True       # eval()+no_grad() forwards run the fused HIP engine; set False for the module path
 
     # ---- fused inference engine (eval + no_grad) ----------------------------------------------------------------
     def _fused(self, x):

@@ -1,0 +1,111 @@
+"""pa_mlp_chain (fused gather / interpolate + shared-MLP + max-pool on MFMA) against a float64 torch restatement of the
+unfused reference sequence (pointops.py:559-570, pt_util.py:16-41, patch_aug_net.py:236, :354-359).
+Tolerance: fp32 MFMA is an exact k-ordered fmaf chain, so only summation order differs from fp64: rtol 2e-5."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def make_layers(dims, seed):
+    """Random folded layers: list of (W (n,k), b (n)) in float64 + engine-format tensors."""
+    g = torch.Generator().manual_seed(seed)
+    ref, eng = [], []
+    for k, n in zip(dims[:-1], dims[1:]):
+        w = torch.randn(n, k, generator=g, dtype=torch.float64) * (2.0 / k) ** 0.5
+        b = torch.randn(n, generator=g, dtype=torch.float64) * 0.1
+        kpad = (k + 3) // 4 * 4
+        wt = torch.zeros(kpad, n, dtype=torch.float64)
+        wt[:k] = w.t()
+        ref.append((w, b))
+        eng.append((wt.float().cuda().contiguous(), b.float().cuda().contiguous(), k, kpad, n))
+    return ref, eng
+
+
+def mlp_ref(x, layers):
+    for w, b in layers:
+        x = torch.relu(x @ w.t() + b)
+    return x
+
+
+def close(got, ref, rtol=2e-5):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    scale = ref.abs().max().item() + 1e-12
+    err = (got - ref).abs().max().item()
+    assert err <= rtol * scale, f"max err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("rows,dims", [(1000, [64, 64, 256]), (4096, [259, 256, 256, 256]), (33, [7, 16]), (5000, [768, 256, 256]),
+                                       (640, [320, 256, 256]), (96, [256, 512]), (200, [12, 32, 32, 64])])
+def test_plain_rows(rows, dims):
+    from patchaugnet_amd.engine import _Chain
+    ref, eng = make_layers(dims, seed=rows)
+    x = torch.randn(rows, dims[0], dtype=torch.float64)
+    got = _Chain(eng).plain(x.float().cuda().contiguous())
+    close(got, mlp_ref(x.float().double(), [(w.float().double(), b.float().double()) for w, b in ref]))
+
+
+def sa_inputs(B, n, m, ns, C, seed):
+    g = torch.Generator().manual_seed(seed)
+    xyz = torch.rand(B, n, 3, generator=g) * 2 - 1
+    feat = xyz.clone() if C == 3 else torch.randn(B, n, C, generator=g)
+    cidx = torch.stack([torch.randperm(n, generator=g)[:m] for _ in range(B)]).int()
+    nbr = torch.randint(0, n, (B, m, ns), generator=g).int()
+    return xyz, feat, cidx, nbr
+
+
+def sa_rows_ref(xyz, feat, cidx, nbr):
+    B, m, ns = nbr.shape
+    bi = torch.arange(B)[:, None, None]
+    p_xyz, p_f = xyz[bi, nbr.long()], feat[bi, nbr.long()]                   # (B, m, ns, .)
+    c_xyz, c_f = xyz[bi[:, :, 0], cidx.long()], feat[bi[:, :, 0], cidx.long()]
+    return torch.cat([p_xyz - c_xyz[:, :, None], p_f - c_f[:, :, None]], dim=-1)  # (B, m, ns, 3+C) fp32 subtraction
+
+
+@pytest.mark.parametrize("B,n,m,ns,C,dims", [(2, 4096, 1024, 20, 3, [6, 32, 32, 64]), (3, 1024, 128, 20, 64, [67, 64, 64, 256]),
+                                              (2, 100, 13, 20, 64, [67, 64, 64, 256]), (1, 64, 9, 16, 8, [11, 16, 32]),
+                                              (2, 50, 6, 32, 3, [6, 32, 48]), (2, 300, 30, 17, 5, [8, 64, 16])])
+def test_sa_pooled(B, n, m, ns, C, dims):
+    from patchaugnet_amd.engine import _Chain
+    ref, eng = make_layers(dims, seed=n + ns)
+    xyz, feat, cidx, nbr = sa_inputs(B, n, m, ns, C, seed=m)
+    rows = sa_rows_ref(xyz, feat, cidx, nbr).double()
+    exp = mlp_ref(rows, [(w.float().double(), b.float().double()) for w, b in ref]).max(dim=2)[0].reshape(B * m, -1)
+    got = _Chain(eng).sa(xyz.cuda(), feat.cuda().contiguous(), cidx.cuda(), nbr.cuda(), C, pooled=True)
+    close(got, exp)
+
+
+@pytest.mark.parametrize("B,n,m,ns,C,dims", [(2, 128, 16, 20, 256, [259, 256, 256, 512]), (1, 40, 5, 7, 4, [7, 32, 16])])
+def test_sa_unpooled_then_rowgroup_max(B, n, m, ns, C, dims):
+    from patchaugnet_amd import _lib
+    from patchaugnet_amd.engine import _Chain
+    ref, eng = make_layers(dims, seed=7)
+    xyz, feat, cidx, nbr = sa_inputs(B, n, m, ns, C, seed=3)
+    rows = sa_rows_ref(xyz, feat, cidx, nbr).double()
+    full = mlp_ref(rows, [(w.float().double(), b.float().double()) for w, b in ref])
+    got = _Chain(eng).sa(xyz.cuda(), feat.cuda().contiguous(), cidx.cuda(), nbr.cuda(), C, pooled=False)
+    close(got, full.reshape(B * m * ns, -1))
+    pooled = torch.empty(B * m, dims[-1], device="cuda")
+    _lib.call("pa_rowgroup_max", B * m, ns, dims[-1], _lib.ptr(got), _lib.ptr(pooled))
+    assert torch.equal(pooled.cpu(), got.view(B * m, ns, -1).max(dim=1)[0].cpu())
+
+
+@pytest.mark.parametrize("B,n,m,c2,c1,dims", [(2, 128, 16, 512, 256, [768, 256, 256]), (2, 1024, 128, 256, 64, [320, 256, 256]),
+                                               (2, 4096, 1024, 256, 3, [259, 256, 256, 256]), (1, 50, 7, 8, 0, [8, 16]), (1, 33, 9, 4, 5, [9, 32, 16])])
+def test_fp_interpolate(B, n, m, c2, c1, dims):
+    from patchaugnet_amd.engine import _Chain
+    ref, eng = make_layers(dims, seed=c2)
+    g = torch.Generator().manual_seed(n)
+    known = torch.randn(B, m, c2, generator=g)
+    skip = torch.randn(B, n, c1, generator=g) if c1 else None
+    idx3 = torch.randint(0, m, (B, n, 3), generator=g).int()
+    w3 = torch.rand(B, n, 3, generator=g)
+    w3 = w3 / w3.sum(-1, keepdim=True)
+    bi = torch.arange(B)[:, None]
+    f = [known[bi, idx3[:, :, t].long()] for t in range(3)]
+    interp = (w3[..., 0:1] * f[0] + w3[..., 1:2] * f[1]) + w3[..., 2:3] * f[2]            # fp32, reference order
+    rows = torch.cat([interp, skip], dim=-1) if c1 else interp
+    exp = mlp_ref(rows.double(), [(w.float().double(), b.float().double()) for w, b in ref]).reshape(B * n, -1)
+    got = _Chain(eng).fp(known.cuda(), idx3.cuda(), w3.cuda().contiguous(), skip.cuda() if c1 else None, B, n, m, c2, c1)
+    close(got, exp)
