@@ -101,6 +101,11 @@ class PatchAugNetEngine:
             self.fp = [_Chain(fold_shared_mlp(m.mlp, self.device)) for m in bb.FP_modules]
         self.agg = model.aggregation
         self._key = self._params_key(model)
+        self.timer = None     # optional profiling.StageTimer: per-stage HIP-event marks (bench.py kernel attribution)
+
+    def _mark(self, name):
+        if self.timer is not None:
+            self.timer.mark(name)
 
     @staticmethod
     def _params_key(model):
@@ -120,10 +125,12 @@ class PatchAugNetEngine:
             cidx = torch.empty((B, m), dtype=torch.int32, device=self.device)
             temp = torch.full((B, n), 1e10, dtype=torch.float32, device=self.device)
             call("pa_furthestsampling", B, n, m, ptr(src), ptr(temp), ptr(cidx))
+            self._mark(f"sa{i}.fps")
             new_xyz = torch.gather(src, 1, cidx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
             nbr = torch.empty((B, m, ns), dtype=torch.int32, device=self.device)
             d2 = torch.empty((B, m, ns), dtype=torch.float32, device=self.device)
             call("pa_knnquery", B, n, m, ns, ptr(src), ptr(new_xyz), ptr(nbr), ptr(d2))
+            self._mark(f"sa{i}.knn")
             feat = l_feat[i]
             if chain.hidden_ok_pooled:
                 y = chain.sa(src, feat, cidx, nbr, c_feat, pooled=True)                      # (B*m, C')
@@ -131,6 +138,7 @@ class PatchAugNetEngine:
                 full = chain.sa(src, feat, cidx, nbr, c_feat, pooled=False)                  # (B*m*ns, C')
                 y = torch.empty((B * m, chain.n_last), dtype=torch.float32, device=self.device)
                 call("pa_rowgroup_max", B * m, ns, chain.n_last, ptr(full), ptr(y))
+            self._mark(f"sa{i}.chain")
             l_xyz.append(new_xyz)
             l_feat.append(y.view(B, m, chain.n_last))
             l_c.append(cidx)
@@ -143,6 +151,7 @@ class PatchAugNetEngine:
             d2 = torch.empty((B, n_u, 3), dtype=torch.float32, device=self.device)
             idx3 = torch.empty((B, n_u, 3), dtype=torch.int32, device=self.device)
             call("pa_nearestneighbor", B, n_u, m_k, ptr(unknown), ptr(known), ptr(d2), ptr(idx3))
+            self._mark(f"fp{nfp + i}.3nn")
             r = 1.0 / (torch.sqrt(d2) + 1e-8)                                                # patch_aug_net.py:351-353
             w3 = (r / torch.sum(r, dim=2, keepdim=True)).contiguous()
             skip = l_feat[i - 1]
@@ -152,6 +161,7 @@ class PatchAugNetEngine:
             c2 = known_feat.shape[-1]
             c1 = skip.shape[-1] if skip is not None else 0
             y = chain.fp(known_feat.contiguous(), idx3, w3, skip.contiguous() if skip is not None else None, B, n_u, m_k, c2, c1)
+            self._mark(f"fp{nfp + i}.chain")
             l_feat[i - 1] = y.view(B, n_u, chain.n_last)
         return l_feat, l_c
 
@@ -168,11 +178,13 @@ class PatchAugNetEngine:
 
     def forward(self, x):
         xyz = x.squeeze(1).contiguous()
+        self._mark("start")
         l_feat, l_c = self.backbone(xyz)
         nfp = len(self.fp)
         feats = [l_feat[j] for j in range(nfp - 1, -1, -1)]                                   # coarse -> fine, (B, N_i, 256)
         agg = self.agg
         v = torch.cat([self._vlad(vl, f) for vl, f in zip(agg.vlads, feats)], dim=-1)       # (B, 256, sum K)
+        self._mark("vlad")
         if agg.aggregation_type == 2:
             desc = agg.afa(v).squeeze(-1)
         elif agg.aggregation_type == 0:
@@ -181,6 +193,7 @@ class PatchAugNetEngine:
             desc = F.normalize(v.max(dim=2)[0])
         if agg.gating:
             desc = agg.context_gating(desc)
+        self._mark("afa")
         c_o = [l_c[0]]
         for i in range(1, len(l_c)):
             c_o.append(torch.gather(c_o[i - 1], -1, l_c[i].long()))

@@ -19,8 +19,25 @@ class StageTimer:
         return out
 
 
+def engine_stage_times(model, x, iters=5):
+    """Average ms per stage of the fused engine (marks recorded by engine.PatchAugNetEngine)."""
+    model(x, return_feat=False)                  # builds the engine
+    eng = model._engine
+    acc = {}
+    for _ in range(iters):
+        eng.timer = StageTimer()
+        model(x, return_feat=False)
+        t, eng.timer = eng.timer, None
+        for k, ms in t.result().items():
+            acc[k] = acc.get(k, 0.0) + ms / iters
+    acc["total"] = sum(acc.values())
+    return acc
+
+
 def stage_times(model, x, iters=5):
     """Average ms per stage over `iters` steps of the module path (stages: fps, knn, group+mlp, 3nn+interp+mlp, vlad, afa)."""
+    if getattr(model, "fused_eval", False):
+        return engine_stage_times(model, x, iters)
     from . import pointops
     bb, agg = model.backbone, model.aggregation
     acc = {}
