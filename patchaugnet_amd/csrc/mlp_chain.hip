@@ -168,17 +168,26 @@ __device__ __forceinline__ void store_pooled(float *__restrict__ out, int ldo, l
     }
 }
 
-template <int RT, int NC, int MODE, bool POOLED>
-__device__ __forceinline__ void run_layer_chunks(float *act, const PaChain &a, int l, long tile, int lane)
+// WPT = waves per tile: 1 = the wave owns its rows end to end (no workgroup barrier anywhere);
+//                       4 = the workgroup's four waves share one tile and split every layer's COLUMNS, for
+//                           problems with too few row tiles to fill 1024 SIMDs (two barriers per hidden layer).
+template <int WPT>
+__device__ __forceinline__ void tile_sync()
+{
+    if (WPT == 1) lds_fence();
+    else __syncthreads();
+}
+
+template <int RT, int NC, int MODE, bool POOLED, int WPT>
+__device__ __forceinline__ void run_layer_chunks(float *act, const PaChain &a, int l, long tile, int lane, int c_begin, int c_end)
 {
     const PaLayer &L = a.L[l];
-    const int nct = L.n >> 4;
     const bool last = (l == a.nlayers - 1);
-    for (int c0 = 0; c0 < nct; c0 += NC) {
+    for (int c0 = c_begin; c0 < c_end; c0 += NC) {
         floatx4 acc[RT][NC];
         gemm_chunk<RT, NC>(act, a.lds_stride, L, c0, lane, acc);
         if (!last) {
-            lds_fence();  // every A read of this layer has landed before its rows are overwritten (single chunk: host-checked)
+            tile_sync<WPT>();  // every A read of this layer has landed before its rows are overwritten (single chunk per wave: host-checked)
             store_hidden<RT, NC>(act, a.lds_stride, L, c0, lane, acc);
         } else if (POOLED) {
             store_pooled<RT, NC>(a.out, a.ldo, tile * 4, a.rows, L, c0, lane, acc);
@@ -187,27 +196,29 @@ __device__ __forceinline__ void run_layer_chunks(float *act, const PaChain &a, i
             store_rows<RT, NC>(a.out, a.ldo, tile * (RT * 16), total_rows, L, c0, lane, acc);
         }
     }
-    lds_fence();
+    if (!last) tile_sync<WPT>();
 }
 
-template <int RT, int NCMAX, int MODE, bool POOLED>
+template <int RT, int NCMAX, int MODE, bool POOLED, int WPT>
 __global__ __launch_bounds__(256) void chain_kernel(PaChain a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int R = RT * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long tile = (long)blockIdx.x * (blockDim.x >> 6) + wave;
+    const long tile = WPT == 1 ? (long)blockIdx.x * (blockDim.x >> 6) + wave : (long)blockIdx.x;
     const long total_rows = (MODE == MODE_SA) ? a.rows * a.ns : a.rows;
     const long ntiles = POOLED ? (a.rows + 3) / 4 : (total_rows + R - 1) / R;
-    if (tile >= ntiles) return;  // wave-uniform; the kernel has no workgroup barrier
-    float *act = smem + (size_t)wave * a.wave_floats;
+    if (tile >= ntiles) return;  // WPT == 1: wave-uniform, and that variant has no workgroup barrier; WPT == 4: grid == ntiles
+    float *act = smem + (WPT == 1 ? (size_t)wave * a.wave_floats : (size_t)0);
+    const int tid = WPT == 1 ? lane : (int)threadIdx.x;  // prologue work is spread over the tile's owner(s)
+    constexpr int NTH = WPT * 64;
     const int stride = a.lds_stride;
     const int k0pad = a.L[0].kpad;
 
     // ---------------------------------------------------------------- prologue: build the A tile of layer 0
     if (MODE == MODE_PLAIN) {
         const long row0 = tile * R;
-        for (int q = lane; q < R * k0pad; q += 64) {
+        for (int q = tid; q < R * k0pad; q += NTH) {
             const int r = q / k0pad, ch = q - r * k0pad;
             const long row = row0 + r;
             act[r * stride + ch] = (row < a.rows && ch < a.k0) ? a.x[row * a.ldx + ch] : 0.f;
@@ -215,7 +226,7 @@ __global__ __launch_bounds__(256) void chain_kernel(PaChain a)
     } else if (MODE == MODE_SA) {
         int *src = reinterpret_cast<int *>(act + R * stride);  // [R] source point (global row), -1 = padding row
         int *ctr = src + R;                                    // [R] centre point (global row)
-        for (int r = lane; r < R; r += 64) {
+        for (int r = tid; r < R; r += NTH) {
             long gid;
             int s;
             if (POOLED) { gid = tile * 4 + (r & 3); s = r >> 2; if (s >= a.ns) s = 0; }
@@ -229,8 +240,8 @@ __global__ __launch_bounds__(256) void chain_kernel(PaChain a)
                 ctr[r] = 0;
             }
         }
-        lds_fence();
-        for (int q = lane; q < R * 3; q += 64) {  // centred coordinates -> channels 0..2 (pointops.py:562)
+        tile_sync<WPT>();
+        for (int q = tid; q < R * 3; q += NTH) {  // centred coordinates -> channels 0..2 (pointops.py:562)
             const int r = q / 3, t = q - r * 3;
             const int s = src[r];
             act[r * stride + t] = s >= 0 ? a.xyz[(size_t)s * 3 + t] - a.xyz[(size_t)ctr[r] * 3 + t] : 0.f;
@@ -239,7 +250,7 @@ __global__ __launch_bounds__(256) void chain_kernel(PaChain a)
         if ((C & 3) == 0) {  // centred features -> channels 3..3+C (pointops.py:567-568), 16-byte loads
             const int qpr = C >> 2;
             const float4 *f4 = reinterpret_cast<const float4 *>(a.feat);
-            for (int q = lane; q < R * qpr; q += 64) {
+            for (int q = tid; q < R * qpr; q += NTH) {
                 const int r = q / qpr, part = q - r * qpr;
                 const int s = src[r];
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -251,13 +262,13 @@ __global__ __launch_bounds__(256) void chain_kernel(PaChain a)
                 d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
             }
         } else {
-            for (int q = lane; q < R * C; q += 64) {
+            for (int q = tid; q < R * C; q += NTH) {
                 const int r = q / C, ch = q - r * C;
                 const int s = src[r];
                 act[r * stride + 3 + ch] = s >= 0 ? a.feat[(size_t)s * C + ch] - a.feat[(size_t)ctr[r] * C + ch] : 0.f;
             }
         }
-        for (int q = lane; q < R * (k0pad - a.k0); q += 64) {  // zero the K padding
+        for (int q = tid; q < R * (k0pad - a.k0); q += NTH) {  // zero the K padding
             const int r = q / (k0pad - a.k0), ch = q - r * (k0pad - a.k0);
             act[r * stride + a.k0 + ch] = 0.f;
         }
@@ -265,7 +276,7 @@ __global__ __launch_bounds__(256) void chain_kernel(PaChain a)
         int *nb = reinterpret_cast<int *>(act + R * stride);  // [R][3] global rows of the three known neighbours
         float *wt = reinterpret_cast<float *>(nb + 3 * R);    // [R][3] interpolation weights
         const long row0 = tile * R;
-        for (int q = lane; q < R * 3; q += 64) {
+        for (int q = tid; q < R * 3; q += NTH) {
             const int r = q / 3;
             const long p = row0 + r;
             if (p < a.rows) {
@@ -277,11 +288,11 @@ __global__ __launch_bounds__(256) void chain_kernel(PaChain a)
                 wt[q] = 0.f;
             }
         }
-        lds_fence();
+        tile_sync<WPT>();
         const int C2 = a.c2, C1 = a.c1;
         const int qpr = C2 >> 2;  // host guarantees c2 % 4 == 0
         const float4 *k4 = reinterpret_cast<const float4 *>(a.known);
-        for (int q = lane; q < R * qpr; q += 64) {
+        for (int q = tid; q < R * qpr; q += NTH) {
             const int r = q / qpr, part = q - r * qpr;
             const float w0 = wt[r * 3 + 0], w1 = wt[r * 3 + 1], w2 = wt[r * 3 + 2];
             const float4 f0 = k4[(size_t)nb[r * 3 + 0] * qpr + part];
@@ -294,22 +305,24 @@ __global__ __launch_bounds__(256) void chain_kernel(PaChain a)
             d[3] = w0 * f0.w + w1 * f1.w + w2 * f2.w;
         }
         const int tail = k0pad - C2;  // skip channels (patch_aug_net.py:359: cat([interpolated, skip])) + zero padding
-        for (int q = lane; q < R * tail; q += 64) {
+        for (int q = tid; q < R * tail; q += NTH) {
             const int r = q / tail, ch = q - r * tail;
             const long p = row0 + r;
             act[r * stride + C2 + ch] = (p < a.rows && ch < C1) ? a.skip[p * C1 + ch] : 0.f;
         }
     }
-    lds_fence();
+    tile_sync<WPT>();
 
     // ---------------------------------------------------------------- layers
     for (int l = 0; l < a.nlayers; ++l) {
         const int nct = a.L[l].n >> 4;
-        if (NCMAX >= 16 && nct % 16 == 0) run_layer_chunks<RT, (NCMAX >= 16 ? 16 : NCMAX), MODE, POOLED>(act, a, l, tile, lane);
-        else if (NCMAX >= 8 && nct % 8 == 0) run_layer_chunks<RT, (NCMAX >= 8 ? 8 : NCMAX), MODE, POOLED>(act, a, l, tile, lane);
-        else if (NCMAX >= 4 && nct % 4 == 0) run_layer_chunks<RT, (NCMAX >= 4 ? 4 : NCMAX), MODE, POOLED>(act, a, l, tile, lane);
-        else if (nct % 2 == 0) run_layer_chunks<RT, 2, MODE, POOLED>(act, a, l, tile, lane);
-        else run_layer_chunks<RT, 1, MODE, POOLED>(act, a, l, tile, lane);
+        const int per = WPT == 1 ? nct : nct / WPT;          // column tiles this wave computes (host: nct % WPT == 0)
+        const int cb = WPT == 1 ? 0 : wave * per, ce = cb + per;
+        if (NCMAX >= 16 && per % 16 == 0) run_layer_chunks<RT, (NCMAX >= 16 ? 16 : NCMAX), MODE, POOLED, WPT>(act, a, l, tile, lane, cb, ce);
+        else if (NCMAX >= 8 && per % 8 == 0) run_layer_chunks<RT, (NCMAX >= 8 ? 8 : NCMAX), MODE, POOLED, WPT>(act, a, l, tile, lane, cb, ce);
+        else if (NCMAX >= 4 && per % 4 == 0) run_layer_chunks<RT, (NCMAX >= 4 ? 4 : NCMAX), MODE, POOLED, WPT>(act, a, l, tile, lane, cb, ce);
+        else if (per % 2 == 0) run_layer_chunks<RT, 2, MODE, POOLED, WPT>(act, a, l, tile, lane, cb, ce);
+        else run_layer_chunks<RT, 1, MODE, POOLED, WPT>(act, a, l, tile, lane, cb, ce);
     }
 }
 
@@ -326,14 +339,23 @@ __global__ __launch_bounds__(256) void rowgroup_max_kernel(long groups, int ns, 
     out[t] = m;
 }
 
-template <int RT, int NCMAX, int MODE, bool POOLED>
+template <int RT, int NCMAX, int MODE, bool POOLED, int WPT>
 int launch_chain(const PaChain &a, int waves_per_wg, long ntiles, hipStream_t st)
 {
-    const size_t lds = (size_t)waves_per_wg * a.wave_floats * 4;
-    auto kern = chain_kernel<RT, NCMAX, MODE, POOLED>;
+    const size_t lds = (size_t)(WPT == 1 ? waves_per_wg : 1) * a.wave_floats * 4;
+    auto kern = chain_kernel<RT, NCMAX, MODE, POOLED, WPT>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(pa_div_up(ntiles, waves_per_wg)), dim3(64 * waves_per_wg), lds, st, a);
+    if (WPT == 1) hipLaunchKernelGGL(kern, dim3(pa_div_up(ntiles, waves_per_wg)), dim3(64 * waves_per_wg), lds, st, a);
+    else hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), lds, st, a);
     return 0;
+}
+
+template <int MODE>
+void launch_rows(const PaChain &a, int rt, bool split, int wpw, long ntiles, hipStream_t st)
+{
+    if (!split) launch_chain<2, 16, MODE, false, 1>(a, wpw, ntiles, st);
+    else if (rt == 2) launch_chain<2, 8, MODE, false, 4>(a, 4, ntiles, st);
+    else launch_chain<1, 8, MODE, false, 4>(a, 4, ntiles, st);
 }
 
 }  // namespace
@@ -370,12 +392,29 @@ PA_API int pa_mlp_chain(int mode, int pooled, int nlayers, const float *const *w
 
     const bool is_pooled = pooled != 0;
     PA_REQUIRE(!is_pooled || mode == MODE_SA, "pa_mlp_chain: pooled output needs mode 1 (set-abstraction gather)");
-    const int RTv = is_pooled ? (ns + 3) / 4 : 2;
+    const long total_rows = (mode == MODE_SA) ? rows * ns : rows;
+    // Tiling choice.  Wave-private tiles (WPT = 1) need >= ~2 tiles per SIMD to hide latency; with fewer row tiles the
+    // four waves of a workgroup share one tile and split the columns (WPT = 4), optionally with 16-row tiles.
+    bool split = false;
+    int RTv = is_pooled ? (ns + 3) / 4 : 2;
+    bool can_split = true;
+    for (int l = 0; l < nlayers; ++l) {  // every layer splits 4 ways; a hidden layer must stay one chunk (<= 8 tiles, power of two) per wave
+        const int per = nout[l] / 64;
+        can_split = can_split && (nout[l] % 64 == 0) && (l + 1 == nlayers || (per <= 8 && (per & (per - 1)) == 0));
+    }
+    if (!is_pooled) {
+        const long t32 = (total_rows + 31) / 32;
+        if (can_split && t32 < 2048) { split = true; RTv = t32 >= 512 ? 2 : 1; }
+    } else {
+        const long tp = (rows + 3) / 4;
+        if (can_split && tp < 2048 && RTv == 5) split = true;
+    }
     const int R = RTv * 16;
-    const int ncmax = is_pooled ? 4 : 16;
-    for (int l = 0; l + 1 < nlayers; ++l)  // hidden layers are written back in place => must be a single column chunk
-        PA_REQUIRE(nout[l] / 16 <= ncmax && ((nout[l] / 16) & (nout[l] / 16 - 1)) == 0,
-                   "pa_mlp_chain: hidden layer %d with n=%d must be 16*2^j <= %d (single column chunk, written back in place)", l, nout[l], ncmax * 16);
+    const int ncmax = split ? 8 : (is_pooled ? 4 : 16);
+    if (!split)
+        for (int l = 0; l + 1 < nlayers; ++l)  // hidden layers are written back in place => must be a single column chunk
+            PA_REQUIRE(nout[l] / 16 <= ncmax && ((nout[l] / 16) & (nout[l] / 16 - 1)) == 0,
+                       "pa_mlp_chain: hidden layer %d with n=%d must be 16*2^j <= %d (single column chunk, written back in place)", l, nout[l], ncmax * 16);
     int scratch = 0;
     if (mode == MODE_PLAIN) {
         PA_REQUIRE(x && ldx >= k0, "pa_mlp_chain: plain mode needs x and ldx >= k0");
@@ -395,24 +434,24 @@ PA_API int pa_mlp_chain(int mode, int pooled, int nlayers, const float *const *w
     }
     a.wave_floats = ((R * a.lds_stride + scratch + 3) / 4) * 4;
     const size_t per_wave = (size_t)a.wave_floats * 4;
-    PA_REQUIRE(per_wave <= 156 * 1024, "pa_mlp_chain: one wave tile needs %zu B of LDS (> 156 KiB); reduce K", per_wave);
+    PA_REQUIRE(per_wave <= 156 * 1024, "pa_mlp_chain: one tile needs %zu B of LDS (> 156 KiB); reduce K", per_wave);
     int wpw = 4;
     while (wpw > 1 && wpw * per_wave > 156 * 1024) wpw >>= 1;
-    const long total_rows = (mode == MODE_SA) ? rows * ns : rows;
     const long ntiles = is_pooled ? (rows + 3) / 4 : (total_rows + R - 1) / R;
 
     if (is_pooled) {
-        switch (RTv) {
-            case 4: launch_chain<4, 4, MODE_SA, true>(a, wpw, ntiles, st); break;
-            case 5: launch_chain<5, 4, MODE_SA, true>(a, wpw, ntiles, st); break;
-            case 8: launch_chain<8, 4, MODE_SA, true>(a, wpw, ntiles, st); break;
+        if (split) launch_chain<5, 4, MODE_SA, true, 4>(a, 4, ntiles, st);
+        else switch (RTv) {
+            case 4: launch_chain<4, 4, MODE_SA, true, 1>(a, wpw, ntiles, st); break;
+            case 5: launch_chain<5, 4, MODE_SA, true, 1>(a, wpw, ntiles, st); break;
+            case 8: launch_chain<8, 4, MODE_SA, true, 1>(a, wpw, ntiles, st); break;
             default:
                 pa_set_error("pa_mlp_chain: pooled tiling is built for nsample in (13..16], (17..20], (29..32]; got %d", ns);
                 return PA_EUNSUPPORTED;
         }
-    } else if (mode == MODE_PLAIN) launch_chain<2, 16, MODE_PLAIN, false>(a, wpw, ntiles, st);
-    else if (mode == MODE_SA) launch_chain<2, 16, MODE_SA, false>(a, wpw, ntiles, st);
-    else launch_chain<2, 16, MODE_FP, false>(a, wpw, ntiles, st);
+    } else if (mode == MODE_PLAIN) launch_rows<MODE_PLAIN>(a, RTv, split, wpw, ntiles, st);
+    else if (mode == MODE_SA) launch_rows<MODE_SA>(a, RTv, split, wpw, ntiles, st);
+    else launch_rows<MODE_FP>(a, RTv, split, wpw, ntiles, st);
     PA_CHECK_LAUNCH("pa_mlp_chain");
     return PA_OK;
 }
