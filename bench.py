@@ -34,6 +34,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-pass", action="store_true")
     p.add_argument("--cpu-batch", type=int, default=4)
+    p.add_argument("--streams", type=int, default=2, help="HIP streams the consecutive steps are issued on (1 = strictly sequential)")
     return p.parse_args()
 
 
@@ -118,21 +119,28 @@ def main():
     x = synthetic_submaps(a.batch, a.points, seed=1234 + rank).cuda()
     descs = torch.empty(a.steps, a.batch, 256, device="cuda")
 
-    def step(i):
+    from patchaugnet_amd.extract import StreamPipeline
+    pipe = StreamPipeline(a.streams)
+
+    def one(i):
         d = model(x, return_feat=False)
         if i >= 0:
             descs[i].copy_(d)
 
     with torch.no_grad():
         torch.manual_seed(0)
-        for _ in range(a.warmup):
-            step(-1)
+        pipe.begin()
+        for _ in range(max(a.warmup, a.streams)):   # every stream (and its allocator pool) gets warmed
+            pipe.submit(one, -1)
+        pipe.end()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        pipe.begin()
         for i in range(a.steps):
-            step(i)
+            pipe.submit(one, i)
+        pipe.end()
         if dist is not None:   # the one exchange step: every rank's descriptors to every rank
             gathered = torch.empty(world * a.steps * a.batch, 256, device="cuda")
             dist.all_gather_into_tensor(gathered, descs.view(-1, 256))
@@ -158,7 +166,7 @@ def main():
         "config": {"workload": f"PatchAugNet inference, {a.points}-pt synthetic submaps, batch={a.batch}, 1xMI355X per rank "
                                "(BASELINE.json configs[1])", "batch_per_gpu": a.batch, "points": a.points,
                    "path": "fused HIP engine" if model.fused_eval else "HIP point ops + torch dense ops (module path)",
-                   "weights": "key-seeded random init", "parallelism": f"dp{world}"},
+                   "weights": "key-seeded random init", "parallelism": f"dp{world}", "streams": a.streams},
     }
     if world == 1:
         if not a.no_kernel_pass:

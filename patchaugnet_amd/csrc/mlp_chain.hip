@@ -67,10 +67,13 @@ enum { MODE_PLAIN = 0, MODE_SA = 1, MODE_FP = 2 };
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // One column chunk (NC tiles of 16 columns starting at tile c0) of one layer for the wave's RT row tiles.
+// Operands are prefetched PD k-steps ahead (a register ring with static indices): a k-step is only RT*NC MFMAs
+// (32 cycles each), so small tiles need a deeper ring to cover the ~500-cycle L2 latency of the weight loads.
 template <int RT, int NC>
 __device__ __forceinline__ void gemm_chunk(const float *__restrict__ act, int stride, const PaLayer &L, int c0, int lane,
                                             floatx4 (&acc)[RT][NC])
 {
+    constexpr int PD = (RT * NC >= 32) ? 2 : (RT * NC >= 16) ? 3 : 4;
     const int ksteps = L.kpad >> 2;
     const float *wp = L.wt + (size_t)(lane >> 4) * L.n + c0 * 16 + (lane & 15);
     const float *ap = act + (lane & 15) * stride + (lane >> 4);
@@ -79,28 +82,34 @@ __device__ __forceinline__ void gemm_chunk(const float *__restrict__ act, int st
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int ct = 0; ct < NC; ++ct) acc[rt][ct] = (floatx4){0.f, 0.f, 0.f, 0.f};
-    float bn[NC], an[RT];
+    float bq[PD][NC], aq[PD][RT];
 #pragma unroll
-    for (int ct = 0; ct < NC; ++ct) bn[ct] = wp[ct * 16];
+    for (int u = 0; u < PD; ++u) {
+        if (u < ksteps) {
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) an[rt] = ap[rt * 16 * stride];
-    for (int ks = 0; ks < ksteps; ++ks) {
-        float bc[NC], ac[RT];
+            for (int ct = 0; ct < NC; ++ct) bq[u][ct] = wp[(size_t)u * wstep + ct * 16];
 #pragma unroll
-        for (int ct = 0; ct < NC; ++ct) bc[ct] = bn[ct];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) ac[rt] = an[rt];
-        if (ks + 1 < ksteps) {
-            const float *wn = wp + (size_t)(ks + 1) * wstep;
-#pragma unroll
-            for (int ct = 0; ct < NC; ++ct) bn[ct] = wn[ct * 16];
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) an[rt] = ap[rt * 16 * stride + (ks + 1) * 4];
+            for (int rt = 0; rt < RT; ++rt) aq[u][rt] = ap[rt * 16 * stride + u * 4];
         }
+    }
+    for (int ks = 0; ks < ksteps; ks += PD) {
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
+        for (int u = 0; u < PD; ++u) {
+            if (ks + u < ksteps) {
 #pragma unroll
-            for (int ct = 0; ct < NC; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[rt], bc[ct], acc[rt][ct], 0, 0, 0);
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < NC; ++ct)
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[u][rt], bq[u][ct], acc[rt][ct], 0, 0, 0);
+                const int nx = ks + u + PD;
+                if (nx < ksteps) {
+#pragma unroll
+                    for (int ct = 0; ct < NC; ++ct) bq[u][ct] = wp[(size_t)nx * wstep + ct * 16];
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) aq[u][rt] = ap[rt * 16 * stride + nx * 4];
+                }
+            }
+        }
     }
 }
 
