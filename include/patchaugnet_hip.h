@@ -118,6 +118,22 @@ int pa_mlp_chain(int mode, int pooled, int nlayers, const float *const *wt, cons
 /* out[g][c] = max over s < ns of in[g*ns + s][c]  (rows of c floats) */
 int pa_rowgroup_max(long groups, int ns, int c, const float *in, float *out, pa_stream_t stream);
 
+/* ---- NetVLAD pyramid + adaptive feature aggregator (MFMA, fp32; evaluation mode) ------------------------------
+ * pa_netvlad: one pyramid scale of place_recognition/patch_aug_net/models/loupe.py:191-222.  x (b, n, 256) POINT-MAJOR;
+ *   wc_t: cluster_weights with BatchNorm1d folded in, K-major (256 x kp), kp = k rounded up to 16, padding columns zero;
+ *   bias: folded BatchNorm shift (kp);  w2: cluster_weights2[0] (256 x k);  scratch: pa_netvlad_scratch_floats(b, n, k) floats;
+ *   writes the intra-normalised VLAD block to out[b][c][koff + j], j < k, with ldo floats per (b, c) row, i.e. straight into the
+ *   concatenated (b, 256, sum k) tensor of loupe.py:301-303.
+ * pa_afa: MLPAttentionLayer + AdaptiveFeatureAggregator (loupe.py:24-41, :57-66).  v (b, 256, ktot); watt (256, 256) row-major
+ *   (out, in) of the single attention conv; fc_wt K-major (256*ktot, nout); fc_bias (nout); scale/shift: BatchNorm1d (eval) folded
+ *   to y*scale + shift; l2norm != 0 applies F.normalize; scratch: pa_afa_scratch_floats(b, 256, ktot, nout) floats; desc (b, nout). */
+long pa_netvlad_scratch_floats(int b, int n, int k);
+int pa_netvlad(int b, int n, int c, int k, const float *x, const float *wc_t, const float *bias, const float *w2, float *scratch,
+               float *out, int ldo, int koff, pa_stream_t stream);
+long pa_afa_scratch_floats(int b, int c, int ktot, int nout);
+int pa_afa(int b, int c, int ktot, int nout, const float *v, const float *watt, const float *fc_wt, const float *fc_bias,
+           const float *scale, const float *shift, int l2norm, float *scratch, float *desc, pa_stream_t stream);
+
 /* ---- the reference's launcher names (group 2) -------------------------------------------------*/
 void furthestsampling_cuda_launcher(int b, int n, int m, const float *dataset, float *temp, int *idxs);
 void gathering_forward_cuda_launcher(int b, int c, int n, int m, const float *points, const int *idx, float *out);

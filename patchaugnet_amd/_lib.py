@@ -39,6 +39,8 @@ _SIGS = {
     "pa_knn_generic": "pipiiipp",
     "pa_mlp_chain": "iiipppplipippppiiiippppiiiipi",
     "pa_rowgroup_max": "liipp",
+    "pa_netvlad": "iiiippppppii",
+    "pa_afa": "iiiippppppipp",
 }
 _T = {"i": _I, "f": _F, "p": _P, "l": ctypes.c_long}
 
@@ -78,6 +80,9 @@ def lib():
         l = ctypes.CDLL(LIB_PATH)
         l.pa_last_error.restype = ctypes.c_char_p
         l.pa_abi_version.restype = _I
+        for name, nargs in (("pa_netvlad_scratch_floats", 3), ("pa_afa_scratch_floats", 4)):
+            getattr(l, name).argtypes = [_I] * nargs
+            getattr(l, name).restype = ctypes.c_long
         _declare(l, _SIGS)
         _lib = l
     return _lib

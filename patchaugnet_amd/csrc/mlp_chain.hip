@@ -67,13 +67,14 @@ enum { MODE_PLAIN = 0, MODE_SA = 1, MODE_FP = 2 };
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // One column chunk (NC tiles of 16 columns starting at tile c0) of one layer for the wave's RT row tiles.
-// Operands are prefetched PD k-steps ahead (a register ring with static indices): a k-step is only RT*NC MFMAs
-// (32 cycles each), so small tiles need a deeper ring to cover the ~500-cycle L2 latency of the weight loads.
-template <int RT, int NC>
+// DEEP = false: operands of k-step i+1 are requested right before the MFMAs of k-step i (enough when a k-step is
+//               >= 16 MFMAs = 512+ cycles; smallest code, best for the short K loops of the SA levels).
+// DEEP = true : a 4-deep register ring with static indices, for the column-split tiling where a k-step is only
+//               RT*NC <= 16 MFMAs and the ~500-cycle L2 latency of the weight loads would otherwise be exposed.
+template <int RT, int NC, bool DEEP>
 __device__ __forceinline__ void gemm_chunk(const float *__restrict__ act, int stride, const PaLayer &L, int c0, int lane,
                                             floatx4 (&acc)[RT][NC])
 {
-    constexpr int PD = (RT * NC >= 32) ? 2 : (RT * NC >= 16) ? 3 : 4;
     const int ksteps = L.kpad >> 2;
     const float *wp = L.wt + (size_t)(lane >> 4) * L.n + c0 * 16 + (lane & 15);
     const float *ap = act + (lane & 15) * stride + (lane >> 4);
@@ -82,31 +83,58 @@ __device__ __forceinline__ void gemm_chunk(const float *__restrict__ act, int st
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int ct = 0; ct < NC; ++ct) acc[rt][ct] = (floatx4){0.f, 0.f, 0.f, 0.f};
-    float bq[PD][NC], aq[PD][RT];
+    if (!DEEP) {
+        float bn[NC], an[RT];
 #pragma unroll
-    for (int u = 0; u < PD; ++u) {
-        if (u < ksteps) {
+        for (int ct = 0; ct < NC; ++ct) bn[ct] = wp[ct * 16];
 #pragma unroll
-            for (int ct = 0; ct < NC; ++ct) bq[u][ct] = wp[(size_t)u * wstep + ct * 16];
+        for (int rt = 0; rt < RT; ++rt) an[rt] = ap[rt * 16 * stride];
+        for (int ks = 0; ks < ksteps; ++ks) {
+            float bc[NC], ac[RT];
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) aq[u][rt] = ap[rt * 16 * stride + u * 4];
+            for (int ct = 0; ct < NC; ++ct) bc[ct] = bn[ct];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) ac[rt] = an[rt];
+            if (ks + 1 < ksteps) {
+                const float *wn = wp + (size_t)(ks + 1) * wstep;
+#pragma unroll
+                for (int ct = 0; ct < NC; ++ct) bn[ct] = wn[ct * 16];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) an[rt] = ap[rt * 16 * stride + (ks + 1) * 4];
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < NC; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[rt], bc[ct], acc[rt][ct], 0, 0, 0);
         }
-    }
-    for (int ks = 0; ks < ksteps; ks += PD) {
+    } else {
+        constexpr int PD = 4;
+        float bq[PD][NC], aq[PD][RT];
 #pragma unroll
         for (int u = 0; u < PD; ++u) {
-            if (ks + u < ksteps) {
+            if (u < ksteps) {
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
+                for (int ct = 0; ct < NC; ++ct) bq[u][ct] = wp[(size_t)u * wstep + ct * 16];
 #pragma unroll
-                    for (int ct = 0; ct < NC; ++ct)
-                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[u][rt], bq[u][ct], acc[rt][ct], 0, 0, 0);
-                const int nx = ks + u + PD;
-                if (nx < ksteps) {
+                for (int rt = 0; rt < RT; ++rt) aq[u][rt] = ap[rt * 16 * stride + u * 4];
+            }
+        }
+        for (int ks = 0; ks < ksteps; ks += PD) {
 #pragma unroll
-                    for (int ct = 0; ct < NC; ++ct) bq[u][ct] = wp[(size_t)nx * wstep + ct * 16];
+            for (int u = 0; u < PD; ++u) {
+                if (ks + u < ksteps) {
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) aq[u][rt] = ap[rt * 16 * stride + nx * 4];
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int ct = 0; ct < NC; ++ct)
+                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[u][rt], bq[u][ct], acc[rt][ct], 0, 0, 0);
+                    const int nx = ks + u + PD;
+                    if (nx < ksteps) {
+#pragma unroll
+                        for (int ct = 0; ct < NC; ++ct) bq[u][ct] = wp[(size_t)nx * wstep + ct * 16];
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) aq[u][rt] = ap[rt * 16 * stride + nx * 4];
+                    }
                 }
             }
         }
@@ -194,7 +222,7 @@ __device__ __forceinline__ void run_layer_chunks(float *act, const PaChain &a, i
     const bool last = (l == a.nlayers - 1);
     for (int c0 = c_begin; c0 < c_end; c0 += NC) {
         floatx4 acc[RT][NC];
-        gemm_chunk<RT, NC>(act, a.lds_stride, L, c0, lane, acc);
+        gemm_chunk<RT, NC, (WPT > 1)>(act, a.lds_stride, L, c0, lane, acc);
         if (!last) {
             tile_sync<WPT>();  // every A read of this layer has landed before its rows are overwritten (single chunk per wave: host-checked)
             store_hidden<RT, NC>(act, a.lds_stride, L, c0, lane, acc);

@@ -1,0 +1,410 @@
+// NetVLAD pyramid + adaptive feature aggregator (APFA) on the MFMA pipe (gfx950, exact fp32 MFMA).
+//
+// Reference semantics (eval mode):
+//   NetVLADBase.forward      place_recognition/patch_aug_net/models/loupe.py:191-222
+//        A = softmax_K( BN1d_K( X Wc ) );  a_sum = sum_n A;  V = (A^T X)^T - a_sum * W2;  V /= max(||V||_2 over C, 1e-12)
+//   MLPAttentionLayer        loupe.py:24-41   w = softmax_k( max_o ( Watt x )[o,k] );  x <- relu(x + x*w)
+//   AdaptiveFeatureAggregator loupe.py:57-66  fc(21504 -> 256) + BN1d + L2 normalise
+//
+// MI355X design.  The reference runs ~14 torch kernels per scale and reads the (B, N, 256) feature map twice (once
+// transposed).  Here X is already point-major (the MLP chain writes it that way); one kernel per scale stages 64-row
+// tiles of X in LDS ONCE and uses them for both contractions: the assignment GEMM (A operand) and the aggregation
+// GEMM A^T X (B operand), with the soft-max done in registers on the MFMA C/D layout in between.  A^T X is
+// accumulated in registers across a workgroup's row tiles; per-workgroup partials are reduced by a tiny finalize
+// kernel that also subtracts a_sum*W2, intra-normalises and writes the concatenated (B, 256, sum K) layout.
+// The aggregator's 22 MB FC weight is streamed exactly once by a split-K MFMA kernel over ~170 workgroups.
+#include <string.h>
+
+#include "pa_common.h"
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int VC = 256;         // feature channels (every shipped config; checked on the host)
+constexpr int VROWS = 64;       // rows of X per LDS tile
+constexpr int XS = VC + 2;      // LDS row stride of the X tile (conflict-free A-fragment reads, see mlp_chain.hip)
+
+// ------------------------------------------------------------------------------------------------ NetVLAD accumulate
+// grid (chunks, B); each workgroup walks rows [chunk*rows_per_wg, +rows_per_wg) of cloud b in 64-row tiles.
+// part[b][chunk][kp][VC] = sum over its rows of A[row][k] * X[row][c];   asum_part[b][chunk][kp] = sum of A[row][k]
+template <int KT>
+__global__ __launch_bounds__(256) void vlad_accum_kernel(int n, int k_true, int rows_per_wg, const float *__restrict__ x_all,
+                                                           const float *__restrict__ wc_t,   // [VC][16*KT] K-major, BN folded
+                                                           const float *__restrict__ bias,   // [16*KT]
+                                                           float *__restrict__ part, float *__restrict__ asum_part)
+{
+    constexpr int KP = 16 * KT;
+    constexpr int AS = KP + 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Xs = smem;                      // [VROWS][XS]
+    float *As = smem + VROWS * XS;         // [VROWS][AS]
+    float *red = As + VROWS * AS;          // [4][KP] cross-wave a_sum
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+    const int row_begin = chunk * rows_per_wg;
+    const int row_end = min(row_begin + rows_per_wg, n);
+    const float *x = x_all + (size_t)b * n * VC;
+
+    floatx4 acc2[KT][4];                   // A^T X: KT cluster tiles x this wave's 4 channel tiles
+#pragma unroll
+    for (int rt = 0; rt < KT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc2[rt][ct] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    float asum[KT];
+#pragma unroll
+    for (int ct = 0; ct < KT; ++ct) asum[ct] = 0.f;
+    float bia[KT];
+#pragma unroll
+    for (int ct = 0; ct < KT; ++ct) bia[ct] = bias[ct * 16 + (lane & 15)];
+
+    for (int r0 = row_begin; r0 < row_end; r0 += VROWS) {
+        const int cnt = min(VROWS, row_end - r0);
+        // 1. stage X rows (zero rows beyond cnt), 16-byte global loads
+        const float4 *x4 = reinterpret_cast<const float4 *>(x + (size_t)r0 * VC);
+        for (int q = tid; q < VROWS * (VC / 4); q += 256) {
+            const int r = q / (VC / 4), part4 = q - r * (VC / 4);
+            const float4 v = r < cnt ? x4[(size_t)r * (VC / 4) + part4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float *d = Xs + r * XS + part4 * 4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+        // 2. assignment logits for this wave's 16 rows: X[16 x 256] * Wc[256 x KP]
+        floatx4 acc[KT];
+#pragma unroll
+        for (int ct = 0; ct < KT; ++ct) acc[ct] = (floatx4){0.f, 0.f, 0.f, 0.f};
+        {
+            const float *ap = Xs + (wave * 16 + (lane & 15)) * XS + (lane >> 4);
+            const float *wp = wc_t + (size_t)(lane >> 4) * KP + (lane & 15);
+            float bn[KT], an = ap[0];
+#pragma unroll
+            for (int ct = 0; ct < KT; ++ct) bn[ct] = wp[ct * 16];
+            for (int ks = 0; ks < VC / 4; ++ks) {
+                float bc[KT];
+                const float ac = an;
+#pragma unroll
+                for (int ct = 0; ct < KT; ++ct) bc[ct] = bn[ct];
+                if (ks + 1 < VC / 4) {
+                    an = ap[(ks + 1) * 4];
+#pragma unroll
+                    for (int ct = 0; ct < KT; ++ct) bn[ct] = wp[(size_t)(ks + 1) * 4 * KP + ct * 16];
+                }
+#pragma unroll
+                for (int ct = 0; ct < KT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac, bc[ct], acc[ct], 0, 0, 0);
+            }
+        }
+        // 3. soft-max over the k_true clusters of each row.  C/D layout: column (cluster) = 16*ct + lane%16,
+        //    row = 4*(lane/16) + r: a row's clusters live in the 16 lanes of a DPP row and the KT tiles.
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v[KT], mx = -3.0e38f;
+#pragma unroll
+            for (int ct = 0; ct < KT; ++ct) {
+                const bool live = ct * 16 + (lane & 15) < k_true;
+                v[ct] = live ? acc[ct][r] + bia[ct] : -3.0e38f;
+                mx = fmaxf(mx, v[ct]);
+            }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            float s = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < KT; ++ct) {
+                v[ct] = (ct * 16 + (lane & 15) < k_true) ? __expf(v[ct] - mx) : 0.f;
+                s += v[ct];
+            }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
+            const float inv = 1.0f / s;
+            const int row = wave * 16 + (lane >> 4) * 4 + r;
+            const bool row_live = row < cnt;
+#pragma unroll
+            for (int ct = 0; ct < KT; ++ct) {
+                const float a = row_live ? v[ct] * inv : 0.f;
+                As[row * AS + ct * 16 + (lane & 15)] = a;
+                asum[ct] += a;
+            }
+        }
+        __syncthreads();
+        // 4. aggregation: acc2[cluster tile][channel tile] += A^T[KP x 64 rows] * X[64 rows x 64 channels of this wave]
+        {
+            const float *ap = As + (lane >> 4) * AS + (lane & 15);            // A^T[i = cluster][k = row] = As[row][cluster]
+            const float *bp = Xs + (lane >> 4) * XS + wave * 64 + (lane & 15);
+            for (int ks = 0; ks < VROWS / 4; ++ks) {
+                float af[KT], bf[4];
+#pragma unroll
+                for (int rt = 0; rt < KT; ++rt) af[rt] = ap[ks * 4 * AS + rt * 16];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) bf[ct] = bp[ks * 4 * XS + ct * 16];
+#pragma unroll
+                for (int rt = 0; rt < KT; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) acc2[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[rt], bf[ct], acc2[rt][ct], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // partial A^T X
+    float *po = part + ((size_t)b * nchunks + chunk) * KP * VC;
+#pragma unroll
+    for (int rt = 0; rt < KT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                po[(size_t)(rt * 16 + (lane >> 4) * 4 + r) * VC + wave * 64 + ct * 16 + (lane & 15)] = acc2[rt][ct][r];
+    // partial a_sum: lanes sharing lane%16 hold different rows of the same cluster
+#pragma unroll
+    for (int ct = 0; ct < KT; ++ct) {
+        float s = asum[ct];
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (lane < 16) red[wave * KP + ct * 16 + lane] = s;
+    }
+    __syncthreads();
+    if (tid < KP) asum_part[((size_t)b * nchunks + chunk) * KP + tid] = (red[tid] + red[KP + tid]) + (red[2 * KP + tid] + red[3 * KP + tid]);
+}
+
+// grid (k_true, B), 256 threads = channels: reduce partials, subtract a_sum*W2, intra-normalise, write (B, VC, ldo) at column koff+k
+__global__ __launch_bounds__(256) void vlad_finalize_kernel(int nchunks, int kp, const float *__restrict__ part, const float *__restrict__ asum_part,
+                                                              const float *__restrict__ w2,  // [VC][k_true]
+                                                              int k_true, float *__restrict__ out, int ldo, int koff)
+{
+    __shared__ float red[4];
+    const int k = blockIdx.x, b = blockIdx.y, c = threadIdx.x;
+    float v = 0.f, a = 0.f;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        v += part[(((size_t)b * nchunks + ch) * kp + k) * VC + c];
+        a += asum_part[((size_t)b * nchunks + ch) * kp + k];
+    }
+    v = v - a * w2[(size_t)c * k_true + k];          // loupe.py:213-219
+    float ss = v * v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) ss += __shfl_xor(ss, o);
+    if ((c & 63) == 0) red[c >> 6] = ss;
+    __syncthreads();
+    const float nrm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+    out[((size_t)b * VC + c) * ldo + koff + k] = v / fmaxf(nrm, 1e-12f);   // F.normalize(dim=1), loupe.py:221
+}
+
+// ------------------------------------------------------------------------------------------------ APFA attention
+// grid (8, B): workgroup p computes r[o][k] = sum_c Watt[o][c] * x[c][k] for its 32 output channels o and all ktot
+// columns, then the column-wise max over those o.  pmax[b][p][k].
+__global__ __launch_bounds__(256) void afa_colmax_kernel(int ktot, const float *__restrict__ v_all,   // (B, VC, ktot)
+                                                           const float *__restrict__ watt,             // [VC][VC] row-major (o, c)
+                                                           float *__restrict__ pmax)                   // (B, 8, ktot)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // x tile [VC][ktp + 2] zero-padded columns
+    const int ktp = (ktot + 15) & ~15;
+    const int xs = ktp + 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, p = blockIdx.x;
+    const float *x = v_all + (size_t)b * VC * ktot;
+    for (int q = tid; q < VC * ktp; q += 256) {
+        const int c = q / ktp, k = q - c * ktp;
+        smem[c * xs + k] = k < ktot ? x[(size_t)c * ktot + k] : 0.f;
+    }
+    __syncthreads();
+    // wave w: output rows o = p*32 + (w&1)*16 + lane%16, column tiles (w>>1), (w>>1)+2, ... of the ktp/16 tiles
+    const int o0 = p * 32 + (wave & 1) * 16;
+    const int nct = ktp >> 4;
+    const float *ap = watt + (size_t)(o0 + (lane & 15)) * VC + (lane >> 4);     // A[i = o][k = c]
+    for (int ct = wave >> 1; ct < nct; ct += 2) {
+        floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
+        const float *bp = smem + (lane >> 4) * xs + ct * 16 + (lane & 15);      // B[k = c][j = column]
+        for (int ks = 0; ks < VC / 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[ks * 4], bp[ks * 4 * xs], acc, 0, 0, 0);
+        float m = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));            // rows 4*(lane/16) + r
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        // two waves (w&1 = 0/1) cover the 32 rows of this workgroup for the same columns: combine through LDS below
+        if (lane < 16) smem[VC * xs + (wave & 1) * ktp + ct * 16 + lane] = m;
+    }
+    __syncthreads();
+    for (int k = tid; k < ktot; k += 256) pmax[((size_t)b * 8 + p) * ktot + k] = fmaxf(smem[VC * xs + k], smem[VC * xs + ktp + k]);
+}
+
+// grid B: w = softmax_k(max_p pmax);  y[c][k] = relu(x + x*w)    (flat (B, VC*ktot), the FC input)
+__global__ __launch_bounds__(256) void afa_reweight_kernel(int ktot, const float *__restrict__ v_all, const float *__restrict__ pmax,
+                                                             float *__restrict__ y_all)
+{
+    __shared__ float w[256];
+    __shared__ float red[8];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float m = -3.0e38f;
+    if (tid < ktot)
+        for (int p = 0; p < 8; ++p) m = fmaxf(m, pmax[((size_t)b * 8 + p) * ktot + tid]);
+    float mx = m;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float e = tid < ktot ? __expf(m - mx) : 0.f;
+    float s = e;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = s;
+    __syncthreads();
+    s = (red[4] + red[5]) + (red[6] + red[7]);
+    w[tid] = e / s;
+    __syncthreads();
+    const float *x = v_all + (size_t)b * VC * ktot;
+    float *y = y_all + (size_t)b * VC * ktot;
+    for (int q = tid; q < VC * ktot; q += 256) {
+        const float xv = x[q];
+        y[q] = fmaxf(xv + xv * w[q % ktot], 0.f);          // loupe.py:33-38
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ split-K FC
+// out_part[s][b][n] = sum_{k in slice s} y[b][k] * Wt[k][n];  Wt K-major (kdim x nout), slices of KS rows, grid = nslices.
+template <int RT>
+__global__ __launch_bounds__(256) void fc_splitk_kernel(int bsz, int kdim, int nout, int ks_rows, const float *__restrict__ y,
+                                                          const float *__restrict__ wt, float *__restrict__ out_part)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = blockIdx.x;
+    const int k_begin = s * ks_rows, k_end = min(k_begin + ks_rows, kdim);
+    const int nct = nout >> 4;
+    for (int c0 = wave * 4; c0 < nct; c0 += 16) {   // this wave: column tiles c0..c0+3
+        floatx4 acc[RT][4];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = (floatx4){0.f, 0.f, 0.f, 0.f};
+        for (int k0 = k_begin; k0 < k_end; k0 += 32) {   // 8 k-steps of operands in flight: the weight stream comes from HBM
+            float af[8][RT], bf[8][4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int kk = k0 + u * 4 + (lane >> 4);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const int row = rt * 16 + (lane & 15);
+                    af[u][rt] = (row < bsz && kk < k_end) ? y[(size_t)row * kdim + kk] : 0.f;
+                }
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    bf[u][ct] = (kk < k_end && c0 + ct < nct) ? wt[(size_t)kk * nout + (c0 + ct) * 16 + (lane & 15)] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u][rt], bf[u][ct], acc[rt][ct], 0, 0, 0);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rt * 16 + (lane >> 4) * 4 + r;
+                    if (row < bsz && c0 + ct < nct) out_part[((size_t)s * bsz + row) * nout + (c0 + ct) * 16 + (lane & 15)] = acc[rt][ct][r];
+                }
+    }
+}
+
+// grid B, nout threads (<= 1024): sum the slices, + bias, BatchNorm (eval) as scale/shift, optional L2 normalise
+__global__ void fc_finalize_kernel(int bsz, int nout, int nslices, const float *__restrict__ out_part, const float *__restrict__ fc_bias,
+                                   const float *__restrict__ scale, const float *__restrict__ shift, int l2norm, float *__restrict__ desc)
+{
+    __shared__ float red[16];
+    const int b = blockIdx.x, n = threadIdx.x;
+    float v = 0.f;
+    for (int s = 0; s < nslices; ++s) v += out_part[((size_t)s * bsz + b) * nout + n];
+    v = (v + fc_bias[n]) * scale[n] + shift[n];
+    if (l2norm) {
+        float ss = v * v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) ss += __shfl_xor(ss, o);
+        if ((n & 63) == 0) red[n >> 6] = ss;
+        __syncthreads();
+        float t = 0.f;
+        for (int w = 0; w < (nout + 63) / 64; ++w) t += red[w];
+        v = v / fmaxf(sqrtf(t), 1e-12f);                   // F.normalize, loupe.py:63-64
+    }
+    desc[(size_t)b * nout + n] = v;
+}
+
+int vlad_chunks(int n) { int rows = n >= 2048 ? 512 : 64; return (n + rows - 1) / rows; }
+int vlad_rows_per_wg(int n) { return n >= 2048 ? 512 : 64; }
+
+}  // namespace
+
+PA_API long pa_netvlad_scratch_floats(int b, int n, int k)
+{
+    const int kp = (k + 15) & ~15;
+    return (long)b * vlad_chunks(n) * ((long)kp * VC + kp);
+}
+
+// X (b, n, 256) point-major -> out[b][c][koff + k], k < k_true, ldo floats per (b, c) row.
+PA_API int pa_netvlad(int b, int n, int c, int k, const float *x, const float *wc_t, const float *bias, const float *w2, float *scratch,
+                      float *out, int ldo, int koff, pa_stream_t stream)
+{
+    PA_REQUIRE(b > 0 && n > 0 && k > 0 && x && wc_t && bias && w2 && scratch && out, "pa_netvlad: bad arguments");
+    PA_REQUIRE(b <= 65535, "pa_netvlad: b=%d exceeds the grid limit", b);
+    if (c != VC || k > 64) { pa_set_error("pa_netvlad: built for 256 channels and <= 64 clusters (got c=%d k=%d)", c, k); return PA_EUNSUPPORTED; }
+    hipStream_t st = (hipStream_t)stream;
+    const int kp = (k + 15) & ~15, kt = kp / 16;
+    const int chunks = vlad_chunks(n), rows = vlad_rows_per_wg(n);
+    float *part = scratch;
+    float *asum = scratch + (size_t)b * chunks * kp * VC;
+    const size_t lds = (size_t)(VROWS * XS + VROWS * (kp + 2) + 4 * kp) * 4;
+#define PA_VLAD_LAUNCH(KT)                                                                                                              \
+    do {                                                                                                                                \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vlad_accum_kernel<KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(vlad_accum_kernel<KT>, dim3(chunks, b), dim3(256), lds, st, n, k, rows, x, wc_t, bias, part, asum);         \
+    } while (0)
+    switch (kt) {
+        case 1: PA_VLAD_LAUNCH(1); break;
+        case 2: PA_VLAD_LAUNCH(2); break;
+        case 3: PA_VLAD_LAUNCH(3); break;
+        default: PA_VLAD_LAUNCH(4); break;
+    }
+#undef PA_VLAD_LAUNCH
+    hipLaunchKernelGGL(vlad_finalize_kernel, dim3(k, b), dim3(256), 0, st, chunks, kp, part, asum, w2, k, out, ldo, koff);
+    PA_CHECK_LAUNCH("pa_netvlad");
+    return PA_OK;
+}
+
+PA_API long pa_afa_scratch_floats(int b, int c, int ktot, int nout)
+{
+    const long kdim = (long)c * ktot;
+    const long nslices = (kdim + 127) / 128;
+    return (long)b * 8 * ktot + (long)b * kdim + nslices * b * nout;
+}
+
+// v (b, 256, ktot) -> desc (b, nout).  watt: (256, 256) row-major (o, c);  fc_wt: K-major (256*ktot, nout);
+// scale/shift: BatchNorm1d (eval) folded to y*scale + shift;  l2norm != 0: F.normalize.
+PA_API int pa_afa(int b, int c, int ktot, int nout, const float *v, const float *watt, const float *fc_wt, const float *fc_bias,
+                  const float *scale, const float *shift, int l2norm, float *scratch, float *desc, pa_stream_t stream)
+{
+    PA_REQUIRE(b > 0 && ktot > 0 && nout > 0 && v && watt && fc_wt && fc_bias && scale && shift && scratch && desc, "pa_afa: bad arguments");
+    if (c != VC || ktot > 256 || nout % 16 || nout > 1024 || b > 64) {
+        pa_set_error("pa_afa: built for 256 channels, <= 256 columns, nout %% 16 == 0, nout <= 1024, b <= 64 (got c=%d ktot=%d nout=%d b=%d)", c, ktot, nout, b);
+        return PA_EUNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int kdim = c * ktot;
+    const int ks_rows = 128;
+    const int nslices = (kdim + ks_rows - 1) / ks_rows;
+    float *pmax = scratch;
+    float *y = pmax + (size_t)b * 8 * ktot;
+    float *opart = y + (size_t)b * kdim;
+    const int ktp = (ktot + 15) & ~15;
+    const size_t lds = (size_t)(VC * (ktp + 2) + 2 * ktp) * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&afa_colmax_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(afa_colmax_kernel, dim3(8, b), dim3(256), lds, st, ktot, v, watt, pmax);
+    hipLaunchKernelGGL(afa_reweight_kernel, dim3(b), dim3(256), 0, st, ktot, v, pmax, y);
+    const int rt = (b + 15) / 16;
+    switch (rt) {
+        case 1: hipLaunchKernelGGL(fc_splitk_kernel<1>, dim3(nslices), dim3(256), 0, st, b, kdim, nout, ks_rows, y, fc_wt, opart); break;
+        case 2: hipLaunchKernelGGL(fc_splitk_kernel<2>, dim3(nslices), dim3(256), 0, st, b, kdim, nout, ks_rows, y, fc_wt, opart); break;
+        case 3: hipLaunchKernelGGL(fc_splitk_kernel<3>, dim3(nslices), dim3(256), 0, st, b, kdim, nout, ks_rows, y, fc_wt, opart); break;
+        default: hipLaunchKernelGGL(fc_splitk_kernel<4>, dim3(nslices), dim3(256), 0, st, b, kdim, nout, ks_rows, y, fc_wt, opart); break;
+    }
+    hipLaunchKernelGGL(fc_finalize_kernel, dim3(b), dim3(nout), 0, st, b, nout, nslices, opart, fc_bias, scale, shift, l2norm, desc);
+    PA_CHECK_LAUNCH("pa_afa");
+    return PA_OK;
+}

@@ -89,6 +89,61 @@ class _Chain:
         return out
 
 
+def fold_bn1d(bn):
+    """BatchNorm1d (eval) as y*scale + shift, fp64 math."""
+    scale = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+    shift = bn.bias.detach().double() - bn.running_mean.detach().double() * scale
+    return scale, shift
+
+
+class _Vlad:
+    """One pyramid scale for pa_netvlad: BatchNorm folded into the K-major assignment weights."""
+
+    def __init__(self, v, device):
+        c, k = v.cluster_weights.shape
+        self.c, self.k, self.n = c, k, v.max_samples
+        kp = (k + 15) // 16 * 16
+        scale, shift = fold_bn1d(v.bn1)
+        wc = torch.zeros(c, kp, dtype=torch.float64)
+        wc[:, :k] = v.cluster_weights.detach().double().cpu() * scale.cpu()[None, :]
+        bias = torch.zeros(kp, dtype=torch.float64)
+        bias[:k] = shift.cpu()
+        self.wc_t = wc.float().contiguous().to(device)
+        self.bias = bias.float().contiguous().to(device)
+        self.w2 = v.cluster_weights2.detach()[0].float().contiguous().to(device)      # (C, K)
+
+    def run(self, x, out, ldo, koff):
+        b = x.shape[0]
+        nfl = _lib.lib().pa_netvlad_scratch_floats(b, self.n, self.k)
+        scratch = torch.empty(nfl, dtype=torch.float32, device=x.device)
+        call("pa_netvlad", b, self.n, self.c, self.k, ptr(x), ptr(self.wc_t), ptr(self.bias), ptr(self.w2), ptr(scratch),
+             ptr(out), ldo, koff)
+
+
+class _Afa:
+    """AdaptiveFeatureAggregator for pa_afa: K-major FC weight, BatchNorm folded to scale/shift."""
+
+    def __init__(self, afa, device):
+        if len(afa.mlpa.mlps) != 1:
+            raise ValueError("fused APFA supports the single-conv attention layer of the shipped configuration")
+        self.watt = afa.mlpa.mlps[0].weight.detach().squeeze(-1).float().contiguous().to(device)   # (out, in)
+        self.fc_wt = afa.fc.weight.detach().t().float().contiguous().to(device)                    # (C*K, nout) K-major
+        self.fc_bias = afa.fc.bias.detach().float().contiguous().to(device)
+        scale, shift = fold_bn1d(afa.bn)
+        self.scale, self.shift = scale.float().contiguous().to(device), shift.float().contiguous().to(device)
+        self.l2 = 1 if afa.l2_norm else 0
+        self.nout = afa.fc.out_features
+
+    def run(self, v):
+        b, c, ktot = v.shape
+        nfl = _lib.lib().pa_afa_scratch_floats(b, c, ktot, self.nout)
+        scratch = torch.empty(nfl, dtype=torch.float32, device=v.device)
+        desc = torch.empty((b, self.nout), dtype=torch.float32, device=v.device)
+        call("pa_afa", b, c, ktot, self.nout, ptr(v), ptr(self.watt), ptr(self.fc_wt), ptr(self.fc_bias), ptr(self.scale),
+             ptr(self.shift), self.l2, ptr(scratch), ptr(desc))
+        return desc
+
+
 class PatchAugNetEngine:
     def __init__(self, model, device):
         self.device = torch.device(device)
@@ -100,6 +155,13 @@ class PatchAugNetEngine:
             self.sa = [_Chain(fold_shared_mlp(m.mlps[0], self.device)) for m in bb.SA_modules]
             self.fp = [_Chain(fold_shared_mlp(m.mlp, self.device)) for m in bb.FP_modules]
         self.agg = model.aggregation
+        agg = self.agg
+        self.fused_head = (agg.aggregation_type == 2 and not agg.gating and all(v.feature_size == 256 and v.cluster_size <= 64 for v in agg.vlads)
+                           and sum(v.cluster_size for v in agg.vlads) <= 256 and agg.afa.fc.out_features % 16 == 0)
+        if self.fused_head:
+            with torch.no_grad():
+                self.vlads = [_Vlad(v, self.device) for v in agg.vlads]
+                self.afa = _Afa(agg.afa, self.device)
         self._key = self._params_key(model)
         self.timer = None     # optional profiling.StageTimer: per-stage HIP-event marks (bench.py kernel attribution)
 
@@ -183,6 +245,17 @@ class PatchAugNetEngine:
         nfp = len(self.fp)
         feats = [l_feat[j] for j in range(nfp - 1, -1, -1)]                                   # coarse -> fine, (B, N_i, 256)
         agg = self.agg
+        if self.fused_head and x.shape[0] <= 64:
+            ktot = sum(v.k for v in self.vlads)
+            v = torch.empty((x.shape[0], 256, ktot), dtype=torch.float32, device=self.device)
+            koff = 0
+            for vl, f in zip(self.vlads, feats):
+                vl.run(f.contiguous(), v, ktot, koff)
+                koff += vl.k
+            self._mark("vlad")
+            desc = self.afa.run(v)
+            self._mark("afa")
+            return desc, self._views(feats, l_c)
         v = torch.cat([self._vlad(vl, f) for vl, f in zip(agg.vlads, feats)], dim=-1)       # (B, 256, sum K)
         self._mark("vlad")
         if agg.aggregation_type == 2:
@@ -194,8 +267,11 @@ class PatchAugNetEngine:
         if agg.gating:
             desc = agg.context_gating(desc)
         self._mark("afa")
+        return desc, self._views(feats, l_c)
+
+    @staticmethod
+    def _views(feats, l_c):
         c_o = [l_c[0]]
         for i in range(1, len(l_c)):
             c_o.append(torch.gather(c_o[i - 1], -1, l_c[i].long()))
-        fp_features = [f.transpose(1, 2).unsqueeze(-1) for f in feats]                       # (B, 256, N_i, 1) views
-        return desc, fp_features, c_o
+        return [f.transpose(1, 2).unsqueeze(-1) for f in feats], c_o                         # (B, 256, N_i, 1) views

@@ -81,7 +81,7 @@ class Network(nn.Module):
             use_engine = self.fused_eval and not self.training and not torch.is_grad_enabled() and nn_dict is None
         fused = use_engine
         if fused:
-            desc, fp_features, center_idx = self._fused(x)
+            desc, (fp_features, center_idx) = self._fused(x)
             return (desc, fp_features, center_idx) if return_feat else desc
         xyz = x.squeeze(1)
         res = self.backbone(xyz)

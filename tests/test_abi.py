@@ -24,7 +24,7 @@ def libpath():
 def declared_symbols():
     src = open(os.path.join(ROOT, "include", "patchaugnet_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|void|const char \*)\s*\*?\s*([a-z_0-9]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(?:int|long|void|const char \*)\s*\*?\s*([a-z_0-9]+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol(libpath):
@@ -39,7 +39,8 @@ def test_library_exports_every_declared_symbol(libpath):
 
 def test_bindings_cover_the_pa_entry_points(libpath):
     from patchaugnet_amd import _lib
-    pa = [n for n in declared_symbols() if n.startswith("pa_") and n not in ("pa_abi_version", "pa_last_error")]
+    pa = [n for n in declared_symbols() if n.startswith("pa_") and n not in ("pa_abi_version", "pa_last_error")
+          and not n.endswith("_scratch_floats")]
     assert sorted(pa) == sorted(_lib._SIGS), set(pa) ^ set(_lib._SIGS)
 
 
