@@ -47,6 +47,10 @@ const char *pa_last_error(void); /* thread-local text of the last non-zero retur
  * k mod block, then lower k). */
 int pa_furthestsampling(int b, int n, int m, const float *xyz, float *temp, int *idx, pa_stream_t stream);
 
+/* Engine form: running minima start at 1e10 and never leave registers (no temp tensor) and the sampled coordinates
+ * new_xyz (b, m, 3) are written next to idx (fuses the gathering call of patch_aug_net.py:222-225).  n <= 8192. */
+int pa_furthestsampling_gather(int b, int n, int m, const float *xyz, int *idx, float *new_xyz, pa_stream_t stream);
+
 /* ---- K2/K3: gathering  (sampling_cuda_kernel.h:15-16, .cu:6-36) -----------------------------
  * forward: out[b,c,j] = points[b,c,idx[b,j]];  backward: grad_points[b,c,idx[b,j]] += grad_out[b,c,j]
  * (grad_points must be zeroed by the caller, libs/pointops/functions/pointops.py:52). */
@@ -72,6 +76,9 @@ int pa_grouping_int_forward(int b, int c, int n, int m, int nsample, const int64
 int pa_nearestneighbor(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx, pa_stream_t stream);
 int pa_interpolation_forward(int b, int c, int m, int n, const float *points, const int *idx, const float *weight, float *out, pa_stream_t stream);
 int pa_interpolation_backward(int b, int c, int n, int m, const float *grad_out, const int *idx, const float *weight, float *grad_points, pa_stream_t stream);
+
+/* K9 with the FP module's inverse-distance weights fused in (patch_aug_net.py:350-353): weight (b,n,3), idx (b,n,3). */
+int pa_three_nn_weights(int b, int n, int m, const float *unknown, const float *known, float *weight, int *idx, pa_stream_t stream);
 
 /* ---- K13: ball query  (ballquery_cuda_kernel.h:17, .cu:47-80); idx caller-zeroed --------------*/
 int pa_ballquery(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int *idx, pa_stream_t stream);

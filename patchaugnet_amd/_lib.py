@@ -40,6 +40,8 @@ _SIGS = {
     "pa_mlp_chain": "iiipppplipippppiiiippppiiiipi",
     "pa_rowgroup_max": "liipp",
     "pa_netvlad": "iiiippppppii",
+    "pa_furthestsampling_gather": "iiippp",
+    "pa_three_nn_weights": "iiipppp",
     "pa_afa": "iiiippppppipp",
 }
 _T = {"i": _I, "f": _F, "p": _P, "l": ctypes.c_long}

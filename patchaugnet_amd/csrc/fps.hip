@@ -40,7 +40,7 @@ __device__ __forceinline__ int fps_decode(u32 lowkey, FpsOrder o)
 // Register-resident path: NT threads, PPT points per lane, n <= NT*PPT, cloud copy in LDS (SoA, 12 B/point).
 template <int NT, int PPT>
 __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, FpsOrder ord, const float *__restrict__ xyz_all,
-                                                       float *__restrict__ temp_all, int *__restrict__ idx_all)
+                                                       float *__restrict__ temp_all, int *__restrict__ idx_all, float *__restrict__ new_xyz_all)
 {
     constexpr int NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -49,8 +49,9 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, FpsOrder ord,
 
     const int b = blockIdx.x, tid = threadIdx.x;
     const float *xyz = xyz_all + (size_t)b * n * 3;
-    float *temp = temp_all + (size_t)b * n;
+    float *temp = temp_all ? temp_all + (size_t)b * n : nullptr;   // nullptr: start from 1e10 (pointops.py:21), do not write back
     int *idxs = idx_all + (size_t)b * m;
+    float *nxyz = new_xyz_all ? new_xyz_all + (size_t)b * m * 3 : nullptr;   // optional fused gather of the sampled coordinates
 
     float px[PPT], py[PPT], pz[PPT], t[PPT];
     u32 low[PPT];
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, FpsOrder ord,
             px[p] = xyz[k * 3 + 0];
             py[p] = xyz[k * 3 + 1];
             pz[p] = xyz[k * 3 + 2];
-            t[p] = temp[k];
+            t[p] = temp ? temp[k] : 1e10f;
             low[p] = fps_lowkey(k, ord);
             sx[k] = px[p];
             sy[k] = py[p];
@@ -75,6 +76,7 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, FpsOrder ord,
     if (tid == 0) idxs[0] = 0;
     __syncthreads();
     float ox = sx[0], oy = sy[0], oz = sz[0];
+    if (tid == 0 && nxyz) { nxyz[0] = ox; nxyz[1] = oy; nxyz[2] = oz; }
 
     for (int j = 1; j < m; ++j) {
         u64 best = 0;
@@ -97,12 +99,17 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, FpsOrder ord,
         ox = sx[old];
         oy = sy[old];
         oz = sz[old];
-        if (tid == 0) idxs[j] = old;
+        if (tid == 0) {
+            idxs[j] = old;
+            if (nxyz) { nxyz[j * 3 + 0] = ox; nxyz[j * 3 + 1] = oy; nxyz[j * 3 + 2] = oz; }
+        }
     }
+    if (temp) {
 #pragma unroll
-    for (int p = 0; p < PPT; ++p) {
-        const int k = tid + p * NT;
-        if (k < n) temp[k] = t[p];
+        for (int p = 0; p < PPT; ++p) {
+            const int k = tid + p * NT;
+            if (k < n) temp[k] = t[p];
+        }
     }
 }
 
@@ -140,22 +147,22 @@ __global__ __launch_bounds__(1024) void fps_stream_kernel(int n, int m, FpsOrder
 }
 
 template <int NT, int PPT>
-int launch_reg(int b, int n, int m, FpsOrder ord, const float *xyz, float *temp, int *idx, hipStream_t st)
+int launch_reg(int b, int n, int m, FpsOrder ord, const float *xyz, float *temp, int *idx, float *new_xyz, hipStream_t st)
 {
     const size_t lds = (size_t)(3 * n + ((3 * n) & 1)) * 4 + 2 * (NT / 64) * 8;
     if (lds > 48 * 1024)  // opt in to the large-LDS carve-out (gfx950: 160 KiB per CU)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_reg_kernel<NT, PPT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((fps_reg_kernel<NT, PPT>), dim3(b), dim3(NT), lds, st, n, m, ord, xyz, temp, idx);
+    hipLaunchKernelGGL((fps_reg_kernel<NT, PPT>), dim3(b), dim3(NT), lds, st, n, m, ord, xyz, temp, idx, new_xyz);
     return 0;
 }
 
 }  // namespace
 
-PA_API int pa_furthestsampling(int b, int n, int m, const float *xyz, float *temp, int *idx, pa_stream_t stream)
+static int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int *idx, float *new_xyz, pa_stream_t stream)
 {
     PA_REQUIRE(b > 0 && n > 0, "pa_furthestsampling: b=%d n=%d must be positive", b, n);
-    PA_REQUIRE(xyz && temp && idx, "pa_furthestsampling: null pointer");
+    PA_REQUIRE(xyz && idx, "pa_furthestsampling: null pointer");
     if (m <= 0) return PA_OK;  // sampling_cuda_kernel.cu:61-62
     hipStream_t st = (hipStream_t)stream;
     const int bs = pa_opt_n_threads(n);
@@ -166,15 +173,34 @@ PA_API int pa_furthestsampling(int b, int n, int m, const float *xyz, float *tem
     ord.qbits = 0;
     while ((1 << ord.qbits) < Q) ++ord.qbits;
 
-    if (n <= 64) launch_reg<64, 1>(b, n, m, ord, xyz, temp, idx, st);
-    else if (n <= 128) launch_reg<64, 2>(b, n, m, ord, xyz, temp, idx, st);
-    else if (n <= 256) launch_reg<64, 4>(b, n, m, ord, xyz, temp, idx, st);
-    else if (n <= 512) launch_reg<64, 8>(b, n, m, ord, xyz, temp, idx, st);
-    else if (n <= 1024) launch_reg<256, 4>(b, n, m, ord, xyz, temp, idx, st);
-    else if (n <= 2048) launch_reg<256, 8>(b, n, m, ord, xyz, temp, idx, st);
-    else if (n <= 4096) launch_reg<256, 16>(b, n, m, ord, xyz, temp, idx, st);
-    else if (n <= 8192) launch_reg<256, 32>(b, n, m, ord, xyz, temp, idx, st);
-    else hipLaunchKernelGGL(fps_stream_kernel, dim3(b), dim3(1024), 0, st, n, m, ord, xyz, temp, idx);
+    if (n <= 64) launch_reg<64, 1>(b, n, m, ord, xyz, temp, idx, new_xyz, st);
+    else if (n <= 128) launch_reg<64, 2>(b, n, m, ord, xyz, temp, idx, new_xyz, st);
+    else if (n <= 256) launch_reg<64, 4>(b, n, m, ord, xyz, temp, idx, new_xyz, st);
+    else if (n <= 512) launch_reg<64, 8>(b, n, m, ord, xyz, temp, idx, new_xyz, st);
+    else if (n <= 1024) launch_reg<256, 4>(b, n, m, ord, xyz, temp, idx, new_xyz, st);
+    else if (n <= 2048) launch_reg<256, 8>(b, n, m, ord, xyz, temp, idx, new_xyz, st);
+    else if (n <= 4096) launch_reg<256, 16>(b, n, m, ord, xyz, temp, idx, new_xyz, st);
+    else if (n <= 8192) launch_reg<256, 32>(b, n, m, ord, xyz, temp, idx, new_xyz, st);
+    else {
+        PA_REQUIRE(temp && !new_xyz, "pa_furthestsampling: clouds above 8192 points need the caller's temp buffer and no fused gather");
+        hipLaunchKernelGGL(fps_stream_kernel, dim3(b), dim3(1024), 0, st, n, m, ord, xyz, temp, idx);
+    }
     PA_CHECK_LAUNCH("pa_furthestsampling");
     return PA_OK;
+}
+
+PA_API int pa_furthestsampling(int b, int n, int m, const float *xyz, float *temp, int *idx, pa_stream_t stream)
+{
+    PA_REQUIRE(temp, "pa_furthestsampling: null temp");
+    return fps_dispatch(b, n, m, xyz, temp, idx, nullptr, stream);
+}
+
+// Fused form used by the inference engine: running minima start at 1e10 and stay in registers (no temp tensor),
+// and the sampled coordinates new_xyz (b, m, 3) are written alongside idx (replaces the gathering call of
+// patch_aug_net.py:222-225).  n <= 8192.
+PA_API int pa_furthestsampling_gather(int b, int n, int m, const float *xyz, int *idx, float *new_xyz, pa_stream_t stream)
+{
+    PA_REQUIRE(new_xyz, "pa_furthestsampling_gather: null new_xyz");
+    PA_REQUIRE(n <= 8192, "pa_furthestsampling_gather: n=%d exceeds the register-resident limit 8192", n);
+    return fps_dispatch(b, n, m, xyz, nullptr, idx, new_xyz, stream);
 }

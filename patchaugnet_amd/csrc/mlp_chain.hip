@@ -21,6 +21,7 @@
 //     (col = l%16, row = 4*(l/16) + reg) the four accumulator registers of a lane are the four groups and the
 //     max over neighbours is a plain v_max across row tiles plus two cross-lane steps -- the widest activation
 //     (the last layer's output) never leaves registers.
+#include <stdlib.h>
 #include <string.h>
 
 #include "pa_common.h"
@@ -439,9 +440,10 @@ PA_API int pa_mlp_chain(int mode, int pooled, int nlayers, const float *const *w
         const int per = nout[l] / 64;
         can_split = can_split && (nout[l] % 64 == 0) && (l + 1 == nlayers || (per <= 8 && (per & (per - 1)) == 0));
     }
+    static const long split_below = getenv("PA_CHAIN_SPLIT_BELOW") ? atol(getenv("PA_CHAIN_SPLIT_BELOW")) : 2048;   // tuning knob
     if (!is_pooled) {
         const long t32 = (total_rows + 31) / 32;
-        if (can_split && t32 < 2048) { split = true; RTv = t32 >= 512 ? 2 : 1; }
+        if (can_split && t32 < split_below) { split = true; RTv = t32 >= 512 ? 2 : 1; }
     } else {
         const long tp = (rows + 3) / 4;
         if (can_split && tp < 2048 && RTv == 5) split = true;

@@ -22,6 +22,7 @@ __device__ __forceinline__ void stage_tile(float4 *s, const float *__restrict__ 
     for (int i = tid; i < count; i += nt) s[i] = make_float4(src[i * 3 + 0], src[i * 3 + 1], src[i * 3 + 2], 0.f);
 }
 
+template <bool WEIGHTS>
 __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float *__restrict__ unknown_all,
                                                          const float *__restrict__ known_all, float *__restrict__ dist2_all,
                                                          int *__restrict__ idx_all)
@@ -59,7 +60,13 @@ __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float
     if (pt < n) {
         float *od = dist2_all + ((size_t)b * n + pt) * 3;
         int *oi = idx_all + ((size_t)b * n + pt) * 3;
-        od[0] = b1; od[1] = b2; od[2] = b3;
+        if (WEIGHTS) {  // patch_aug_net.py:350-353: d = sqrt(d2); r = 1/(d + 1e-8); w = r / ((r0 + r1) + r2)
+            const float r1 = 1.0f / (sqrtf(b1) + 1e-8f), r2 = 1.0f / (sqrtf(b2) + 1e-8f), r3 = 1.0f / (sqrtf(b3) + 1e-8f);
+            const float norm = (r1 + r2) + r3;
+            od[0] = r1 / norm; od[1] = r2 / norm; od[2] = r3 / norm;
+        } else {
+            od[0] = b1; od[1] = b2; od[2] = b3;
+        }
         oi[0] = i1; oi[1] = i2; oi[2] = i3;
     }
 }
@@ -167,8 +174,20 @@ PA_API int pa_nearestneighbor(int b, int n, int m, const float *unknown, const f
     PA_REQUIRE(b > 0 && n > 0 && m > 0, "pa_nearestneighbor: b=%d n=%d m=%d must be positive", b, n, m);
     PA_REQUIRE(unknown && known && dist2 && idx, "pa_nearestneighbor: null pointer");
     PA_GRID_B(b, "pa_nearestneighbor");
-    hipLaunchKernelGGL(three_nn_kernel, dim3(pa_div_up(n, 256), b), dim3(256), 0, (hipStream_t)stream, n, m, unknown, known, dist2, idx);
+    hipLaunchKernelGGL(three_nn_kernel<false>, dim3(pa_div_up(n, 256), b), dim3(256), 0, (hipStream_t)stream, n, m, unknown, known, dist2, idx);
     PA_CHECK_LAUNCH("pa_nearestneighbor");
+    return PA_OK;
+}
+
+// 3-NN with the inverse-distance interpolation weights of the FP module fused in (patch_aug_net.py:350-353):
+// weight (b, n, 3) instead of dist2.  Same neighbours, same order.
+PA_API int pa_three_nn_weights(int b, int n, int m, const float *unknown, const float *known, float *weight, int *idx, pa_stream_t stream)
+{
+    PA_REQUIRE(b > 0 && n > 0 && m > 0, "pa_three_nn_weights: b=%d n=%d m=%d must be positive", b, n, m);
+    PA_REQUIRE(unknown && known && weight && idx, "pa_three_nn_weights: null pointer");
+    PA_GRID_B(b, "pa_three_nn_weights");
+    hipLaunchKernelGGL(three_nn_kernel<true>, dim3(pa_div_up(n, 256), b), dim3(256), 0, (hipStream_t)stream, n, m, unknown, known, weight, idx);
+    PA_CHECK_LAUNCH("pa_three_nn_weights");
     return PA_OK;
 }
 

@@ -208,10 +208,14 @@ __global__ __launch_bounds__(256) void afa_colmax_kernel(int ktot, const float *
     const int o0 = p * 32 + (wave & 1) * 16;
     const int nct = ktp >> 4;
     const float *ap = watt + (size_t)(o0 + (lane & 15)) * VC + (lane >> 4);     // A[i = o][k = c]
+    float af[VC / 4];                                                             // the wave's whole A panel: reused by every column tile
+#pragma unroll
+    for (int ks = 0; ks < VC / 4; ++ks) af[ks] = ap[ks * 4];
     for (int ct = wave >> 1; ct < nct; ct += 2) {
         floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
         const float *bp = smem + (lane >> 4) * xs + ct * 16 + (lane & 15);      // B[k = c][j = column]
-        for (int ks = 0; ks < VC / 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[ks * 4], bp[ks * 4 * xs], acc, 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < VC / 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks], bp[ks * 4 * xs], acc, 0, 0, 0);
         float m = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));            // rows 4*(lane/16) + r
         m = fmaxf(m, __shfl_xor(m, 16));
         m = fmaxf(m, __shfl_xor(m, 32));
@@ -311,8 +315,16 @@ __global__ void fc_finalize_kernel(int bsz, int nout, int nslices, const float *
 {
     __shared__ float red[16];
     const int b = blockIdx.x, n = threadIdx.x;
-    float v = 0.f;
-    for (int s = 0; s < nslices; ++s) v += out_part[((size_t)s * bsz + b) * nout + n];
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;   // four independent chains: the loop is pure load latency otherwise
+    int s = 0;
+    for (; s + 4 <= nslices; s += 4) {
+        v0 += out_part[((size_t)(s + 0) * bsz + b) * nout + n];
+        v1 += out_part[((size_t)(s + 1) * bsz + b) * nout + n];
+        v2 += out_part[((size_t)(s + 2) * bsz + b) * nout + n];
+        v3 += out_part[((size_t)(s + 3) * bsz + b) * nout + n];
+    }
+    for (; s < nslices; ++s) v0 += out_part[((size_t)s * bsz + b) * nout + n];
+    float v = (v0 + v1) + (v2 + v3);
     v = (v + fc_bias[n]) * scale[n] + shift[n];
     if (l2norm) {
         float ss = v * v;

@@ -185,10 +185,9 @@ class PatchAugNetEngine:
             src = l_xyz[i]
             n, m, ns = src.shape[1], self.sampling[i], self.knn[i]
             cidx = torch.empty((B, m), dtype=torch.int32, device=self.device)
-            temp = torch.full((B, n), 1e10, dtype=torch.float32, device=self.device)
-            call("pa_furthestsampling", B, n, m, ptr(src), ptr(temp), ptr(cidx))
+            new_xyz = torch.empty((B, m, 3), dtype=torch.float32, device=self.device)
+            call("pa_furthestsampling_gather", B, n, m, ptr(src), ptr(cidx), ptr(new_xyz))
             self._mark(f"sa{i}.fps")
-            new_xyz = torch.gather(src, 1, cidx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
             nbr = torch.empty((B, m, ns), dtype=torch.int32, device=self.device)
             d2 = torch.empty((B, m, ns), dtype=torch.float32, device=self.device)
             call("pa_knnquery", B, n, m, ns, ptr(src), ptr(new_xyz), ptr(nbr), ptr(d2))
@@ -210,12 +209,10 @@ class PatchAugNetEngine:
             chain = self.fp[nfp + i]
             unknown, known = l_xyz[i - 1], l_xyz[i]
             n_u, m_k = unknown.shape[1], known.shape[1]
-            d2 = torch.empty((B, n_u, 3), dtype=torch.float32, device=self.device)
+            w3 = torch.empty((B, n_u, 3), dtype=torch.float32, device=self.device)
             idx3 = torch.empty((B, n_u, 3), dtype=torch.int32, device=self.device)
-            call("pa_nearestneighbor", B, n_u, m_k, ptr(unknown), ptr(known), ptr(d2), ptr(idx3))
+            call("pa_three_nn_weights", B, n_u, m_k, ptr(unknown), ptr(known), ptr(w3), ptr(idx3))   # patch_aug_net.py:350-353
             self._mark(f"fp{nfp + i}.3nn")
-            r = 1.0 / (torch.sqrt(d2) + 1e-8)                                                # patch_aug_net.py:351-353
-            w3 = (r / torch.sum(r, dim=2, keepdim=True)).contiguous()
             skip = l_feat[i - 1]
             if i == -nfp and not self.use_origin:
                 skip = None

@@ -198,3 +198,33 @@ def test_full_size_properties(P):
     g = P.grouping(x.transpose(1, 2).contiguous(), ki)
     d = g - new_xyz.transpose(1, 2).unsqueeze(-1)
     assert torch.allclose((d * d).sum(1), kd, atol=1e-6)                             # gathered points are at dist2
+
+
+@pytest.mark.parametrize("b,n,m,kind", [(2, 4096, 1024, "uniform"), (2, 1024, 128, "lattice"), (3, 128, 16, "uniform"), (1, 700, 50, "dup")])
+def test_fps_gather_form(b, n, m, kind):
+    """Engine form: no temp tensor, new_xyz written by the sampling kernel itself."""
+    from patchaugnet_amd import _lib
+    x = cloud(b, n, kind)
+    xd = dev(x)
+    idx = torch.empty((b, m), dtype=torch.int32, device="cuda")
+    nx = torch.empty((b, m, 3), device="cuda")
+    _lib.call("pa_furthestsampling_gather", b, n, m, _lib.ptr(xd), _lib.ptr(idx), _lib.ptr(nx))
+    ref = o.furthestsampling(x, m)
+    assert np.array_equal(idx.cpu().numpy(), ref)
+    assert np.array_equal(nx.cpu().numpy(), np.take_along_axis(x, ref[..., None].astype(np.int64), 1))
+
+
+@pytest.mark.parametrize("b,n,m", [(2, 4096, 1024), (2, 128, 16), (1, 77, 5)])
+def test_three_nn_weights_form(b, n, m):
+    from patchaugnet_amd import _lib
+    u, kn = cloud(b, n), cloud(b, m)
+    u[0, :3] = kn[0, :3]                      # exact coincidences: d = 0 -> 1/(0 + 1e-8)
+    w = torch.empty((b, n, 3), device="cuda")
+    idx = torch.empty((b, n, 3), dtype=torch.int32, device="cuda")
+    ud, kd = dev(u), dev(kn)
+    _lib.call("pa_three_nn_weights", b, n, m, _lib.ptr(ud), _lib.ptr(kd), _lib.ptr(w), _lib.ptr(idx))
+    rd, ri = o.nearestneighbor(u, kn)
+    assert np.array_equal(idx.cpu().numpy(), ri)
+    r = 1.0 / (torch.sqrt(torch.from_numpy(rd)) + 1e-8)       # patch_aug_net.py:351-353
+    ref = r / torch.sum(r, dim=2, keepdim=True)
+    assert torch.allclose(w.cpu(), ref, rtol=1e-6, atol=1e-9)
