@@ -14,11 +14,14 @@
 // consecutive indices once (int4), reuses them for all CT rows, gathers from LDS and writes one coalesced 16-byte
 // store per row.  HBM traffic is therefore the algorithmic minimum 4*(c*n + m*k + c*m*k) bytes per batch element
 // plus an idx re-read per channel tile (c/CT times, L2-resident).  K2 is K5 with nsample = 1.
+#include <stdlib.h>
+
 #include "pa_common.h"
 
 namespace {
 
 constexpr int GT = 256;  // threads per workgroup
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 // rows: CT channel rows of length n staged in LDS; cols: flattened (j,s) output columns [col0, col1)
 template <int CT>
@@ -52,8 +55,8 @@ __global__ __launch_bounds__(GT) void group_lds_kernel(int c, int n, int mk, int
             for (int r = 0; r < CT; ++r) {
                 if (r < ct) {
                     const float *row = rows + r * n;
-                    const float4 v = make_float4(row[i4.x], row[i4.y], row[i4.z], row[i4.w]);
-                    *reinterpret_cast<float4 *>(o + (size_t)r * mk + t) = v;
+                    const v4f v = {row[i4.x], row[i4.y], row[i4.z], row[i4.w]};
+                    __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(o + (size_t)r * mk + t));   // write-once stream
                 }
             }
         }
@@ -143,16 +146,18 @@ __global__ __launch_bounds__(GT) void interp_backward_kernel(int c, int n, int m
     atomicAdd(gp + id[2], g * w[2]);
 }
 
-// pick the channel tile so CT rows fit in 64 KiB of LDS (two workgroups per CU) and the column split so that the
-// launch has >= ~1024 workgroups whenever the problem is big enough
+// pick the channel tile so CT rows fit in 32 KiB of LDS (>= 4 workgroups per CU: one stages while others gather and
+// stream out) and the column split so that the launch has >= ~1024 workgroups whenever the problem is big enough
 struct GatherPlan { int ct; int cols_per_block; int col_blocks; size_t lds; };
 
 GatherPlan plan(int b, int c, int row_len, int cols)
 {
     GatherPlan p;
     const size_t row_bytes = (size_t)row_len * 4;
-    p.ct = 16;
-    while (p.ct > 1 && (p.ct * row_bytes > 64 * 1024 || p.ct / 2 >= c)) p.ct /= 2;
+    static const int ct_max = getenv("PA_GROUP_CT") ? atoi(getenv("PA_GROUP_CT")) : 4;   // tuning knobs; defaults from the MI355X sweep in profiles/r01_grouping_sweep.txt
+    static const size_t lds_cap = getenv("PA_GROUP_LDS_KB") ? (size_t)atoi(getenv("PA_GROUP_LDS_KB")) * 1024 : 32 * 1024;
+    p.ct = ct_max;
+    while (p.ct > 1 && (p.ct * row_bytes > lds_cap || p.ct / 2 >= c)) p.ct /= 2;
     p.lds = (size_t)p.ct * row_bytes;
     const long wg = (long)b * pa_div_up(c, p.ct);
     int split = 1;

@@ -1,0 +1,5 @@
+import sys, os, json
+sys.path.insert(0, os.getcwd())
+import torch
+import bench
+print(json.dumps({k: (round(v["ms"],4), round(v["GBps"])) for k, v in bench.grouping_roofline().items()}))
