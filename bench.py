@@ -33,7 +33,7 @@ def parse():
     p.add_argument("--module-path", action="store_true", help="force the unfused module path instead of the fused engine")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-pass", action="store_true")
-    p.add_argument("--cpu-batch", type=int, default=4)
+    p.add_argument("--cpu-batch", type=int, default=8)
     p.add_argument("--streams", type=int, default=2, help="HIP streams the consecutive steps are issued on (1 = strictly sequential)")
     return p.parse_args()
 
@@ -75,11 +75,46 @@ def stage_pass(model, x, iters=5):
         return profiling.stage_times(model, x, iters)
 
 
+def dominant_kernel_roofline(st, cfg, batch, points, grouping):
+    """Roofline of the kernel that owns the most CU-time in a step.
+
+    Stage times come from HIP events on the launch stream (patchaugnet_amd/profiling.py).  CU-time = duration x share of the
+    256 CUs the launch can occupy: the FPS launches are 1 workgroup per cloud (batch/256 of the chip) and are latency-bound,
+    every other launch fills the chip.  In round 1 the owner is the finest feature-propagation chain (fp0: 259->256->256->256
+    on batch*points rows), an MFMA-bound kernel; its algorithmic FLOPs are 2*rows*sum(K_l*N_l) with the TRUE K (no padding)."""
+    if "fp0.chain" not in st:
+        mc = grouping["micro_c64"]
+        return {"roofline": {"kernel": "group_lds_kernel (pa_grouping_forward)", "bound": "hbm", "achieved": mc["GBps"], "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": mc["GBps"] / HBM_PEAK_GBS, "traffic": None}}
+    fs = cfg["FEATURE_SIZE"]
+    dims = [fs[1] + (3 if cfg["USE_ORIGIN_PC_IN_FP"] else 0), 256, 256, fs[0]]
+    rows = batch * points
+    flops = 2.0 * rows * sum(k * n for k, n in zip(dims[:-1], dims[1:]))
+    ms = st["fp0.chain"]
+    tf = flops / (ms * 1e-3) / 1e12
+    cu_time = {k: v * (min(batch, 256) / 256.0 if k.endswith(".fps") else 1.0) for k, v in st.items() if k != "total"}
+    owner = max(cu_time, key=cu_time.get)
+    mc = grouping["micro_c64"]
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(pmc):   # HBM bytes per launch from rocprofv3 PMC passes of this kernel at this shape (profiles/)
+        traffic = json.load(open(pmc)).get("chain_fp0_bytes_per_launch")
+    return {
+        "roofline": {"kernel": "chain_kernel<2,16,FP,0,1> (pa_mlp_chain, fp0: 3-NN interpolate + 259->256->256->256 shared MLP)",
+                     "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
+                     "traffic": traffic, "algorithmic_flops_per_launch": flops, "ms_per_launch": ms, "cu_time_owner": owner},
+        "roofline_grouping": {"kernel": "group_lds_kernel (pa_grouping_forward, K5)", "bound": "hbm", "achieved": mc["GBps"], "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": mc["GBps"] / HBM_PEAK_GBS, "traffic": None, "shape": mc["shape"],
+                              "algorithmic_bytes_per_launch": mc["algorithmic_bytes"], "ms_per_launch": mc["ms"]},
+    }
+
+
 def cpu_baseline(cfg, sd, batch, points):
     """The CPU oracle (a port) on this host's cores: same model, same weights, bounded sample."""
     from oracle import models_cpu
     from patchaugnet_amd.weights import synthetic_submaps
-    cores = os.cpu_count()
+    cores = min(os.cpu_count(), 64)          # beyond ~64 threads the OpenMP/ATen pools of this small workload only thrash
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     torch.set_num_threads(cores)
     x = synthetic_submaps(batch, points, seed=1234)
     with torch.no_grad():
@@ -171,15 +206,11 @@ def main():
     if world == 1:
         if not a.no_kernel_pass:
             g = grouping_roofline()
-            mc = g["micro_c64"]
-            # round 1: the graded kernel is the K5 neighbourhood gather; once the fused engine
-            # lands, the dominant-by-time kernel of the step is reported here instead and K5 moves to "kernels"
-            line["roofline"] = {"kernel": "group_lds_kernel (pa_grouping_forward)", "bound": "hbm", "achieved": mc["GBps"],
-                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": mc["GBps"] / HBM_PEAK_GBS, "traffic": None,
-                                "shape": mc["shape"], "algorithmic_bytes_per_launch": mc["algorithmic_bytes"], "ms_per_launch": mc["ms"]}
             line["kernels"] = {"grouping": g}
             try:
-                line["kernels"]["stages_ms"] = stage_pass(model, x)
+                st = stage_pass(model, x)
+                line["kernels"]["stages_ms"] = st
+                line.update(dominant_kernel_roofline(st, cfg, a.batch, a.points, g))
             except Exception as ex:  # attribution is diagnostics; never lose the bench line over it
                 line["kernels"]["stages_ms"] = {"error": repr(ex)}
         if not a.no_cpu_baseline:

@@ -1,0 +1,26 @@
+#!/usr/bin/env python
+"""Workload for the rocprofv3 --pmc passes: 3 engine steps at the bench shape (B=32, 4096 pts) + the K5 micro-benchmark."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from patchaugnet_amd import _lib, configs, patch_aug_net
+from patchaugnet_amd.weights import seeded_state_dict, synthetic_submaps
+
+cfg = configs.patch_aug_net_config()
+model = patch_aug_net.Network(param=cfg, use_a2a_recon=True, use_l2_norm=True)
+model.load_state_dict(seeded_state_dict(model.state_dict()))
+model = model.cuda().eval()
+x = synthetic_submaps(32, 4096, seed=1234).cuda()
+with torch.no_grad():
+    for _ in range(3):
+        model(x, return_feat=False)
+b, c, n, m, k = 4096, 64, 1024, 128, 20
+pts = torch.randn(b, c, n, device="cuda")
+idx = torch.randint(0, n, (b, m, k), device="cuda", dtype=torch.int32)
+o = torch.empty(b, c, m, k, device="cuda")
+for _ in range(3):
+    _lib.call("pa_grouping_forward", b, c, n, m, k, _lib.ptr(pts), _lib.ptr(idx), _lib.ptr(o))
+torch.cuda.synchronize()
