@@ -104,7 +104,8 @@ def dominant_kernel_roofline(st, cfg, batch, points, grouping):
                      "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
                      "traffic": traffic, "algorithmic_flops_per_launch": flops, "ms_per_launch": ms, "cu_time_owner": owner},
         "roofline_grouping": {"kernel": "group_lds_kernel (pa_grouping_forward, K5)", "bound": "hbm", "achieved": mc["GBps"], "peak": HBM_PEAK_GBS,
-                              "unit": "GB/s", "frac": mc["GBps"] / HBM_PEAK_GBS, "traffic": None, "shape": mc["shape"],
+                              "unit": "GB/s", "frac": mc["GBps"] / HBM_PEAK_GBS,
+                              "traffic": json.load(open(pmc)).get("grouping_bytes_per_launch") if os.path.exists(pmc) else None, "shape": mc["shape"],
                               "algorithmic_bytes_per_launch": mc["algorithmic_bytes"], "ms_per_launch": mc["ms"]},
     }
 
