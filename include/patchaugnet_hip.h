@@ -102,6 +102,22 @@ int pa_chamfer_forward(int B, int n, int m, const float *xyz1, const float *xyz2
 int pa_chamfer_backward(int B, int n, int m, const float *xyz1, const float *xyz2, const int *idx1, const int *idx2,
                         const float *grad_dist1, const float *grad_dist2, float *grad_xyz1, float *grad_xyz2, pa_stream_t stream);
 
+/* ---- Earth mover's distance, auction algorithm  (libs/emd_module/emd.cpp:6-30, emd_cuda.cu:228-317) ------------
+ * forward: xyz1, xyz2 (b,n,3) with n == m, n % 1024 == 0, b <= 512 (the reference's rules, emd_cuda.cu:236-249; other
+ * shapes return PA_EUNSUPPORTED where the reference returns -1) and n <= 8192.  State tensors are the caller's, initialised
+ * as libs/emd_module/emd_module.py:42-53 does: assignment, assignment_inv = -1; price, max_increments = 0; bid,
+ * bid_increments, max_idx any.  Runs `iters` auction rounds (eps = minimum bid increment) and writes dist (b,n) =
+ * |xyz1[j] - xyz2[assignment[j]]|^2.  The reference's thread-timing-dependent choices are fixed deterministically (lowest
+ * object index among equal values; highest bidder index among matching increments), exactly as oracle_emd_forward.
+ * The reference's unass_idx / unass_cnt / unass_cnt_sum / cnt_tmp scratch tensors are not needed (the list of unassigned
+ * points lives in LDS).
+ * backward: grad_xyz (b,n,3) += 2 grad_dist (xyz1 - xyz2[idx]); gradient w.r.t. xyz1 only, like the reference. */
+int pa_emd_forward(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist, int *assignment, float *price,
+                   int *assignment_inv, int *bid, float *bid_increments, float *max_increments, int *max_idx, float eps, int iters,
+                   pa_stream_t stream);
+int pa_emd_backward(int b, int n, const float *xyz1, const float *xyz2, float *grad_xyz, const float *grad_dist, const int *idx,
+                    pa_stream_t stream);
+
 /* ---- Generic-dimension brute-force kNN  (libs/KNN_CUDA/knn_cuda/csrc/cuda/knn.cpp:23-56, knn.cu:232-269)
  * ref (dim,nr), query (dim,nq) -> dist (k,nq) fp32 L2 (sqrt applied), ind (k,nq) int64 1-BASED, order (dist asc, row asc). */
 int pa_knn_generic(const float *ref, int nr, const float *query, int nq, int dim, int k, float *dist, int64_t *ind, pa_stream_t stream);

@@ -251,7 +251,7 @@ def knn_generic(ref, query, k):
     return dist, ind
 
 
-def emd_forward(xyz1, xyz2, eps, iters):
+def emd_forward(xyz1, xyz2, eps, iters, full_state=False):
     """-> (status, dist (b,n), assignment (b,n)); state initialised like emd_module.py:42-53."""
     xyz1, p1 = _f(xyz1)
     xyz2, p2 = _f(xyz2)
@@ -269,6 +269,9 @@ def emd_forward(xyz1, xyz2, eps, iters):
                                   price.ctypes.data_as(_fp), assignment_inv.ctypes.data_as(_ip), bid.ctypes.data_as(_ip),
                                   bid_inc.ctypes.data_as(_fp), max_inc.ctypes.data_as(_fp), max_idx.ctypes.data_as(_ip),
                                   c_float(eps), int(iters))
+    if full_state:
+        return int(st), dist, assignment, {"price": price, "assignment_inv": assignment_inv, "bid": bid, "bid_increments": bid_inc,
+                                           "max_increments": max_inc, "max_idx": max_idx}
     return int(st), dist, assignment
 
 

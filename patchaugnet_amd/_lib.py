@@ -37,6 +37,8 @@ _SIGS = {
     "pa_chamfer_forward": "iiipppppp",
     "pa_chamfer_backward": "iiipppppppp",
     "pa_knn_generic": "pipiiipp",
+    "pa_emd_forward": "iiippppppppppfi",
+    "pa_emd_backward": "iippppp",
     "pa_mlp_chain": "iiipppplipippppiiiippppiiiipi",
     "pa_rowgroup_max": "liipp",
     "pa_netvlad": "iiiippppppii",
