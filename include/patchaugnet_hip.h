@@ -138,6 +138,19 @@ int pa_mlp_chain(int mode, int pooled, int nlayers, const float *const *wt, cons
                  const float *xyz, const float *feat, const int *center_idx, const int *nbr_idx, int n_src, int m_ctr, int ns, int c_feat,
                  const float *known, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2, int c1,
                  float *out, int ldo, pa_stream_t stream);
+/* One dense layer on point-major rows (the chain kernel's plain mode with a selectable epilogue):
+ * out[r][:] = residual[r][:] + act(x[r][:k] . Wt + bias), act = ReLU if relu != 0 else identity; residual may be NULL.
+ * wt K-major (kpad x n), kpad = k rounded up to 4 with zero rows, n % 16 == 0. */
+int pa_linear(long rows, int k, int n, const float *x, int ldx, const float *wt, const float *bias, int relu, const float *residual, int ldr,
+              float *out, int ldo, pa_stream_t stream);
+
+/* ---- PPT-Net grouped self-attention core  (place_recognition/pptnet_origin/models/pptnet.py:261-282; twin GroupSALayer,
+ * place_recognition/patch_aug_net/models/loupe.py:69-114).  yv (b, n, 2c) point-major = [Y | V] with Y = q_conv(x) = k_conv(x)
+ * (tied grouped conv expanded to a dense block-diagonal weight) and V = v_conv(x) + bias; x (b, n, c).
+ * Writes d (b, n, c) = x - x_r, x_r = V^T attn, attn = row soft-max of Y Y^T re-normalised by (1e-9 + column sums).
+ * stats: scratch of 2*b*n floats (row max and 1/row-sum).  Any n >= 1; c in {64, 128, 256, 512}. */
+int pa_sa_attention(int b, int n, int c, const float *yv, const float *x, float *stats, float *d, pa_stream_t stream);
+
 /* out[g][c] = max over s < ns of in[g*ns + s][c]  (rows of c floats) */
 int pa_rowgroup_max(long groups, int ns, int c, const float *in, float *out, pa_stream_t stream);
 
@@ -156,6 +169,15 @@ int pa_netvlad(int b, int n, int c, int k, const float *x, const float *wc_t, co
 long pa_afa_scratch_floats(int b, int c, int ktot, int nout);
 int pa_afa(int b, int c, int ktot, int nout, const float *v, const float *watt, const float *fc_wt, const float *fc_bias,
            const float *scale, const float *shift, int l2norm, float *scratch, float *desc, pa_stream_t stream);
+
+/* Split-K fully connected layer with folded BatchNorm1d, for the aggregation heads
+ * (PPT-Net: hidden_weights + bn2, then GatingContext -- place_recognition/pptnet_origin/models/loupe.py:98-105, :108-137):
+ * out (b, nout) = g(BN(y (b, kdim) . fc_wt + fc_bias)), fc_wt K-major (kdim x nout); g = identity, or gate_x * sigmoid(.) when
+ * gate_x (b, nout) is given; l2norm != 0 applies F.normalize last.  fc_bias and gate_x may be NULL.
+ * scratch: pa_fc_scratch_floats(b, kdim, nout) floats. */
+long pa_fc_scratch_floats(int b, int kdim, int nout);
+int pa_fc(int b, int kdim, int nout, const float *y, const float *fc_wt, const float *fc_bias, const float *scale, const float *shift,
+          int l2norm, const float *gate_x, float *scratch, float *out, pa_stream_t stream);
 
 /* ---- the reference's launcher names (group 2) -------------------------------------------------*/
 void furthestsampling_cuda_launcher(int b, int n, int m, const float *dataset, float *temp, int *idxs);

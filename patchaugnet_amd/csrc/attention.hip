@@ -1,0 +1,189 @@
+// Grouped self-attention of the pyramid point transformer (PPT-Net) as two MFMA passes, without the (B, gp, N, N) tensor.
+//
+// Reference: SA_Layer.forward, place_recognition/pptnet_origin/models/pptnet.py:261-282 (twin: GroupSALayer,
+// place_recognition/patch_aug_net/models/loupe.py:69-114):
+//     Y = q_conv(x) = k_conv(x)  (tied grouped 1x1 conv)         energy = sum_g Y_g^T Y_g = Y^T Y           (:264-274)
+//     attn = softmax(energy, dim=-1);  attn = attn / (1e-9 + attn.sum(dim=1))                               (:276-277)
+//     x_r = v_conv(x) @ attn;   x = x + relu(BN(trans_conv(x - x_r)))                                       (:278-281)
+// The reference materialises (B, 8, N, N) per-group products (32 MB per submap at N = 1024), sums them, and runs soft-max,
+// column sum, division and a second batched matmul as separate kernels.
+//
+// MI355X plan (activations point-major, like the rest of the engine).  A preceding linear launch produces
+// YV = [Y | V] (B, N, 2C).  The energy matrix is symmetric, so "row i of the soft-max" needs only row statistics
+// m_i = max_j e_ij and l_i = sum_j exp(e_ij - m_i):
+//   pass 1  every wavefront owns 16 points j, streams all points i through LDS tiles and computes
+//           e(i, j) = Y_i . Y_j with v_mfma_f32_16x16x4_f32 (own rows as the B operand, held in registers); by symmetry
+//           the column statistics it accumulates ARE the row statistics of its own points -> stats (m, 1/l);
+//   pass 2  the same e(i, j) tiles again, p = exp(e - m_i) / l_i on the accumulator layout; the accumulator registers
+//           are fed straight back as the B operand of x_r^T += V^T p (the contraction index is permuted consistently on
+//           both operands, so no LDS round trip), column sums alongside; epilogue divides by (1e-9 + sum_i p) and
+//           writes d = x - x_r.
+// The trans_conv + BatchNorm + ReLU + residual that follows is one pa_linear launch (mlp_chain.hip).
+// HBM traffic per cloud: YV read N/64 times from L2 (it is 0.5 MB at N = 1024, C = 64), nothing N x N ever leaves the CU.
+#include "pa_common.h"
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+template <int C>
+struct AttnCfg {
+    static constexpr int TJ = C <= 128 ? 64 : (C == 256 ? 32 : 16);   // rows of Y / V per LDS tile
+    static constexpr int YS = C + 2;                                  // conflict-free A-fragment reads (row l%16, k = k0 + l/16)
+    static constexpr int VS = C + 4;                                  // conflict-free reads of V[4g + r][c0 + l%16]
+};
+
+template <int C, int PASS>
+__global__ __launch_bounds__(256) void sa_attn_kernel(int n, const float *__restrict__ yv_all, const float *__restrict__ x_all,
+                                                       float *__restrict__ stats_all, float *__restrict__ d_all)
+{
+    using Cfg = AttnCfg<C>;
+    constexpr int TJ = Cfg::TJ, YS = Cfg::YS, VS = Cfg::VS, KS = C / 4, CT = C / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Ys = smem;                                  // [TJ][YS]
+    float *Vs = Ys + TJ * YS;                          // [TJ][VS]      (pass 2)
+    float *Ms = Vs + (PASS == 2 ? TJ * VS : 0);        // [TJ] m_i, [TJ] 1/l_i   (pass 2)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const int j0 = blockIdx.x * 64 + wave * 16;
+    const bool active = j0 < n;                        // wave-uniform; lanes whose own point is >= n compute on a clamped row and store nothing
+    const float *yv = yv_all + (size_t)b * n * (2 * C);
+    const float *stats = stats_all + (size_t)b * n * 2;
+
+    float yb[KS];                                      // own points as the B operand: B[k = 4ks + l/16][j = l%16] = Y[j0 + l%16][k]
+    if (active) {
+        const float *p = yv + (size_t)min(j0 + (lane & 15), n - 1) * (2 * C) + (lane >> 4);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) yb[ks] = p[ks * 4];
+    }
+    float m_run = -INFINITY, l_run = 0.f, s_run = 0.f;
+    floatx4 o[PASS == 2 ? CT : 1];
+#pragma unroll
+    for (int ct = 0; ct < (PASS == 2 ? CT : 1); ++ct) o[ct] = (floatx4){0.f, 0.f, 0.f, 0.f};
+
+    for (int t0 = 0; t0 < n; t0 += TJ) {
+        // ---- stage rows t0 .. t0+TJ-1 of Y (and V, m, 1/l) -------------------------------------------------------
+        constexpr int Q = C / 4;
+        for (int q = tid; q < TJ * Q; q += 256) {
+            const int r = q / Q, part = q - r * Q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t0 + r < n) v = *reinterpret_cast<const float4 *>(yv + (size_t)(t0 + r) * (2 * C) + part * 4);
+            float2 *d = reinterpret_cast<float2 *>(Ys + r * YS + part * 4);
+            d[0] = make_float2(v.x, v.y);
+            d[1] = make_float2(v.z, v.w);
+            if (PASS == 2) {
+                float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t0 + r < n) w = *reinterpret_cast<const float4 *>(yv + (size_t)(t0 + r) * (2 * C) + C + part * 4);
+                *reinterpret_cast<float4 *>(Vs + r * VS + part * 4) = w;
+            }
+        }
+        if (PASS == 2 && tid < TJ) {
+            const bool ok = t0 + tid < n;
+            Ms[tid] = ok ? stats[(size_t)(t0 + tid) * 2] : 0.f;
+            Ms[TJ + tid] = ok ? stats[(size_t)(t0 + tid) * 2 + 1] : 0.f;
+        }
+        __syncthreads();
+        if (active) {
+            const int nit = (min(TJ, n - t0) + 15) >> 4;
+            for (int it = 0; it < nit; ++it) {
+                floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
+                const float *ap = Ys + (it * 16 + (lane & 15)) * YS + (lane >> 4);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[ks * 4], yb[ks], acc, 0, 0, 0);
+                // acc[r] = e(i = t0 + 16it + 4(l/16) + r, j = j0 + l%16)
+                if (PASS == 1) {
+                    const int ig = t0 + it * 16 + (lane >> 4) * 4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (ig + r >= n) acc[r] = -INFINITY;                   // rows past the cloud contribute exp(-inf) = 0
+                    const float mt = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
+                    const float mn = fmaxf(m_run, mt);
+                    if (mn > -INFINITY) {
+                        l_run = l_run * expf(m_run - mn) + ((expf(acc[0] - mn) + expf(acc[1] - mn)) + (expf(acc[2] - mn) + expf(acc[3] - mn)));
+                        m_run = mn;
+                    }
+                } else {
+                    const int ib = it * 16 + (lane >> 4) * 4;
+                    float p[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p[r] = expf(acc[r] - Ms[ib + r]) * Ms[TJ + ib + r];
+                    s_run += (p[0] + p[1]) + (p[2] + p[3]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float *vp = Vs + (ib + r) * VS + (lane & 15);   // A[c = 16ct + l%16][slot g = l/16] = V[i = 16it + 4g + r][c]
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) o[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[ct * 16], p[r], o[ct], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+
+    if (PASS == 1) {
+        // merge the four lane groups that hold different i for the same own point j = l%16
+#pragma unroll
+        for (int sft = 16; sft < 64; sft <<= 1) {
+            const float mo = __shfl_xor(m_run, sft), lo = __shfl_xor(l_run, sft);
+            const float mn = fmaxf(m_run, mo);
+            l_run = mn > -INFINITY ? l_run * expf(m_run - mn) + lo * expf(mo - mn) : 0.f;
+            m_run = mn;
+        }
+        if (lane < 16 && j0 + lane < n) {
+            float *st = stats_all + ((size_t)b * n + j0 + lane) * 2;
+            st[0] = m_run;
+            st[1] = 1.0f / l_run;
+        }
+    } else {
+        s_run += __shfl_xor(s_run, 16);
+        s_run += __shfl_xor(s_run, 32);
+        const float den = 1e-9f + s_run;                                       // pptnet.py:277
+        if (j0 + (lane & 15) >= n) return;
+        const size_t row = (size_t)b * n + j0 + (lane & 15);
+        const float *xr = x_all + row * C;
+        float *dr = d_all + row * C;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int c = ct * 16 + (lane >> 4) * 4;                           // o[ct][rr]: channel c + rr, point j = l%16
+            const float4 xv = *reinterpret_cast<const float4 *>(xr + c);
+            float4 d;
+            d.x = xv.x - o[ct][0] / den;
+            d.y = xv.y - o[ct][1] / den;
+            d.z = xv.z - o[ct][2] / den;
+            d.w = xv.w - o[ct][3] / den;
+            *reinterpret_cast<float4 *>(dr + c) = d;
+        }
+    }
+}
+
+template <int C>
+int launch_attn(int b, int n, const float *yv, const float *x, float *stats, float *d, hipStream_t st)
+{
+    using Cfg = AttnCfg<C>;
+    const size_t lds1 = (size_t)Cfg::TJ * Cfg::YS * 4;
+    const size_t lds2 = (size_t)(Cfg::TJ * Cfg::YS + Cfg::TJ * Cfg::VS + 2 * Cfg::TJ) * 4;
+    const dim3 grid(pa_div_up(n, 64), b);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_attn_kernel<C, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    hipLaunchKernelGGL((sa_attn_kernel<C, 1>), grid, dim3(256), lds1, st, n, yv, x, stats, d);
+    hipLaunchKernelGGL((sa_attn_kernel<C, 2>), grid, dim3(256), lds2, st, n, yv, x, stats, d);
+    return 0;
+}
+
+}  // namespace
+
+PA_API int pa_sa_attention(int b, int n, int c, const float *yv, const float *x, float *stats, float *d, pa_stream_t stream)
+{
+    PA_REQUIRE(b > 0 && n > 0 && yv && x && stats && d, "pa_sa_attention: bad arguments");
+    PA_REQUIRE(b <= 65535, "pa_sa_attention: b=%d exceeds the grid limit", b);
+    hipStream_t st = (hipStream_t)stream;
+    switch (c) {
+        case 64: launch_attn<64>(b, n, yv, x, stats, d, st); break;
+        case 128: launch_attn<128>(b, n, yv, x, stats, d, st); break;
+        case 256: launch_attn<256>(b, n, yv, x, stats, d, st); break;
+        case 512: launch_attn<512>(b, n, yv, x, stats, d, st); break;
+        default: pa_set_error("pa_sa_attention: built for 64/128/256/512 channels (PPT-Net widths), got %d", c); return PA_EUNSUPPORTED;
+    }
+    PA_CHECK_LAUNCH("pa_sa_attention");
+    return PA_OK;
+}

@@ -59,6 +59,10 @@ struct PaChain {
     int n_unknown, m_known, c2, c1;
     float *out;
     int ldo;
+    // last-layer epilogue (plain rows only): out = residual + act(acc + bias), act = ReLU when relu_last != 0 else identity
+    int relu_last;
+    const float *residual;   // (rows, ldr) or null
+    int ldr;
 };
 
 namespace {
@@ -163,8 +167,9 @@ __device__ __forceinline__ void store_hidden(float *act, int stride, const PaLay
 // last layer, plain: bias + ReLU to global memory (row-major, ldo)
 template <int RT, int NC>
 __device__ __forceinline__ void store_rows(float *__restrict__ out, int ldo, long row0, long rows, const PaLayer &L, int c0, int lane,
-                                            floatx4 (&acc)[RT][NC])
+                                            floatx4 (&acc)[RT][NC], int relu, const float *__restrict__ residual, int ldr)
 {
+    const float floor_v = relu ? 0.f : -INFINITY;
 #pragma unroll
     for (int ct = 0; ct < NC; ++ct) {
         const int col = (c0 + ct) * 16 + (lane & 15);
@@ -174,7 +179,11 @@ __device__ __forceinline__ void store_rows(float *__restrict__ out, int ldo, lon
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const long row = row0 + rt * 16 + (lane >> 4) * 4 + r;
-                if (row < rows) out[row * ldo + col] = fmaxf(acc[rt][ct][r] + bias, 0.f);
+                if (row < rows) {
+                    float v = fmaxf(acc[rt][ct][r] + bias, floor_v);
+                    if (residual) v = residual[row * ldr + col] + v;
+                    out[row * ldo + col] = v;
+                }
             }
     }
 }
@@ -231,7 +240,7 @@ __device__ __forceinline__ void run_layer_chunks(float *act, const PaChain &a, i
             store_pooled<RT, NC>(a.out, a.ldo, tile * 4, a.rows, L, c0, lane, acc);
         } else {
             const long total_rows = (MODE == MODE_SA) ? a.rows * a.ns : a.rows;
-            store_rows<RT, NC>(a.out, a.ldo, tile * (RT * 16), total_rows, L, c0, lane, acc);
+            store_rows<RT, NC>(a.out, a.ldo, tile * (RT * 16), total_rows, L, c0, lane, acc, a.relu_last, a.residual, a.ldr);
         }
     }
     if (!last) tile_sync<WPT>();
@@ -400,12 +409,12 @@ void launch_rows(const PaChain &a, int rt, bool split, int wpw, long ntiles, hip
 
 // Generic entry point.  mode: 0 plain rows, 1 set-abstraction gather, 2 feature-propagation interpolate.
 // wt[l] is K-major (kpad[l] x n[l]) with BN folded in and zero rows beyond the true K; bias[l] has n[l] entries.
-PA_API int pa_mlp_chain(int mode, int pooled, int nlayers, const float *const *wt, const float *const *bias, const int *kpad, const int *nout,
-                        long rows, int k0,
-                        const float *x, int ldx,
-                        const float *xyz, const float *feat, const int *center_idx, const int *nbr_idx, int n_src, int m_ctr, int ns, int c_feat,
-                        const float *known, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2, int c1,
-                        float *out, int ldo, pa_stream_t stream)
+static int chain_dispatch(int mode, int pooled, int nlayers, const float *const *wt, const float *const *bias, const int *kpad, const int *nout,
+                          long rows, int k0,
+                          const float *x, int ldx,
+                          const float *xyz, const float *feat, const int *center_idx, const int *nbr_idx, int n_src, int m_ctr, int ns, int c_feat,
+                          const float *known, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2, int c1,
+                          float *out, int ldo, int relu_last, const float *residual, int ldr, pa_stream_t stream)
 {
     PA_REQUIRE(nlayers >= 1 && nlayers <= 3, "pa_mlp_chain: nlayers=%d must be 1..3", nlayers);
     PA_REQUIRE(rows > 0 && k0 > 0 && out, "pa_mlp_chain: rows/k0 must be positive and out non-null");
@@ -426,6 +435,7 @@ PA_API int pa_mlp_chain(int mode, int pooled, int nlayers, const float *const *w
     a.xyz = xyz; a.feat = feat; a.center_idx = center_idx; a.nbr_idx = nbr_idx; a.n_src = n_src; a.m_ctr = m_ctr; a.ns = ns; a.c_feat = c_feat;
     a.known = known; a.idx3 = idx3; a.w3 = w3; a.skip = skip; a.n_unknown = n_unknown; a.m_known = m_known; a.c2 = c2; a.c1 = c1;
     a.out = out; a.ldo = ldo;
+    a.relu_last = relu_last; a.residual = residual; a.ldr = ldr;
     hipStream_t st = (hipStream_t)stream;
 
     const bool is_pooled = pooled != 0;
@@ -493,6 +503,27 @@ PA_API int pa_mlp_chain(int mode, int pooled, int nlayers, const float *const *w
     else launch_rows<MODE_FP>(a, RTv, split, wpw, ntiles, st);
     PA_CHECK_LAUNCH("pa_mlp_chain");
     return PA_OK;
+}
+
+PA_API int pa_mlp_chain(int mode, int pooled, int nlayers, const float *const *wt, const float *const *bias, const int *kpad, const int *nout,
+                        long rows, int k0,
+                        const float *x, int ldx,
+                        const float *xyz, const float *feat, const int *center_idx, const int *nbr_idx, int n_src, int m_ctr, int ns, int c_feat,
+                        const float *known, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2, int c1,
+                        float *out, int ldo, pa_stream_t stream)
+{
+    return chain_dispatch(mode, pooled, nlayers, wt, bias, kpad, nout, rows, k0, x, ldx, xyz, feat, center_idx, nbr_idx, n_src, m_ctr, ns, c_feat,
+                          known, idx3, w3, skip, n_unknown, m_known, c2, c1, out, ldo, 1, nullptr, 0, stream);
+}
+
+// One dense layer on point-major rows: out = residual + act(x Wt + bias); wt K-major (kpad x n), kpad = k rounded up to 4.
+PA_API int pa_linear(long rows, int k, int n, const float *x, int ldx, const float *wt, const float *bias, int relu, const float *residual, int ldr,
+                     float *out, int ldo, pa_stream_t stream)
+{
+    PA_REQUIRE(residual == nullptr || ldr >= n, "pa_linear: residual row stride %d < n=%d", ldr, n);
+    const int kpad = (k + 3) / 4 * 4;
+    return chain_dispatch(0, 0, 1, &wt, &bias, &kpad, &n, rows, k, x, ldx, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0,
+                          nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, out, ldo, relu, residual, ldr, stream);
 }
 
 PA_API int pa_rowgroup_max(long groups, int ns, int c, const float *in, float *out, pa_stream_t stream)

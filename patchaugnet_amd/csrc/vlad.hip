@@ -311,7 +311,8 @@ __global__ __launch_bounds__(256) void fc_splitk_kernel(int bsz, int kdim, int n
 
 // grid B, nout threads (<= 1024): sum the slices, + bias, BatchNorm (eval) as scale/shift, optional L2 normalise
 __global__ void fc_finalize_kernel(int bsz, int nout, int nslices, const float *__restrict__ out_part, const float *__restrict__ fc_bias,
-                                   const float *__restrict__ scale, const float *__restrict__ shift, int l2norm, float *__restrict__ desc)
+                                   const float *__restrict__ scale, const float *__restrict__ shift, int l2norm, const float *__restrict__ gate_x,
+                                   float *__restrict__ desc)
 {
     __shared__ float red[16];
     const int b = blockIdx.x, n = threadIdx.x;
@@ -325,7 +326,8 @@ __global__ void fc_finalize_kernel(int bsz, int nout, int nslices, const float *
     }
     for (; s < nslices; ++s) v0 += out_part[((size_t)s * bsz + b) * nout + n];
     float v = (v0 + v1) + (v2 + v3);
-    v = (v + fc_bias[n]) * scale[n] + shift[n];
+    v = (v + (fc_bias ? fc_bias[n] : 0.f)) * scale[n] + shift[n];
+    if (gate_x) v = gate_x[(size_t)b * nout + n] * (1.0f / (1.0f + expf(-v)));   // GatingContext, loupe.py:332-361: x * sigmoid(BN(x W))
     if (l2norm) {
         float ss = v * v;
 #pragma unroll
@@ -341,6 +343,27 @@ __global__ void fc_finalize_kernel(int bsz, int nout, int nslices, const float *
 
 int vlad_chunks(int n) { int rows = n >= 2048 ? 512 : 64; return (n + rows - 1) / rows; }
 int vlad_rows_per_wg(int n) { return n >= 2048 ? 512 : 64; }
+
+// split-K FC + finalize for any batch size: rows are processed 64 at a time (the split-K kernel holds <= 4 row tiles)
+int fc_launch(int b, int kdim, int nout, const float *y, const float *fc_wt, const float *fc_bias, const float *scale, const float *shift, int l2norm,
+              const float *gate_x, float *opart, float *out, hipStream_t st)
+{
+    const int ks_rows = 128;
+    const int nslices = (kdim + ks_rows - 1) / ks_rows;
+    for (int b0 = 0; b0 < b; b0 += 64) {
+        const int bc = b - b0 < 64 ? b - b0 : 64;
+        const float *yc = y + (size_t)b0 * kdim;
+        switch ((bc + 15) / 16) {
+            case 1: hipLaunchKernelGGL(fc_splitk_kernel<1>, dim3(nslices), dim3(256), 0, st, bc, kdim, nout, ks_rows, yc, fc_wt, opart); break;
+            case 2: hipLaunchKernelGGL(fc_splitk_kernel<2>, dim3(nslices), dim3(256), 0, st, bc, kdim, nout, ks_rows, yc, fc_wt, opart); break;
+            case 3: hipLaunchKernelGGL(fc_splitk_kernel<3>, dim3(nslices), dim3(256), 0, st, bc, kdim, nout, ks_rows, yc, fc_wt, opart); break;
+            default: hipLaunchKernelGGL(fc_splitk_kernel<4>, dim3(nslices), dim3(256), 0, st, bc, kdim, nout, ks_rows, yc, fc_wt, opart); break;
+        }
+        hipLaunchKernelGGL(fc_finalize_kernel, dim3(bc), dim3(nout), 0, st, bc, nout, nslices, opart, fc_bias, scale, shift, l2norm,
+                           gate_x ? gate_x + (size_t)b0 * nout : nullptr, out + (size_t)b0 * nout);
+    }
+    return PA_OK;
+}
 
 }  // namespace
 
@@ -384,7 +407,7 @@ PA_API long pa_afa_scratch_floats(int b, int c, int ktot, int nout)
 {
     const long kdim = (long)c * ktot;
     const long nslices = (kdim + 127) / 128;
-    return (long)b * 8 * ktot + (long)b * kdim + nslices * b * nout;
+    return (long)b * 8 * ktot + (long)b * kdim + nslices * (b < 64 ? b : 64) * nout;
 }
 
 // v (b, 256, ktot) -> desc (b, nout).  watt: (256, 256) row-major (o, c);  fc_wt: K-major (256*ktot, nout);
@@ -393,14 +416,12 @@ PA_API int pa_afa(int b, int c, int ktot, int nout, const float *v, const float 
                   const float *scale, const float *shift, int l2norm, float *scratch, float *desc, pa_stream_t stream)
 {
     PA_REQUIRE(b > 0 && ktot > 0 && nout > 0 && v && watt && fc_wt && fc_bias && scale && shift && scratch && desc, "pa_afa: bad arguments");
-    if (c != VC || ktot > 256 || nout % 16 || nout > 1024 || b > 64) {
-        pa_set_error("pa_afa: built for 256 channels, <= 256 columns, nout %% 16 == 0, nout <= 1024, b <= 64 (got c=%d ktot=%d nout=%d b=%d)", c, ktot, nout, b);
+    if (c != VC || ktot > 256 || nout % 16 || nout > 1024 || b > 65535) {
+        pa_set_error("pa_afa: built for 256 channels, <= 256 columns, nout %% 16 == 0, nout <= 1024 (got c=%d ktot=%d nout=%d b=%d)", c, ktot, nout, b);
         return PA_EUNSUPPORTED;
     }
     hipStream_t st = (hipStream_t)stream;
     const int kdim = c * ktot;
-    const int ks_rows = 128;
-    const int nslices = (kdim + ks_rows - 1) / ks_rows;
     float *pmax = scratch;
     float *y = pmax + (size_t)b * 8 * ktot;
     float *opart = y + (size_t)b * kdim;
@@ -409,14 +430,27 @@ PA_API int pa_afa(int b, int c, int ktot, int nout, const float *v, const float 
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&afa_colmax_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(afa_colmax_kernel, dim3(8, b), dim3(256), lds, st, ktot, v, watt, pmax);
     hipLaunchKernelGGL(afa_reweight_kernel, dim3(b), dim3(256), 0, st, ktot, v, pmax, y);
-    const int rt = (b + 15) / 16;
-    switch (rt) {
-        case 1: hipLaunchKernelGGL(fc_splitk_kernel<1>, dim3(nslices), dim3(256), 0, st, b, kdim, nout, ks_rows, y, fc_wt, opart); break;
-        case 2: hipLaunchKernelGGL(fc_splitk_kernel<2>, dim3(nslices), dim3(256), 0, st, b, kdim, nout, ks_rows, y, fc_wt, opart); break;
-        case 3: hipLaunchKernelGGL(fc_splitk_kernel<3>, dim3(nslices), dim3(256), 0, st, b, kdim, nout, ks_rows, y, fc_wt, opart); break;
-        default: hipLaunchKernelGGL(fc_splitk_kernel<4>, dim3(nslices), dim3(256), 0, st, b, kdim, nout, ks_rows, y, fc_wt, opart); break;
-    }
-    hipLaunchKernelGGL(fc_finalize_kernel, dim3(b), dim3(nout), 0, st, b, nout, nslices, opart, fc_bias, scale, shift, l2norm, desc);
+    const int rc = fc_launch(b, kdim, nout, y, fc_wt, fc_bias, scale, shift, l2norm, nullptr, opart, desc, st);
+    if (rc != PA_OK) return rc;
     PA_CHECK_LAUNCH("pa_afa");
+    return PA_OK;
+}
+
+PA_API long pa_fc_scratch_floats(int b, int kdim, int nout)
+{
+    const long nslices = (kdim + 127) / 128;
+    return nslices * (b < 64 ? b : 64) * nout;
+}
+
+// out (b, nout) = [gate_x *] f(BN(y (b, kdim) . fc_wt (kdim x nout, K-major) + fc_bias)), f = sigmoid when gate_x is given
+// (GatingContext, loupe.py:332-361) else identity; then optional F.normalize.  fc_bias / gate_x may be NULL.
+PA_API int pa_fc(int b, int kdim, int nout, const float *y, const float *fc_wt, const float *fc_bias, const float *scale, const float *shift,
+                 int l2norm, const float *gate_x, float *scratch, float *out, pa_stream_t stream)
+{
+    PA_REQUIRE(b > 0 && kdim > 0 && nout > 0 && y && fc_wt && scale && shift && scratch && out, "pa_fc: bad arguments");
+    if (nout % 16 || nout > 1024) { pa_set_error("pa_fc: nout=%d must be a multiple of 16 and <= 1024", nout); return PA_EUNSUPPORTED; }
+    const int rc = fc_launch(b, kdim, nout, y, fc_wt, fc_bias, scale, shift, l2norm, gate_x, scratch, out, (hipStream_t)stream);
+    if (rc != PA_OK) return rc;
+    PA_CHECK_LAUNCH("pa_fc");
     return PA_OK;
 }

@@ -144,24 +144,117 @@ class _Afa:
         return desc
 
 
+class _Attn:
+    """Grouped self-attention level of PPT-Net (pptnet.py:246-282) for pa_linear + pa_sa_attention + pa_linear.
+
+    The tied grouped q/k conv is expanded to a dense block-diagonal (C, C) matrix and concatenated with v_conv into one
+    K-major (C, 2C) weight; trans_conv + after_norm (eval) fold into one K-major (C, C) weight + bias."""
+
+    def __init__(self, sa, device):
+        c, gp = sa.v_conv.weight.shape[0], sa.gp
+        if c not in (64, 128, 256, 512):
+            raise ValueError(f"fused attention is built for 64/128/256/512 channels, got {c}")
+        cg = c // gp
+        wq = sa.k_conv.weight.detach().double().squeeze(-1)                   # (C, C/gp): row o uses inputs of group o // cg
+        dense = torch.zeros(c, c, dtype=torch.float64)
+        for g in range(gp):
+            dense[g * cg:(g + 1) * cg, g * cg:(g + 1) * cg] = wq[g * cg:(g + 1) * cg].cpu()
+        wv = sa.v_conv.weight.detach().double().squeeze(-1).cpu()              # (C_out, C_in)
+        self.wqv_t = torch.cat([dense.t(), wv.t()], dim=1).float().contiguous().to(device)                 # (C, 2C) K-major
+        self.bqv = torch.cat([torch.zeros(c, dtype=torch.float64), sa.v_conv.bias.detach().double().cpu()]).float().contiguous().to(device)
+        scale, shift = fold_bn1d(sa.after_norm)
+        wt = sa.trans_conv.weight.detach().double().squeeze(-1).cpu() * scale.cpu()[:, None]
+        self.wt_t = wt.t().float().contiguous().to(device)                                                   # (C, C) K-major
+        self.bt = (sa.trans_conv.bias.detach().double().cpu() * scale.cpu() + shift.cpu()).float().contiguous().to(device)
+        self.c = c
+
+    def run(self, x, B, n):
+        """x (B*n, C) point-major -> x + relu(BN(trans_conv(x - x_r)))."""
+        c, dev = self.c, x.device
+        rows = B * n
+        yv = torch.empty((rows, 2 * c), dtype=torch.float32, device=dev)
+        call("pa_linear", rows, c, 2 * c, ptr(x), c, ptr(self.wqv_t), ptr(self.bqv), 0, None, 0, ptr(yv), 2 * c)
+        stats = torch.empty((rows, 2), dtype=torch.float32, device=dev)
+        d = torch.empty((rows, c), dtype=torch.float32, device=dev)
+        call("pa_sa_attention", B, n, c, ptr(yv), ptr(x), ptr(stats), ptr(d))
+        out = torch.empty((rows, c), dtype=torch.float32, device=dev)
+        call("pa_linear", rows, c, c, ptr(d), c, ptr(self.wt_t), ptr(self.bt), 1, ptr(x), c, ptr(out), c)
+        return out
+
+
+class _PptHead:
+    """PPT-Net head after the pyramid VLADs (pptnet_origin/models/loupe.py:94-105): flat concat -> hidden_weights -> bn2 ->
+    context gating.  The VLAD kernel writes the (B, 256, sum K) layout, so the FC weight rows are permuted once from
+    the reference's per-scale C-major flattening (off_i + c*K_i + k) to c*sum K + koff_i + k."""
+
+    def __init__(self, agg, ks, use_normalize, device):
+        c, ktot = 256, sum(ks)
+        hw = agg.hidden_weights.detach()
+        perm = torch.empty(c * ktot, dtype=torch.long)
+        off, koff = 0, 0
+        for k in ks:
+            cc, kk = torch.meshgrid(torch.arange(c), torch.arange(k), indexing="ij")
+            perm[(cc * ktot + koff + kk).flatten()] = (off + cc * k + kk).flatten()
+            off += c * k
+            koff += k
+        self.fc_wt = hw[perm.to(hw.device)].float().contiguous().to(device)                 # (256*ktot, nout) K-major
+        scale, shift = fold_bn1d(agg.bn2)
+        self.scale, self.shift = scale.float().contiguous().to(device), shift.float().contiguous().to(device)
+        self.nout = hw.shape[1]
+        self.gating = agg.gating
+        if self.gating:
+            g = agg.context_gating
+            self.g_wt = g.gating_weights.detach().float().contiguous().to(device)          # (dim, dim): x @ W, already K-major
+            gs, gh = fold_bn1d(g.bn1)
+            self.g_scale, self.g_shift = gs.float().contiguous().to(device), gh.float().contiguous().to(device)
+        self.l2 = 1 if use_normalize else 0
+
+    def run(self, v):
+        b, kdim, dev = v.shape[0], v.shape[1] * v.shape[2], v.device
+        scratch = torch.empty(_lib.lib().pa_fc_scratch_floats(b, kdim, self.nout), dtype=torch.float32, device=dev)
+        h = torch.empty((b, self.nout), dtype=torch.float32, device=dev)
+        call("pa_fc", b, kdim, self.nout, ptr(v), ptr(self.fc_wt), None, ptr(self.scale), ptr(self.shift),
+             0 if self.gating else self.l2, None, ptr(scratch), ptr(h))
+        if not self.gating:
+            return h
+        out = torch.empty_like(h)
+        call("pa_fc", b, self.nout, self.nout, ptr(h), ptr(self.g_wt), None, ptr(self.g_scale), ptr(self.g_shift), self.l2, ptr(h),
+             ptr(scratch), ptr(out))
+        return out
+
+
 class PatchAugNetEngine:
+    """Fused evaluation plan for both model families (PatchAugNet: 3 levels + APFA head; PPT-Net: 4 levels with grouped
+    self-attention + FC/gating head).  Reads the parameters of the nn.Module tree; holds folded copies."""
+
     def __init__(self, model, device):
         self.device = torch.device(device)
         cfg = model.param
         self.sampling, self.knn = list(cfg["SAMPLING"]), list(cfg["KNN"])
-        self.use_origin = cfg["USE_ORIGIN_PC_IN_FP"]
+        self.use_origin = cfg.get("USE_ORIGIN_PC_IN_FP", True)
         bb = model.backbone
         with torch.no_grad():
             self.sa = [_Chain(fold_shared_mlp(m.mlps[0], self.device)) for m in bb.SA_modules]
             self.fp = [_Chain(fold_shared_mlp(m.mlp, self.device)) for m in bb.FP_modules]
+            self.attn = [_Attn(m.sas[0], self.device) if hasattr(m, "sas") else None for m in bb.SA_modules]
         self.agg = model.aggregation
         agg = self.agg
-        self.fused_head = (agg.aggregation_type == 2 and not agg.gating and all(v.feature_size == 256 and v.cluster_size <= 64 for v in agg.vlads)
-                           and sum(v.cluster_size for v in agg.vlads) <= 256 and agg.afa.fc.out_features % 16 == 0)
+        self.ppt = hasattr(agg, "vlad0")
+        vl = [getattr(agg, f"vlad{i}") for i in range(4)] if self.ppt else list(agg.vlads)
+        ok = all(v.feature_size == 256 and v.cluster_size <= 64 for v in vl) and sum(v.cluster_size for v in vl) <= 256
+        if self.ppt:
+            self.fused_head = ok and agg.hidden_weights.shape[1] % 16 == 0
+        else:
+            self.fused_head = ok and agg.aggregation_type == 2 and not agg.gating and agg.afa.fc.out_features % 16 == 0
         if self.fused_head:
             with torch.no_grad():
-                self.vlads = [_Vlad(v, self.device) for v in agg.vlads]
-                self.afa = _Afa(agg.afa, self.device)
+                self.vlads = [_Vlad(v, self.device) for v in vl]
+                if self.ppt:
+                    self.head = _PptHead(agg, [v.cluster_size for v in vl], model.use_normalize, self.device)
+                else:
+                    self.afa = _Afa(agg.afa, self.device)
+        elif self.ppt:
+            raise ValueError("PPT-Net fused engine needs 256-wide features and <= 64 clusters per scale")
         self._key = self._params_key(model)
         self.timer = None     # optional profiling.StageTimer: per-stage HIP-event marks (bench.py kernel attribution)
 
@@ -200,6 +293,9 @@ class PatchAugNetEngine:
                 y = torch.empty((B * m, chain.n_last), dtype=torch.float32, device=self.device)
                 call("pa_rowgroup_max", B * m, ns, chain.n_last, ptr(full), ptr(y))
             self._mark(f"sa{i}.chain")
+            if self.attn[i] is not None:
+                y = self.attn[i].run(y, B, m)
+                self._mark(f"sa{i}.attn")
             l_xyz.append(new_xyz)
             l_feat.append(y.view(B, m, chain.n_last))
             l_c.append(cidx)
@@ -242,7 +338,7 @@ class PatchAugNetEngine:
         nfp = len(self.fp)
         feats = [l_feat[j] for j in range(nfp - 1, -1, -1)]                                   # coarse -> fine, (B, N_i, 256)
         agg = self.agg
-        if self.fused_head and x.shape[0] <= 64:
+        if self.fused_head:
             ktot = sum(v.k for v in self.vlads)
             v = torch.empty((x.shape[0], 256, ktot), dtype=torch.float32, device=self.device)
             koff = 0
@@ -250,7 +346,7 @@ class PatchAugNetEngine:
                 vl.run(f.contiguous(), v, ktot, koff)
                 koff += vl.k
             self._mark("vlad")
-            desc = self.afa.run(v)
+            desc = self.head.run(v) if self.ppt else self.afa.run(v)
             self._mark("afa")
             return desc, self._views(feats, l_c)
         v = torch.cat([self._vlad(vl, f) for vl, f in zip(agg.vlads, feats)], dim=-1)       # (B, 256, sum K)

@@ -5,6 +5,7 @@ Model API of ``place_recognition/pptnet_origin/models/pptnet.py:24-62`` as const
 ``forward(x: (B,1,N,3)) -> (desc (B,256), fp_features, center_idx)``.  State-dict keys equal the reference's
 (tests/golden/pptnet_state_dict_keys.json), including the doubly-saved tied q/k weights.
 """
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -28,8 +29,27 @@ class Network(nn.Module):
             feature_size=param["FEATURE_SIZE"], max_samples=param["MAX_SAMPLES"], cluster_size=param["CLUSTER_SIZE"],
             output_dim=param["OUTPUT_DIM"], gating=param["GATING"], add_batch_norm=True)
         self.use_normalize = use_normalize
+        self.param = dict(param)
+        self._engine = None
+        self.fused_eval = True       # eval()+no_grad() forwards run the fused HIP engine; set False for the module path
 
-    def forward(self, x, return_feat=True):
+    def train(self, mode=True):
+        self._engine = None
+        return super().train(mode)
+
+    def load_state_dict(self, *a, **k):
+        self._engine = None
+        return super().load_state_dict(*a, **k)
+
+    def forward(self, x, return_feat=True, use_engine=None):
+        if use_engine is None:
+            use_engine = self.fused_eval and not self.training and not torch.is_grad_enabled()
+        if use_engine:
+            from .engine import PatchAugNetEngine
+            if self._engine is None or not self._engine.matches(self, x):
+                self._engine = PatchAugNetEngine(self, x.device)
+            d, (fp, cidx) = self._engine.forward(x)
+            return (d, fp, cidx) if return_feat else d
         res = self.backbone(x.squeeze(1))
         fp = res["fp_features"]
         d = self.aggregation(fp[0], fp[1], fp[2], fp[3])

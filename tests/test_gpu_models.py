@@ -88,7 +88,8 @@ def test_patch_aug_net_vs_oracle_fresh_inputs(fused):
 
 
 @pytest.mark.parametrize("tag", ["small", "full"])
-def test_pptnet_vs_reference_vectors(tag):
+@pytest.mark.parametrize("fused", [False, True])
+def test_pptnet_vs_reference_vectors(tag, fused):
     from patchaugnet_amd import pptnet
     g = golden("pptnet")
     cfg = configs.pptnet_config()
@@ -101,7 +102,7 @@ def test_pptnet_vs_reference_vectors(tag):
         m.load_state_dict(sd, strict=True)
         m = m.cuda().eval()
         with torch.no_grad():
-            d, fp, cidx = m(x)
+            d, fp, cidx = m(x, use_engine=fused)
         ref = g[key]
         scale = np.abs(ref).max()
         assert np.abs(d.cpu().numpy() - ref).max() <= 2e-4 * scale
