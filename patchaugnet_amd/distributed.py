@@ -1,0 +1,70 @@
+"""Data-parallel descriptor extraction over the GPUs of one node (one process per GPU, RCCL over xGMI).
+
+The path shards embarrassingly: in eval mode every submap is independent, so each rank extracts a
+contiguous block of the record list (the reference's single-GPU loop is ``SceneDataSet.make_descs``,
+datasets/scene_dataset.py:494-711) and the ONLY exchange is one ``all_gather_into_tensor`` of the (n_r, 256) descriptor
+blocks -- at most ~0.4 MB per rank for an Oxford-sized set, i.e. latency-bound, so it is issued once, after the last batch,
+not per batch.  Retrieval then shards the trip pairs (patchaugnet_amd/retrieval.py).
+"""
+import math
+
+import torch
+
+
+def dist_info():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous block [lo, hi) of rank `rank`: ceil(n / world) records per rank, the tail ranks may be short or empty."""
+    per = math.ceil(n / world) if n else 0
+    lo = min(rank * per, n)
+    return lo, min(lo + per, n)
+
+
+def all_gather_descriptors(local, n_total):
+    """local: this rank's (hi - lo, D) block -> the full (n_total, D) matrix on every rank (one collective, padded tail)."""
+    dist, rank, world = dist_info()
+    if dist is None:
+        return local
+    per = math.ceil(n_total / world)
+    pad = torch.zeros((per, local.shape[1]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    full = torch.empty((world * per, local.shape[1]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(full, pad)
+    return full[:n_total]
+
+
+@torch.no_grad()
+def extract_dataset(model, load_batch, n_total, batch_size=32, n_streams=2, dim=256, device=None):
+    """Descriptors of records 0..n_total-1 on every rank.
+
+    load_batch(lo, hi) -> (hi - lo, 1, N, 3) fp32 tensor on the compute device (the caller owns file I/O / H2D);
+    model(x, return_feat=False) -> (B, dim).  Batches of this rank's shard are issued round-robin on `n_streams` HIP streams
+    (patchaugnet_amd/extract.py); n_streams = 0 runs them inline on the current stream (CPU stand-ins in tests)."""
+    _, rank, world = dist_info()
+    lo, hi = shard_bounds(n_total, rank, world)
+    if device is None:
+        device = next(model.parameters()).device if hasattr(model, "parameters") else torch.device("cpu")
+    local = torch.empty((hi - lo, dim), dtype=torch.float32, device=device)
+    pipe = None
+    if n_streams > 0:
+        from .extract import StreamPipeline
+        pipe = StreamPipeline(n_streams, device)
+        pipe.begin()
+    for b0 in range(lo, hi, batch_size):
+        b1 = min(b0 + batch_size, hi)
+        dst = local[b0 - lo:b1 - lo]
+
+        def step(b0=b0, b1=b1, dst=dst):
+            dst.copy_(model(load_batch(b0, b1), return_feat=False))
+        if pipe is not None:
+            pipe.submit(step)
+        else:
+            step()
+    if pipe is not None:
+        pipe.end()
+    return all_gather_descriptors(local, n_total)

@@ -1,0 +1,154 @@
+"""Descriptor retrieval + Recall@N bookkeeping (the caller-side step after descriptor extraction).
+
+Counterpart of the reference's evaluation loop:
+  * ``PlaceRecognitionDataSet.get_recall_precision``  datasets/place_recognition_dataset.py:52-70   (KDTree per reference trip,
+    every query trip against it)
+  * ``SceneDataSet.get_recall_precision``             datasets/scene_dataset.py:1016-1099           (per-pair recall / precision /
+    top-1% recall, self-match skipping, 1 % threshold with Python's round-half-to-even)
+  * the averaging in ``evaluate.run``                 place_recognition/evaluate.py:173-237
+
+MI355X plan: the reference walks the queries one at a time through a CPU KD-tree in 256-D (where a KD-tree degenerates to
+brute force anyway).  Here all queries of a trip pair go through ONE brute-force kNN launch on the GPU
+(``pa_knn_generic``, exact KNN_CUDA arithmetic: direct sum of squared differences, order (distance, index)); with
+``torch.distributed`` initialised the query trips are dealt round-robin to the ranks and the small index blocks are gathered.
+Only the integer bookkeeping (which of the k hits is a true positive) stays on the host.
+"""
+import numpy as np
+import torch
+
+from . import knn_cuda
+
+
+def hip_knn(database, queries, k):
+    """database (nd, dim), queries (nq, dim) fp32 HIP tensors -> idx (nq, k) int64, 0-based, ascending (distance, index)."""
+    _, ind = knn_cuda.knn(database.t().contiguous(), queries.t().contiguous(), k)       # KNN_CUDA layout: (dim, n) -> (k, nq)
+    return ind.t().contiguous()
+
+
+def indices_in_dataset(records_size_list):
+    """scene_dataset.py:116-124 -- dataset indices of each trip."""
+    out, s = [], 0
+    for n in records_size_list:
+        out.append(np.arange(s, s + n))
+        s += n
+    return out
+
+
+def one_percent_threshold(num_database):
+    """scene_dataset.py:1026 -- ``max(int(round(n / 100.0)), 1)``; Python 3 ``round`` is half-to-even."""
+    return max(int(round(num_database / 100.0)), 1)
+
+
+def real_top_k(num_database, top_k):
+    """scene_dataset.py:1027-1029 -- neighbours actually queried: top_k + 1, or threshold + 1 if that is larger."""
+    return max(top_k + 1, one_percent_threshold(num_database) + 1)
+
+
+def pair_recall_precision(found, query_indices, positives, num_database, top_k=25):
+    """Bookkeeping of scene_dataset.py:1047-1099 for one (query trip, reference trip) pair.
+
+    found[i]: dataset indices retrieved for query_indices[i], nearest first, self-match column already dropped when the
+    reference would drop it (:1058-1063).  positives: dict query index -> list of true positives.  Queries without
+    positives are not evaluated (:1050-1051).  Returns the reference's 8-tuple; its ``query_results`` entry (per-query
+    record dumps for logging) is reduced to the per-query state 0 (top-1 hit) / 1 (top-1 % hit) / 2 (miss)."""
+    threshold = one_percent_threshold(num_database)
+    recall, precision = np.zeros(top_k), np.zeros(top_k)
+    num_evaluated = one_percent_retrieved = 0
+    states = []
+    for row, q in zip(found, query_indices):
+        tp = positives.get(int(q), [])
+        if not tp:
+            continue
+        num_evaluated += 1
+        tp_set = set(tp)
+        found_positive = False
+        for j, idx in enumerate(row[:top_k]):
+            if idx == q:
+                continue
+            if idx in tp_set:
+                if not found_positive:
+                    recall[j] += 1
+                    found_positive = True
+                precision[j] += 1
+        state = 2
+        if tp_set.intersection(int(v) for v in row[:threshold]):
+            one_percent_retrieved += 1
+            state = 1
+        if int(row[0]) in tp_set:
+            state = 0
+        states.append(state)
+    one_percent_recall = 0.0
+    if num_evaluated > 0:
+        one_percent_recall = (one_percent_retrieved / float(num_evaluated)) * 100
+        recall = (np.cumsum(recall) / float(num_evaluated)) * 100
+        precision = (np.cumsum(precision) / float(num_evaluated)) * 100 / np.arange(1, top_k + 1, 1)
+    return recall, precision, one_percent_recall, num_evaluated - one_percent_retrieved, threshold, states, num_evaluated, num_database
+
+
+def _dist_info():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
+def get_recall_precision(global_descs, records_size_list, tuples, top_k=25, skip_trip_itself=False, query_trips=None, knn=hip_knn):
+    """place_recognition_dataset.py:52-70 over all trip pairs.
+
+    global_descs: (N, D) fp32 tensor on the device the kNN runs on, rows ordered trip by trip; tuples[(q_trip, r_trip)]
+    [query index] -> list of positive dataset indices (``QueryPosNegTuple.positive_indices``).  Returns
+    {(q_trip, r_trip): 8-tuple of scene_dataset.py:1098-1099}.  With torch.distributed initialised every rank searches the
+    pairs (q_trip * n_trips + r_trip) % world == rank and the results are exchanged with all_gather_object (kilobytes)."""
+    dist, rank, world = _dist_info()
+    sample_indices = indices_in_dataset(records_size_list)
+    ntrips = len(records_size_list)
+    mine = {}
+    for r in range(ntrips):
+        db_idx = sample_indices[r]
+        database = None
+        for q in range(ntrips):
+            if skip_trip_itself and q == r:
+                continue
+            if query_trips is not None and q not in query_trips:
+                continue
+            if (q * ntrips + r) % world != rank:
+                continue
+            if database is None:
+                database = global_descs[int(db_idx[0]):int(db_idx[-1]) + 1]
+            q_idx = sample_indices[q]
+            pos = tuples.get((q, r), {})
+            evaluated = np.array([i for i in q_idx if pos.get(int(i))], dtype=np.int64)
+            k = real_top_k(len(db_idx), top_k)
+            if len(evaluated) == 0:
+                found = np.zeros((0, k), dtype=np.int64)
+            else:
+                sel = torch.as_tensor(evaluated, device=global_descs.device)
+                found = knn(database, global_descs.index_select(0, sel), min(k, len(db_idx)))
+                found = db_idx[found.cpu().numpy()]
+                if q == r and not skip_trip_itself:        # `add_one_more`: the first hit is the query itself (:1058-1060)
+                    found = found[:, 1:]
+            mine[q, r] = pair_recall_precision(found, evaluated, pos, len(db_idx), top_k)
+    if dist is None:
+        return mine
+    parts = [None] * world
+    dist.all_gather_object(parts, mine)
+    out = {}
+    for p in parts:
+        out.update(p)
+    return dict(sorted(out.items(), key=lambda kv: (kv[0][1], kv[0][0])))
+
+
+def average(recall_dict, top_k=25):
+    """evaluate.py:173-237 for a public dataset: skips q == r pairs and pairs without evaluated queries; returns
+    (ave_recall[top_k], ave_precision[top_k], ave_one_percent_recall, lost_mean, lost_sum)."""
+    recall, precision, count = np.zeros(top_k), np.zeros(top_k), 0
+    opr, lost = [], []
+    for (q, r), res in recall_dict.items():
+        if q == r or res[6] == 0:
+            continue
+        recall += np.array(res[0])
+        precision += np.array(res[1])
+        count += 1
+        opr.append(res[2])
+        lost.append(res[3])
+    return recall / count, precision / count, float(np.mean(opr)), float(np.mean(lost)), int(np.sum(lost))

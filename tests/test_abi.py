@@ -87,3 +87,25 @@ def test_state_dict_keys_match_the_reference(name):
     assert list(sd.keys()) == list(ref.keys())
     for k, (shape, dt) in ref.items():
         assert list(sd[k].shape) == shape and str(sd[k].dtype) == dt, k
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/libs/pointops"), reason="reference tree only exists in the build container")
+def test_reference_op_layer_imports_against_the_mirrors():
+    """INTEGRATION.md route 1: the reference's own pointops.py / chamfer_dist / emd_module import cleanly when this repo's
+    mirrors are registered under the native module names, and every native function they call exists in the mirror."""
+    import re
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.dont_write_bytecode = True; sys.path.insert(0, %r); sys.path.insert(1, '/root/reference')\n"
+        "import patchaugnet_amd.pointops_cuda as pc, patchaugnet_amd.chamfer_dist as ch, patchaugnet_amd.emd_module as emd\n"
+        "sys.modules['pointops_cuda'] = pc; sys.modules['chamfer'] = ch; sys.modules['emd'] = emd\n"
+        "from libs.pointops.functions import pointops\n"
+        "import libs.chamfer_dist as cd\n"
+        "from libs.emd_module.emd_module import emdModule\n"
+        "print('OK', pointops.furthestsampling is not None, cd.ChamferDistanceL1 is not None, emdModule is not None)\n") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp")
+    assert out.returncode == 0 and "OK True True True" in out.stdout, out.stderr[-2000:]
+    from patchaugnet_amd import pointops_cuda
+    used = set(re.findall(r"pointops_cuda\.(\w+)\(", open("/root/reference/libs/pointops/functions/pointops.py").read()))
+    assert used and not (used - set(dir(pointops_cuda)))
