@@ -153,15 +153,43 @@ def gen_pptnet():
     np.savez_compressed(os.path.join(GOLD, "pptnet.npz"), **out)
 
 
+def gen_pointnet_vlad():
+    """BASELINE.json configs[0]: PointNetVlad as evaluate.py:88-90 builds it; the reference class runs on CPU unmodified."""
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, ROOT)
+    sys.path.insert(1, REF)
+    from patchaugnet_amd.weights import seeded_state_dict
+    from place_recognition.pointnet_vlad import PointNetVlad as ref
+    out = {}
+    for tag, npts in (("full", 4096), ("small", 512)):
+        model = ref.PointNetVlad(global_feat=True, feature_transform=True, max_pool=False, output_dim=256, num_points=npts)
+        sd = seeded_state_dict(model.state_dict())
+        model.load_state_dict(sd, strict=True)
+        model.eval()
+        x = _inputs(npts)
+        with torch.no_grad():
+            desc = model(x)
+            d1 = model(x[:1])                                   # batch = 1, the configuration BASELINE.json names
+        assert torch.allclose(d1, desc[:1], atol=2e-5), (d1 - desc[:1]).abs().max()
+        out[f"{tag}_x"] = x.numpy()
+        out[f"{tag}_desc"] = desc.numpy()
+        if tag == "full":
+            keys = {k: [list(v.shape), str(v.dtype)] for k, v in model.state_dict().items()}
+            with open(os.path.join(GOLD, "pointnet_vlad_state_dict_keys.json"), "w") as f:
+                json.dump(keys, f, indent=0)
+        print(f"[pointnet_vlad/{tag}] desc {tuple(desc.shape)} |desc|max {desc.abs().max():.3f}")
+    np.savez_compressed(os.path.join(GOLD, "pointnet_vlad.npz"), **out)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["patch_aug_net", "pptnet"]
+    which = sys.argv[1:] or ["patch_aug_net", "pptnet", "pointnet_vlad"]
     if len(which) > 1:
         for w in which:
             subprocess.check_call([sys.executable, "-m", "oracle.gen_golden", w], cwd=ROOT,
                                   env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
         return
-    {"patch_aug_net": gen_patch_aug_net, "pptnet": gen_pptnet}[which[0]]()
+    {"patch_aug_net": gen_patch_aug_net, "pptnet": gen_pptnet, "pointnet_vlad": gen_pointnet_vlad}[which[0]]()
 
 
 if __name__ == "__main__":

@@ -108,3 +108,24 @@ def test_pptnet_vs_reference_vectors(tag, fused):
         assert np.abs(d.cpu().numpy() - ref).max() <= 2e-4 * scale
         for i in range(4):
             assert np.array_equal(cidx[i].cpu().numpy(), g[f"{tag}_center_idx{i}"])
+
+
+def test_training_step_quadruplet_plus_patch_chamfer():
+    """BASELINE.json configs[3] in miniature: one quadruplet tuple (1 query + 2 positives + 14 negatives + 1 other = 18 clouds,
+    configs/patch_aug_net.yaml:60-62) of 512 points, nn_dict with the two (query, positive) pairs -> 3 related clouds;
+    quadruplet loss + HIP patch-Chamfer loss, backward through the HIP backward kernels, one Adam step."""
+    from patchaugnet_amd import train
+    from patchaugnet_amd.weights import synthetic_submaps
+    cfg = configs.scaled_config(configs.patch_aug_net_config(), 512)
+    m = _pan(cfg)
+    x = synthetic_submaps(18, 512, 5).squeeze(1)
+    q, pos, neg, oth = x[None, :1], x[None, 1:3], x[None, 3:17], x[None, 17:]
+    opt = torch.optim.Adam(m.parameters(), 1e-4)
+    before = {k: v.detach().clone() for k, v in m.named_parameters()}
+    torch.manual_seed(3)
+    out = train.training_step(m, opt, q, pos, neg, oth, nn_dict={(0, 1): None, (0, 2): None}, num_points=512)
+    assert set(out) == {"place_recognition", "patch_recon_a2a", "total"} and all(np.isfinite(v) for v in out.values())
+    assert out["patch_recon_a2a"] > 0 and abs(out["total"] - out["place_recognition"] - out["patch_recon_a2a"]) < 1e-5
+    moved = [k for k, v in m.named_parameters() if not torch.equal(v.detach(), before[k])]
+    for part in ("backbone.SA_modules.0", "backbone.FP_modules.0", "aggregation.vlads.2", "aggregation.afa.fc", "decoder.fc3"):
+        assert any(k.startswith(part) for k in moved), part
