@@ -54,8 +54,8 @@ def training_step(model, optimizer, queries, positives, negatives, other_neg, nn
     for k in cur:
         cur[k] = cur[k] * loss_alpha.get(k, 1.0)
         total = total + cur[k]
-    if float(total) > 1e-10:                                      # :390-392
+    if float(total.detach()) > 1e-10:                             # :390-392
         total.backward()
         optimizer.step()
     cur["total"] = total
-    return {k: float(v) for k, v in cur.items()}
+    return {k: float(v.detach()) for k, v in cur.items()}
