@@ -140,9 +140,22 @@ int pa_mlp_chain(int mode, int pooled, int nlayers, const float *const *wt, cons
                  float *out, int ldo, pa_stream_t stream);
 /* One dense layer on point-major rows (the chain kernel's plain mode with a selectable epilogue):
  * out[r][:] = residual[r][:] + act(x[r][:k] . Wt + bias), act = ReLU if relu != 0 else identity; residual may be NULL.
- * wt K-major (kpad x n), kpad = k rounded up to 4 with zero rows, n % 16 == 0. */
-int pa_linear(long rows, int k, int n, const float *x, int ldx, const float *wt, const float *bias, int relu, const float *residual, int ldr,
-              float *out, int ldo, pa_stream_t stream);
+ * wt K-major (kpad x n), kpad = k rounded up to 4 with zero rows, n % 16 == 0; wpk: optional packed copy (below) or NULL. */
+int pa_linear(long rows, int k, int n, const float *x, int ldx, const float *wt, const float *wpk, const float *bias, int relu,
+              const float *residual, int ldr, float *out, int ldo, pa_stream_t stream);
+
+/* Fragment-major packing of a K-major (kpad x n) weight matrix, n % 64 == 0:
+ *   wp[((cg * (kpad/4) + ks) * 64 + l) * 4 + j] = wt[(4 ks + l/16) * n + 64 cg + 16 j + l%16]
+ * i.e. the four v_mfma_f32_16x16x4_f32 B fragments a lane needs for a 64-column group sit in one 16-byte word, so the chain
+ * kernels fetch weights with 4 instead of 16 loads per k-step.  pa_mlp_chain_packed = pa_mlp_chain with one packed copy per
+ * layer (wpk[l] may be NULL: that layer then reads wt[l]); pa_linear takes the packed copy as `wpk` (or NULL). */
+int pa_pack_weights(int kpad, int n, const float *wt, float *wp, pa_stream_t stream);
+int pa_mlp_chain_packed(int mode, int pooled, int nlayers, const float *const *wt, const float *const *wpk, const float *const *bias,
+                        const int *kpad, const int *nout, long rows, int k0,
+                        const float *x, int ldx,
+                        const float *xyz, const float *feat, const int *center_idx, const int *nbr_idx, int n_src, int m_ctr, int ns, int c_feat,
+                        const float *known, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2, int c1,
+                        float *out, int ldo, pa_stream_t stream);
 
 /* ---- PPT-Net grouped self-attention core  (place_recognition/pptnet_origin/models/pptnet.py:261-282; twin GroupSALayer,
  * place_recognition/patch_aug_net/models/loupe.py:69-114).  yv (b, n, 2c) point-major = [Y | V] with Y = q_conv(x) = k_conv(x)
@@ -150,6 +163,10 @@ int pa_linear(long rows, int k, int n, const float *x, int ldx, const float *wt,
  * Writes d (b, n, c) = x - x_r, x_r = V^T attn, attn = row soft-max of Y Y^T re-normalised by (1e-9 + column sums).
  * stats: scratch of 2*b*n floats (row max and 1/row-sum).  Any n >= 1; c in {64, 128, 256, 512}. */
 int pa_sa_attention(int b, int n, int c, const float *yv, const float *x, float *stats, float *d, pa_stream_t stream);
+
+/* Profiling hook: when set to a device buffer of 512 x 8 int64, the chain kernels store cycle-counter stamps at their phase
+ * boundaries (tile start, prologue done, each layer done) for the first 512 tiles.  NULL (the default) turns it off. */
+void pa_chain_debug_buffer(long long *buf);
 
 /* out[g][c] = max over s < ns of in[g*ns + s][c]  (rows of c floats) */
 int pa_rowgroup_max(long groups, int ns, int c, const float *in, float *out, pa_stream_t stream);

@@ -41,7 +41,9 @@ _SIGS = {
     "pa_emd_backward": "iippppp",
     "pa_mlp_chain": "iiipppplipippppiiiippppiiiipi",
     "pa_rowgroup_max": "liipp",
-    "pa_linear": "liipippipipi",
+    "pa_linear": "liipipppipipi",
+    "pa_pack_weights": "iipp",
+    "pa_mlp_chain_packed": "iiippppplipippppiiiippppiiiipi",
     "pa_sa_attention": "iiipppp",
     "pa_netvlad": "iiiippppppii",
     "pa_furthestsampling_gather": "iiippp",

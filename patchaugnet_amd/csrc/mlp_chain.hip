@@ -30,6 +30,7 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 struct PaLayer {
     const float *wt;    // [kpad][n], K-major, rows >= k are zero
+    const float *wp;    // optional fragment-major packing of the same matrix (pa_pack_weights), n % 64 == 0; null = use wt
     const float *bias;  // [n]
     int kpad;           // multiple of 4
     int n;              // multiple of 16
@@ -63,6 +64,8 @@ struct PaChain {
     int relu_last;
     const float *residual;   // (rows, ldr) or null
     int ldr;
+    long long *dbg;          // profiling only: per-tile s_memtime stamps at phase boundaries (null in production)
+    int ep_stride;           // > 0: the last layer's tile is transposed through LDS (row stride ep_stride floats) and written as 16-byte row segments
 };
 
 namespace {
@@ -72,76 +75,110 @@ enum { MODE_PLAIN = 0, MODE_SA = 1, MODE_FP = 2 };
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // One column chunk (NC tiles of 16 columns starting at tile c0) of one layer for the wave's RT row tiles.
-// DEEP = false: operands of k-step i+1 are requested right before the MFMAs of k-step i (enough when a k-step is
-//               >= 16 MFMAs = 512+ cycles; smallest code, best for the short K loops of the SA levels).
-// DEEP = true : a 4-deep register ring with static indices, for the column-split tiling where a k-step is only
-//               RT*NC <= 16 MFMAs and the ~500-cycle L2 latency of the weight loads would otherwise be exposed.
-template <int RT, int NC, bool DEEP>
+//
+// Operand ring: PD register sets; set u holds k-step ks+u and is refilled for k-step ks+u+PD right after its last use, so the
+// weight fragments get PD k-steps of latency cover with no register-to-register copies.  PD = 2 when a k-step is >= 32 MFMAs,
+// 4 for the column-split tilings whose k-steps are only 8-16 MFMAs.
+//
+// Weight layouts.  K-major (L.wt): lane l's fragment for column tile ct is Wt[4ks + l/16][16ct + l%16] -- one 4-byte load
+// per column tile, 16 VMEM instructions per k-step at NC = 16.  Measured on MI355X every non-MFMA instruction in the stream
+// costs the matrix pipe ~6-7 cycles (one wave per SIMD: nobody else fills the slot), and 18 of them per 32 MFMAs held the
+// loop at 42-44 cycles per MFMA instead of 32.  Fragment-major packed weights (L.wp, pa_pack_weights):
+//     wp[((cg * ksteps + ks) * 64 + l) * 4 + j] = Wt[4ks + l/16][64cg + 16j + l%16]
+// put a lane's four fragments of a 64-column group in one 16-byte word: 4 dwordx4 loads per k-step, each wave-load one
+// contiguous 1 KB segment (37 cycles per MFMA in the same loop).
+template <int RT, int NC, int PD>
 __device__ __forceinline__ void gemm_chunk(const float *__restrict__ act, int stride, const PaLayer &L, int c0, int lane,
                                             floatx4 (&acc)[RT][NC])
 {
-    const int ksteps = L.kpad >> 2;
-    const float *wp = L.wt + (size_t)(lane >> 4) * L.n + c0 * 16 + (lane & 15);
+    const int ksteps = L.kpad >> 2, last = ksteps - 1;
     const float *ap = act + (lane & 15) * stride + (lane >> 4);
-    const size_t wstep = (size_t)4 * L.n;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int ct = 0; ct < NC; ++ct) acc[rt][ct] = (floatx4){0.f, 0.f, 0.f, 0.f};
-    if (!DEEP) {
-        float bn[NC], an[RT];
-#pragma unroll
-        for (int ct = 0; ct < NC; ++ct) bn[ct] = wp[ct * 16];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) an[rt] = ap[rt * 16 * stride];
-        for (int ks = 0; ks < ksteps; ++ks) {
-            float bc[NC], ac[RT];
-#pragma unroll
-            for (int ct = 0; ct < NC; ++ct) bc[ct] = bn[ct];
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) ac[rt] = an[rt];
-            if (ks + 1 < ksteps) {
-                const float *wn = wp + (size_t)(ks + 1) * wstep;
-#pragma unroll
-                for (int ct = 0; ct < NC; ++ct) bn[ct] = wn[ct * 16];
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) an[rt] = ap[rt * 16 * stride + (ks + 1) * 4];
-            }
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int ct = 0; ct < NC; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[rt], bc[ct], acc[rt][ct], 0, 0, 0);
-        }
-    } else {
-        constexpr int PD = 4;
-        float bq[PD][NC], aq[PD][RT];
+    float bq[PD][NC], aq[PD][RT];
+    int ks = 0;
+    if ((NC % 4 == 0) && L.wp != nullptr) {
+        constexpr int NQ = NC / 4 > 0 ? NC / 4 : 1;
+        const float4 *wq = reinterpret_cast<const float4 *>(L.wp) + (size_t)(c0 >> 2) * ksteps * 64 + lane;
+        const size_t gstep = (size_t)ksteps * 64;   // float4s between consecutive 64-column groups
 #pragma unroll
         for (int u = 0; u < PD; ++u) {
-            if (u < ksteps) {
+            const int k = min(u, last);
 #pragma unroll
-                for (int ct = 0; ct < NC; ++ct) bq[u][ct] = wp[(size_t)u * wstep + ct * 16];
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) aq[u][rt] = ap[rt * 16 * stride + u * 4];
+            for (int q = 0; q < NQ; ++q) {
+                const float4 v = wq[q * gstep + (size_t)k * 64];
+                bq[u][4 * q] = v.x; bq[u][4 * q + 1] = v.y; bq[u][4 * q + 2] = v.z; bq[u][4 * q + 3] = v.w;
             }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) aq[u][rt] = ap[rt * 16 * stride + k * 4];
         }
-        for (int ks = 0; ks < ksteps; ks += PD) {
+        for (; ks + PD <= ksteps; ks += PD) {
 #pragma unroll
             for (int u = 0; u < PD; ++u) {
-                if (ks + u < ksteps) {
+                const int nx = min(ks + u + PD, last);
+                float an[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) an[rt] = ap[rt * 16 * stride + nx * 4];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt)
+                            acc[rt][4 * q + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[u][rt], bq[u][4 * q + c], acc[rt][4 * q + c], 0, 0, 0);
+                    const float4 v = wq[q * gstep + (size_t)nx * 64];
+                    bq[u][4 * q] = v.x; bq[u][4 * q + 1] = v.y; bq[u][4 * q + 2] = v.z; bq[u][4 * q + 3] = v.w;
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * RT, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) aq[u][rt] = an[rt];
+            }
+        }
+    } else {
+        const float *wp = L.wt + (size_t)(lane >> 4) * L.n + c0 * 16 + (lane & 15);
+        const size_t wstep = (size_t)4 * L.n;
+#pragma unroll
+        for (int u = 0; u < PD; ++u) {
+            const int k = min(u, last);
+#pragma unroll
+            for (int ct = 0; ct < NC; ++ct) bq[u][ct] = wp[(size_t)k * wstep + ct * 16];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) aq[u][rt] = ap[rt * 16 * stride + k * 4];
+        }
+        for (; ks + PD <= ksteps; ks += PD) {
+#pragma unroll
+            for (int u = 0; u < PD; ++u) {
+                const int nx = min(ks + u + PD, last);
+                const float *wn = wp + (size_t)nx * wstep;
+                float an[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) an[rt] = ap[rt * 16 * stride + nx * 4];
+#pragma unroll
+                for (int ct = 0; ct < NC; ++ct) {
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                        for (int ct = 0; ct < NC; ++ct)
-                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[u][rt], bq[u][ct], acc[rt][ct], 0, 0, 0);
-                    const int nx = ks + u + PD;
-                    if (nx < ksteps) {
-#pragma unroll
-                        for (int ct = 0; ct < NC; ++ct) bq[u][ct] = wp[(size_t)nx * wstep + ct * 16];
-#pragma unroll
-                        for (int rt = 0; rt < RT; ++rt) aq[u][rt] = ap[rt * 16 * stride + nx * 4];
-                    }
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[u][rt], bq[u][ct], acc[rt][ct], 0, 0, 0);
+                    bq[u][ct] = wn[ct * 16];
+                    __builtin_amdgcn_sched_group_barrier(0x008, RT, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) aq[u][rt] = an[rt];
             }
+        }
+    }
+    // tail: the sets that still hold valid (not clamped) k-steps
+#pragma unroll
+    for (int u = 0; u < PD - 1; ++u) {
+        if (ks + u < ksteps) {
+#pragma unroll
+            for (int ct = 0; ct < NC; ++ct)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[u][rt], bq[u][ct], acc[rt][ct], 0, 0, 0);
         }
     }
 }
@@ -185,6 +222,42 @@ __device__ __forceinline__ void store_rows(float *__restrict__ out, int ldo, lon
                     out[row * ldo + col] = v;
                 }
             }
+    }
+}
+
+// last layer, plain, via LDS: the accumulator layout gives a lane 4-byte pieces of 64-byte row segments (128 store
+// instructions per lane for a 32 x 256 tile -- store-issue bound).  Writing the tile to the (now dead) activation region
+// and reading it back row-major turns that into 16-byte stores of whole contiguous rows, 4x fewer and fully coalesced.
+template <int RT, int NC>
+__device__ __forceinline__ void stage_rows_lds(float *act, int ostride, const PaLayer &L, int c0, int lane, floatx4 (&acc)[RT][NC], int relu)
+{
+    const float floor_v = relu ? 0.f : -INFINITY;
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) {
+        const int col = (c0 + ct) * 16 + (lane & 15);
+        const float bias = L.bias[col];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) act[(rt * 16 + (lane >> 4) * 4 + r) * ostride + col] = fmaxf(acc[rt][ct][r] + bias, floor_v);
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void copy_rows_out(const float *act, int ostride, int n, float *__restrict__ out, int ldo, long row0, long rows,
+                                              const float *__restrict__ residual, int ldr, int tid, int nth)
+{
+    const int qpr = n >> 2;
+    for (int q = tid; q < R * qpr; q += nth) {
+        const int r = q / qpr, part = q - r * qpr;
+        const long row = row0 + r;
+        if (row >= rows) continue;
+        float4 v = *reinterpret_cast<const float4 *>(act + r * ostride + part * 4);
+        if (residual) {
+            const float4 rr = *reinterpret_cast<const float4 *>(residual + row * ldr + part * 4);
+            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        *reinterpret_cast<float4 *>(out + row * ldo + part * 4) = v;
     }
 }
 
@@ -232,22 +305,33 @@ __device__ __forceinline__ void run_layer_chunks(float *act, const PaChain &a, i
     const bool last = (l == a.nlayers - 1);
     for (int c0 = c_begin; c0 < c_end; c0 += NC) {
         floatx4 acc[RT][NC];
-        gemm_chunk<RT, NC, (WPT > 1)>(act, a.lds_stride, L, c0, lane, acc);
+        gemm_chunk<RT, NC, (WPT > 1 ? 4 : 2)>(act, a.lds_stride, L, c0, lane, acc);
         if (!last) {
             tile_sync<WPT>();  // every A read of this layer has landed before its rows are overwritten (single chunk per wave: host-checked)
             store_hidden<RT, NC>(act, a.lds_stride, L, c0, lane, acc);
         } else if (POOLED) {
             store_pooled<RT, NC>(a.out, a.ldo, tile * 4, a.rows, L, c0, lane, acc);
+        } else if (a.ep_stride > 0) {   // host guarantees a single chunk per wave here
+            tile_sync<WPT>();           // every A read of the last layer has landed: the activation tile is dead
+            stage_rows_lds<RT, NC>(act, a.ep_stride, L, c0, lane, acc, a.relu_last);
         } else {
             const long total_rows = (MODE == MODE_SA) ? a.rows * a.ns : a.rows;
             store_rows<RT, NC>(a.out, a.ldo, tile * (RT * 16), total_rows, L, c0, lane, acc, a.relu_last, a.residual, a.ldr);
         }
     }
     if (!last) tile_sync<WPT>();
+    else if (!POOLED && a.ep_stride > 0) {
+        tile_sync<WPT>();
+        const long total_rows = (MODE == MODE_SA) ? a.rows * a.ns : a.rows;
+        copy_rows_out<RT * 16>(act, a.ep_stride, L.n, a.out, a.ldo, tile * (RT * 16), total_rows, a.residual, a.ldr,
+                               WPT == 1 ? lane : (int)threadIdx.x, WPT * 64);
+    }
 }
 
+// Pooled wave-private kernels (the set-abstraction levels) are gather-latency bound in their prologue: keep two waves per SIMD
+// (<= 256 registers) there; the plain row kernels trade occupancy for their 128 accumulator registers.
 template <int RT, int NCMAX, int MODE, bool POOLED, int WPT>
-__global__ __launch_bounds__(256) void chain_kernel(PaChain a)
+__global__ __launch_bounds__(256, (POOLED && WPT == 1 && RT <= 5) ? 2 : 1) void chain_kernel(PaChain a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int R = RT * 16;
@@ -261,6 +345,8 @@ __global__ __launch_bounds__(256) void chain_kernel(PaChain a)
     constexpr int NTH = WPT * 64;
     const int stride = a.lds_stride;
     const int k0pad = a.L[0].kpad;
+#define PA_STAMP(i) do { if (a.dbg && tile < 512 && lane == 0 && (WPT == 1 || wave == 0)) a.dbg[tile * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+    PA_STAMP(0);
 
     // ---------------------------------------------------------------- prologue: build the A tile of layer 0
     if (MODE == MODE_PLAIN) {
@@ -359,6 +445,7 @@ __global__ __launch_bounds__(256) void chain_kernel(PaChain a)
         }
     }
     tile_sync<WPT>();
+    PA_STAMP(1);
 
     // ---------------------------------------------------------------- layers
     for (int l = 0; l < a.nlayers; ++l) {
@@ -370,7 +457,9 @@ __global__ __launch_bounds__(256) void chain_kernel(PaChain a)
         else if (NCMAX >= 4 && per % 4 == 0) run_layer_chunks<RT, (NCMAX >= 4 ? 4 : NCMAX), MODE, POOLED, WPT>(act, a, l, tile, lane, cb, ce);
         else if (per % 2 == 0) run_layer_chunks<RT, 2, MODE, POOLED, WPT>(act, a, l, tile, lane, cb, ce);
         else run_layer_chunks<RT, 1, MODE, POOLED, WPT>(act, a, l, tile, lane, cb, ce);
+        PA_STAMP(2 + l);
     }
+#undef PA_STAMP
 }
 
 // max over groups of `ns` consecutive rows: out[g][c] = max_s in[g*ns + s][c]   (patch_aug_net.py:236 for the unfused SA level)
@@ -401,6 +490,7 @@ template <int MODE>
 void launch_rows(const PaChain &a, int rt, bool split, int wpw, long ntiles, hipStream_t st)
 {
     if (!split) launch_chain<2, 16, MODE, false, 1>(a, wpw, ntiles, st);
+    else if (rt == 8) launch_chain<8, 4, MODE, false, 4>(a, 4, ntiles, st);
     else if (rt == 2) launch_chain<2, 8, MODE, false, 4>(a, 4, ntiles, st);
     else launch_chain<1, 8, MODE, false, 4>(a, 4, ntiles, st);
 }
@@ -409,7 +499,11 @@ void launch_rows(const PaChain &a, int rt, bool split, int wpw, long ntiles, hip
 
 // Generic entry point.  mode: 0 plain rows, 1 set-abstraction gather, 2 feature-propagation interpolate.
 // wt[l] is K-major (kpad[l] x n[l]) with BN folded in and zero rows beyond the true K; bias[l] has n[l] entries.
-static int chain_dispatch(int mode, int pooled, int nlayers, const float *const *wt, const float *const *bias, const int *kpad, const int *nout,
+static long long *g_chain_dbg = nullptr;
+// profiling hook (tools/chain_phases.py): device buffer of 512 x 8 int64 receiving s_memtime stamps of the next launches; NULL = off
+PA_API void pa_chain_debug_buffer(long long *buf) { g_chain_dbg = buf; }
+
+static int chain_dispatch(int mode, int pooled, int nlayers, const float *const *wt, const float *const *wpk, const float *const *bias, const int *kpad, const int *nout,
                           long rows, int k0,
                           const float *x, int ldx,
                           const float *xyz, const float *feat, const int *center_idx, const int *nbr_idx, int n_src, int m_ctr, int ns, int c_feat,
@@ -427,6 +521,8 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
         PA_REQUIRE(kpad[l] % 4 == 0 && kpad[l] >= kin && kpad[l] < kin + 4, "pa_mlp_chain: layer %d kpad=%d must be k=%d rounded up to 4", l, kpad[l], kin);
         PA_REQUIRE(nout[l] % 16 == 0 && nout[l] > 0, "pa_mlp_chain: layer %d n=%d must be a positive multiple of 16", l, nout[l]);
         a.L[l].wt = wt[l]; a.L[l].bias = bias[l]; a.L[l].kpad = kpad[l]; a.L[l].n = nout[l];
+        static const bool no_packed = getenv("PA_CHAIN_NO_PACKED") != nullptr;   // A/B knob
+        a.L[l].wp = (!no_packed && wpk && wpk[l] && nout[l] % 64 == 0) ? wpk[l] : nullptr;
         if (kpad[l] > maxk) maxk = kpad[l];
         kin = nout[l];
     }
@@ -436,6 +532,7 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
     a.known = known; a.idx3 = idx3; a.w3 = w3; a.skip = skip; a.n_unknown = n_unknown; a.m_known = m_known; a.c2 = c2; a.c1 = c1;
     a.out = out; a.ldo = ldo;
     a.relu_last = relu_last; a.residual = residual; a.ldr = ldr;
+    a.dbg = g_chain_dbg;
     hipStream_t st = (hipStream_t)stream;
 
     const bool is_pooled = pooled != 0;
@@ -454,6 +551,13 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
     if (!is_pooled) {
         const long t32 = (total_rows + 31) / 32;
         if (can_split && t32 < split_below) { split = true; RTv = t32 >= 512 ? 2 : 1; }
+        // Many rows and every layer exactly 256 wide: 128-row tiles shared by the four waves, each wave owning 64 output columns.
+        // A wave then pulls only ITS quarter of each weight matrix (1 KB per k-step instead of 4 KB four times per CU).
+        // (kept selectable for experiments; with packed weights the wave-private tiling is faster at every size measured: default off)
+        static const long big_above = getenv("PA_CHAIN_BIG_ABOVE") ? atol(getenv("PA_CHAIN_BIG_ABOVE")) : (1L << 60);
+        bool all256 = true;
+        for (int l = 0; l < nlayers; ++l) all256 = all256 && nout[l] == 256;
+        if (!split && all256 && total_rows >= big_above && (size_t)128 * (maxk + 2) * 4 <= 150 * 1024) { split = true; RTv = 8; }
     } else {
         const long tp = (rows + 3) / 4;
         if (can_split && tp < 2048 && RTv == 5) split = true;
@@ -464,6 +568,21 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
         for (int l = 0; l + 1 < nlayers; ++l)  // hidden layers are written back in place => must be a single column chunk
             PA_REQUIRE(nout[l] / 16 <= ncmax && ((nout[l] / 16) & (nout[l] / 16 - 1)) == 0,
                        "pa_mlp_chain: hidden layer %d with n=%d must be 16*2^j <= %d (single column chunk, written back in place)", l, nout[l], ncmax * 16);
+    // LDS-transposed epilogue: needs the last layer to be one chunk per wave (so its A tile is dead when the results are staged),
+    // the staged tile to fit the activation region, and 16-byte aligned rows in the output / residual.
+    int ep_floats = 0;
+    if (!is_pooled) {
+        const int nl = nout[nlayers - 1];
+        const int per = split ? nl / 64 : nl / 16;
+        const int nc = (ncmax >= 16 && per % 16 == 0) ? 16 : (ncmax >= 8 && per % 8 == 0) ? 8 : (ncmax >= 4 && per % 4 == 0) ? 4 : (per % 2 == 0) ? 2 : 1;
+        const int ostride = nl + 4;
+        static const bool ep_off = getenv("PA_CHAIN_NO_LDS_EPILOGUE") != nullptr;
+        if (!ep_off && nc == per && (ostride <= a.lds_stride || (size_t)R * ostride * 4 <= 40 * 1024) && ldo % 4 == 0 && ((uintptr_t)out & 15) == 0 &&
+            (residual == nullptr || (ldr % 4 == 0 && ((uintptr_t)residual & 15) == 0))) {
+            a.ep_stride = ostride;
+            ep_floats = R * ostride;
+        }
+    }
     int scratch = 0;
     if (mode == MODE_PLAIN) {
         PA_REQUIRE(x && ldx >= k0, "pa_mlp_chain: plain mode needs x and ldx >= k0");
@@ -482,6 +601,7 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
         PA_REQUIRE(false, "pa_mlp_chain: unknown mode %d", mode);
     }
     a.wave_floats = ((R * a.lds_stride + scratch + 3) / 4) * 4;
+    if (ep_floats > a.wave_floats) a.wave_floats = ep_floats;
     const size_t per_wave = (size_t)a.wave_floats * 4;
     PA_REQUIRE(per_wave <= 156 * 1024, "pa_mlp_chain: one tile needs %zu B of LDS (> 156 KiB); reduce K", per_wave);
     int wpw = 4;
@@ -512,18 +632,55 @@ PA_API int pa_mlp_chain(int mode, int pooled, int nlayers, const float *const *w
                         const float *known, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2, int c1,
                         float *out, int ldo, pa_stream_t stream)
 {
-    return chain_dispatch(mode, pooled, nlayers, wt, bias, kpad, nout, rows, k0, x, ldx, xyz, feat, center_idx, nbr_idx, n_src, m_ctr, ns, c_feat,
+    return chain_dispatch(mode, pooled, nlayers, wt, nullptr, bias, kpad, nout, rows, k0, x, ldx, xyz, feat, center_idx, nbr_idx, n_src, m_ctr, ns, c_feat,
                           known, idx3, w3, skip, n_unknown, m_known, c2, c1, out, ldo, 1, nullptr, 0, stream);
 }
 
-// One dense layer on point-major rows: out = residual + act(x Wt + bias); wt K-major (kpad x n), kpad = k rounded up to 4.
-PA_API int pa_linear(long rows, int k, int n, const float *x, int ldx, const float *wt, const float *bias, int relu, const float *residual, int ldr,
-                     float *out, int ldo, pa_stream_t stream)
+// Same, with fragment-major packed copies of the weights (wpk[l] from pa_pack_weights, or NULL for a layer to use wt[l]).
+PA_API int pa_mlp_chain_packed(int mode, int pooled, int nlayers, const float *const *wt, const float *const *wpk, const float *const *bias,
+                               const int *kpad, const int *nout, long rows, int k0,
+                               const float *x, int ldx,
+                               const float *xyz, const float *feat, const int *center_idx, const int *nbr_idx, int n_src, int m_ctr, int ns, int c_feat,
+                               const float *known, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2, int c1,
+                               float *out, int ldo, pa_stream_t stream)
+{
+    return chain_dispatch(mode, pooled, nlayers, wt, wpk, bias, kpad, nout, rows, k0, x, ldx, xyz, feat, center_idx, nbr_idx, n_src, m_ctr, ns, c_feat,
+                          known, idx3, w3, skip, n_unknown, m_known, c2, c1, out, ldo, 1, nullptr, 0, stream);
+}
+
+// One dense layer on point-major rows: out = residual + act(x Wt + bias); wt K-major (kpad x n), kpad = k rounded up to 4;
+// wpk: optional packed copy of wt (NULL = none).
+PA_API int pa_linear(long rows, int k, int n, const float *x, int ldx, const float *wt, const float *wpk, const float *bias, int relu,
+                     const float *residual, int ldr, float *out, int ldo, pa_stream_t stream)
 {
     PA_REQUIRE(residual == nullptr || ldr >= n, "pa_linear: residual row stride %d < n=%d", ldr, n);
     const int kpad = (k + 3) / 4 * 4;
-    return chain_dispatch(0, 0, 1, &wt, &bias, &kpad, &n, rows, k, x, ldx, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0,
+    return chain_dispatch(0, 0, 1, &wt, &wpk, &bias, &kpad, &n, rows, k, x, ldx, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0,
                           nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, out, ldo, relu, residual, ldr, stream);
+}
+
+namespace {
+// wp[((cg * ksteps + ks) * 64 + l) * 4 + j] = wt[(4ks + l/16) * n + 64cg + 16j + l%16]
+__global__ void pack_weights_kernel(int kpad, int n, const float *__restrict__ wt, float *__restrict__ wp)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)kpad * n) return;
+    const int j = (int)(t & 3), l = (int)((t >> 2) & 63);
+    const long rest = t >> 8;
+    const int ksteps = kpad >> 2;
+    const int ks = (int)(rest % ksteps), cg = (int)(rest / ksteps);
+    wp[t] = wt[(size_t)(4 * ks + (l >> 4)) * n + 64 * cg + 16 * j + (l & 15)];
+}
+}  // namespace
+
+// Fragment-major packing of a K-major (kpad x n) weight matrix for the MFMA chain kernels; n % 64 == 0, kpad % 4 == 0.
+PA_API int pa_pack_weights(int kpad, int n, const float *wt, float *wp, pa_stream_t stream)
+{
+    PA_REQUIRE(kpad > 0 && kpad % 4 == 0 && n > 0 && n % 64 == 0 && wt && wp, "pa_pack_weights: need kpad %% 4 == 0, n %% 64 == 0 (kpad=%d n=%d)", kpad, n);
+    const long total = (long)kpad * n;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(pa_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, kpad, n, wt, wp);
+    PA_CHECK_LAUNCH("pa_pack_weights");
+    return PA_OK;
 }
 
 PA_API int pa_rowgroup_max(long groups, int ns, int c, const float *in, float *out, pa_stream_t stream)

@@ -44,6 +44,16 @@ def fold_shared_mlp(mlp, device):
     return out
 
 
+def pack_weights(wt):
+    """K-major (kpad, n) device tensor -> fragment-major packed copy (pa_pack_weights), or None when n % 64 != 0."""
+    kpad, n = wt.shape
+    if n % 64:
+        return None
+    wp = torch.empty(kpad * n, dtype=torch.float32, device=wt.device)
+    call("pa_pack_weights", kpad, n, ptr(wt), ptr(wp))
+    return wp
+
+
 class _Chain:
     """Host-side descriptor of one pa_mlp_chain call (pointer arrays are built once)."""
 
@@ -52,6 +62,8 @@ class _Chain:
         n = len(layers)
         self.n = n
         self.wt = (ctypes.c_void_p * n)(*[l[0].data_ptr() for l in layers])
+        self.packed = [pack_weights(l[0]) for l in layers]
+        self.wpk = (ctypes.c_void_p * n)(*[(p.data_ptr() if p is not None else None) for p in self.packed])
         self.bias = (ctypes.c_void_p * n)(*[l[1].data_ptr() for l in layers])
         self.kpad = (ctypes.c_int * n)(*[l[3] for l in layers])
         self.nout = (ctypes.c_int * n)(*[l[4] for l in layers])
@@ -60,7 +72,7 @@ class _Chain:
         self.hidden_ok_pooled = all(l[4] <= 64 for l in layers[:-1])
 
     def _common(self):
-        return (self.n, ctypes.cast(self.wt, ctypes.c_void_p), ctypes.cast(self.bias, ctypes.c_void_p),
+        return (self.n, ctypes.cast(self.wt, ctypes.c_void_p), ctypes.cast(self.wpk, ctypes.c_void_p), ctypes.cast(self.bias, ctypes.c_void_p),
                 ctypes.cast(self.kpad, ctypes.c_void_p), ctypes.cast(self.nout, ctypes.c_void_p))
 
     def sa(self, xyz, feat, center_idx, nbr_idx, c_feat, pooled):
@@ -68,7 +80,7 @@ class _Chain:
         m, ns = nbr_idx.shape[1], nbr_idx.shape[2]
         groups = B * m
         out = torch.empty((groups if pooled else groups * ns, self.n_last), dtype=torch.float32, device=xyz.device)
-        call("pa_mlp_chain", 1, 1 if pooled else 0, *self._common(), groups, self.k0, None, 0,
+        call("pa_mlp_chain_packed", 1, 1 if pooled else 0, *self._common(), groups, self.k0, None, 0,
              ptr(xyz), ptr(feat), ptr(center_idx), ptr(nbr_idx), n_src, m, ns, c_feat,
              None, None, None, None, 0, 0, 0, 0, ptr(out), self.n_last)
         return out
@@ -76,7 +88,7 @@ class _Chain:
     def fp(self, known_feat, idx3, w3, skip, B, n_unknown, m_known, c2, c1):
         rows = B * n_unknown
         out = torch.empty((rows, self.n_last), dtype=torch.float32, device=known_feat.device)
-        call("pa_mlp_chain", 2, 0, *self._common(), rows, self.k0, None, 0,
+        call("pa_mlp_chain_packed", 2, 0, *self._common(), rows, self.k0, None, 0,
              None, None, None, None, 0, 0, 0, 0,
              ptr(known_feat), ptr(idx3), ptr(w3), ptr(skip), n_unknown, m_known, c2, c1, ptr(out), self.n_last)
         return out
@@ -84,7 +96,7 @@ class _Chain:
     def plain(self, x):
         rows, k = x.shape
         out = torch.empty((rows, self.n_last), dtype=torch.float32, device=x.device)
-        call("pa_mlp_chain", 0, 0, *self._common(), rows, self.k0, ptr(x), k,
+        call("pa_mlp_chain_packed", 0, 0, *self._common(), rows, self.k0, ptr(x), k,
              None, None, None, None, 0, 0, 0, 0, None, None, None, None, 0, 0, 0, 0, ptr(out), self.n_last)
         return out
 
@@ -167,18 +179,19 @@ class _Attn:
         self.wt_t = wt.t().float().contiguous().to(device)                                                   # (C, C) K-major
         self.bt = (sa.trans_conv.bias.detach().double().cpu() * scale.cpu() + shift.cpu()).float().contiguous().to(device)
         self.c = c
+        self.wqv_p, self.wt_p = pack_weights(self.wqv_t), pack_weights(self.wt_t)
 
     def run(self, x, B, n):
         """x (B*n, C) point-major -> x + relu(BN(trans_conv(x - x_r)))."""
         c, dev = self.c, x.device
         rows = B * n
         yv = torch.empty((rows, 2 * c), dtype=torch.float32, device=dev)
-        call("pa_linear", rows, c, 2 * c, ptr(x), c, ptr(self.wqv_t), ptr(self.bqv), 0, None, 0, ptr(yv), 2 * c)
+        call("pa_linear", rows, c, 2 * c, ptr(x), c, ptr(self.wqv_t), ptr(self.wqv_p), ptr(self.bqv), 0, None, 0, ptr(yv), 2 * c)
         stats = torch.empty((rows, 2), dtype=torch.float32, device=dev)
         d = torch.empty((rows, c), dtype=torch.float32, device=dev)
         call("pa_sa_attention", B, n, c, ptr(yv), ptr(x), ptr(stats), ptr(d))
         out = torch.empty((rows, c), dtype=torch.float32, device=dev)
-        call("pa_linear", rows, c, c, ptr(d), c, ptr(self.wt_t), ptr(self.bt), 1, ptr(x), c, ptr(out), c)
+        call("pa_linear", rows, c, c, ptr(d), c, ptr(self.wt_t), ptr(self.wt_p), ptr(self.bt), 1, ptr(x), c, ptr(out), c)
         return out
 
 

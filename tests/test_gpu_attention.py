@@ -43,7 +43,12 @@ def test_pa_linear(rows, k, n, relu, res):
     wt = torch.zeros(kpad, n, device="cuda")
     wt[:k] = w.t()
     out = torch.empty(rows, n, device="cuda")
-    call("pa_linear", rows, k, n, ptr(x), k, ptr(wt), ptr(bias), relu, ptr(r), n if res else 0, ptr(out), n)
+    call("pa_linear", rows, k, n, ptr(x), k, ptr(wt), None, ptr(bias), relu, ptr(r), n if res else 0, ptr(out), n)
+    if n % 64 == 0:                                              # the fragment-major packed weight path must give the same bits
+        from patchaugnet_amd.engine import pack_weights
+        out2 = torch.empty(rows, n, device="cuda")
+        call("pa_linear", rows, k, n, ptr(x), k, ptr(wt), ptr(pack_weights(wt)), ptr(bias), relu, ptr(r), n if res else 0, ptr(out2), n)
+        assert torch.equal(out, out2)
     ref = x.double() @ w.double().t() + bias.double()
     if relu:
         ref = ref.clamp_min(0)
