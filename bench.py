@@ -89,7 +89,13 @@ def dominant_kernel_roofline(st, cfg, batch, points, grouping):
     fs = cfg["FEATURE_SIZE"]
     dims = [fs[1] + (3 if cfg["USE_ORIGIN_PC_IN_FP"] else 0), 256, 256, fs[0]]
     rows = batch * points
-    flops = 2.0 * rows * sum(k * n for k, n in zip(dims[:-1], dims[1:]))
+    premul = "fp0.premul" in st
+    if premul:   # first layer folded into the prologue (pa_fp_chain_premul): the launch runs layers 2.. on MFMA + 2*3*256 VALU FLOPs per row
+        flops = 2.0 * rows * (sum(k * n for k, n in zip(dims[1:-1], dims[2:])) + (dims[0] - fs[1]) * dims[1])
+        kname = "chain_kernel<2,16,FPX,0,1> (pa_fp_chain_premul, fp0: 3-NN interpolation of the pre-multiplied coarse features + xyz term, then 256->256->256 on MFMA)"
+    else:
+        flops = 2.0 * rows * sum(k * n for k, n in zip(dims[:-1], dims[1:]))
+        kname = "chain_kernel<2,16,FP,0,1> (pa_mlp_chain, fp0: 3-NN interpolate + 259->256->256->256 shared MLP)"
     ms = st["fp0.chain"]
     tf = flops / (ms * 1e-3) / 1e12
     cu_time = {k: v * (min(batch, 256) / 256.0 if k.endswith(".fps") else 1.0) for k, v in st.items() if k != "total"}
@@ -100,7 +106,7 @@ def dominant_kernel_roofline(st, cfg, batch, points, grouping):
     if os.path.exists(pmc):   # HBM bytes per launch from rocprofv3 PMC passes of this kernel at this shape (profiles/)
         traffic = json.load(open(pmc)).get("chain_fp0_bytes_per_launch")
     return {
-        "roofline": {"kernel": "chain_kernel<2,16,FP,0,1> (pa_mlp_chain, fp0: 3-NN interpolate + 259->256->256->256 shared MLP)",
+        "roofline": {"kernel": kname,
                      "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
                      "traffic": traffic, "algorithmic_flops_per_launch": flops, "ms_per_launch": ms, "cu_time_owner": owner},
         "roofline_grouping": {"kernel": "group_lds_kernel (pa_grouping_forward, K5)", "bound": "hbm", "achieved": mc["GBps"], "peak": HBM_PEAK_GBS,

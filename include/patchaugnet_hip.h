@@ -138,6 +138,16 @@ int pa_mlp_chain(int mode, int pooled, int nlayers, const float *const *wt, cons
                  const float *xyz, const float *feat, const int *center_idx, const int *nbr_idx, int n_src, int m_ctr, int ns, int c_feat,
                  const float *known, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2, int c1,
                  float *out, int ldo, pa_stream_t stream);
+/* Feature propagation with the first layer folded into the prologue (interpolation is linear):
+ *   relu(W1 [interp(f); skip] + b1) = relu(interp(W1a f) + W1b skip + b1).
+ * g (b*m_known, c2) = known features already multiplied by W1a (pa_linear, no bias, no ReLU); skip (b*n_unknown, c1), 1 <= c1 <= 4
+ * (the xyz channels of the finest level, patch_aug_net.py:359); wskip (c1 x c2) K-major and bias0 (c2): W1b and b1 with
+ * BatchNorm folded.  wt/wpk/bias/kpad/nout describe the REMAINING nlayers layers (input width c2).  Same result as mode 2 of
+ * pa_mlp_chain up to fp32 summation order; (n_unknown/m_known) x fewer first-layer FLOPs. */
+int pa_fp_chain_premul(int nlayers, const float *const *wt, const float *const *wpk, const float *const *bias, const int *kpad, const int *nout,
+                       long rows, const float *g, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2,
+                       int c1, const float *wskip, const float *bias0, float *out, int ldo, pa_stream_t stream);
+
 /* One dense layer on point-major rows (the chain kernel's plain mode with a selectable epilogue):
  * out[r][:] = residual[r][:] + act(x[r][:k] . Wt + bias), act = ReLU if relu != 0 else identity; residual may be NULL.
  * wt K-major (kpad x n), kpad = k rounded up to 4 with zero rows, n % 16 == 0; wpk: optional packed copy (below) or NULL. */

@@ -43,6 +43,7 @@ _SIGS = {
     "pa_rowgroup_max": "liipp",
     "pa_linear": "liipipppipipi",
     "pa_pack_weights": "iipp",
+    "pa_fp_chain_premul": "ippppplppppiiiipppi",
     "pa_mlp_chain_packed": "iiippppplipippppiiiippppiiiipi",
     "pa_sa_attention": "iiipppp",
     "pa_netvlad": "iiiippppppii",

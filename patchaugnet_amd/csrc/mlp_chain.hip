@@ -58,6 +58,9 @@ struct PaChain {
     const float *w3;     // (B, n_unknown, 3)
     const float *skip;   // (B, n_unknown, c1) point-major
     int n_unknown, m_known, c2, c1;
+    // MODE 3: feature propagation with the first layer folded into the prologue (known = W1a-premultiplied features, see pa_fp_chain_premul)
+    const float *wskip;  // (c1, c2) K-major: the first layer's weights for the skip channels, BatchNorm folded
+    const float *bias0;  // (c2)
     float *out;
     int ldo;
     // last-layer epilogue (plain rows only): out = residual + act(acc + bias), act = ReLU when relu_last != 0 else identity
@@ -65,12 +68,13 @@ struct PaChain {
     const float *residual;   // (rows, ldr) or null
     int ldr;
     long long *dbg;          // profiling only: per-tile s_memtime stamps at phase boundaries (null in production)
+    int xcd_remap;           // != 0: contiguous tile ranges per XCD (see chain_kernel)
     int ep_stride;           // > 0: the last layer's tile is transposed through LDS (row stride ep_stride floats) and written as 16-byte row segments
 };
 
 namespace {
 
-enum { MODE_PLAIN = 0, MODE_SA = 1, MODE_FP = 2 };
+enum { MODE_PLAIN = 0, MODE_SA = 1, MODE_FP = 2, MODE_FPX = 3 };
 
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
@@ -336,7 +340,12 @@ __global__ __launch_bounds__(256, (POOLED && WPT == 1 && RT <= 5) ? 2 : 1) void 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int R = RT * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long tile = WPT == 1 ? (long)blockIdx.x * (blockDim.x >> 6) + wave : (long)blockIdx.x;
+    // XCD-aware order: workgroup b is dispatched to XCD b % 8 (observed round-robin), and each XCD has its own 4 MB L2.  Giving
+    // every XCD one CONTIGUOUS eighth of the tiles (= a few whole clouds) keeps the rows its gathers touch (1 MB of coarse features
+    // per cloud at fp0) inside that L2 instead of spreading every cloud over all eight.  Purely a performance mapping.
+    const long nblk = gridDim.x;
+    const long blk = (a.xcd_remap && (nblk & 7) == 0) ? (long)(blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3) : (long)blockIdx.x;
+    const long tile = WPT == 1 ? blk * (blockDim.x >> 6) + wave : blk;
     const long total_rows = (MODE == MODE_SA) ? a.rows * a.ns : a.rows;
     const long ntiles = POOLED ? (a.rows + 3) / 4 : (total_rows + R - 1) / R;
     if (tile >= ntiles) return;  // WPT == 1: wave-uniform, and that variant has no workgroup barrier; WPT == 4: grid == ntiles
@@ -405,9 +414,10 @@ __global__ __launch_bounds__(256, (POOLED && WPT == 1 && RT <= 5) ? 2 : 1) void 
             const int r = q / (k0pad - a.k0), ch = q - r * (k0pad - a.k0);
             act[r * stride + a.k0 + ch] = 0.f;
         }
-    } else {  // MODE_FP
+    } else {  // MODE_FP / MODE_FPX
         int *nb = reinterpret_cast<int *>(act + R * stride);  // [R][3] global rows of the three known neighbours
         float *wt = reinterpret_cast<float *>(nb + 3 * R);    // [R][3] interpolation weights
+        float *sk = wt + 3 * R;                               // [R][4] skip channels (MODE_FPX)
         const long row0 = tile * R;
         for (int q = tid; q < R * 3; q += NTH) {
             const int r = q / 3;
@@ -421,27 +431,99 @@ __global__ __launch_bounds__(256, (POOLED && WPT == 1 && RT <= 5) ? 2 : 1) void 
                 wt[q] = 0.f;
             }
         }
-        tile_sync<WPT>();
         const int C2 = a.c2, C1 = a.c1;
+        if (MODE == MODE_FPX)
+            for (int q = tid; q < R * 4; q += NTH) {
+                const int r = q >> 2, t = q & 3;
+                const long p = row0 + r;
+                sk[q] = (p < a.rows && t < C1) ? a.skip[p * C1 + t] : 0.f;
+            }
+        tile_sync<WPT>();
         const int qpr = C2 >> 2;  // host guarantees c2 % 4 == 0
         const float4 *k4 = reinterpret_cast<const float4 *>(a.known);
-        for (int q = tid; q < R * qpr; q += NTH) {
-            const int r = q / qpr, part = q - r * qpr;
-            const float w0 = wt[r * 3 + 0], w1 = wt[r * 3 + 1], w2 = wt[r * 3 + 2];
-            const float4 f0 = k4[(size_t)nb[r * 3 + 0] * qpr + part];
-            const float4 f1 = k4[(size_t)nb[r * 3 + 1] * qpr + part];
-            const float4 f2 = k4[(size_t)nb[r * 3 + 2] * qpr + part];
-            float *d = act + r * stride + part * 4;  // interpolation_cuda_kernel.cu:194: (w0*p0 + w1*p1) + w2*p2
-            d[0] = w0 * f0.x + w1 * f1.x + w2 * f2.x;
-            d[1] = w0 * f0.y + w1 * f1.y + w2 * f2.y;
-            d[2] = w0 * f0.z + w1 * f1.z + w2 * f2.z;
-            d[3] = w0 * f0.w + w1 * f1.w + w2 * f2.w;
+        const int items = R * qpr;
+        if (MODE == MODE_FPX && WPT == 1 && C2 == 256) {
+            // Common shape (256-wide features, wave-private tile): lane l owns float4 column l of every row, so the bias and the
+            // skip weights are loop invariants, row / column indices need no division, and addresses are 32-bit.  This part is
+            // not bit-matched to anything (the first layer is already re-associated), so FMA contraction is allowed here.
+#pragma clang fp contract(fast)
+            const float4 bz = *reinterpret_cast<const float4 *>(a.bias0 + lane * 4);
+            float4 wv[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                wv[t] = t < C1 ? *reinterpret_cast<const float4 *>(a.wskip + (size_t)t * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int r0 = 0; r0 < R; r0 += 4) {
+                float4 f[4][3];
+                float w[4][3];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        w[u][t] = wt[(r0 + u) * 3 + t];
+                        f[u][t] = k4[(unsigned)nb[(r0 + u) * 3 + t] * 64u + (unsigned)lane];
+                    }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float *s4 = sk + (r0 + u) * 4;
+                    const float sx = s4[0], sy = s4[1], sz = s4[2], sw = s4[3];
+                    float v[4];
+                    v[0] = bz.x + sx * wv[0].x + sy * wv[1].x + sz * wv[2].x + sw * wv[3].x + w[u][0] * f[u][0].x + w[u][1] * f[u][1].x + w[u][2] * f[u][2].x;
+                    v[1] = bz.y + sx * wv[0].y + sy * wv[1].y + sz * wv[2].y + sw * wv[3].y + w[u][0] * f[u][0].y + w[u][1] * f[u][1].y + w[u][2] * f[u][2].y;
+                    v[2] = bz.z + sx * wv[0].z + sy * wv[1].z + sz * wv[2].z + sw * wv[3].z + w[u][0] * f[u][0].z + w[u][1] * f[u][1].z + w[u][2] * f[u][2].z;
+                    v[3] = bz.w + sx * wv[0].w + sy * wv[1].w + sz * wv[2].w + sw * wv[3].w + w[u][0] * f[u][0].w + w[u][1] * f[u][1].w + w[u][2] * f[u][2].w;
+                    float2 *d = reinterpret_cast<float2 *>(act + (r0 + u) * stride + lane * 4);   // stride is even: 8-byte aligned
+                    d[0] = make_float2(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
+                    d[1] = make_float2(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+                }
+            }
+        } else
+        // four items per trip with all twelve 16-byte gathers issued before the first use: the known features of a whole batch
+        // (33 MB at fp0) live in the Infinity Cache, not in L2, and a wave-private tile has nobody else to hide that latency
+        for (int q0 = tid; q0 < items; q0 += NTH * 4) {
+            float4 f[4][3];
+            float w[4][3];
+            int rr[4], pp[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = min(q0 + u * NTH, items - 1);
+                rr[u] = q / qpr;
+                pp[u] = q - rr[u] * qpr;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    w[u][t] = wt[rr[u] * 3 + t];
+                    f[u][t] = k4[(size_t)nb[rr[u] * 3 + t] * qpr + pp[u]];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (q0 + u * NTH >= items) break;
+                float v[4];  // interpolation_cuda_kernel.cu:194: (w0*p0 + w1*p1) + w2*p2
+                v[0] = w[u][0] * f[u][0].x + w[u][1] * f[u][1].x + w[u][2] * f[u][2].x;
+                v[1] = w[u][0] * f[u][0].y + w[u][1] * f[u][1].y + w[u][2] * f[u][2].y;
+                v[2] = w[u][0] * f[u][0].z + w[u][1] * f[u][1].z + w[u][2] * f[u][2].z;
+                v[3] = w[u][0] * f[u][0].w + w[u][1] * f[u][1].w + w[u][2] * f[u][2].w;
+                if (MODE == MODE_FPX) {  // + skip . Wskip + bias, ReLU: this IS the first layer's output (linearity of interpolation)
+                    const float4 bz = *reinterpret_cast<const float4 *>(a.bias0 + pp[u] * 4);
+                    float s[4] = {bz.x, bz.y, bz.z, bz.w};
+                    for (int t = 0; t < C1; ++t) {
+                        const float4 wv = *reinterpret_cast<const float4 *>(a.wskip + (size_t)t * C2 + pp[u] * 4);
+                        const float xv = sk[rr[u] * 4 + t];
+                        s[0] += xv * wv.x; s[1] += xv * wv.y; s[2] += xv * wv.z; s[3] += xv * wv.w;
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c] + s[c], 0.f);
+                }
+                float *d = act + rr[u] * stride + pp[u] * 4;
+                d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+            }
         }
-        const int tail = k0pad - C2;  // skip channels (patch_aug_net.py:359: cat([interpolated, skip])) + zero padding
-        for (int q = tid; q < R * tail; q += NTH) {
-            const int r = q / tail, ch = q - r * tail;
-            const long p = row0 + r;
-            act[r * stride + C2 + ch] = (p < a.rows && ch < C1) ? a.skip[p * C1 + ch] : 0.f;
+        if (MODE == MODE_FP) {
+            const int tail = k0pad - C2;  // skip channels (patch_aug_net.py:359: cat([interpolated, skip])) + zero padding
+            for (int q = tid; q < R * tail; q += NTH) {
+                const int r = q / tail, ch = q - r * tail;
+                const long p = row0 + r;
+                act[r * stride + C2 + ch] = (p < a.rows && ch < C1) ? a.skip[p * C1 + ch] : 0.f;
+            }
         }
     }
     tile_sync<WPT>();
@@ -508,7 +590,8 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
                           const float *x, int ldx,
                           const float *xyz, const float *feat, const int *center_idx, const int *nbr_idx, int n_src, int m_ctr, int ns, int c_feat,
                           const float *known, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2, int c1,
-                          float *out, int ldo, int relu_last, const float *residual, int ldr, pa_stream_t stream)
+                          float *out, int ldo, int relu_last, const float *residual, int ldr, pa_stream_t stream,
+                          const float *wskip = nullptr, const float *bias0 = nullptr)
 {
     PA_REQUIRE(nlayers >= 1 && nlayers <= 3, "pa_mlp_chain: nlayers=%d must be 1..3", nlayers);
     PA_REQUIRE(rows > 0 && k0 > 0 && out, "pa_mlp_chain: rows/k0 must be positive and out non-null");
@@ -530,9 +613,12 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
     a.x = x; a.ldx = ldx;
     a.xyz = xyz; a.feat = feat; a.center_idx = center_idx; a.nbr_idx = nbr_idx; a.n_src = n_src; a.m_ctr = m_ctr; a.ns = ns; a.c_feat = c_feat;
     a.known = known; a.idx3 = idx3; a.w3 = w3; a.skip = skip; a.n_unknown = n_unknown; a.m_known = m_known; a.c2 = c2; a.c1 = c1;
+    a.wskip = wskip; a.bias0 = bias0;
     a.out = out; a.ldo = ldo;
     a.relu_last = relu_last; a.residual = residual; a.ldr = ldr;
     a.dbg = g_chain_dbg;
+    static const bool no_xcd = getenv("PA_CHAIN_NO_XCD_REMAP") != nullptr;   // A/B knob
+    a.xcd_remap = no_xcd ? 0 : 1;
     hipStream_t st = (hipStream_t)stream;
 
     const bool is_pooled = pooled != 0;
@@ -597,6 +683,11 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
         PA_REQUIRE(c2 % 4 == 0 && k0 == c2 + c1, "pa_mlp_chain: FP mode needs c2 %% 4 == 0 and k0 == c2 + c1");
         PA_REQUIRE(rows % n_unknown == 0, "pa_mlp_chain: FP rows=%ld must be B*n", rows);
         scratch = 6 * R;
+    } else if (mode == MODE_FPX) {
+        PA_REQUIRE(known && idx3 && w3 && skip && wskip && bias0 && n_unknown > 0 && m_known > 0, "pa_fp_chain_premul: null argument");
+        PA_REQUIRE(c2 % 4 == 0 && c1 >= 1 && c1 <= 4 && k0 == c2, "pa_fp_chain_premul: needs c2 %% 4 == 0, 1 <= c1 <= 4 (c2=%d c1=%d)", c2, c1);
+        PA_REQUIRE(rows % n_unknown == 0, "pa_fp_chain_premul: rows=%ld must be B*n", rows);
+        scratch = 10 * R;
     } else {
         PA_REQUIRE(false, "pa_mlp_chain: unknown mode %d", mode);
     }
@@ -620,7 +711,8 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
         }
     } else if (mode == MODE_PLAIN) launch_rows<MODE_PLAIN>(a, RTv, split, wpw, ntiles, st);
     else if (mode == MODE_SA) launch_rows<MODE_SA>(a, RTv, split, wpw, ntiles, st);
-    else launch_rows<MODE_FP>(a, RTv, split, wpw, ntiles, st);
+    else if (mode == MODE_FP) launch_rows<MODE_FP>(a, RTv, split, wpw, ntiles, st);
+    else launch_rows<MODE_FPX>(a, RTv, split, wpw, ntiles, st);
     PA_CHECK_LAUNCH("pa_mlp_chain");
     return PA_OK;
 }
@@ -657,6 +749,19 @@ PA_API int pa_linear(long rows, int k, int n, const float *x, int ldx, const flo
     const int kpad = (k + 3) / 4 * 4;
     return chain_dispatch(0, 0, 1, &wt, &wpk, &bias, &kpad, &n, rows, k, x, ldx, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0,
                           nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, out, ldo, relu, residual, ldr, stream);
+}
+
+// Feature propagation with the first layer folded into the prologue.  Interpolation is linear, so
+//     relu(W1 [interp(f); skip] + b1) = relu(interp(W1a f) + W1b skip + b1):
+// g = known features already multiplied by W1a (one pa_linear over the B*m known rows instead of a 259-wide layer over the B*n
+// unknown rows, n/m = 4 at fp0); this kernel interpolates g, adds the skip term on the VALU (c1 <= 4 channels: xyz) and the bias,
+// applies ReLU, and runs the REMAINING layers (wt/wpk/bias/kpad/nout describe layers 2..) on the MFMA pipe.
+PA_API int pa_fp_chain_premul(int nlayers, const float *const *wt, const float *const *wpk, const float *const *bias, const int *kpad, const int *nout,
+                              long rows, const float *g, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2,
+                              int c1, const float *wskip, const float *bias0, float *out, int ldo, pa_stream_t stream)
+{
+    return chain_dispatch(MODE_FPX, 0, nlayers, wt, wpk, bias, kpad, nout, rows, c2, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0,
+                          g, idx3, w3, skip, n_unknown, m_known, c2, c1, out, ldo, 1, nullptr, 0, stream, wskip, bias0);
 }
 
 namespace {

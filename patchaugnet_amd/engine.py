@@ -16,6 +16,7 @@ What the reference computes per op is cited in csrc/*.hip; parity is checked in 
 reference-generated golden vectors and the CPU oracle.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn.functional as F
@@ -91,6 +92,36 @@ class _Chain:
         call("pa_mlp_chain_packed", 2, 0, *self._common(), rows, self.k0, None, 0,
              None, None, None, None, 0, 0, 0, 0,
              ptr(known_feat), ptr(idx3), ptr(w3), ptr(skip), n_unknown, m_known, c2, c1, ptr(out), self.n_last)
+        return out
+
+    def fp_premul(self, known_feat, idx3, w3, skip, B, n_unknown, m_known, c2, c1, mark=None):
+        """Finest feature-propagation level: the first layer is applied to the m_known coarse points BEFORE interpolation
+        (pa_fp_chain_premul; interpolation is linear), the skip (xyz) term is added in the kernel's prologue."""
+        dev = known_feat.device
+        if not hasattr(self, "_premul"):
+            wt0, b0, _, _, n0 = self.layers[0]
+            w1a = wt0[:c2].contiguous()
+            rest = self.layers[1:]
+            m = len(rest)
+            self._premul = {
+                "w1a": w1a, "w1a_p": pack_weights(w1a), "zero": torch.zeros(n0, dtype=torch.float32, device=dev),
+                "wskip": wt0[c2:c2 + c1].contiguous(), "bias0": b0, "n0": n0, "m": m,
+                "wt": (ctypes.c_void_p * m)(*[l[0].data_ptr() for l in rest]),
+                "wpk": (ctypes.c_void_p * m)(*[(p.data_ptr() if p is not None else None) for p in self.packed[1:]]),
+                "bias": (ctypes.c_void_p * m)(*[l[1].data_ptr() for l in rest]),
+                "kpad": (ctypes.c_int * m)(*[l[3] for l in rest]), "nout": (ctypes.c_int * m)(*[l[4] for l in rest]),
+            }
+        pm = self._premul
+        g = torch.empty((B * m_known, pm["n0"]), dtype=torch.float32, device=dev)
+        call("pa_linear", B * m_known, c2, pm["n0"], ptr(known_feat), c2, ptr(pm["w1a"]), ptr(pm["w1a_p"]), ptr(pm["zero"]), 0, None, 0,
+             ptr(g), pm["n0"])
+        if mark is not None:
+            mark()
+        rows = B * n_unknown
+        out = torch.empty((rows, self.n_last), dtype=torch.float32, device=dev)
+        cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
+        call("pa_fp_chain_premul", pm["m"], cast(pm["wt"]), cast(pm["wpk"]), cast(pm["bias"]), cast(pm["kpad"]), cast(pm["nout"]), rows,
+             ptr(g), ptr(idx3), ptr(w3), ptr(skip), n_unknown, m_known, pm["n0"], c1, ptr(pm["wskip"]), ptr(pm["bias0"]), ptr(out), self.n_last)
         return out
 
     def plain(self, x):
@@ -268,6 +299,7 @@ class PatchAugNetEngine:
                     self.afa = _Afa(agg.afa, self.device)
         elif self.ppt:
             raise ValueError("PPT-Net fused engine needs 256-wide features and <= 64 clusters per scale")
+        self.premul = os.environ.get("PA_ENGINE_NO_PREMUL") is None     # fold the finest FP level's first layer into its prologue
         self._key = self._params_key(model)
         self.timer = None     # optional profiling.StageTimer: per-stage HIP-event marks (bench.py kernel attribution)
 
@@ -328,7 +360,11 @@ class PatchAugNetEngine:
             known_feat = l_feat[i]
             c2 = known_feat.shape[-1]
             c1 = skip.shape[-1] if skip is not None else 0
-            y = chain.fp(known_feat.contiguous(), idx3, w3, skip.contiguous() if skip is not None else None, B, n_u, m_k, c2, c1)
+            if self.premul and 1 <= c1 <= 4 and chain.n >= 2 and n_u >= 2 * m_k and c2 % 4 == 0 and chain.layers[0][4] % 16 == 0:
+                y = chain.fp_premul(known_feat.contiguous(), idx3, w3, skip.contiguous(), B, n_u, m_k, c2, c1,
+                                    mark=lambda k=nfp + i: self._mark(f"fp{k}.premul"))
+            else:
+                y = chain.fp(known_feat.contiguous(), idx3, w3, skip.contiguous() if skip is not None else None, B, n_u, m_k, c2, c1)
             self._mark(f"fp{nfp + i}.chain")
             l_feat[i - 1] = y.view(B, n_u, chain.n_last)
         return l_feat, l_c

@@ -17,7 +17,8 @@ with torch.no_grad():
     for _ in range(2):
         model(x, return_feat=False)
     eng = model._engine
-    orig = eng.fp[0].fp
+    name = "fp_premul" if eng.premul else "fp"
+    orig = getattr(eng.fp[0], name)
     buf = torch.zeros(512 * 8, dtype=torch.int64, device="cuda")
 
     def wrapped(*a, **k):
@@ -25,13 +26,14 @@ with torch.no_grad():
         r = orig(*a, **k)
         lib.pa_chain_debug_buffer(None)
         return r
-    eng.fp[0].fp = wrapped
+    setattr(eng.fp[0], name, wrapped)
     model(x, return_feat=False)
     torch.cuda.synchronize()
 t = buf.view(512, 8).cpu().numpy()
-d = t[:, 1:5] - t[:, 0:4]
+nl = 3 if eng.premul else 4
+d = t[:, 1:nl + 1] - t[:, 0:nl]
 import numpy as np
-names = ["prologue", "layer0", "layer1", "layer2+epilogue"]
+names = ["prologue", "layer0", "layer1", "layer2+epilogue"] if nl == 4 else ["prologue(+folded layer)", "layer1", "layer2+epilogue"]
 for i, n in enumerate(names):
     print(f"{n:18s} median {np.median(d[:, i]):10.0f}  min {d[:, i].min():10.0f}  max {d[:, i].max():10.0f}  (counter ticks)")
-print("total median", np.median(t[:, 4] - t[:, 0]), " start spread", t[:, 0].max() - t[:, 0].min())
+print("total median", np.median(t[:, nl] - t[:, 0]), " start spread", t[:, 0].max() - t[:, 0].min())

@@ -2,11 +2,17 @@
 // (A) 16 dword weight loads per k-step (K-major weights) vs (B) 4 dwordx4 loads per k-step (fragment-major packed weights).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#ifndef PWAVES
+#define PWAVES 4
+#endif
 typedef float floatx4 __attribute__((ext_vector_type(4)));
-constexpr int RT = 2, NC = 16, STR = 262;
+#ifndef PRT
+#define PRT 2
+#endif
+constexpr int RT = PRT, NC = 16, STR = 262;
 
 template <int PACKED, int SCHED>
-__global__ __launch_bounds__(256) void probe(const float *__restrict__ w, int n, int ksteps, float *out, long long *cyc)
+__global__ __launch_bounds__(64 * PWAVES) void probe(const float *__restrict__ w, int n, int ksteps, float *out, long long *cyc)
 {
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -65,8 +71,8 @@ __global__ __launch_bounds__(256) void probe(const float *__restrict__ w, int n,
     const long long t1 = __builtin_readcyclecounter();
     float s = 0;
     for (int rt = 0; rt < RT; ++rt) for (int ct = 0; ct < NC; ++ct) s += acc[rt][ct][0] + acc[rt][ct][1] + acc[rt][ct][2] + acc[rt][ct][3];
-    out[blockIdx.x * 256 + threadIdx.x] = s;
-    if (lane == 0) cyc[blockIdx.x * 4 + wave] = t1 - t0;
+    out[blockIdx.x * 64 * PWAVES + threadIdx.x] = s;
+    if (lane == 0 && wave < 4) cyc[blockIdx.x * 4 + wave] = t1 - t0;
 }
 
 template <int PACKED, int SCHED>
@@ -75,8 +81,8 @@ void run(const char *name, int blocks, int waves)
     const int n = 256, ksteps = 256;
     float *w, *out; long long *cyc;
     (void)hipMalloc(&w, 256 * n * 4); (void)hipMemset(w, 0, 256 * n * 4);
-    (void)hipMalloc(&out, blocks * 256 * 4); (void)hipMalloc(&cyc, blocks * 4 * 8);
-    size_t ldsb = (size_t)(4 * RT * 16 * STR) * 4;
+    (void)hipMalloc(&out, blocks * 64 * PWAVES * 4); (void)hipMalloc(&cyc, blocks * 4 * 8);
+    size_t ldsb = (size_t)(PWAVES * RT * 16 * STR) * 4;
     (void)hipFuncSetAttribute((const void *)probe<PACKED, SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int it = 0; it < 2; ++it) {
@@ -93,11 +99,8 @@ void run(const char *name, int blocks, int waves)
 
 int main()
 {
-    run<0, 1>("dword loads, sched barriers", 1024, 4);
-    run<0, 0>("dword loads, compiler order", 1024, 4);
-    run<1, 1>("packed dwordx4 loads, sched barriers", 1024, 4);
-    run<1, 0>("packed dwordx4 loads, compiler order", 1024, 4);
-    run<0, 1>("dword loads, sched, 1 wave", 1, 1);
-    run<1, 1>("packed dwordx4, sched, 1 wave", 1, 1);
+    run<1, 1>("packed dwordx4, sched", 1024, PWAVES);
+    run<1, 0>("packed dwordx4, compiler order", 1024, PWAVES);
+    run<0, 1>("dword, sched", 1024, PWAVES);
     return 0;
 }
