@@ -177,6 +177,7 @@ int pa_sa_attention(int b, int n, int c, const float *yv, const float *x, float 
 /* Profiling hook: when set to a device buffer of 512 x 8 int64, the chain kernels store cycle-counter stamps at their phase
  * boundaries (tile start, prologue done, each layer done) for the first 512 tiles.  NULL (the default) turns it off. */
 void pa_chain_debug_buffer(long long *buf);
+void pa_knn_debug_buffer(long long *buf);   /* same for the pruned kNN kernel: 6 int64 (prologue cycles, query cycles, chunks visited, insertions, sort cycles, queries per wave) */
 
 /* out[g][c] = max over s < ns of in[g*ns + s][c]  (rows of c floats) */
 int pa_rowgroup_max(long groups, int ns, int c, const float *in, float *out, pa_stream_t stream);

@@ -10,6 +10,8 @@
 //      key = float_bits(d2) << 32 | index        (d2 >= 0, so unsigned order == (d2, index) order)
 // A ballot finds the lanes whose candidate beats the current k-th key (kept in SGPRs); each such candidate is
 // inserted with a single wave_shr:1 DPP shift + two compares.  No local memory, no shared-memory sort.
+#include <stdlib.h>
+
 #include "pa_common.h"
 
 namespace {
@@ -80,6 +82,267 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(int n, int m, int k, int 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Spatially pruned variant (same results, bit for bit).  The brute-force kernel above evaluates all n sources for every
+// query and spends most of its instructions inserting early, far-away candidates into the running list.  Here every
+// workgroup first sorts its cloud into 512 Morton-ordered cells (counting sort in LDS, a few microseconds), so that each
+// run of 64 consecutive sorted points -- a "chunk" -- is spatially compact, and records each chunk's bounding box.  A query
+// (still one wavefront) then
+//   1. computes in one wave-wide step the squared distance to all <= 64 chunk boxes (one lane per chunk);
+//   2. visits chunks in ascending box distance (a wave-min per visit) and stops at the first box farther than the current
+//      k-th neighbour -- typically ~10 of 64 chunks at n = 4096, k = 20;
+//   3. seeds the list from the nearest chunk with one bitonic sort instead of ~45 serial insertions.
+// Exactness: a box distance is computed with the same fp32 operation order as a point distance on per-axis differences that
+// are, by monotonicity of IEEE rounding, no larger in magnitude than those of any point inside the box, so it never exceeds
+// the fp32 distance of a member point; a chunk is skipped only when its box distance is STRICTLY greater than the k-th
+// distance, so equal-distance candidates with a lower index are still seen.  The order inside a cell depends on LDS atomics
+// and varies between runs; the selected (distance, index) keys do not.  Points with non-finite coordinates can never be
+// selected (their distance is never < a finite or infinite best) and are left out of the chunks.
+constexpr int KG_CELLS = 512;
+
+__device__ __forceinline__ u32 kg_spread3(u32 v)  // 3 bits -> every third bit
+{
+    return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4);
+}
+
+__device__ __forceinline__ u64 kg_shfl_xor_u64(u64 v, int m)
+{
+    const u32 lo = (u32)__shfl_xor((int)(u32)v, m), hi = (u32)__shfl_xor((int)(u32)(v >> 32), m);
+    return ((u64)hi << 32) | lo;
+}
+
+__device__ __forceinline__ u64 kg_wave_min_u64(u64 v) { return ~pa_wave_max_u64(~v); }
+
+__device__ __forceinline__ float kg_wave_min_f(float v)
+{
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) v = fminf(v, __shfl_xor(v, s));
+    return v;
+}
+__device__ __forceinline__ float kg_wave_max_f(float v)
+{
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) v = fmaxf(v, __shfl_xor(v, s));
+    return v;
+}
+
+// ascending bitonic sort of one u64 key per lane across the wavefront
+__device__ __forceinline__ u64 kg_sort64(u64 key, int lane)
+{
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const u64 other = kg_shfl_xor_u64(key, j);
+            const bool up = (lane & k) == 0, low = (lane & j) == 0;
+            const u64 mn = key < other ? key : other, mx = key < other ? other : key;
+            key = (low == up) ? mn : mx;
+        }
+    return key;
+}
+
+template <int PTS, int NT, bool DBG>   // NT threads per workgroup, PTS points per thread: n <= NT * PTS; DBG: cycle stamps for tools/knn_phases.py
+__global__ __launch_bounds__(NT, NT / 128) void knn_grid_kernel(int n, int m, int k, int q_per_block, const float *__restrict__ xyz_all,
+                                                         const float *__restrict__ new_xyz_all, int *__restrict__ idx_all,
+                                                         float *__restrict__ dist2_all, long long *dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const long long t_start = DBG ? (long long)__builtin_readcyclecounter() : 0;
+    long long n_visit = 0, n_ins = 0, t_sort = 0;
+    float4 *sorted = reinterpret_cast<float4 *>(smem);                        // [n] x, y, z, original index (bits)
+    float *box = smem + 4 * (size_t)n;                                        // [64][8] lo.xyz, hi.xyz
+    int *cnt = reinterpret_cast<int *>(box + 64 * 8);                         // [KG_CELLS + 1] histogram -> running offsets
+    float *red = reinterpret_cast<float *>(cnt + KG_CELLS + 1);               // [NW][6] cross-wave bounding box
+    constexpr int NW = NT / 64;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *xyz = xyz_all + (size_t)b * n * 3;
+
+    // ---- 1. cloud bounding box over the finite points
+    float px[PTS], py[PTS], pz[PTS];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int u = 0; u < PTS; ++u) {
+        const int i = tid + u * NT;
+        if (i < n) {
+            px[u] = xyz[i * 3 + 0]; py[u] = xyz[i * 3 + 1]; pz[u] = xyz[i * 3 + 2];
+            if (isfinite(px[u]) && isfinite(py[u]) && isfinite(pz[u])) {
+                lo[0] = fminf(lo[0], px[u]); hi[0] = fmaxf(hi[0], px[u]);
+                lo[1] = fminf(lo[1], py[u]); hi[1] = fmaxf(hi[1], py[u]);
+                lo[2] = fminf(lo[2], pz[u]); hi[2] = fmaxf(hi[2], pz[u]);
+            }
+        }
+    }
+    for (int c = tid; c <= KG_CELLS; c += NT) cnt[c] = 0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        lo[t] = kg_wave_min_f(lo[t]);
+        hi[t] = kg_wave_max_f(hi[t]);
+        if (lane == 0) { red[wave * 6 + t] = lo[t]; red[wave * 6 + 3 + t] = hi[t]; }
+    }
+    __syncthreads();
+    float scale[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        lo[t] = red[t];
+        hi[t] = red[3 + t];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) { lo[t] = fminf(lo[t], red[w * 6 + t]); hi[t] = fmaxf(hi[t], red[w * 6 + 3 + t]); }
+        const float ext = hi[t] - lo[t];
+        scale[t] = (ext > 0.f && isfinite(ext)) ? 8.0f / ext : 0.f;
+    }
+    // ---- 2. Morton cell of every point, histogram
+    int cell[PTS];
+#pragma unroll
+    for (int u = 0; u < PTS; ++u) {
+        const int i = tid + u * NT;
+        cell[u] = -1;
+        if (i < n) {
+            cell[u] = KG_CELLS;                                                  // non-finite points: last bin, never a candidate
+            if (isfinite(px[u]) && isfinite(py[u]) && isfinite(pz[u])) {
+                const u32 cx = (u32)min(max((int)((px[u] - lo[0]) * scale[0]), 0), 7);
+                const u32 cy = (u32)min(max((int)((py[u] - lo[1]) * scale[1]), 0), 7);
+                const u32 cz = (u32)min(max((int)((pz[u] - lo[2]) * scale[2]), 0), 7);
+                cell[u] = (int)(kg_spread3(cx) | (kg_spread3(cy) << 1) | (kg_spread3(cz) << 2));
+            }
+            atomicAdd(&cnt[cell[u]], 1);
+        }
+    }
+    __syncthreads();
+    // ---- 3. exclusive scan of the 513 bins (wave 0, 9 bins per lane), scatter
+    if (wave == 0) {
+        int v[9], sum = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int c = lane * 9 + t;
+            v[t] = c <= KG_CELLS ? cnt[c] : 0;
+            sum += v[t];
+        }
+        int incl = sum;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const int o = __shfl_up(incl, s);
+            if (lane >= s) incl += o;
+        }
+        int run = incl - sum;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int c = lane * 9 + t;
+            if (c <= KG_CELLS) cnt[c] = run;
+            run += v[t];
+        }
+    }
+    __syncthreads();
+    const int n_valid = cnt[KG_CELLS];                                           // start of the non-finite bin == number of finite points
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PTS; ++u) {
+        const int i = tid + u * NT;
+        if (i < n && cell[u] < KG_CELLS) {
+            const int pos = atomicAdd(&cnt[cell[u]], 1);
+            sorted[pos] = make_float4(px[u], py[u], pz[u], __int_as_float(i));
+        }
+    }
+    __syncthreads();
+    // ---- 4. chunk bounding boxes: four threads per chunk, 16 points each, combined inside the quad
+    const int nchunks = (n_valid + 63) >> 6;
+    {
+        const int c = tid >> 2, part = tid & 3;
+        float bl[3] = {INFINITY, INFINITY, INFINITY}, bh[3] = {-INFINITY, -INFINITY, -INFINITY};
+        if (c < nchunks) {
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j) {
+                const int i = c * 64 + part * 16 + j;
+                if (i < n_valid) {
+                    const float4 p = sorted[i];
+                    bl[0] = fminf(bl[0], p.x); bh[0] = fmaxf(bh[0], p.x);
+                    bl[1] = fminf(bl[1], p.y); bh[1] = fmaxf(bh[1], p.y);
+                    bl[2] = fminf(bl[2], p.z); bh[2] = fmaxf(bh[2], p.z);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            bl[t] = fminf(bl[t], __shfl_xor(bl[t], 1)); bh[t] = fmaxf(bh[t], __shfl_xor(bh[t], 1));
+            bl[t] = fminf(bl[t], __shfl_xor(bl[t], 2)); bh[t] = fmaxf(bh[t], __shfl_xor(bh[t], 2));
+        }
+        if (c < nchunks && part == 0) {
+            float *bx = box + c * 8;
+            bx[0] = bl[0]; bx[1] = bl[1]; bx[2] = bl[2]; bx[3] = bh[0]; bx[4] = bh[1]; bx[5] = bh[2];
+        }
+    }
+    __syncthreads();
+
+    const long long t_pro = DBG ? (long long)__builtin_readcyclecounter() : 0;
+    // ---- 5. queries
+    const int q_begin = blockIdx.x * q_per_block;
+    const int q_end = min(q_begin + q_per_block, m);
+    for (int q = q_begin + wave; q < q_end; q += NW) {
+        const float *qp = new_xyz_all + ((size_t)b * m + q) * 3;
+        const float qx = qp[0], qy = qp[1], qz = qp[2];
+        // box distance of chunk `lane`: per axis the signed difference to the nearest face (0 inside), same order of operations as a point
+        u64 ckey = ~0ull;
+        if (lane < nchunks) {
+            const float *bx = box + lane * 8;
+            const float ax = qx < bx[0] ? qx - bx[0] : (qx > bx[3] ? qx - bx[3] : 0.f);
+            const float ay = qy < bx[1] ? qy - bx[1] : (qy > bx[4] ? qy - bx[4] : 0.f);
+            const float az = qz < bx[2] ? qz - bx[2] : (qz > bx[5] ? qz - bx[5] : 0.f);
+            const float lb = ax * ax + ay * ay + az * az;
+            ckey = pa_make_key(lb, (u32)lane);
+        }
+        u64 list = KNN_INF0, thresh = KNN_INF0;
+        // seed: the chunk with the nearest box, sorted in one go
+        int c = -1;
+        {
+            const u64 best = kg_wave_min_u64(ckey);
+            if (best != ~0ull && (u32)(best >> 32) <= 0x7F800000u) c = (int)(u32)best;   // NaN box distance (NaN query): nothing to do
+        }
+        bool seed = true;
+        while (c >= 0) {
+            if (DBG) ++n_visit;
+            const int i = c * 64 + lane;
+            u64 key = ~0ull;
+            if (i < n_valid) {
+                const float4 p = sorted[i];
+                const float d2 = (qx - p.x) * (qx - p.x) + (qy - p.y) * (qy - p.y) + (qz - p.z) * (qz - p.z);  // knnquery_cuda_kernel.cu:31
+                key = pa_make_key(d2, (u32)__float_as_int(p.w));
+                if (key >= KNN_INF0) key = ~0ull;                                 // inf / NaN distance: never admitted (:32 strict <)
+            }
+            if (seed) {
+                seed = false;
+                const long long ts = DBG ? (long long)__builtin_readcyclecounter() : 0;
+                const u64 s = kg_sort64(key, lane);
+                if (DBG) t_sort += (long long)__builtin_readcyclecounter() - ts;
+                list = s == ~0ull ? KNN_INF0 : s;
+            } else {
+                // every candidate below the k-th key AS OF THE START of this chunk is inserted; one that turns out not to be among the
+                // k best just lands behind position k-1, so the per-candidate re-check (two readlanes on the critical path) is dropped
+                u64 mask = __ballot(key < thresh);
+                while (mask) {
+                    const int src = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    list = knn_insert(list, pa_readlane_u64(key, src));
+                    if (DBG) ++n_ins;
+                }
+            }
+            thresh = pa_readlane_u64(list, k - 1);
+            // next: the nearest unvisited box, if it is not farther than the k-th neighbour (ascending box distance keeps both the
+            // number of chunks visited and the number of insertions about 2x lower than index order)
+            if (lane == c) ckey = ~0ull;
+            const u64 best = kg_wave_min_u64(ckey);
+            c = (best != ~0ull && (u32)(best >> 32) <= (u32)(thresh >> 32)) ? (int)(u32)best : -1;
+        }
+        if (lane < k) {
+            const size_t o = ((size_t)b * m + q) * k + lane;
+            idx_all[o] = (int)(u32)list;
+            dist2_all[o] = __uint_as_float((u32)(list >> 32));
+        }
+    }
+    if (DBG && dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+        dbg[0] = t_pro - t_start; dbg[1] = (long long)__builtin_readcyclecounter() - t_pro; dbg[2] = n_visit; dbg[3] = n_ins; dbg[4] = t_sort;
+        dbg[5] = (q_end - q_begin + NW - 1) / NW;
+    }
+}
+
 // nsample > 64: successive-minimum selection, one wave per query, O(k * n / 64) per query.  Rarely used
 // (every shipped config has nsample <= 40); kept so that any nsample the reference accepts works.
 __global__ __launch_bounds__(256) void knn_select_kernel(int n, int m, int k, const float *__restrict__ xyz_all,
@@ -116,6 +379,9 @@ __global__ __launch_bounds__(256) void knn_select_kernel(int n, int m, int k, co
 
 }  // namespace
 
+static long long *g_knn_dbg = nullptr;
+PA_API void pa_knn_debug_buffer(long long *buf) { g_knn_dbg = buf; }   // profiling hook (6 int64), NULL = off
+
 PA_API int pa_knnquery(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx, float *dist2,
                        pa_stream_t stream)
 {
@@ -131,6 +397,19 @@ PA_API int pa_knnquery(int b, int n, int m, int nsample, const float *xyz, const
     // queries per workgroup: enough workgroups to fill 256 CUs several times over, but amortise the LDS staging
     int qpb = 4;
     while (qpb < 64 && (long)b * pa_div_up(m, qpb * 2) >= 1024) qpb *= 2;
+    static const bool no_grid = getenv("PA_KNN_NO_GRID") != nullptr;   // A/B knob
+    if (!no_grid && n >= 2048 && n <= 4096) {
+        // spatially pruned kernel: <= 64 chunks of 64 points, sorted cloud (16 n bytes) in LDS, 8 waves per workgroup so that the two
+        // resident workgroups of a CU put four waves on every SIMD (the per-query work is a chain of dependent cross-lane steps)
+        qpb = 16;
+        while (qpb < 128 && (long)b * pa_div_up(m, qpb * 2) >= 512) qpb *= 2;
+        const size_t lds = (size_t)n * 16 + 64 * 8 * 4 + (KG_CELLS + 1) * 4 + 16 * 6 * 4;
+        auto kern = g_knn_dbg ? knn_grid_kernel<8, 512, true> : knn_grid_kernel<8, 512, false>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(pa_div_up(m, qpb), b), dim3(512), lds, st, n, m, nsample, qpb, xyz, new_xyz, idx, dist2, g_knn_dbg);
+        PA_CHECK_LAUNCH("pa_knnquery(grid)");
+        return PA_OK;
+    }
     const size_t lds = (size_t)n * 12;
     if (lds <= 96 * 1024) {
         if (lds > 48 * 1024)
