@@ -194,6 +194,17 @@ int pa_rowgroup_max(long groups, int ns, int c, const float *in, float *out, pa_
 long pa_netvlad_scratch_floats(int b, int n, int k);
 int pa_netvlad(int b, int n, int c, int k, const float *x, const float *wc_t, const float *bias, const float *w2, float *scratch,
                float *out, int ldo, int koff, pa_stream_t stream);
+/* Cluster-major variants used by the fused engine: pa_netvlad_rows writes out[b][koff + j][c] ((b, ktot, 256): one contiguous
+ * 1 KB row per cluster); pa_afa_rows consumes that layout: the attention logits become one dense-layer launch on b*ktot rows
+ * (watt_t = the attention conv as a K-major (in, out) matrix, watt_p its packed copy or NULL, zero_bias = 256 zeros), and the FC
+ * weight must have its ROWS ORDERED k*256 + c (the reference's nn.Linear weight is c*ktot + k: permute once on the host).
+ * scratch: pa_afa_rows_scratch_floats(b, 256, ktot, nout) floats. */
+int pa_netvlad_rows(int b, int n, int c, int k, const float *x, const float *wc_t, const float *bias, const float *w2, float *scratch,
+                    float *out, int ktot, int koff, pa_stream_t stream);
+long pa_afa_rows_scratch_floats(int b, int c, int ktot, int nout);
+int pa_afa_rows(int b, int c, int ktot, int nout, const float *vt, const float *watt_t, const float *watt_p, const float *zero_bias,
+                const float *fc_wt, const float *fc_bias, const float *scale, const float *shift, int l2norm, float *scratch,
+                float *desc, pa_stream_t stream);
 long pa_afa_scratch_floats(int b, int c, int ktot, int nout);
 int pa_afa(int b, int c, int ktot, int nout, const float *v, const float *watt, const float *fc_wt, const float *fc_bias,
            const float *scale, const float *shift, int l2norm, float *scratch, float *desc, pa_stream_t stream);

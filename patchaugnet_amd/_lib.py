@@ -50,6 +50,8 @@ _SIGS = {
     "pa_furthestsampling_gather": "iiippp",
     "pa_three_nn_weights": "iiipppp",
     "pa_afa": "iiiippppppipp",
+    "pa_netvlad_rows": "iiiippppppii",
+    "pa_afa_rows": "iiiippppppppipp",
     "pa_fc": "iiipppppippp",
 }
 _T = {"i": _I, "f": _F, "p": _P, "l": ctypes.c_long}
@@ -90,7 +92,7 @@ def lib():
         l = ctypes.CDLL(LIB_PATH)
         l.pa_last_error.restype = ctypes.c_char_p
         l.pa_abi_version.restype = _I
-        for name, nargs in (("pa_netvlad_scratch_floats", 3), ("pa_afa_scratch_floats", 4), ("pa_fc_scratch_floats", 3)):
+        for name, nargs in (("pa_netvlad_scratch_floats", 3), ("pa_afa_scratch_floats", 4), ("pa_fc_scratch_floats", 3), ("pa_afa_rows_scratch_floats", 4)):
             getattr(l, name).argtypes = [_I] * nargs
             getattr(l, name).restype = ctypes.c_long
         _declare(l, _SIGS)

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void vlad_accum_kernel(int n, int k_true, int 
 // grid (k_true, B), 256 threads = channels: reduce partials, subtract a_sum*W2, intra-normalise, write (B, VC, ldo) at column koff+k
 __global__ __launch_bounds__(256) void vlad_finalize_kernel(int nchunks, int kp, const float *__restrict__ part, const float *__restrict__ asum_part,
                                                               const float *__restrict__ w2,  // [VC][k_true]
-                                                              int k_true, float *__restrict__ out, int ldo, int koff)
+                                                              int k_true, float *__restrict__ out, int ldo, int koff, int rows_layout)
 {
     __shared__ float red[4];
     const int k = blockIdx.x, b = blockIdx.y, c = threadIdx.x;
@@ -183,7 +183,9 @@ __global__ __launch_bounds__(256) void vlad_finalize_kernel(int nchunks, int kp,
     if ((c & 63) == 0) red[c >> 6] = ss;
     __syncthreads();
     const float nrm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
-    out[((size_t)b * VC + c) * ldo + koff + k] = v / fmaxf(nrm, 1e-12f);   // F.normalize(dim=1), loupe.py:221
+    const float r = v / fmaxf(nrm, 1e-12f);                                // F.normalize(dim=1), loupe.py:221
+    if (rows_layout) out[((size_t)b * ldo + koff + k) * VC + c] = r;        // (B, sum K, C): one contiguous 1 KB row per cluster
+    else out[((size_t)b * VC + c) * ldo + koff + k] = r;                    // (B, C, sum K): the reference's layout
 }
 
 // ------------------------------------------------------------------------------------------------ APFA attention
@@ -309,23 +311,29 @@ __global__ __launch_bounds__(256) void fc_splitk_kernel(int bsz, int kdim, int n
     }
 }
 
-// grid B, nout threads (<= 1024): sum the slices, + bias, BatchNorm (eval) as scale/shift, optional L2 normalise
+// grid B, 4 x nout threads (nout <= 256) or nout threads: sum the slices, + bias, BatchNorm (eval) as scale/shift, optional gating,
+// optional L2 normalise.  The slice sum is pure load latency, so four thread groups take every fourth slice with eight
+// independent accumulators each and meet in LDS.
 __global__ void fc_finalize_kernel(int bsz, int nout, int nslices, const float *__restrict__ out_part, const float *__restrict__ fc_bias,
                                    const float *__restrict__ scale, const float *__restrict__ shift, int l2norm, const float *__restrict__ gate_x,
                                    float *__restrict__ desc)
 {
     __shared__ float red[16];
-    const int b = blockIdx.x, n = threadIdx.x;
-    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;   // four independent chains: the loop is pure load latency otherwise
-    int s = 0;
-    for (; s + 4 <= nslices; s += 4) {
-        v0 += out_part[((size_t)(s + 0) * bsz + b) * nout + n];
-        v1 += out_part[((size_t)(s + 1) * bsz + b) * nout + n];
-        v2 += out_part[((size_t)(s + 2) * bsz + b) * nout + n];
-        v3 += out_part[((size_t)(s + 3) * bsz + b) * nout + n];
+    __shared__ float grp[3 * 256];
+    const int b = blockIdx.x, n = threadIdx.x % nout, g = threadIdx.x / nout, ng = blockDim.x / nout;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int s = g;
+    for (; s + 7 * ng < nslices; s += 8 * ng)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] += out_part[((size_t)(s + u * ng) * bsz + b) * nout + n];
+    for (; s < nslices; s += ng) a[0] += out_part[((size_t)s * bsz + b) * nout + n];
+    float v = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    if (ng > 1) {
+        if (g > 0) grp[(g - 1) * nout + n] = v;
+        __syncthreads();
+        if (g > 0) return;
+        for (int o = 0; o < ng - 1; ++o) v += grp[o * nout + n];
     }
-    for (; s < nslices; ++s) v0 += out_part[((size_t)s * bsz + b) * nout + n];
-    float v = (v0 + v1) + (v2 + v3);
     v = (v + (fc_bias ? fc_bias[n] : 0.f)) * scale[n] + shift[n];
     if (gate_x) v = gate_x[(size_t)b * nout + n] * (1.0f / (1.0f + expf(-v)));   // GatingContext, loupe.py:332-361: x * sigmoid(BN(x W))
     if (l2norm) {
@@ -333,12 +341,53 @@ __global__ void fc_finalize_kernel(int bsz, int nout, int nslices, const float *
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) ss += __shfl_xor(ss, o);
         if ((n & 63) == 0) red[n >> 6] = ss;
-        __syncthreads();
+        __syncthreads();                                    // only group 0 (nout threads, whole waves) is still here
         float t = 0.f;
         for (int w = 0; w < (nout + 63) / 64; ++w) t += red[w];
         v = v / fmaxf(sqrtf(t), 1e-12f);                   // F.normalize, loupe.py:63-64
     }
     desc[(size_t)b * nout + n] = v;
+}
+
+// cluster-major head, grid B x 256 threads: w = softmax_k(max_o logits[b][k][o]) (loupe.py:33-36), y[b][k][:] = relu(x + x*w[k])
+__global__ __launch_bounds__(256) void afa_rows_reweight_kernel(int ktot, const float *__restrict__ vt_all, const float *__restrict__ logits_all,
+                                                                  float *__restrict__ y_all)
+{
+    __shared__ float w[256];
+    __shared__ float red[8];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float4 *lg = reinterpret_cast<const float4 *>(logits_all + (size_t)b * ktot * VC);
+    for (int k = wave; k < ktot; k += 4) {                      // row max: one wavefront per 1 KB row
+        const float4 v = lg[(size_t)k * 64 + lane];
+        float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) w[k] = m;
+    }
+    __syncthreads();
+    const float m = tid < ktot ? w[tid] : -3.0e38f;
+    float mx = m;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float e = tid < ktot ? __expf(m - mx) : 0.f;
+    float s = e;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+    if (lane == 0) red[4 + wave] = s;
+    __syncthreads();
+    s = (red[4] + red[5]) + (red[6] + red[7]);
+    w[tid] = e / s;
+    __syncthreads();
+    const float4 *x4 = reinterpret_cast<const float4 *>(vt_all + (size_t)b * ktot * VC);
+    float4 *y4 = reinterpret_cast<float4 *>(y_all + (size_t)b * ktot * VC);
+    for (int q = tid; q < ktot * 64; q += 256) {
+        const float wk = w[q >> 6];
+        const float4 xv = x4[q];
+        y4[q] = make_float4(fmaxf(xv.x + xv.x * wk, 0.f), fmaxf(xv.y + xv.y * wk, 0.f), fmaxf(xv.z + xv.z * wk, 0.f), fmaxf(xv.w + xv.w * wk, 0.f));
+    }
 }
 
 int vlad_chunks(int n) { int rows = n >= 2048 ? 512 : 64; return (n + rows - 1) / rows; }
@@ -359,7 +408,7 @@ int fc_launch(int b, int kdim, int nout, const float *y, const float *fc_wt, con
             case 3: hipLaunchKernelGGL(fc_splitk_kernel<3>, dim3(nslices), dim3(256), 0, st, bc, kdim, nout, ks_rows, yc, fc_wt, opart); break;
             default: hipLaunchKernelGGL(fc_splitk_kernel<4>, dim3(nslices), dim3(256), 0, st, bc, kdim, nout, ks_rows, yc, fc_wt, opart); break;
         }
-        hipLaunchKernelGGL(fc_finalize_kernel, dim3(bc), dim3(nout), 0, st, bc, nout, nslices, opart, fc_bias, scale, shift, l2norm,
+        hipLaunchKernelGGL(fc_finalize_kernel, dim3(bc), dim3(nout <= 256 ? 4 * nout : nout), 0, st, bc, nout, nslices, opart, fc_bias, scale, shift, l2norm,
                            gate_x ? gate_x + (size_t)b0 * nout : nullptr, out + (size_t)b0 * nout);
     }
     return PA_OK;
@@ -374,8 +423,8 @@ PA_API long pa_netvlad_scratch_floats(int b, int n, int k)
 }
 
 // X (b, n, 256) point-major -> out[b][c][koff + k], k < k_true, ldo floats per (b, c) row.
-PA_API int pa_netvlad(int b, int n, int c, int k, const float *x, const float *wc_t, const float *bias, const float *w2, float *scratch,
-                      float *out, int ldo, int koff, pa_stream_t stream)
+static int netvlad_impl(int b, int n, int c, int k, const float *x, const float *wc_t, const float *bias, const float *w2, float *scratch,
+                        float *out, int ldo, int koff, int rows_layout, pa_stream_t stream)
 {
     PA_REQUIRE(b > 0 && n > 0 && k > 0 && x && wc_t && bias && w2 && scratch && out, "pa_netvlad: bad arguments");
     PA_REQUIRE(b <= 65535, "pa_netvlad: b=%d exceeds the grid limit", b);
@@ -398,9 +447,23 @@ PA_API int pa_netvlad(int b, int n, int c, int k, const float *x, const float *w
         default: PA_VLAD_LAUNCH(4); break;
     }
 #undef PA_VLAD_LAUNCH
-    hipLaunchKernelGGL(vlad_finalize_kernel, dim3(k, b), dim3(256), 0, st, chunks, kp, part, asum, w2, k, out, ldo, koff);
+    hipLaunchKernelGGL(vlad_finalize_kernel, dim3(k, b), dim3(256), 0, st, chunks, kp, part, asum, w2, k, out, ldo, koff, rows_layout);
     PA_CHECK_LAUNCH("pa_netvlad");
     return PA_OK;
+}
+
+PA_API int pa_netvlad(int b, int n, int c, int k, const float *x, const float *wc_t, const float *bias, const float *w2, float *scratch,
+                      float *out, int ldo, int koff, pa_stream_t stream)
+{
+    return netvlad_impl(b, n, c, k, x, wc_t, bias, w2, scratch, out, ldo, koff, 0, stream);
+}
+
+// Same, writing cluster-major rows: out[b][koff + j][c] with ktot = ldo rows of 256 floats per batch element -- the layout the
+// row-oriented head (pa_afa_rows) consumes with whole-row loads.
+PA_API int pa_netvlad_rows(int b, int n, int c, int k, const float *x, const float *wc_t, const float *bias, const float *w2, float *scratch,
+                           float *out, int ktot, int koff, pa_stream_t stream)
+{
+    return netvlad_impl(b, n, c, k, x, wc_t, bias, w2, scratch, out, ktot, koff, 1, stream);
 }
 
 PA_API long pa_afa_scratch_floats(int b, int c, int ktot, int nout)
@@ -452,5 +515,40 @@ PA_API int pa_fc(int b, int kdim, int nout, const float *y, const float *fc_wt, 
     const int rc = fc_launch(b, kdim, nout, y, fc_wt, fc_bias, scale, shift, l2norm, gate_x, scratch, out, (hipStream_t)stream);
     if (rc != PA_OK) return rc;
     PA_CHECK_LAUNCH("pa_fc");
+    return PA_OK;
+}
+
+PA_API long pa_afa_rows_scratch_floats(int b, int c, int ktot, int nout)
+{
+    const long kdim = (long)c * ktot;
+    const long nslices = (kdim + 127) / 128;
+    return 2 * (long)b * kdim + nslices * (b < 64 ? b : 64) * nout;
+}
+
+// Cluster-major APFA head.  vt (b, ktot, 256) from pa_netvlad_rows; watt_t: the attention conv as a K-major (in, out) matrix (+ its
+// packed copy or NULL); zero_bias: 256 zeros; fc_wt: K-major (ktot*256, nout) with ROWS ORDERED k*256 + c (the reference's FC weight
+// has rows c*ktot + k; the caller permutes once).  Launches: logits = vt . watt_t (MFMA chain kernel), row max + soft-max +
+// re-weighting, split-K FC, finalize.
+PA_API int pa_afa_rows(int b, int c, int ktot, int nout, const float *vt, const float *watt_t, const float *watt_p, const float *zero_bias,
+                       const float *fc_wt, const float *fc_bias, const float *scale, const float *shift, int l2norm, float *scratch,
+                       float *desc, pa_stream_t stream)
+{
+    PA_REQUIRE(b > 0 && ktot > 0 && nout > 0 && vt && watt_t && zero_bias && fc_wt && fc_bias && scale && shift && scratch && desc,
+               "pa_afa_rows: bad arguments");
+    if (c != VC || ktot > 256 || nout % 16 || nout > 1024) {
+        pa_set_error("pa_afa_rows: built for 256 channels, <= 256 clusters, nout %% 16 == 0, nout <= 1024 (got c=%d ktot=%d nout=%d)", c, ktot, nout);
+        return PA_EUNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int kdim = c * ktot;
+    float *logits = scratch;
+    float *y = logits + (size_t)b * kdim;
+    float *opart = y + (size_t)b * kdim;
+    int rc = pa_linear((long)b * ktot, VC, VC, vt, VC, watt_t, watt_p, zero_bias, 0, nullptr, 0, logits, VC, stream);
+    if (rc != PA_OK) return rc;
+    hipLaunchKernelGGL(afa_rows_reweight_kernel, dim3(b), dim3(256), 0, st, ktot, vt, logits, y);
+    rc = fc_launch(b, kdim, nout, y, fc_wt, fc_bias, scale, shift, l2norm, nullptr, opart, desc, st);
+    if (rc != PA_OK) return rc;
+    PA_CHECK_LAUNCH("pa_afa_rows");
     return PA_OK;
 }

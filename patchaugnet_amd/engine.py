@@ -155,12 +155,13 @@ class _Vlad:
         self.bias = bias.float().contiguous().to(device)
         self.w2 = v.cluster_weights2.detach()[0].float().contiguous().to(device)      # (C, K)
 
-    def run(self, x, out, ldo, koff):
+    def run(self, x, out, ldo, koff, rows=False):
+        """rows=False: out (B, C, ldo) as the reference lays it out; rows=True: out (B, ldo, C), one contiguous row per cluster."""
         b = x.shape[0]
         nfl = _lib.lib().pa_netvlad_scratch_floats(b, self.n, self.k)
         scratch = torch.empty(nfl, dtype=torch.float32, device=x.device)
-        call("pa_netvlad", b, self.n, self.c, self.k, ptr(x), ptr(self.wc_t), ptr(self.bias), ptr(self.w2), ptr(scratch),
-             ptr(out), ldo, koff)
+        call("pa_netvlad_rows" if rows else "pa_netvlad", b, self.n, self.c, self.k, ptr(x), ptr(self.wc_t), ptr(self.bias), ptr(self.w2),
+             ptr(scratch), ptr(out), ldo, koff)
 
 
 class _Afa:
@@ -176,6 +177,23 @@ class _Afa:
         self.scale, self.shift = scale.float().contiguous().to(device), shift.float().contiguous().to(device)
         self.l2 = 1 if afa.l2_norm else 0
         self.nout = afa.fc.out_features
+        # cluster-major variant (pa_afa_rows): attention conv as a K-major (in, out) matrix, FC rows re-ordered from c*K + k to k*C + c
+        c = self.watt.shape[0]
+        k = afa.fc.in_features // c
+        self.watt_t = self.watt.t().contiguous()
+        self.watt_p = pack_weights(self.watt_t)
+        self.zero = torch.zeros(c, dtype=torch.float32, device=device)
+        self.fc_wt_rows = afa.fc.weight.detach().float().view(self.nout, c, k).permute(2, 1, 0).reshape(k * c, self.nout).contiguous().to(device)
+
+    def run_rows(self, vt):
+        """vt (B, ktot, C) from _Vlad.run(rows=True)."""
+        b, ktot, c = vt.shape
+        nfl = _lib.lib().pa_afa_rows_scratch_floats(b, c, ktot, self.nout)
+        scratch = torch.empty(nfl, dtype=torch.float32, device=vt.device)
+        desc = torch.empty((b, self.nout), dtype=torch.float32, device=vt.device)
+        call("pa_afa_rows", b, c, ktot, self.nout, ptr(vt), ptr(self.watt_t), ptr(self.watt_p), ptr(self.zero), ptr(self.fc_wt_rows),
+             ptr(self.fc_bias), ptr(self.scale), ptr(self.shift), self.l2, ptr(scratch), ptr(desc))
+        return desc
 
     def run(self, v):
         b, c, ktot = v.shape
@@ -228,8 +246,8 @@ class _Attn:
 
 class _PptHead:
     """PPT-Net head after the pyramid VLADs (pptnet_origin/models/loupe.py:94-105): flat concat -> hidden_weights -> bn2 ->
-    context gating.  The VLAD kernel writes the (B, 256, sum K) layout, so the FC weight rows are permuted once from
-    the reference's per-scale C-major flattening (off_i + c*K_i + k) to c*sum K + koff_i + k."""
+    context gating.  The VLAD kernel writes cluster-major rows (B, sum K, 256), so the FC weight rows are permuted once from
+    the reference's per-scale C-major flattening (off_i + c*K_i + k) to (koff_i + k)*256 + c."""
 
     def __init__(self, agg, ks, use_normalize, device):
         c, ktot = 256, sum(ks)
@@ -238,7 +256,7 @@ class _PptHead:
         off, koff = 0, 0
         for k in ks:
             cc, kk = torch.meshgrid(torch.arange(c), torch.arange(k), indexing="ij")
-            perm[(cc * ktot + koff + kk).flatten()] = (off + cc * k + kk).flatten()
+            perm[((koff + kk) * c + cc).flatten()] = (off + cc * k + kk).flatten()
             off += c * k
             koff += k
         self.fc_wt = hw[perm.to(hw.device)].float().contiguous().to(device)                 # (256*ktot, nout) K-major
@@ -389,13 +407,13 @@ class PatchAugNetEngine:
         agg = self.agg
         if self.fused_head:
             ktot = sum(v.k for v in self.vlads)
-            v = torch.empty((x.shape[0], 256, ktot), dtype=torch.float32, device=self.device)
+            v = torch.empty((x.shape[0], ktot, 256), dtype=torch.float32, device=self.device)     # cluster-major rows
             koff = 0
             for vl, f in zip(self.vlads, feats):
-                vl.run(f.contiguous(), v, ktot, koff)
+                vl.run(f.contiguous(), v, ktot, koff, rows=True)
                 koff += vl.k
             self._mark("vlad")
-            desc = self.head.run(v) if self.ppt else self.afa.run(v)
+            desc = self.head.run(v) if self.ppt else self.afa.run_rows(v)
             self._mark("afa")
             return desc, self._views(feats, l_c)
         v = torch.cat([self._vlad(vl, f) for vl, f in zip(agg.vlads, feats)], dim=-1)       # (B, 256, sum K)

@@ -71,5 +71,5 @@ def test_ppt_head_fc_and_gating(b, norm):
         ref = agg.context_gating(ref)
         if norm:
             ref = torch.nn.functional.normalize(ref)
-        got = _PptHead(agg, ks, norm, flat.device).run(torch.cat(vl, dim=-1).contiguous())   # (B, 256, 85) layout of the VLAD kernel
+        got = _PptHead(agg, ks, norm, flat.device).run(torch.cat(vl, dim=-1).transpose(1, 2).contiguous())   # (B, 85, 256) rows of the VLAD kernel
     assert (got - ref).abs().max().item() <= 3e-5 * max(ref.abs().max().item(), 1.0)

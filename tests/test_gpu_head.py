@@ -23,13 +23,16 @@ def test_netvlad_scale(b, n, k):
         ref = v(x.transpose(1, 2).unsqueeze(-1))                         # (B, 256, K)
         out = torch.full((b, 256, k + 5), 7.0, device="cuda")
         _Vlad(v, x.device).run(x, out, k + 5, 3)
+        out_t = torch.full((b, k + 5, 256), 7.0, device="cuda")
+        _Vlad(v, x.device).run(x, out_t, k + 5, 3, rows=True)                              # cluster-major rows (B, sum K, C)
     got = out[:, :, 3:3 + k]
     assert torch.all(out[:, :, :3] == 7.0) and torch.all(out[:, :, 3 + k:] == 7.0)       # neighbours of the block untouched
     err = (got - ref).abs().max().item()
     assert err <= 2e-5, err
+    assert torch.equal(out_t[:, 3:3 + k].transpose(1, 2), got) and torch.all(out_t[:, :3] == 7.0) and torch.all(out_t[:, 3 + k:] == 7.0)
 
 
-@pytest.mark.parametrize("b,ktot", [(32, 84), (2, 84), (5, 21), (17, 100)])
+@pytest.mark.parametrize("b,ktot", [(32, 84), (2, 84), (5, 21), (17, 100), (70, 84)])
 def test_afa(b, ktot):
     from patchaugnet_amd import loupe
     from patchaugnet_amd.engine import _Afa
@@ -37,6 +40,9 @@ def test_afa(b, ktot):
     v = torch.nn.functional.normalize(torch.randn(b, 256, ktot, device="cuda"), dim=1)
     with torch.no_grad():
         ref = afa(v).squeeze(-1)
-        got = _Afa(afa, v.device).run(v.contiguous())
+        eng = _Afa(afa, v.device)
+        got = eng.run(v.contiguous())
+        got_rows = eng.run_rows(v.transpose(1, 2).contiguous())                            # cluster-major path of the fused engine
     err = (got - ref).abs().max().item()
     assert err <= 2e-5, err
+    assert (got_rows - ref).abs().max().item() <= 2e-5

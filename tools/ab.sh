@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of env-var knobs on the GPU box: tools/ab.sh "VAR=1" -> prints stage times with and without
 export TMPDIR=/tmp
-python -m pytest tests/test_gpu_ops.py tests/test_gpu_chain.py tests/test_gpu_attention.py tests/test_gpu_models.py -m gpu -x -q 2>&1 | tail -3
+python -m pytest tests/test_gpu_head.py tests/test_gpu_ops.py tests/test_gpu_chain.py tests/test_gpu_attention.py tests/test_gpu_models.py -m gpu -x -q 2>&1 | tail -3
 for cfg in "$@" ""; do
   echo "=== env: [$cfg]"
   env $cfg python bench.py --no-cpu-baseline --steps 30 --warmup 6 | python -c "
