@@ -50,7 +50,7 @@ _SIGS = {
     "pa_furthestsampling_gather": "iiippp",
     "pa_three_nn_weights": "iiipppp",
     "pa_afa": "iiiippppppipp",
-    "pa_netvlad_rows": "iiiippppppii",
+    "pa_netvlad_rows": "iiiipppppppii",
     "pa_afa_rows": "iiiippppppppipp",
     "pa_fc": "iiipppppippp",
 }

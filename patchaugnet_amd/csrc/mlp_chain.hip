@@ -309,7 +309,7 @@ __device__ __forceinline__ void run_layer_chunks(float *act, const PaChain &a, i
     const bool last = (l == a.nlayers - 1);
     for (int c0 = c_begin; c0 < c_end; c0 += NC) {
         floatx4 acc[RT][NC];
-        gemm_chunk<RT, NC, (WPT > 1 ? 4 : 2)>(act, a.lds_stride, L, c0, lane, acc);
+        gemm_chunk<RT, NC, (WPT == 1 ? 2 : (RT * NC >= 16 ? 4 : 8))>(act, a.lds_stride, L, c0, lane, acc);
         if (!last) {
             tile_sync<WPT>();  // every A read of this layer has landed before its rows are overwritten (single chunk per wave: host-checked)
             store_hidden<RT, NC>(act, a.lds_stride, L, c0, lane, acc);
@@ -335,7 +335,7 @@ __device__ __forceinline__ void run_layer_chunks(float *act, const PaChain &a, i
 // Pooled wave-private kernels (the set-abstraction levels) are gather-latency bound in their prologue: keep two waves per SIMD
 // (<= 256 registers) there; the plain row kernels trade occupancy for their 128 accumulator registers.
 template <int RT, int NCMAX, int MODE, bool POOLED, int WPT>
-__global__ __launch_bounds__(256, (POOLED && WPT == 1 && RT <= 5) ? 2 : 1) void chain_kernel(PaChain a)
+__global__ __launch_bounds__(256, (POOLED && RT <= 5) ? 2 : 1) void chain_kernel(PaChain a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int R = RT * 16;

@@ -21,6 +21,24 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+// all-reduce over the 16 lanes of a DPP row with row rotations (one VALU op per step; __shfl_xor would be an LDS round trip each)
+#define PA_DPP_ROW_ROR(n) (0x120 + (n))
+template <int N>
+__device__ __forceinline__ float row_ror(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), PA_DPP_ROW_ROR(N), 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_max(float v)
+{
+    v = fmaxf(v, row_ror<8>(v)); v = fmaxf(v, row_ror<4>(v)); v = fmaxf(v, row_ror<2>(v)); v = fmaxf(v, row_ror<1>(v));
+    return v;
+}
+__device__ __forceinline__ float row16_sum(float v)
+{
+    v += row_ror<8>(v); v += row_ror<4>(v); v += row_ror<2>(v); v += row_ror<1>(v);
+    return v;
+}
+
 constexpr int VC = 256;         // feature channels (every shipped config; checked on the host)
 constexpr int VROWS = 64;       // rows of X per LDS tile
 constexpr int XS = VC + 2;      // LDS row stride of the X tile (conflict-free A-fragment reads, see mlp_chain.hip)
@@ -31,6 +49,7 @@ constexpr int XS = VC + 2;      // LDS row stride of the X tile (conflict-free A
 template <int KT>
 __global__ __launch_bounds__(256) void vlad_accum_kernel(int n, int k_true, int rows_per_wg, const float *__restrict__ x_all,
                                                            const float *__restrict__ wc_t,   // [VC][16*KT] K-major, BN folded
+                                                           const float *__restrict__ wc_p,   // optional fragment-major packing of wc_t (KT == 4), or null
                                                            const float *__restrict__ bias,   // [16*KT]
                                                            float *__restrict__ part, float *__restrict__ asum_part)
 {
@@ -58,22 +77,63 @@ __global__ __launch_bounds__(256) void vlad_accum_kernel(int n, int k_true, int 
 #pragma unroll
     for (int ct = 0; ct < KT; ++ct) bia[ct] = bias[ct * 16 + (lane & 15)];
 
+    // X tiles are prefetched one tile ahead into registers (16 float4 per thread): the global loads of tile t+1 are in flight
+    // during the two GEMM phases of tile t, and LDS is refilled right after the barrier that ends phase 4.
+    constexpr int PF = VROWS * (VC / 4) / 256;
+    float4 pre[PF];
+    auto fetch = [&](int r0) {
+        const int cnt = min(VROWS, row_end - r0);
+        const float4 *x4 = reinterpret_cast<const float4 *>(x + (size_t)r0 * VC);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int q = tid + u * 256, r = q / (VC / 4);
+            pre[u] = (r0 < row_end && r < cnt) ? x4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    fetch(row_begin);
     for (int r0 = row_begin; r0 < row_end; r0 += VROWS) {
         const int cnt = min(VROWS, row_end - r0);
-        // 1. stage X rows (zero rows beyond cnt), 16-byte global loads
-        const float4 *x4 = reinterpret_cast<const float4 *>(x + (size_t)r0 * VC);
-        for (int q = tid; q < VROWS * (VC / 4); q += 256) {
-            const int r = q / (VC / 4), part4 = q - r * (VC / 4);
-            const float4 v = r < cnt ? x4[(size_t)r * (VC / 4) + part4] : make_float4(0.f, 0.f, 0.f, 0.f);
-            float *d = Xs + r * XS + part4 * 4;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        // 1. registers -> LDS (XS is even: 8-byte aligned stores), then start fetching the next tile
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int q = tid + u * 256, r = q / (VC / 4), part4 = q - r * (VC / 4);
+            float2 *d = reinterpret_cast<float2 *>(Xs + r * XS + part4 * 4);
+            d[0] = make_float2(pre[u].x, pre[u].y);
+            d[1] = make_float2(pre[u].z, pre[u].w);
         }
         __syncthreads();
+        fetch(r0 + VROWS);
         // 2. assignment logits for this wave's 16 rows: X[16 x 256] * Wc[256 x KP]
         floatx4 acc[KT];
 #pragma unroll
         for (int ct = 0; ct < KT; ++ct) acc[ct] = (floatx4){0.f, 0.f, 0.f, 0.f};
-        {
+        if (KT == 4 && wc_p != nullptr) {
+            // packed weights: one 16-byte load per k-step brings the lane's four cluster-tile fragments; two k-steps of lookahead
+            const float *ap = Xs + (wave * 16 + (lane & 15)) * XS + (lane >> 4);
+            const float4 *wq = reinterpret_cast<const float4 *>(wc_p) + lane;
+            float4 b0 = wq[0], b1 = wq[64];
+            float a0 = ap[0], a1 = ap[4];
+            for (int ks = 0; ks < VC / 4; ks += 2) {
+                const int n0 = min(ks + 2, VC / 4 - 1), n1 = min(ks + 3, VC / 4 - 1);
+                const float an0 = ap[n0 * 4], an1 = ap[n1 * 4];
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0.x, acc[0], 0, 0, 0);
+                acc[1 % KT] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0.y, acc[1 % KT], 0, 0, 0);
+                acc[2 % KT] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0.z, acc[2 % KT], 0, 0, 0);
+                acc[3 % KT] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0.w, acc[3 % KT], 0, 0, 0);
+                b0 = wq[(size_t)n0 * 64];
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1.x, acc[0], 0, 0, 0);
+                acc[1 % KT] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1.y, acc[1 % KT], 0, 0, 0);
+                acc[2 % KT] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1.z, acc[2 % KT], 0, 0, 0);
+                acc[3 % KT] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1.w, acc[3 % KT], 0, 0, 0);
+                b1 = wq[(size_t)n1 * 64];
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                a0 = an0;
+                a1 = an1;
+            }
+        } else {
             const float *ap = Xs + (wave * 16 + (lane & 15)) * XS + (lane >> 4);
             const float *wp = wc_t + (size_t)(lane >> 4) * KP + (lane & 15);
             float bn[KT], an = ap[0];
@@ -104,16 +164,14 @@ __global__ __launch_bounds__(256) void vlad_accum_kernel(int n, int k_true, int 
                 v[ct] = live ? acc[ct][r] + bia[ct] : -3.0e38f;
                 mx = fmaxf(mx, v[ct]);
             }
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            mx = row16_max(mx);
             float s = 0.f;
 #pragma unroll
             for (int ct = 0; ct < KT; ++ct) {
                 v[ct] = (ct * 16 + (lane & 15) < k_true) ? __expf(v[ct] - mx) : 0.f;
                 s += v[ct];
             }
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
+            s = row16_sum(s);
             const float inv = 1.0f / s;
             const int row = wave * 16 + (lane >> 4) * 4 + r;
             const bool row_live = row < cnt;
@@ -423,8 +481,8 @@ PA_API long pa_netvlad_scratch_floats(int b, int n, int k)
 }
 
 // X (b, n, 256) point-major -> out[b][c][koff + k], k < k_true, ldo floats per (b, c) row.
-static int netvlad_impl(int b, int n, int c, int k, const float *x, const float *wc_t, const float *bias, const float *w2, float *scratch,
-                        float *out, int ldo, int koff, int rows_layout, pa_stream_t stream)
+static int netvlad_impl(int b, int n, int c, int k, const float *x, const float *wc_t, const float *wc_p, const float *bias, const float *w2,
+                        float *scratch, float *out, int ldo, int koff, int rows_layout, pa_stream_t stream)
 {
     PA_REQUIRE(b > 0 && n > 0 && k > 0 && x && wc_t && bias && w2 && scratch && out, "pa_netvlad: bad arguments");
     PA_REQUIRE(b <= 65535, "pa_netvlad: b=%d exceeds the grid limit", b);
@@ -438,7 +496,7 @@ static int netvlad_impl(int b, int n, int c, int k, const float *x, const float 
 #define PA_VLAD_LAUNCH(KT)                                                                                                              \
     do {                                                                                                                                \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vlad_accum_kernel<KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(vlad_accum_kernel<KT>, dim3(chunks, b), dim3(256), lds, st, n, k, rows, x, wc_t, bias, part, asum);         \
+        hipLaunchKernelGGL(vlad_accum_kernel<KT>, dim3(chunks, b), dim3(256), lds, st, n, k, rows, x, wc_t, wc_p, bias, part, asum);         \
     } while (0)
     switch (kt) {
         case 1: PA_VLAD_LAUNCH(1); break;
@@ -455,15 +513,15 @@ static int netvlad_impl(int b, int n, int c, int k, const float *x, const float 
 PA_API int pa_netvlad(int b, int n, int c, int k, const float *x, const float *wc_t, const float *bias, const float *w2, float *scratch,
                       float *out, int ldo, int koff, pa_stream_t stream)
 {
-    return netvlad_impl(b, n, c, k, x, wc_t, bias, w2, scratch, out, ldo, koff, 0, stream);
+    return netvlad_impl(b, n, c, k, x, wc_t, nullptr, bias, w2, scratch, out, ldo, koff, 0, stream);
 }
 
 // Same, writing cluster-major rows: out[b][koff + j][c] with ktot = ldo rows of 256 floats per batch element -- the layout the
 // row-oriented head (pa_afa_rows) consumes with whole-row loads.
-PA_API int pa_netvlad_rows(int b, int n, int c, int k, const float *x, const float *wc_t, const float *bias, const float *w2, float *scratch,
-                           float *out, int ktot, int koff, pa_stream_t stream)
+PA_API int pa_netvlad_rows(int b, int n, int c, int k, const float *x, const float *wc_t, const float *wc_p, const float *bias, const float *w2,
+                           float *scratch, float *out, int ktot, int koff, pa_stream_t stream)
 {
-    return netvlad_impl(b, n, c, k, x, wc_t, bias, w2, scratch, out, ktot, koff, 1, stream);
+    return netvlad_impl(b, n, c, k, x, wc_t, (k > 48 ? wc_p : nullptr), bias, w2, scratch, out, ktot, koff, 1, stream);
 }
 
 PA_API long pa_afa_scratch_floats(int b, int c, int ktot, int nout)

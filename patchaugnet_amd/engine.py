@@ -154,14 +154,18 @@ class _Vlad:
         self.wc_t = wc.float().contiguous().to(device)
         self.bias = bias.float().contiguous().to(device)
         self.w2 = v.cluster_weights2.detach()[0].float().contiguous().to(device)      # (C, K)
+        self.wc_p = pack_weights(self.wc_t) if kp == 64 else None
 
     def run(self, x, out, ldo, koff, rows=False):
         """rows=False: out (B, C, ldo) as the reference lays it out; rows=True: out (B, ldo, C), one contiguous row per cluster."""
         b = x.shape[0]
         nfl = _lib.lib().pa_netvlad_scratch_floats(b, self.n, self.k)
         scratch = torch.empty(nfl, dtype=torch.float32, device=x.device)
-        call("pa_netvlad_rows" if rows else "pa_netvlad", b, self.n, self.c, self.k, ptr(x), ptr(self.wc_t), ptr(self.bias), ptr(self.w2),
-             ptr(scratch), ptr(out), ldo, koff)
+        if rows:
+            call("pa_netvlad_rows", b, self.n, self.c, self.k, ptr(x), ptr(self.wc_t), ptr(self.wc_p), ptr(self.bias), ptr(self.w2),
+                 ptr(scratch), ptr(out), ldo, koff)
+        else:
+            call("pa_netvlad", b, self.n, self.c, self.k, ptr(x), ptr(self.wc_t), ptr(self.bias), ptr(self.w2), ptr(scratch), ptr(out), ldo, koff)
 
 
 class _Afa:

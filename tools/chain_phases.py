@@ -1,7 +1,8 @@
 #!/usr/bin/env python
-"""Per-phase cycle stamps of the fp0 chain kernel (profiling aid): prologue / layer0 / layer1 / layer2+epilogue."""
+"""Per-phase cycle stamps of the chain kernels (profiling aid): python tools/chain_phases.py [sa0|sa1|sa2|fp0|fp1|fp2 ...]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
 import torch
 from patchaugnet_amd import _lib, configs, patch_aug_net
 from patchaugnet_amd.weights import seeded_state_dict, synthetic_submaps
@@ -17,23 +18,26 @@ with torch.no_grad():
     for _ in range(2):
         model(x, return_feat=False)
     eng = model._engine
-    name = "fp_premul" if eng.premul else "fp"
-    orig = getattr(eng.fp[0], name)
-    buf = torch.zeros(512 * 8, dtype=torch.int64, device="cuda")
+    for which in (sys.argv[1:] or ["fp0"]):
+        kind, lvl = which[:2], int(which[2])
+        chain = (eng.sa if kind == "sa" else eng.fp)[lvl]
+        name = "sa" if kind == "sa" else ("fp_premul" if (eng.premul and lvl == 0) else "fp")
+        orig = getattr(chain, name)
+        buf = torch.zeros(512 * 8, dtype=torch.int64, device="cuda")
 
-    def wrapped(*a, **k):
-        lib.pa_chain_debug_buffer(ctypes.c_void_p(buf.data_ptr()))
-        r = orig(*a, **k)
-        lib.pa_chain_debug_buffer(None)
-        return r
-    setattr(eng.fp[0], name, wrapped)
-    model(x, return_feat=False)
-    torch.cuda.synchronize()
-t = buf.view(512, 8).cpu().numpy()
-nl = 3 if eng.premul else 4
-d = t[:, 1:nl + 1] - t[:, 0:nl]
-import numpy as np
-names = ["prologue", "layer0", "layer1", "layer2+epilogue"] if nl == 4 else ["prologue(+folded layer)", "layer1", "layer2+epilogue"]
-for i, n in enumerate(names):
-    print(f"{n:18s} median {np.median(d[:, i]):10.0f}  min {d[:, i].min():10.0f}  max {d[:, i].max():10.0f}  (counter ticks)")
-print("total median", np.median(t[:, nl] - t[:, 0]), " start spread", t[:, 0].max() - t[:, 0].min())
+        def wrapped(*a, _o=orig, **k):
+            lib.pa_chain_debug_buffer(ctypes.c_void_p(buf.data_ptr()))
+            r = _o(*a, **k)
+            lib.pa_chain_debug_buffer(None)
+            return r
+        setattr(chain, name, wrapped)
+        model(x, return_feat=False)
+        torch.cuda.synchronize()
+        setattr(chain, name, orig)
+        t = buf.view(512, 8).cpu().numpy()
+        t = t[t[:, 0] > 0]
+        nl = chain.n - (1 if name == "fp_premul" else 0)
+        d = t[:, 1:nl + 2] - t[:, 0:nl + 1]
+        parts = ["prologue"] + [f"layer{i}" for i in range(nl)]
+        print(which, f"({len(t)} tiles stamped)", "  ".join(f"{p} {np.median(d[:, i]):.0f}" for i, p in enumerate(parts)),
+              " total", np.median(t[:, nl + 1] - t[:, 0]))
