@@ -34,7 +34,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-pass", action="store_true")
     p.add_argument("--cpu-batch", type=int, default=8)
-    p.add_argument("--streams", type=int, default=2, help="HIP streams the consecutive steps are issued on (1 = strictly sequential)")
+    p.add_argument("--streams", type=int, default=3, help="HIP streams the consecutive steps are issued on (1 = strictly sequential)")
     return p.parse_args()
 
 

@@ -37,7 +37,7 @@ class StreamPipeline:
 
 
 @torch.no_grad()
-def extract_descriptors(model, batches, n_streams=2, out=None):
+def extract_descriptors(model, batches, n_streams=3, out=None):
     """batches: iterable of (B,1,N,3) device tensors -> (sum B, 256) descriptors in input order."""
     batches = list(batches)
     total = sum(b.shape[0] for b in batches)

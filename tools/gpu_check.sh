@@ -1,6 +1,7 @@
 #!/bin/bash
-# One GPU-box visit: parity tests, default bench line, rocprofv3 kernel stats of the same bench command.
-# usage: gpurun --timeout 1500 -- 'bash tools/gpu_check.sh TAG'
+# One GPU-box visit: parity tests, default bench line, rocprofv3 kernel stats of the same bench command (+ a 1-stream trace whose
+# per-kernel durations are free of cross-stream overlap), PMC traffic of the dominant kernels.
+# usage: gpurun --timeout 1800 -- 'bash tools/gpu_check.sh TAG'
 TAG=${1:-r01}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -8,7 +9,19 @@ timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_tests.log 2>
 tail -5 gpurun_out/${TAG}_tests.log
 timeout 600 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"
 cat gpurun_out/${TAG}_bench.json
-rm -rf gpurun_out/${TAG}_prof
-timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_prof -o ${TAG} -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_prof.log 2>&1; echo "rocprof rc=$?"
-python tools/rocprof_summary.py $(ls gpurun_out/${TAG}_prof/*results.db | head -1) gpurun_out/${TAG}_kernel_stats.csv
-head -12 gpurun_out/${TAG}_kernel_stats.csv | cut -c1-200
+for S in default 1; do
+  rm -rf gpurun_out/${TAG}_prof
+  EXTRA=""; [ "$S" = "1" ] && EXTRA="--streams 1"
+  timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_prof -o ${TAG} -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline $EXTRA > gpurun_out/${TAG}_prof_$S.log 2>&1; echo "rocprof($S) rc=$?"
+  python tools/rocprof_summary.py $(ls gpurun_out/${TAG}_prof/*results.db | head -1) gpurun_out/${TAG}_kernel_stats_streams_$S.csv
+  rm -rf gpurun_out/${TAG}_prof
+done
+head -8 gpurun_out/${TAG}_kernel_stats_streams_1.csv | cut -c1-160
+cd /tmp
+for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmc_$C
+  timeout 300 rocprofv3 --kernel-trace --pmc $C -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$C -o pmc -- python $GRAFT_REPO_ROOT/tools/pmc_target.py > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_$C.log 2>&1
+  python $GRAFT_REPO_ROOT/tools/pmc_summary.py $(ls $GRAFT_REPO_ROOT/gpurun_out/pmc_$C/*results.db | head -1) > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_$C.txt 2>&1
+  rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmc_$C
+  grep -E "chain_kernel<2, 16, 3|group_lds_kernel<4>|knn_grid|vlad_accum_kernel<4>" $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_$C.txt | cut -c1-60,90-200
+done
