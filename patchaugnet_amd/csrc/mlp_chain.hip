@@ -445,8 +445,7 @@ __global__ __launch_bounds__(256, (POOLED && RT <= 5) ? 2 : 1) void chain_kernel
         if (MODE == MODE_FPX && WPT == 1 && C2 == 256) {
             // Common shape (256-wide features, wave-private tile): lane l owns float4 column l of every row, so the bias and the
             // skip weights are loop invariants, row / column indices need no division, and addresses are 32-bit.  This part is
-            // not bit-matched to anything (the first layer is already re-associated), so FMA contraction is allowed here.
-#pragma clang fp contract(fast)
+            // not bit-matched to anything (the first layer is already re-associated), so it uses explicit fmaf chains.
             const float4 bz = *reinterpret_cast<const float4 *>(a.bias0 + lane * 4);
             float4 wv[4];
 #pragma unroll
@@ -466,11 +465,20 @@ __global__ __launch_bounds__(256, (POOLED && RT <= 5) ? 2 : 1) void chain_kernel
                 for (int u = 0; u < 4; ++u) {
                     const float *s4 = sk + (r0 + u) * 4;
                     const float sx = s4[0], sy = s4[1], sz = s4[2], sw = s4[3];
-                    float v[4];
-                    v[0] = bz.x + sx * wv[0].x + sy * wv[1].x + sz * wv[2].x + sw * wv[3].x + w[u][0] * f[u][0].x + w[u][1] * f[u][1].x + w[u][2] * f[u][2].x;
-                    v[1] = bz.y + sx * wv[0].y + sy * wv[1].y + sz * wv[2].y + sw * wv[3].y + w[u][0] * f[u][0].y + w[u][1] * f[u][1].y + w[u][2] * f[u][2].y;
-                    v[2] = bz.z + sx * wv[0].z + sy * wv[1].z + sz * wv[2].z + sw * wv[3].z + w[u][0] * f[u][0].z + w[u][1] * f[u][1].z + w[u][2] * f[u][2].z;
-                    v[3] = bz.w + sx * wv[0].w + sy * wv[1].w + sz * wv[2].w + sw * wv[3].w + w[u][0] * f[u][0].w + w[u][1] * f[u][1].w + w[u][2] * f[u][2].w;
+                    // fixed fmaf order (bias, skip channels, then the three interpolation terms): the generic path below uses the same
+                    // chain, so the result does not depend on which tiling a batch size selects
+                    float v[4] = {bz.x, bz.y, bz.z, bz.w};
+                    const float sv[4] = {sx, sy, sz, sw};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        v[0] = fmaf(sv[t], wv[t].x, v[0]); v[1] = fmaf(sv[t], wv[t].y, v[1]);
+                        v[2] = fmaf(sv[t], wv[t].z, v[2]); v[3] = fmaf(sv[t], wv[t].w, v[3]);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        v[0] = fmaf(w[u][t], f[u][t].x, v[0]); v[1] = fmaf(w[u][t], f[u][t].y, v[1]);
+                        v[2] = fmaf(w[u][t], f[u][t].z, v[2]); v[3] = fmaf(w[u][t], f[u][t].w, v[3]);
+                    }
                     float2 *d = reinterpret_cast<float2 *>(act + (r0 + u) * stride + lane * 4);   // stride is even: 8-byte aligned
                     d[0] = make_float2(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
                     d[1] = make_float2(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
@@ -497,21 +505,27 @@ __global__ __launch_bounds__(256, (POOLED && RT <= 5) ? 2 : 1) void chain_kernel
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (q0 + u * NTH >= items) break;
-                float v[4];  // interpolation_cuda_kernel.cu:194: (w0*p0 + w1*p1) + w2*p2
-                v[0] = w[u][0] * f[u][0].x + w[u][1] * f[u][1].x + w[u][2] * f[u][2].x;
-                v[1] = w[u][0] * f[u][0].y + w[u][1] * f[u][1].y + w[u][2] * f[u][2].y;
-                v[2] = w[u][0] * f[u][0].z + w[u][1] * f[u][1].z + w[u][2] * f[u][2].z;
-                v[3] = w[u][0] * f[u][0].w + w[u][1] * f[u][1].w + w[u][2] * f[u][2].w;
-                if (MODE == MODE_FPX) {  // + skip . Wskip + bias, ReLU: this IS the first layer's output (linearity of interpolation)
+                float v[4];
+                if (MODE == MODE_FPX) {  // bias + skip . Wskip + interpolation, ReLU: this IS the first layer's output (linearity of interpolation)
                     const float4 bz = *reinterpret_cast<const float4 *>(a.bias0 + pp[u] * 4);
-                    float s[4] = {bz.x, bz.y, bz.z, bz.w};
+                    v[0] = bz.x; v[1] = bz.y; v[2] = bz.z; v[3] = bz.w;
                     for (int t = 0; t < C1; ++t) {
                         const float4 wv = *reinterpret_cast<const float4 *>(a.wskip + (size_t)t * C2 + pp[u] * 4);
                         const float xv = sk[rr[u] * 4 + t];
-                        s[0] += xv * wv.x; s[1] += xv * wv.y; s[2] += xv * wv.z; s[3] += xv * wv.w;
+                        v[0] = fmaf(xv, wv.x, v[0]); v[1] = fmaf(xv, wv.y, v[1]); v[2] = fmaf(xv, wv.z, v[2]); v[3] = fmaf(xv, wv.w, v[3]);
                     }
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c] + s[c], 0.f);
+                    for (int t = 0; t < 3; ++t) {
+                        v[0] = fmaf(w[u][t], f[u][t].x, v[0]); v[1] = fmaf(w[u][t], f[u][t].y, v[1]);
+                        v[2] = fmaf(w[u][t], f[u][t].z, v[2]); v[3] = fmaf(w[u][t], f[u][t].w, v[3]);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+                } else {                 // interpolation_cuda_kernel.cu:194: (w0*p0 + w1*p1) + w2*p2
+                    v[0] = w[u][0] * f[u][0].x + w[u][1] * f[u][1].x + w[u][2] * f[u][2].x;
+                    v[1] = w[u][0] * f[u][0].y + w[u][1] * f[u][1].y + w[u][2] * f[u][2].y;
+                    v[2] = w[u][0] * f[u][0].z + w[u][1] * f[u][1].z + w[u][2] * f[u][2].z;
+                    v[3] = w[u][0] * f[u][0].w + w[u][1] * f[u][1].w + w[u][2] * f[u][2].w;
                 }
                 float *d = act + rr[u] * stride + pp[u] * 4;
                 d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];

@@ -129,3 +129,25 @@ def test_training_step_quadruplet_plus_patch_chamfer():
     moved = [k for k, v in m.named_parameters() if not torch.equal(v.detach(), before[k])]
     for part in ("backbone.SA_modules.0", "backbone.FP_modules.0", "aggregation.vlads.2", "aggregation.afa.fc", "decoder.fc3"):
         assert any(k.startswith(part) for k in moved), part
+
+
+@pytest.mark.parametrize("model_name", ["patch_aug_net", "pptnet"])
+def test_fused_engine_is_batch_size_invariant(model_name):
+    """evaluate.py:170 extracts with batch 100; BASELINE's bench uses 32.  Every submap is independent in eval mode, and the
+    engine's per-row / per-cloud arithmetic does not depend on how clouds are batched: descriptors must be bit-identical for
+    B = 1, 3, 32, 100 (heads with B > 64 take the chunked split-K path)."""
+    from patchaugnet_amd import pptnet
+    from patchaugnet_amd.weights import synthetic_submaps
+    if model_name == "patch_aug_net":
+        m = _pan(configs.patch_aug_net_config())
+    else:
+        m = pptnet.Network(param=configs.pptnet_config(), use_normalize=True)
+        m.load_state_dict(seeded_sd_from_table("pptnet"), strict=True)
+        m = m.cuda().eval()
+    x = torch.cat([synthetic_submaps(60, 4096, 11, "uniform"), synthetic_submaps(40, 4096, 12, "street")]).cuda()
+    with torch.no_grad():
+        full = m(x, return_feat=False)
+        assert full.shape == (100, 256) and torch.isfinite(full).all()
+        for lo, hi in ((0, 1), (5, 8), (20, 52), (60, 100)):
+            part = m(x[lo:hi].contiguous(), return_feat=False)
+            assert torch.equal(part, full[lo:hi]), (lo, hi, (part - full[lo:hi]).abs().max().item())
