@@ -10,7 +10,7 @@ import subprocess
 import torch
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "libpatchaugnet_hip.so")
+LIB_PATH = os.environ.get("PA_LIB_PATH", os.path.join(_CSRC, "libpatchaugnet_hip.so"))   # override: A/B of two builds in one session
 _lib = None
 
 _I, _F, _P = ctypes.c_int, ctypes.c_float, ctypes.c_void_p

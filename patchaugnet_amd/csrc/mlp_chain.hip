@@ -69,7 +69,8 @@ struct PaChain {
     int ldr;
     long long *dbg;          // profiling only: per-tile s_memtime stamps at phase boundaries (null in production)
     int xcd_remap;           // != 0: contiguous tile ranges per XCD (see chain_kernel)
-    int ep_stride;           // > 0: the last layer's tile is transposed through LDS (row stride ep_stride floats) and written as 16-byte row segments
+    int ep_stride;           // > 0: the last layer's tile is staged through LDS (row stride ep_stride floats) and leaves as whole rows
+    int vec_out;             // != 0: out (and residual) rows are 16-byte aligned -> 16-byte stores
 };
 
 namespace {
@@ -79,6 +80,12 @@ enum { MODE_PLAIN = 0, MODE_SA = 1, MODE_FP = 2, MODE_FPX = 3 };
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // One column chunk (NC tiles of 16 columns starting at tile c0) of one layer for the wave's RT row tiles.
+//
+// Operand roles: the WEIGHT fragment is passed as the MFMA's A operand and the activation fragment as its B operand, i.e. the
+// instruction computes the transposed tile D[i = channel][j = point].  The fragment values are exactly those of the natural
+// order (the A map (i = l%16, k = l/16) and the B map (k = l/16, j = l%16) coincide), but in the C/D layout a lane now holds FOUR
+// CONSECUTIVE CHANNELS of ONE point (channel 16ct + 4(l/16) + r, point 16rt + l%16): hidden activations go back to LDS and
+// results go to memory as 8/16-byte row segments instead of four scattered 4-byte words per accumulator.
 //
 // Operand ring: PD register sets; set u holds k-step ks+u and is refilled for k-step ks+u+PD right after its last use, so the
 // weight fragments get PD k-steps of latency cover with no register-to-register copies.  PD = 2 when a k-step is >= 32 MFMAs,
@@ -91,7 +98,14 @@ __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)
 //     wp[((cg * ksteps + ks) * 64 + l) * 4 + j] = Wt[4ks + l/16][64cg + 16j + l%16]
 // put a lane's four fragments of a 64-column group in one 16-byte word: 4 dwordx4 loads per k-step, each wave-load one
 // contiguous 1 KB segment (37 cycles per MFMA in the same loop).
-template <int RT, int NC, int PD>
+// activation fragment x weight fragment; SWAP: the weight fragment is the MFMA's A operand (transposed tile, see gemm_chunk)
+template <bool SWAP>
+__device__ __forceinline__ floatx4 mfma_ab(float act_frag, float w_frag, floatx4 acc)
+{
+    return SWAP ? __builtin_amdgcn_mfma_f32_16x16x4f32(w_frag, act_frag, acc, 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x4f32(act_frag, w_frag, acc, 0, 0, 0);
+}
+
+template <int RT, int NC, int PD, bool SWAP>
 __device__ __forceinline__ void gemm_chunk(const float *__restrict__ act, int stride, const PaLayer &L, int c0, int lane,
                                             floatx4 (&acc)[RT][NC])
 {
@@ -131,7 +145,7 @@ __device__ __forceinline__ void gemm_chunk(const float *__restrict__ act, int st
                     for (int c = 0; c < 4; ++c)
 #pragma unroll
                         for (int rt = 0; rt < RT; ++rt)
-                            acc[rt][4 * q + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[u][rt], bq[u][4 * q + c], acc[rt][4 * q + c], 0, 0, 0);
+                            acc[rt][4 * q + c] = mfma_ab<SWAP>(aq[u][rt], bq[u][4 * q + c], acc[rt][4 * q + c]);
                     const float4 v = wq[q * gstep + (size_t)nx * 64];
                     bq[u][4 * q] = v.x; bq[u][4 * q + 1] = v.y; bq[u][4 * q + 2] = v.z; bq[u][4 * q + 3] = v.w;
                     __builtin_amdgcn_sched_group_barrier(0x008, 4 * RT, 0);
@@ -164,7 +178,7 @@ __device__ __forceinline__ void gemm_chunk(const float *__restrict__ act, int st
                 for (int ct = 0; ct < NC; ++ct) {
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt)
-                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[u][rt], bq[u][ct], acc[rt][ct], 0, 0, 0);
+                        acc[rt][ct] = mfma_ab<SWAP>(aq[u][rt], bq[u][ct], acc[rt][ct]);
                     bq[u][ct] = wn[ct * 16];
                     __builtin_amdgcn_sched_group_barrier(0x008, RT, 0);
                     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
@@ -182,14 +196,17 @@ __device__ __forceinline__ void gemm_chunk(const float *__restrict__ act, int st
             for (int ct = 0; ct < NC; ++ct)
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[u][rt], bq[u][ct], acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = mfma_ab<SWAP>(aq[u][rt], bq[u][ct], acc[rt][ct]);
         }
     }
 }
 
+// ---- natural operand order (activation = A operand): a lane holds 4 ROWS x 1 column per accumulator.  Kept for the wave-private
+// plain-row kernels, where hipcc 7.2 turns the operand-swapped loop's loop-carried vmcnt(7) into vmcnt(0) (the weight prefetch then
+// no longer overlaps the MFMAs: 45 instead of 38 cycles per MFMA at fp0).
 // hidden layer: bias + ReLU, written back in place as the next layer's A tile
 template <int RT, int NC>
-__device__ __forceinline__ void store_hidden(float *act, int stride, const PaLayer &L, int c0, int lane, floatx4 (&acc)[RT][NC])
+__device__ __forceinline__ void store_hidden_nat(float *act, int stride, const PaLayer &L, int c0, int lane, floatx4 (&acc)[RT][NC])
 {
 #pragma unroll
     for (int ct = 0; ct < NC; ++ct) {
@@ -207,7 +224,7 @@ __device__ __forceinline__ void store_hidden(float *act, int stride, const PaLay
 
 // last layer, plain: bias + ReLU to global memory (row-major, ldo)
 template <int RT, int NC>
-__device__ __forceinline__ void store_rows(float *__restrict__ out, int ldo, long row0, long rows, const PaLayer &L, int c0, int lane,
+__device__ __forceinline__ void store_rows_nat(float *__restrict__ out, int ldo, long row0, long rows, const PaLayer &L, int c0, int lane,
                                             floatx4 (&acc)[RT][NC], int relu, const float *__restrict__ residual, int ldr)
 {
     const float floor_v = relu ? 0.f : -INFINITY;
@@ -233,7 +250,7 @@ __device__ __forceinline__ void store_rows(float *__restrict__ out, int ldo, lon
 // instructions per lane for a 32 x 256 tile -- store-issue bound).  Writing the tile to the (now dead) activation region
 // and reading it back row-major turns that into 16-byte stores of whole contiguous rows, 4x fewer and fully coalesced.
 template <int RT, int NC>
-__device__ __forceinline__ void stage_rows_lds(float *act, int ostride, const PaLayer &L, int c0, int lane, floatx4 (&acc)[RT][NC], int relu)
+__device__ __forceinline__ void stage_rows_lds_nat(float *act, int ostride, const PaLayer &L, int c0, int lane, floatx4 (&acc)[RT][NC], int relu)
 {
     const float floor_v = relu ? 0.f : -INFINITY;
 #pragma unroll
@@ -244,6 +261,79 @@ __device__ __forceinline__ void stage_rows_lds(float *act, int ostride, const Pa
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) act[(rt * 16 + (lane >> 4) * 4 + r) * ostride + col] = fmaxf(acc[rt][ct][r] + bias, floor_v);
+    }
+}
+
+// hidden layer: bias + ReLU, written back in place as the next layer's activation tile (row stride is even: 8-byte stores)
+template <int RT, int NC>
+__device__ __forceinline__ void store_hidden(float *act, int stride, const PaLayer &L, int c0, int lane, floatx4 (&acc)[RT][NC])
+{
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) {
+        const int col = (c0 + ct) * 16 + (lane >> 4) * 4;
+        const float4 bias = *reinterpret_cast<const float4 *>(L.bias + col);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+#ifdef PA_HIDDEN_SCALAR
+            float *d = act + (rt * 16 + (lane & 15)) * stride + col;
+            d[0] = fmaxf(acc[rt][ct][0] + bias.x, 0.f); d[1] = fmaxf(acc[rt][ct][1] + bias.y, 0.f);
+            d[2] = fmaxf(acc[rt][ct][2] + bias.z, 0.f); d[3] = fmaxf(acc[rt][ct][3] + bias.w, 0.f);
+#else
+            float2 *d = reinterpret_cast<float2 *>(act + (rt * 16 + (lane & 15)) * stride + col);
+            d[0] = make_float2(fmaxf(acc[rt][ct][0] + bias.x, 0.f), fmaxf(acc[rt][ct][1] + bias.y, 0.f));
+            d[1] = make_float2(fmaxf(acc[rt][ct][2] + bias.z, 0.f), fmaxf(acc[rt][ct][3] + bias.w, 0.f));
+#endif
+        }
+    }
+}
+
+// last layer, plain: out = residual + act(acc + bias), 16-byte row segments (VEC: out / residual rows are 16-byte aligned)
+template <int RT, int NC, bool VEC>
+__device__ __forceinline__ void store_rows(float *__restrict__ out, int ldo, long row0, long rows, const PaLayer &L, int c0, int lane,
+                                            floatx4 (&acc)[RT][NC], int relu, const float *__restrict__ residual, int ldr)
+{
+    const float floor_v = relu ? 0.f : -INFINITY;
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) {
+        const int col = (c0 + ct) * 16 + (lane >> 4) * 4;
+        const float4 bias = *reinterpret_cast<const float4 *>(L.bias + col);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const long row = row0 + rt * 16 + (lane & 15);
+            if (row >= rows) continue;
+            float4 v = make_float4(fmaxf(acc[rt][ct][0] + bias.x, floor_v), fmaxf(acc[rt][ct][1] + bias.y, floor_v),
+                                   fmaxf(acc[rt][ct][2] + bias.z, floor_v), fmaxf(acc[rt][ct][3] + bias.w, floor_v));
+            if (VEC) {
+                if (residual) {
+                    const float4 rr = *reinterpret_cast<const float4 *>(residual + row * ldr + col);
+                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                }
+                *reinterpret_cast<float4 *>(out + row * ldo + col) = v;
+            } else {
+                float *o = out + row * ldo + col;
+                const float *rr = residual ? residual + row * ldr + col : nullptr;
+                o[0] = v.x + (rr ? rr[0] : 0.f); o[1] = v.y + (rr ? rr[1] : 0.f); o[2] = v.z + (rr ? rr[2] : 0.f); o[3] = v.w + (rr ? rr[3] : 0.f);
+            }
+        }
+    }
+}
+
+// last layer, plain, staged through LDS: the tile goes to the (now dead) activation region with 8-byte stores and comes back
+// row-major, so that global memory sees whole contiguous rows (1 KB per wave-store at 256 columns) instead of 64-byte segments.
+template <int RT, int NC>
+__device__ __forceinline__ void stage_rows_lds(float *act, int ostride, const PaLayer &L, int c0, int lane, floatx4 (&acc)[RT][NC], int relu)
+{
+    const float floor_v = relu ? 0.f : -INFINITY;
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) {
+        const int col = (c0 + ct) * 16 + (lane >> 4) * 4;
+        const float4 bias = *reinterpret_cast<const float4 *>(L.bias + col);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            float2 *d = reinterpret_cast<float2 *>(act + (rt * 16 + (lane & 15)) * ostride + col);
+            d[0] = make_float2(fmaxf(acc[rt][ct][0] + bias.x, floor_v), fmaxf(acc[rt][ct][1] + bias.y, floor_v));
+            d[1] = make_float2(fmaxf(acc[rt][ct][2] + bias.z, floor_v), fmaxf(acc[rt][ct][3] + bias.w, floor_v));
+        }
     }
 }
 
@@ -265,8 +355,10 @@ __device__ __forceinline__ void copy_rows_out(const float *act, int ostride, int
     }
 }
 
-// last layer, pooled: max over the wave's neighbour slots, then bias + ReLU (both monotone, so the order is exact)
-template <int RT, int NC>
+// last layer, pooled: rows are neighbour-major (row = slot*4 + group), so a lane's point 16rt + l%16 belongs to group l%4: the max
+// over a group's neighbours is a max across row tiles (registers) and across the lanes l%16 = g, g+4, g+8, g+12 (two DPP row
+// rotations); then bias + ReLU (both monotone, so the order is exact) and one 16-byte store per group and channel quad.
+template <int RT, int NC, bool VEC>
 __device__ __forceinline__ void store_pooled(float *__restrict__ out, int ldo, long group0, long groups, const PaLayer &L, int c0, int lane,
                                               floatx4 (&acc)[RT][NC])
 {
@@ -279,15 +371,17 @@ __device__ __forceinline__ void store_pooled(float *__restrict__ out, int ldo, l
             for (int r = 0; r < 4; ++r) m[r] = fmaxf(m[r], acc[rt][ct][r]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            m[r] = fmaxf(m[r], __shfl_xor(m[r], 16));
-            m[r] = fmaxf(m[r], __shfl_xor(m[r], 32));
+            m[r] = fmaxf(m[r], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m[r]), 0x120 + 4, 0xf, 0xf, true)));   // row_ror:4
+            m[r] = fmaxf(m[r], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m[r]), 0x120 + 8, 0xf, 0xf, true)));   // row_ror:8
         }
-        if (lane < 16) {
-            const int col = (c0 + ct) * 16 + lane;
-            const float bias = L.bias[col];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (group0 + r < groups) out[(group0 + r) * ldo + col] = fmaxf(m[r] + bias, 0.f);
+        const int g = lane & 15;
+        if (g < 4 && group0 + g < groups) {
+            const int col = (c0 + ct) * 16 + (lane >> 4) * 4;
+            const float4 bias = *reinterpret_cast<const float4 *>(L.bias + col);
+            const float4 v = make_float4(fmaxf(m[0] + bias.x, 0.f), fmaxf(m[1] + bias.y, 0.f), fmaxf(m[2] + bias.z, 0.f), fmaxf(m[3] + bias.w, 0.f));
+            float *o = out + (group0 + g) * ldo + col;
+            if (VEC) *reinterpret_cast<float4 *>(o) = v;
+            else { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
         }
     }
 }
@@ -305,22 +399,28 @@ __device__ __forceinline__ void tile_sync()
 template <int RT, int NC, int MODE, bool POOLED, int WPT>
 __device__ __forceinline__ void run_layer_chunks(float *act, const PaChain &a, int l, long tile, int lane, int c_begin, int c_end)
 {
+    constexpr bool SWAP = POOLED || WPT > 1;   // see the note above store_hidden_nat
     const PaLayer &L = a.L[l];
     const bool last = (l == a.nlayers - 1);
     for (int c0 = c_begin; c0 < c_end; c0 += NC) {
         floatx4 acc[RT][NC];
-        gemm_chunk<RT, NC, (WPT == 1 ? 2 : (RT * NC >= 16 ? 4 : 8))>(act, a.lds_stride, L, c0, lane, acc);
+        gemm_chunk<RT, NC, (WPT == 1 ? 2 : (RT * NC >= 16 ? 4 : 8)), SWAP>(act, a.lds_stride, L, c0, lane, acc);
         if (!last) {
             tile_sync<WPT>();  // every A read of this layer has landed before its rows are overwritten (single chunk per wave: host-checked)
-            store_hidden<RT, NC>(act, a.lds_stride, L, c0, lane, acc);
+            if (SWAP) store_hidden<RT, NC>(act, a.lds_stride, L, c0, lane, acc);
+            else store_hidden_nat<RT, NC>(act, a.lds_stride, L, c0, lane, acc);
         } else if (POOLED) {
-            store_pooled<RT, NC>(a.out, a.ldo, tile * 4, a.rows, L, c0, lane, acc);
+            if (a.vec_out) store_pooled<RT, NC, true>(a.out, a.ldo, tile * 4, a.rows, L, c0, lane, acc);
+            else store_pooled<RT, NC, false>(a.out, a.ldo, tile * 4, a.rows, L, c0, lane, acc);
         } else if (a.ep_stride > 0) {   // host guarantees a single chunk per wave here
             tile_sync<WPT>();           // every A read of the last layer has landed: the activation tile is dead
-            stage_rows_lds<RT, NC>(act, a.ep_stride, L, c0, lane, acc, a.relu_last);
+            if (SWAP) stage_rows_lds<RT, NC>(act, a.ep_stride, L, c0, lane, acc, a.relu_last);
+            else stage_rows_lds_nat<RT, NC>(act, a.ep_stride, L, c0, lane, acc, a.relu_last);
         } else {
             const long total_rows = (MODE == MODE_SA) ? a.rows * a.ns : a.rows;
-            store_rows<RT, NC>(a.out, a.ldo, tile * (RT * 16), total_rows, L, c0, lane, acc, a.relu_last, a.residual, a.ldr);
+            if (!SWAP) store_rows_nat<RT, NC>(a.out, a.ldo, tile * (RT * 16), total_rows, L, c0, lane, acc, a.relu_last, a.residual, a.ldr);
+            else if (a.vec_out) store_rows<RT, NC, true>(a.out, a.ldo, tile * (RT * 16), total_rows, L, c0, lane, acc, a.relu_last, a.residual, a.ldr);
+            else store_rows<RT, NC, false>(a.out, a.ldo, tile * (RT * 16), total_rows, L, c0, lane, acc, a.relu_last, a.residual, a.ldr);
         }
     }
     if (!last) tile_sync<WPT>();
@@ -668,14 +768,14 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
         for (int l = 0; l + 1 < nlayers; ++l)  // hidden layers are written back in place => must be a single column chunk
             PA_REQUIRE(nout[l] / 16 <= ncmax && ((nout[l] / 16) & (nout[l] / 16 - 1)) == 0,
                        "pa_mlp_chain: hidden layer %d with n=%d must be 16*2^j <= %d (single column chunk, written back in place)", l, nout[l], ncmax * 16);
-    // LDS-transposed epilogue: needs the last layer to be one chunk per wave (so its A tile is dead when the results are staged),
-    // the staged tile to fit the activation region, and 16-byte aligned rows in the output / residual.
+    // LDS-staged epilogue: needs the last layer to be one chunk per wave (its A tile is dead when the results are staged), the staged
+    // tile to fit the activation region (or 40 KB), and 16-byte aligned rows in the output / residual.
     int ep_floats = 0;
     if (!is_pooled) {
         const int nl = nout[nlayers - 1];
         const int per = split ? nl / 64 : nl / 16;
         const int nc = (ncmax >= 16 && per % 16 == 0) ? 16 : (ncmax >= 8 && per % 8 == 0) ? 8 : (ncmax >= 4 && per % 4 == 0) ? 4 : (per % 2 == 0) ? 2 : 1;
-        const int ostride = nl + 4;
+        const int ostride = nl + 4;   // multiple of 4: the row-major read-back uses 16-byte LDS loads
         static const bool ep_off = getenv("PA_CHAIN_NO_LDS_EPILOGUE") != nullptr;
         if (!ep_off && nc == per && (ostride <= a.lds_stride || (size_t)R * ostride * 4 <= 40 * 1024) && ldo % 4 == 0 && ((uintptr_t)out & 15) == 0 &&
             (residual == nullptr || (ldr % 4 == 0 && ((uintptr_t)residual & 15) == 0))) {
@@ -683,6 +783,7 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
             ep_floats = R * ostride;
         }
     }
+    a.vec_out = (ldo % 4 == 0 && ((uintptr_t)out & 15) == 0 && (residual == nullptr || (ldr % 4 == 0 && ((uintptr_t)residual & 15) == 0))) ? 1 : 0;
     int scratch = 0;
     if (mode == MODE_PLAIN) {
         PA_REQUIRE(x && ldx >= k0, "pa_mlp_chain: plain mode needs x and ldx >= k0");
