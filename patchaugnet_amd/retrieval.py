@@ -152,3 +152,22 @@ def average(recall_dict, top_k=25):
         opr.append(res[2])
         lost.append(res[3])
     return recall / count, precision / count, float(np.mean(opr)), float(np.mean(lost)), int(np.sum(lost))
+
+
+def get_hard_negatives(query_latent_vector, ref_latent_vectors, negative_indices, num_hard_neg=10, knn=hip_knn):
+    """``SceneDataSet.__get_hard_negatives`` (datasets/scene_dataset.py:1101-1113): the num_hard_neg negatives nearest to the query
+    in descriptor space, nearest first; [] when there are fewer negatives than requested.  The reference builds a KD-tree over
+    the (up to 3000 sampled) negatives for every query; here it is one brute-force kNN launch.
+
+    query_latent_vector (D,), ref_latent_vectors (N, D) device tensors; negative_indices: list of row indices."""
+    if len(negative_indices) < num_hard_neg:
+        return []
+    neg = torch.as_tensor(negative_indices, device=ref_latent_vectors.device, dtype=torch.long)
+    found = knn(ref_latent_vectors.index_select(0, neg).contiguous(), query_latent_vector.reshape(1, -1).contiguous(), num_hard_neg)
+    return neg[found[0]].tolist()
+
+
+def get_hard_negatives_batch(query_vectors, ref_latent_vectors, negative_index_lists, num_hard_neg=10, knn=hip_knn):
+    """The mining refresh of training (train_place_recognition.py:403-406 -> scene_dataset.py:473-492) for a list of queries.
+    Candidate sets differ per query, so this is one small kNN launch per query (the descriptors stay on the device)."""
+    return [get_hard_negatives(q, ref_latent_vectors, negs, num_hard_neg, knn) for q, negs in zip(query_vectors, negative_index_lists)]
