@@ -26,58 +26,9 @@
 
 #include "pa_common.h"
 
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-
-struct PaLayer {
-    const float *wt;    // [kpad][n], K-major, rows >= k are zero
-    const float *wp;    // optional fragment-major packing of the same matrix (pa_pack_weights), n % 64 == 0; null = use wt
-    const float *bias;  // [n]
-    int kpad;           // multiple of 4
-    int n;              // multiple of 16
-};
-
-struct PaChain {
-    int nlayers;
-    PaLayer L[3];
-    long rows;        // plain / FP: number of rows; SA: number of groups (B*m)
-    int k0;           // true number of input channels
-    int lds_stride;   // floats per activation row in LDS (max kpad over layer inputs + 2)
-    int wave_floats;  // floats of LDS per wave (activation tile + prologue scratch)
-    // MODE 0: plain rows
-    const float *x;
-    int ldx;
-    // MODE 1: set-abstraction gather
-    const float *xyz;        // (B, n_src, 3)
-    const float *feat;       // (B, n_src, c_feat) point-major
-    const int *center_idx;   // (B, m_ctr)
-    const int *nbr_idx;      // (B, m_ctr, ns)
-    int n_src, m_ctr, ns, c_feat;
-    // MODE 2: feature-propagation interpolate + skip
-    const float *known;  // (B, m_known, c2) point-major
-    const int *idx3;     // (B, n_unknown, 3)
-    const float *w3;     // (B, n_unknown, 3)
-    const float *skip;   // (B, n_unknown, c1) point-major
-    int n_unknown, m_known, c2, c1;
-    // MODE 3: feature propagation with the first layer folded into the prologue (known = W1a-premultiplied features, see pa_fp_chain_premul)
-    const float *wskip;  // (c1, c2) K-major: the first layer's weights for the skip channels, BatchNorm folded
-    const float *bias0;  // (c2)
-    float *out;
-    int ldo;
-    // last-layer epilogue (plain rows only): out = residual + act(acc + bias), act = ReLU when relu_last != 0 else identity
-    int relu_last;
-    const float *residual;   // (rows, ldr) or null
-    int ldr;
-    long long *dbg;          // profiling only: per-tile s_memtime stamps at phase boundaries (null in production)
-    int xcd_remap;           // != 0: contiguous tile ranges per XCD (see chain_kernel)
-    int ep_stride;           // > 0: the last layer's tile is staged through LDS (row stride ep_stride floats) and leaves as whole rows
-    int vec_out;             // != 0: out (and residual) rows are 16-byte aligned -> 16-byte stores
-};
+#include "pa_chain.h"
 
 namespace {
-
-enum { MODE_PLAIN = 0, MODE_SA = 1, MODE_FP = 2, MODE_FPX = 3 };
-
-__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // One column chunk (NC tiles of 16 columns starting at tile c0) of one layer for the wave's RT row tiles.
 //
@@ -386,16 +337,6 @@ __device__ __forceinline__ void store_pooled(float *__restrict__ out, int ldo, l
     }
 }
 
-// WPT = waves per tile: 1 = the wave owns its rows end to end (no workgroup barrier anywhere);
-//                       4 = the workgroup's four waves share one tile and split every layer's COLUMNS, for
-//                           problems with too few row tiles to fill 1024 SIMDs (two barriers per hidden layer).
-template <int WPT>
-__device__ __forceinline__ void tile_sync()
-{
-    if (WPT == 1) lds_fence();
-    else __syncthreads();
-}
-
 template <int RT, int NC, int MODE, bool POOLED, int WPT>
 __device__ __forceinline__ void run_layer_chunks(float *act, const PaChain &a, int l, long tile, int lane, int c_begin, int c_end)
 {
@@ -435,7 +376,7 @@ __device__ __forceinline__ void run_layer_chunks(float *act, const PaChain &a, i
 // Pooled wave-private kernels (the set-abstraction levels) are gather-latency bound in their prologue: keep two waves per SIMD
 // (<= 256 registers) there; the plain row kernels trade occupancy for their 128 accumulator registers.
 template <int RT, int NCMAX, int MODE, bool POOLED, int WPT>
-__global__ __launch_bounds__(256, (POOLED && RT <= 5) ? 2 : 1) void chain_kernel(PaChain a)
+__global__ __launch_bounds__((!POOLED && WPT == 1 && RT == 1) ? 512 : 256, (POOLED && RT <= 5) ? 2 : 1) void chain_kernel(PaChain a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int R = RT * 16;
@@ -451,195 +392,12 @@ __global__ __launch_bounds__(256, (POOLED && RT <= 5) ? 2 : 1) void chain_kernel
     if (tile >= ntiles) return;  // WPT == 1: wave-uniform, and that variant has no workgroup barrier; WPT == 4: grid == ntiles
     float *act = smem + (WPT == 1 ? (size_t)wave * a.wave_floats : (size_t)0);
     const int tid = WPT == 1 ? lane : (int)threadIdx.x;  // prologue work is spread over the tile's owner(s)
-    constexpr int NTH = WPT * 64;
     const int stride = a.lds_stride;
     const int k0pad = a.L[0].kpad;
 #define PA_STAMP(i) do { if (a.dbg && tile < 512 && lane == 0 && (WPT == 1 || wave == 0)) a.dbg[tile * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
     PA_STAMP(0);
 
-    // ---------------------------------------------------------------- prologue: build the A tile of layer 0
-    if (MODE == MODE_PLAIN) {
-        const long row0 = tile * R;
-        for (int q = tid; q < R * k0pad; q += NTH) {
-            const int r = q / k0pad, ch = q - r * k0pad;
-            const long row = row0 + r;
-            act[r * stride + ch] = (row < a.rows && ch < a.k0) ? a.x[row * a.ldx + ch] : 0.f;
-        }
-    } else if (MODE == MODE_SA) {
-        int *src = reinterpret_cast<int *>(act + R * stride);  // [R] source point (global row), -1 = padding row
-        int *ctr = src + R;                                    // [R] centre point (global row)
-        for (int r = tid; r < R; r += NTH) {
-            long gid;
-            int s;
-            if (POOLED) { gid = tile * 4 + (r & 3); s = r >> 2; if (s >= a.ns) s = 0; }
-            else { const long grow = tile * R + r; gid = grow / a.ns; s = (int)(grow - gid * a.ns); }
-            if (gid < a.rows) {
-                const long b = gid / a.m_ctr;
-                src[r] = (int)(b * a.n_src + a.nbr_idx[gid * a.ns + s]);
-                ctr[r] = (int)(b * a.n_src + a.center_idx[gid]);
-            } else {
-                src[r] = -1;
-                ctr[r] = 0;
-            }
-        }
-        tile_sync<WPT>();
-        for (int q = tid; q < R * 3; q += NTH) {  // centred coordinates -> channels 0..2 (pointops.py:562)
-            const int r = q / 3, t = q - r * 3;
-            const int s = src[r];
-            act[r * stride + t] = s >= 0 ? a.xyz[(size_t)s * 3 + t] - a.xyz[(size_t)ctr[r] * 3 + t] : 0.f;
-        }
-        const int C = a.c_feat;
-        if ((C & 3) == 0) {  // centred features -> channels 3..3+C (pointops.py:567-568), 16-byte loads
-            const int qpr = C >> 2;
-            const float4 *f4 = reinterpret_cast<const float4 *>(a.feat);
-            for (int q = tid; q < R * qpr; q += NTH) {
-                const int r = q / qpr, part = q - r * qpr;
-                const int s = src[r];
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (s >= 0) {
-                    const float4 p = f4[(size_t)s * qpr + part], c = f4[(size_t)ctr[r] * qpr + part];
-                    v = make_float4(p.x - c.x, p.y - c.y, p.z - c.z, p.w - c.w);
-                }
-                float *d = act + r * stride + 3 + part * 4;
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-            }
-        } else {
-            for (int q = tid; q < R * C; q += NTH) {
-                const int r = q / C, ch = q - r * C;
-                const int s = src[r];
-                act[r * stride + 3 + ch] = s >= 0 ? a.feat[(size_t)s * C + ch] - a.feat[(size_t)ctr[r] * C + ch] : 0.f;
-            }
-        }
-        for (int q = tid; q < R * (k0pad - a.k0); q += NTH) {  // zero the K padding
-            const int r = q / (k0pad - a.k0), ch = q - r * (k0pad - a.k0);
-            act[r * stride + a.k0 + ch] = 0.f;
-        }
-    } else {  // MODE_FP / MODE_FPX
-        int *nb = reinterpret_cast<int *>(act + R * stride);  // [R][3] global rows of the three known neighbours
-        float *wt = reinterpret_cast<float *>(nb + 3 * R);    // [R][3] interpolation weights
-        float *sk = wt + 3 * R;                               // [R][4] skip channels (MODE_FPX)
-        const long row0 = tile * R;
-        for (int q = tid; q < R * 3; q += NTH) {
-            const int r = q / 3;
-            const long p = row0 + r;
-            if (p < a.rows) {
-                const long b = p / a.n_unknown;
-                nb[q] = (int)(b * a.m_known + a.idx3[p * 3 + (q - r * 3)]);
-                wt[q] = a.w3[p * 3 + (q - r * 3)];
-            } else {
-                nb[q] = 0;
-                wt[q] = 0.f;
-            }
-        }
-        const int C2 = a.c2, C1 = a.c1;
-        if (MODE == MODE_FPX)
-            for (int q = tid; q < R * 4; q += NTH) {
-                const int r = q >> 2, t = q & 3;
-                const long p = row0 + r;
-                sk[q] = (p < a.rows && t < C1) ? a.skip[p * C1 + t] : 0.f;
-            }
-        tile_sync<WPT>();
-        const int qpr = C2 >> 2;  // host guarantees c2 % 4 == 0
-        const float4 *k4 = reinterpret_cast<const float4 *>(a.known);
-        const int items = R * qpr;
-        if (MODE == MODE_FPX && WPT == 1 && C2 == 256) {
-            // Common shape (256-wide features, wave-private tile): lane l owns float4 column l of every row, so the bias and the
-            // skip weights are loop invariants, row / column indices need no division, and addresses are 32-bit.  This part is
-            // not bit-matched to anything (the first layer is already re-associated), so it uses explicit fmaf chains.
-            const float4 bz = *reinterpret_cast<const float4 *>(a.bias0 + lane * 4);
-            float4 wv[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                wv[t] = t < C1 ? *reinterpret_cast<const float4 *>(a.wskip + (size_t)t * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int r0 = 0; r0 < R; r0 += 4) {
-                float4 f[4][3];
-                float w[4][3];
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) {
-                        w[u][t] = wt[(r0 + u) * 3 + t];
-                        f[u][t] = k4[(unsigned)nb[(r0 + u) * 3 + t] * 64u + (unsigned)lane];
-                    }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float *s4 = sk + (r0 + u) * 4;
-                    const float sx = s4[0], sy = s4[1], sz = s4[2], sw = s4[3];
-                    // fixed fmaf order (bias, skip channels, then the three interpolation terms): the generic path below uses the same
-                    // chain, so the result does not depend on which tiling a batch size selects
-                    float v[4] = {bz.x, bz.y, bz.z, bz.w};
-                    const float sv[4] = {sx, sy, sz, sw};
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        v[0] = fmaf(sv[t], wv[t].x, v[0]); v[1] = fmaf(sv[t], wv[t].y, v[1]);
-                        v[2] = fmaf(sv[t], wv[t].z, v[2]); v[3] = fmaf(sv[t], wv[t].w, v[3]);
-                    }
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) {
-                        v[0] = fmaf(w[u][t], f[u][t].x, v[0]); v[1] = fmaf(w[u][t], f[u][t].y, v[1]);
-                        v[2] = fmaf(w[u][t], f[u][t].z, v[2]); v[3] = fmaf(w[u][t], f[u][t].w, v[3]);
-                    }
-                    float2 *d = reinterpret_cast<float2 *>(act + (r0 + u) * stride + lane * 4);   // stride is even: 8-byte aligned
-                    d[0] = make_float2(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
-                    d[1] = make_float2(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
-                }
-            }
-        } else
-        // four items per trip with all twelve 16-byte gathers issued before the first use: the known features of a whole batch
-        // (33 MB at fp0) live in the Infinity Cache, not in L2, and a wave-private tile has nobody else to hide that latency
-        for (int q0 = tid; q0 < items; q0 += NTH * 4) {
-            float4 f[4][3];
-            float w[4][3];
-            int rr[4], pp[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int q = min(q0 + u * NTH, items - 1);
-                rr[u] = q / qpr;
-                pp[u] = q - rr[u] * qpr;
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    w[u][t] = wt[rr[u] * 3 + t];
-                    f[u][t] = k4[(size_t)nb[rr[u] * 3 + t] * qpr + pp[u]];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (q0 + u * NTH >= items) break;
-                float v[4];
-                if (MODE == MODE_FPX) {  // bias + skip . Wskip + interpolation, ReLU: this IS the first layer's output (linearity of interpolation)
-                    const float4 bz = *reinterpret_cast<const float4 *>(a.bias0 + pp[u] * 4);
-                    v[0] = bz.x; v[1] = bz.y; v[2] = bz.z; v[3] = bz.w;
-                    for (int t = 0; t < C1; ++t) {
-                        const float4 wv = *reinterpret_cast<const float4 *>(a.wskip + (size_t)t * C2 + pp[u] * 4);
-                        const float xv = sk[rr[u] * 4 + t];
-                        v[0] = fmaf(xv, wv.x, v[0]); v[1] = fmaf(xv, wv.y, v[1]); v[2] = fmaf(xv, wv.z, v[2]); v[3] = fmaf(xv, wv.w, v[3]);
-                    }
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) {
-                        v[0] = fmaf(w[u][t], f[u][t].x, v[0]); v[1] = fmaf(w[u][t], f[u][t].y, v[1]);
-                        v[2] = fmaf(w[u][t], f[u][t].z, v[2]); v[3] = fmaf(w[u][t], f[u][t].w, v[3]);
-                    }
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
-                } else {                 // interpolation_cuda_kernel.cu:194: (w0*p0 + w1*p1) + w2*p2
-                    v[0] = w[u][0] * f[u][0].x + w[u][1] * f[u][1].x + w[u][2] * f[u][2].x;
-                    v[1] = w[u][0] * f[u][0].y + w[u][1] * f[u][1].y + w[u][2] * f[u][2].y;
-                    v[2] = w[u][0] * f[u][0].z + w[u][1] * f[u][1].z + w[u][2] * f[u][2].z;
-                    v[3] = w[u][0] * f[u][0].w + w[u][1] * f[u][1].w + w[u][2] * f[u][2].w;
-                }
-                float *d = act + rr[u] * stride + pp[u] * 4;
-                d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
-            }
-        }
-        if (MODE == MODE_FP) {
-            const int tail = k0pad - C2;  // skip channels (patch_aug_net.py:359: cat([interpolated, skip])) + zero padding
-            for (int q = tid; q < R * tail; q += NTH) {
-                const int r = q / tail, ch = q - r * tail;
-                const long p = row0 + r;
-                act[r * stride + C2 + ch] = (p < a.rows && ch < C1) ? a.skip[p * C1 + ch] : 0.f;
-            }
-        }
-    }
+    chain_prologue<float, R, MODE, POOLED, WPT>(act, act + R * stride, a, tile, tid, lane, stride, k0pad);
     tile_sync<WPT>();
     PA_STAMP(1);
 
@@ -685,7 +443,8 @@ int launch_chain(const PaChain &a, int waves_per_wg, long ntiles, hipStream_t st
 template <int MODE>
 void launch_rows(const PaChain &a, int rt, bool split, int wpw, long ntiles, hipStream_t st)
 {
-    if (!split) launch_chain<2, 16, MODE, false, 1>(a, wpw, ntiles, st);
+    if (!split && rt == 1) launch_chain<1, 16, MODE, false, 1>(a, wpw, ntiles, st);   // 16-row wave tiles, 8 waves per workgroup (2 per SIMD)
+    else if (!split) launch_chain<2, 16, MODE, false, 1>(a, wpw, ntiles, st);
     else if (rt == 8) launch_chain<8, 4, MODE, false, 4>(a, 4, ntiles, st);
     else if (rt == 2) launch_chain<2, 8, MODE, false, 4>(a, 4, ntiles, st);
     else launch_chain<1, 8, MODE, false, 4>(a, 4, ntiles, st);
@@ -758,6 +517,11 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
         bool all256 = true;
         for (int l = 0; l < nlayers; ++l) all256 = all256 && nout[l] == 256;
         if (!split && all256 && total_rows >= big_above && (size_t)128 * (maxk + 2) * 4 <= 150 * 1024) { split = true; RTv = 8; }
+        // Wave-private tiles of 16 rows with EIGHT waves per workgroup: two waves per SIMD fill each other's issue gaps (every
+        // non-MFMA instruction costs a lone wave ~6-7 matrix-pipe cycles) and one wave's gather prologue / store epilogue runs under
+        // the other's MFMA loop.  Needs 8 x 16 x (K+2) x 4 bytes of LDS.
+        static const long rt1_above = getenv("PA_CHAIN_RT1_ABOVE") ? atol(getenv("PA_CHAIN_RT1_ABOVE")) : (1L << 60);
+        if (!split && total_rows >= rt1_above && (size_t)8 * (16 * (maxk + 2) + 160) * 4 <= 156 * 1024) RTv = 1;
     } else {
         const long tp = (rows + 3) / 4;
         if (can_split && tp < 2048 && RTv == 5) split = true;
@@ -810,7 +574,7 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
     if (ep_floats > a.wave_floats) a.wave_floats = ep_floats;
     const size_t per_wave = (size_t)a.wave_floats * 4;
     PA_REQUIRE(per_wave <= 156 * 1024, "pa_mlp_chain: one tile needs %zu B of LDS (> 156 KiB); reduce K", per_wave);
-    int wpw = 4;
+    int wpw = (!is_pooled && !split && RTv == 1) ? 8 : 4;
     while (wpw > 1 && wpw * per_wave > 156 * 1024) wpw >>= 1;
     const long ntiles = is_pooled ? (rows + 3) / 4 : (total_rows + R - 1) / R;
 

@@ -1,0 +1,271 @@
+// Shared between the fp32 and fp16 shared-MLP chain kernels (mlp_chain.hip, mlp_chain_f16.hip): launch descriptor, tile
+// synchronisation and the gather / interpolate PROLOGUE that builds the first layer's activation tile in LDS.
+#pragma once
+#include "pa_common.h"
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+struct PaLayer {
+    const float *wt;    // [kpad][n], K-major, rows >= k are zero
+    const float *wp;    // optional fragment-major packing of the same matrix (pa_pack_weights), n % 64 == 0; null = use wt
+    const float *bias;  // [n]
+    int kpad;           // multiple of 4
+    int n;              // multiple of 16
+};
+
+struct PaChain {
+    int nlayers;
+    PaLayer L[3];
+    long rows;        // plain / FP: number of rows; SA: number of groups (B*m)
+    int k0;           // true number of input channels
+    int lds_stride;   // floats per activation row in LDS (max kpad over layer inputs + 2)
+    int wave_floats;  // floats of LDS per wave (activation tile + prologue scratch)
+    // MODE 0: plain rows
+    const float *x;
+    int ldx;
+    // MODE 1: set-abstraction gather
+    const float *xyz;        // (B, n_src, 3)
+    const float *feat;       // (B, n_src, c_feat) point-major
+    const int *center_idx;   // (B, m_ctr)
+    const int *nbr_idx;      // (B, m_ctr, ns)
+    int n_src, m_ctr, ns, c_feat;
+    // MODE 2: feature-propagation interpolate + skip
+    const float *known;  // (B, m_known, c2) point-major
+    const int *idx3;     // (B, n_unknown, 3)
+    const float *w3;     // (B, n_unknown, 3)
+    const float *skip;   // (B, n_unknown, c1) point-major
+    int n_unknown, m_known, c2, c1;
+    // MODE 3: feature propagation with the first layer folded into the prologue (known = W1a-premultiplied features, see pa_fp_chain_premul)
+    const float *wskip;  // (c1, c2) K-major: the first layer's weights for the skip channels, BatchNorm folded
+    const float *bias0;  // (c2)
+    float *out;
+    int ldo;
+    // last-layer epilogue (plain rows only): out = residual + act(acc + bias), act = ReLU when relu_last != 0 else identity
+    int relu_last;
+    const float *residual;   // (rows, ldr) or null
+    int ldr;
+    long long *dbg;          // profiling only: per-tile s_memtime stamps at phase boundaries (null in production)
+    int xcd_remap;           // != 0: contiguous tile ranges per XCD (see chain_kernel)
+    int ep_stride;           // > 0: the last layer's tile is staged through LDS (row stride ep_stride floats) and leaves as whole rows
+    int vec_out;             // != 0: out (and residual) rows are 16-byte aligned -> 16-byte stores
+};
+
+namespace {
+
+enum { MODE_PLAIN = 0, MODE_SA = 1, MODE_FP = 2, MODE_FPX = 3 };
+
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// WPT = waves per tile: 1 = the wave owns its rows end to end (no workgroup barrier anywhere);
+//                       4 = the workgroup's four waves share one tile and split every layer's COLUMNS, for
+//                           problems with too few row tiles to fill 1024 SIMDs (two barriers per hidden layer).
+template <int WPT>
+__device__ __forceinline__ void tile_sync()
+{
+    if (WPT == 1) lds_fence();
+    else __syncthreads();
+}
+
+// four consecutive activations to LDS (8-byte aligned destination)
+__device__ __forceinline__ void pa_store4(float *p, float a, float b, float c, float d)
+{
+    float2 *q = reinterpret_cast<float2 *>(p);
+    q[0] = make_float2(a, b);
+    q[1] = make_float2(c, d);
+}
+__device__ __forceinline__ void pa_store4(_Float16 *p, float a, float b, float c, float d)
+{
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+    half4 h = {(_Float16)a, (_Float16)b, (_Float16)c, (_Float16)d};
+    *reinterpret_cast<half4 *>(p) = h;
+}
+
+// Builds the R x k0pad activation tile of layer 0 (element type T, row stride `stride` elements) for tile `tile`.
+// scratch: per-tile LDS scratch (indices / weights) right behind the tile.  The caller synchronises (tile_sync) afterwards.
+template <typename T, int R, int MODE, bool POOLED, int WPT>
+__device__ __forceinline__ void chain_prologue(T *act, float *scratch, const PaChain &a, long tile, int tid, int lane, int stride, int k0pad)
+{
+    constexpr int NTH = WPT * 64;
+    // ---------------------------------------------------------------- prologue: build the A tile of layer 0
+    if (MODE == MODE_PLAIN) {
+        const long row0 = tile * R;
+        for (int q = tid; q < R * k0pad; q += NTH) {
+            const int r = q / k0pad, ch = q - r * k0pad;
+            const long row = row0 + r;
+            act[r * stride + ch] = (row < a.rows && ch < a.k0) ? a.x[row * a.ldx + ch] : 0.f;
+        }
+    } else if (MODE == MODE_SA) {
+        int *src = reinterpret_cast<int *>(scratch);  // [R] source point (global row), -1 = padding row
+        int *ctr = src + R;                                    // [R] centre point (global row)
+        for (int r = tid; r < R; r += NTH) {
+            long gid;
+            int s;
+            if (POOLED) { gid = tile * 4 + (r & 3); s = r >> 2; if (s >= a.ns) s = 0; }
+            else { const long grow = tile * R + r; gid = grow / a.ns; s = (int)(grow - gid * a.ns); }
+            if (gid < a.rows) {
+                const long b = gid / a.m_ctr;
+                src[r] = (int)(b * a.n_src + a.nbr_idx[gid * a.ns + s]);
+                ctr[r] = (int)(b * a.n_src + a.center_idx[gid]);
+            } else {
+                src[r] = -1;
+                ctr[r] = 0;
+            }
+        }
+        tile_sync<WPT>();
+        for (int q = tid; q < R * 3; q += NTH) {  // centred coordinates -> channels 0..2 (pointops.py:562)
+            const int r = q / 3, t = q - r * 3;
+            const int s = src[r];
+            act[r * stride + t] = s >= 0 ? a.xyz[(size_t)s * 3 + t] - a.xyz[(size_t)ctr[r] * 3 + t] : 0.f;
+        }
+        const int C = a.c_feat;
+        if ((C & 3) == 0) {  // centred features -> channels 3..3+C (pointops.py:567-568), 16-byte loads
+            const int qpr = C >> 2;
+            const float4 *f4 = reinterpret_cast<const float4 *>(a.feat);
+            for (int q = tid; q < R * qpr; q += NTH) {
+                const int r = q / qpr, part = q - r * qpr;
+                const int s = src[r];
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (s >= 0) {
+                    const float4 p = f4[(size_t)s * qpr + part], c = f4[(size_t)ctr[r] * qpr + part];
+                    v = make_float4(p.x - c.x, p.y - c.y, p.z - c.z, p.w - c.w);
+                }
+                T *d = act + r * stride + 3 + part * 4;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        } else {
+            for (int q = tid; q < R * C; q += NTH) {
+                const int r = q / C, ch = q - r * C;
+                const int s = src[r];
+                act[r * stride + 3 + ch] = s >= 0 ? a.feat[(size_t)s * C + ch] - a.feat[(size_t)ctr[r] * C + ch] : 0.f;
+            }
+        }
+        for (int q = tid; q < R * (k0pad - a.k0); q += NTH) {  // zero the K padding
+            const int r = q / (k0pad - a.k0), ch = q - r * (k0pad - a.k0);
+            act[r * stride + a.k0 + ch] = 0.f;
+        }
+    } else {  // MODE_FP / MODE_FPX
+        int *nb = reinterpret_cast<int *>(scratch);  // [R][3] global rows of the three known neighbours
+        float *wt = reinterpret_cast<float *>(nb + 3 * R);    // [R][3] interpolation weights
+        float *sk = wt + 3 * R;                               // [R][4] skip channels (MODE_FPX)
+        const long row0 = tile * R;
+        for (int q = tid; q < R * 3; q += NTH) {
+            const int r = q / 3;
+            const long p = row0 + r;
+            if (p < a.rows) {
+                const long b = p / a.n_unknown;
+                nb[q] = (int)(b * a.m_known + a.idx3[p * 3 + (q - r * 3)]);
+                wt[q] = a.w3[p * 3 + (q - r * 3)];
+            } else {
+                nb[q] = 0;
+                wt[q] = 0.f;
+            }
+        }
+        const int C2 = a.c2, C1 = a.c1;
+        if (MODE == MODE_FPX)
+            for (int q = tid; q < R * 4; q += NTH) {
+                const int r = q >> 2, t = q & 3;
+                const long p = row0 + r;
+                sk[q] = (p < a.rows && t < C1) ? a.skip[p * C1 + t] : 0.f;
+            }
+        tile_sync<WPT>();
+        const int qpr = C2 >> 2;  // host guarantees c2 % 4 == 0
+        const float4 *k4 = reinterpret_cast<const float4 *>(a.known);
+        const int items = R * qpr;
+        if (MODE == MODE_FPX && WPT == 1 && C2 == 256) {
+            // Common shape (256-wide features, wave-private tile): lane l owns float4 column l of every row, so the bias and the
+            // skip weights are loop invariants, row / column indices need no division, and addresses are 32-bit.  This part is
+            // not bit-matched to anything (the first layer is already re-associated), so it uses explicit fmaf chains.
+            const float4 bz = *reinterpret_cast<const float4 *>(a.bias0 + lane * 4);
+            float4 wv[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                wv[t] = t < C1 ? *reinterpret_cast<const float4 *>(a.wskip + (size_t)t * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int r0 = 0; r0 < R; r0 += 4) {
+                float4 f[4][3];
+                float w[4][3];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        w[u][t] = wt[(r0 + u) * 3 + t];
+                        f[u][t] = k4[(unsigned)nb[(r0 + u) * 3 + t] * 64u + (unsigned)lane];
+                    }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float *s4 = sk + (r0 + u) * 4;
+                    const float sx = s4[0], sy = s4[1], sz = s4[2], sw = s4[3];
+                    // fixed fmaf order (bias, skip channels, then the three interpolation terms): the generic path below uses the same
+                    // chain, so the result does not depend on which tiling a batch size selects
+                    float v[4] = {bz.x, bz.y, bz.z, bz.w};
+                    const float sv[4] = {sx, sy, sz, sw};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        v[0] = fmaf(sv[t], wv[t].x, v[0]); v[1] = fmaf(sv[t], wv[t].y, v[1]);
+                        v[2] = fmaf(sv[t], wv[t].z, v[2]); v[3] = fmaf(sv[t], wv[t].w, v[3]);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        v[0] = fmaf(w[u][t], f[u][t].x, v[0]); v[1] = fmaf(w[u][t], f[u][t].y, v[1]);
+                        v[2] = fmaf(w[u][t], f[u][t].z, v[2]); v[3] = fmaf(w[u][t], f[u][t].w, v[3]);
+                    }
+                    pa_store4(act + (r0 + u) * stride + lane * 4, fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+                }
+            }
+        } else
+        // four items per trip with all twelve 16-byte gathers issued before the first use: the known features of a whole batch
+        // (33 MB at fp0) live in the Infinity Cache, not in L2, and a wave-private tile has nobody else to hide that latency
+        for (int q0 = tid; q0 < items; q0 += NTH * 4) {
+            float4 f[4][3];
+            float w[4][3];
+            int rr[4], pp[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = min(q0 + u * NTH, items - 1);
+                rr[u] = q / qpr;
+                pp[u] = q - rr[u] * qpr;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    w[u][t] = wt[rr[u] * 3 + t];
+                    f[u][t] = k4[(size_t)nb[rr[u] * 3 + t] * qpr + pp[u]];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (q0 + u * NTH >= items) break;
+                float v[4];
+                if (MODE == MODE_FPX) {  // bias + skip . Wskip + interpolation, ReLU: this IS the first layer's output (linearity of interpolation)
+                    const float4 bz = *reinterpret_cast<const float4 *>(a.bias0 + pp[u] * 4);
+                    v[0] = bz.x; v[1] = bz.y; v[2] = bz.z; v[3] = bz.w;
+                    for (int t = 0; t < C1; ++t) {
+                        const float4 wv = *reinterpret_cast<const float4 *>(a.wskip + (size_t)t * C2 + pp[u] * 4);
+                        const float xv = sk[rr[u] * 4 + t];
+                        v[0] = fmaf(xv, wv.x, v[0]); v[1] = fmaf(xv, wv.y, v[1]); v[2] = fmaf(xv, wv.z, v[2]); v[3] = fmaf(xv, wv.w, v[3]);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        v[0] = fmaf(w[u][t], f[u][t].x, v[0]); v[1] = fmaf(w[u][t], f[u][t].y, v[1]);
+                        v[2] = fmaf(w[u][t], f[u][t].z, v[2]); v[3] = fmaf(w[u][t], f[u][t].w, v[3]);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+                } else {                 // interpolation_cuda_kernel.cu:194: (w0*p0 + w1*p1) + w2*p2
+                    v[0] = w[u][0] * f[u][0].x + w[u][1] * f[u][1].x + w[u][2] * f[u][2].x;
+                    v[1] = w[u][0] * f[u][0].y + w[u][1] * f[u][1].y + w[u][2] * f[u][2].y;
+                    v[2] = w[u][0] * f[u][0].z + w[u][1] * f[u][1].z + w[u][2] * f[u][2].z;
+                    v[3] = w[u][0] * f[u][0].w + w[u][1] * f[u][1].w + w[u][2] * f[u][2].w;
+                }
+                pa_store4(act + rr[u] * stride + pp[u] * 4, v[0], v[1], v[2], v[3]);
+            }
+        }
+        if (MODE == MODE_FP) {
+            const int tail = k0pad - C2;  // skip channels (patch_aug_net.py:359: cat([interpolated, skip])) + zero padding
+            for (int q = tid; q < R * tail; q += NTH) {
+                const int r = q / tail, ch = q - r * tail;
+                const long p = row0 + r;
+                act[r * stride + C2 + ch] = (p < a.rows && ch < C1) ? a.skip[p * C1 + ch] : 0.f;
+            }
+        }
+    }
+}
+
+}  // namespace
