@@ -34,6 +34,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-pass", action="store_true")
     p.add_argument("--cpu-batch", type=int, default=8)
+    p.add_argument("--model", choices=["patch_aug_net", "pptnet"], default="patch_aug_net", help="pptnet = BASELINE.json configs[4]")
+    p.add_argument("--mlp-dtype", choices=["f32", "f16"], default="f32",
+                   help="f16: shared-MLP chains on fp16 MFMA (fp32 accumulate; cosine >= 0.999 contract) -- not the headline configuration")
     p.add_argument("--streams", type=int, default=3, help="HIP streams the consecutive steps are issued on (1 = strictly sequential)")
     return p.parse_args()
 
@@ -184,10 +187,16 @@ def main():
     cfg = configs.patch_aug_net_config()
     if a.points != 4096:
         cfg = configs.scaled_config(cfg, a.points)
-    model = patch_aug_net.Network(param=cfg, use_a2a_recon=True, use_l2_norm=True)
+    if a.model == "pptnet":
+        from patchaugnet_amd import pptnet
+        cfg = configs.pptnet_config() if a.points == 4096 else configs.scaled_config(configs.pptnet_config(), a.points)
+        model = pptnet.Network(param=cfg, use_normalize=True)
+    else:
+        model = patch_aug_net.Network(param=cfg, use_a2a_recon=True, use_l2_norm=True)
     sd = seeded_state_dict(model.state_dict())
     model.load_state_dict(sd, strict=True)
     model = model.cuda().eval()
+    model.mlp_dtype = a.mlp_dtype
     if a.module_path:
         model.fused_eval = False
     x = synthetic_submaps(a.batch, a.points, seed=1234 + rank).cuda()
@@ -233,16 +242,23 @@ def main():
 
     submaps = world * a.steps * a.batch
     line = {
-        "metric": "4096-pt submaps/sec descriptor extraction (PatchAugNet, inputs resident in HBM)",
+        "metric": f"4096-pt submaps/sec descriptor extraction ({'PatchAugNet' if a.model == 'patch_aug_net' else 'PPT-Net'}, inputs resident in HBM)",
         "value": submaps / dt, "unit": "submaps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"PatchAugNet inference, {a.points}-pt synthetic submaps, batch={a.batch}, 1xMI355X per rank "
-                               "(BASELINE.json configs[1])", "batch_per_gpu": a.batch, "points": a.points,
+        "dtype": "f32" if a.mlp_dtype == "f32" else "f16 MFMA operands in the shared-MLP chains, fp32 accumulate / everything else fp32", "data": "synthetic",
+        "config": {"workload": (f"PatchAugNet inference, {a.points}-pt synthetic submaps, batch={a.batch}, 1xMI355X per rank (BASELINE.json configs[1])"
+                                if a.model == "patch_aug_net" else
+                                f"PPT-Net inference, {a.points}-pt synthetic submaps, batch={a.batch} per MI355X (BASELINE.json configs[4])"),
+                   "batch_per_gpu": a.batch, "points": a.points,
                    "path": "fused HIP engine" if model.fused_eval else "HIP point ops + torch dense ops (module path)",
                    "weights": "key-seeded random init", "parallelism": f"dp{world}", "streams": a.streams},
     }
-    if world == 1:
+    if world == 1 and (a.model != "patch_aug_net" or a.mlp_dtype != "f32"):   # non-headline configurations: stage times only
+        try:
+            line["kernels"] = {"stages_ms": stage_pass(model, x)}
+        except Exception as ex:
+            line["kernels"] = {"stages_ms": {"error": repr(ex)}}
+    elif world == 1:
         if not a.no_kernel_pass:
             g = grouping_roofline()
             line["kernels"] = {"grouping": g}

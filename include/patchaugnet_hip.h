@@ -148,6 +148,25 @@ int pa_fp_chain_premul(int nlayers, const float *const *wt, const float *const *
                        long rows, const float *g, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2,
                        int c1, const float *wskip, const float *bias0, float *out, int ldo, pa_stream_t stream);
 
+/* ---- fp16-operand variants of the chain kernels (opt-in; BASELINE.json configs[4] "fp16 MFMA MLP path") ---------------------
+ * Same fusion and fp32 inputs / outputs; inside the kernel activations are held as fp16 in LDS, weights are fp16 fragments
+ * (pa_pack_weights_f16: wp16[(((ct*ceil(kpad/32) + ks)*64 + l)*8 + e] = wt[(32ks + 8(l/16) + e)*n + 16ct + l%16], zero past kpad;
+ * pa_pack_weights_f16_halfs = number of fp16 elements) and every layer is v_mfma_f32_16x16x32_f16 with fp32 accumulation.
+ * Hidden widths must be multiples of 32.  Results agree with the fp32 path to fp16 rounding (cosine >= 0.999 on descriptors). */
+long pa_pack_weights_f16_halfs(int kpad, int n);
+int pa_pack_weights_f16(int kpad, int n, const float *wt, void *wp16, pa_stream_t stream);
+int pa_mlp_chain_f16(int mode, int pooled, int nlayers, const float *const *wt, const void *const *wp16, const float *const *bias,
+                     const int *kpad, const int *nout, long rows, int k0,
+                     const float *x, int ldx,
+                     const float *xyz, const float *feat, const int *center_idx, const int *nbr_idx, int n_src, int m_ctr, int ns, int c_feat,
+                     const float *known, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2, int c1,
+                     float *out, int ldo, pa_stream_t stream);
+int pa_linear_f16(long rows, int k, int n, const float *x, int ldx, const float *wt, const void *wp16, const float *bias, int relu,
+                  const float *residual, int ldr, float *out, int ldo, pa_stream_t stream);
+int pa_fp_chain_premul_f16(int nlayers, const float *const *wt, const void *const *wp16, const float *const *bias, const int *kpad,
+                           const int *nout, long rows, const float *g, const int *idx3, const float *w3, const float *skip, int n_unknown,
+                           int m_known, int c2, int c1, const float *wskip, const float *bias0, float *out, int ldo, pa_stream_t stream);
+
 /* One dense layer on point-major rows (the chain kernel's plain mode with a selectable epilogue):
  * out[r][:] = residual[r][:] + act(x[r][:k] . Wt + bias), act = ReLU if relu != 0 else identity; residual may be NULL.
  * wt K-major (kpad x n), kpad = k rounded up to 4 with zero rows, n % 16 == 0; wpk: optional packed copy (below) or NULL. */

@@ -43,6 +43,10 @@ _SIGS = {
     "pa_rowgroup_max": "liipp",
     "pa_linear": "liipipppipipi",
     "pa_pack_weights": "iipp",
+    "pa_pack_weights_f16": "iipp",
+    "pa_mlp_chain_f16": "iiippppplipippppiiiippppiiiipi",
+    "pa_linear_f16": "liipipppipipi",
+    "pa_fp_chain_premul_f16": "ippppplppppiiiipppi",
     "pa_fp_chain_premul": "ippppplppppiiiipppi",
     "pa_mlp_chain_packed": "iiippppplipippppiiiippppiiiipi",
     "pa_sa_attention": "iiipppp",
@@ -92,7 +96,7 @@ def lib():
         l = ctypes.CDLL(LIB_PATH)
         l.pa_last_error.restype = ctypes.c_char_p
         l.pa_abi_version.restype = _I
-        for name, nargs in (("pa_netvlad_scratch_floats", 3), ("pa_afa_scratch_floats", 4), ("pa_fc_scratch_floats", 3), ("pa_afa_rows_scratch_floats", 4)):
+        for name, nargs in (("pa_netvlad_scratch_floats", 3), ("pa_afa_scratch_floats", 4), ("pa_fc_scratch_floats", 3), ("pa_afa_rows_scratch_floats", 4), ("pa_pack_weights_f16_halfs", 2)):
             getattr(l, name).argtypes = [_I] * nargs
             getattr(l, name).restype = ctypes.c_long
         _declare(l, _SIGS)

@@ -238,37 +238,6 @@ __device__ __forceinline__ void store_hidden(float *act, int stride, const PaLay
     }
 }
 
-// last layer, plain: out = residual + act(acc + bias), 16-byte row segments (VEC: out / residual rows are 16-byte aligned)
-template <int RT, int NC, bool VEC>
-__device__ __forceinline__ void store_rows(float *__restrict__ out, int ldo, long row0, long rows, const PaLayer &L, int c0, int lane,
-                                            floatx4 (&acc)[RT][NC], int relu, const float *__restrict__ residual, int ldr)
-{
-    const float floor_v = relu ? 0.f : -INFINITY;
-#pragma unroll
-    for (int ct = 0; ct < NC; ++ct) {
-        const int col = (c0 + ct) * 16 + (lane >> 4) * 4;
-        const float4 bias = *reinterpret_cast<const float4 *>(L.bias + col);
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const long row = row0 + rt * 16 + (lane & 15);
-            if (row >= rows) continue;
-            float4 v = make_float4(fmaxf(acc[rt][ct][0] + bias.x, floor_v), fmaxf(acc[rt][ct][1] + bias.y, floor_v),
-                                   fmaxf(acc[rt][ct][2] + bias.z, floor_v), fmaxf(acc[rt][ct][3] + bias.w, floor_v));
-            if (VEC) {
-                if (residual) {
-                    const float4 rr = *reinterpret_cast<const float4 *>(residual + row * ldr + col);
-                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-                }
-                *reinterpret_cast<float4 *>(out + row * ldo + col) = v;
-            } else {
-                float *o = out + row * ldo + col;
-                const float *rr = residual ? residual + row * ldr + col : nullptr;
-                o[0] = v.x + (rr ? rr[0] : 0.f); o[1] = v.y + (rr ? rr[1] : 0.f); o[2] = v.z + (rr ? rr[2] : 0.f); o[3] = v.w + (rr ? rr[3] : 0.f);
-            }
-        }
-    }
-}
-
 // last layer, plain, staged through LDS: the tile goes to the (now dead) activation region with 8-byte stores and comes back
 // row-major, so that global memory sees whole contiguous rows (1 KB per wave-store at 256 columns) instead of 64-byte segments.
 template <int RT, int NC>
@@ -303,37 +272,6 @@ __device__ __forceinline__ void copy_rows_out(const float *act, int ostride, int
             v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
         }
         *reinterpret_cast<float4 *>(out + row * ldo + part * 4) = v;
-    }
-}
-
-// last layer, pooled: rows are neighbour-major (row = slot*4 + group), so a lane's point 16rt + l%16 belongs to group l%4: the max
-// over a group's neighbours is a max across row tiles (registers) and across the lanes l%16 = g, g+4, g+8, g+12 (two DPP row
-// rotations); then bias + ReLU (both monotone, so the order is exact) and one 16-byte store per group and channel quad.
-template <int RT, int NC, bool VEC>
-__device__ __forceinline__ void store_pooled(float *__restrict__ out, int ldo, long group0, long groups, const PaLayer &L, int c0, int lane,
-                                              floatx4 (&acc)[RT][NC])
-{
-#pragma unroll
-    for (int ct = 0; ct < NC; ++ct) {
-        floatx4 m = acc[0][ct];
-#pragma unroll
-        for (int rt = 1; rt < RT; ++rt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) m[r] = fmaxf(m[r], acc[rt][ct][r]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            m[r] = fmaxf(m[r], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m[r]), 0x120 + 4, 0xf, 0xf, true)));   // row_ror:4
-            m[r] = fmaxf(m[r], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m[r]), 0x120 + 8, 0xf, 0xf, true)));   // row_ror:8
-        }
-        const int g = lane & 15;
-        if (g < 4 && group0 + g < groups) {
-            const int col = (c0 + ct) * 16 + (lane >> 4) * 4;
-            const float4 bias = *reinterpret_cast<const float4 *>(L.bias + col);
-            const float4 v = make_float4(fmaxf(m[0] + bias.x, 0.f), fmaxf(m[1] + bias.y, 0.f), fmaxf(m[2] + bias.z, 0.f), fmaxf(m[3] + bias.w, 0.f));
-            float *o = out + (group0 + g) * ldo + col;
-            if (VEC) *reinterpret_cast<float4 *>(o) = v;
-            else { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
-        }
     }
 }
 
@@ -454,6 +392,8 @@ void launch_rows(const PaChain &a, int rt, bool split, int wpw, long ntiles, hip
 
 // Generic entry point.  mode: 0 plain rows, 1 set-abstraction gather, 2 feature-propagation interpolate.
 // wt[l] is K-major (kpad[l] x n[l]) with BN folded in and zero rows beyond the true K; bias[l] has n[l] entries.
+int pa_chain16_launch(PaChain &a, int mode, bool is_pooled, bool split, int RTv, int scratch_floats, hipStream_t st);   // mlp_chain_f16.hip
+
 static long long *g_chain_dbg = nullptr;
 // profiling hook (tools/chain_phases.py): device buffer of 512 x 8 int64 receiving s_memtime stamps of the next launches; NULL = off
 PA_API void pa_chain_debug_buffer(long long *buf) { g_chain_dbg = buf; }
@@ -464,7 +404,7 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
                           const float *xyz, const float *feat, const int *center_idx, const int *nbr_idx, int n_src, int m_ctr, int ns, int c_feat,
                           const float *known, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2, int c1,
                           float *out, int ldo, int relu_last, const float *residual, int ldr, pa_stream_t stream,
-                          const float *wskip = nullptr, const float *bias0 = nullptr)
+                          const float *wskip = nullptr, const float *bias0 = nullptr, const void *const *wp16 = nullptr)
 {
     PA_REQUIRE(nlayers >= 1 && nlayers <= 3, "pa_mlp_chain: nlayers=%d must be 1..3", nlayers);
     PA_REQUIRE(rows > 0 && k0 > 0 && out, "pa_mlp_chain: rows/k0 must be positive and out non-null");
@@ -479,6 +419,7 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
         a.L[l].wt = wt[l]; a.L[l].bias = bias[l]; a.L[l].kpad = kpad[l]; a.L[l].n = nout[l];
         static const bool no_packed = getenv("PA_CHAIN_NO_PACKED") != nullptr;   // A/B knob
         a.L[l].wp = (!no_packed && wpk && wpk[l] && nout[l] % 64 == 0) ? wpk[l] : nullptr;
+        a.L[l].wp16 = wp16 ? reinterpret_cast<const _Float16 *>(wp16[l]) : nullptr;
         if (kpad[l] > maxk) maxk = kpad[l];
         kin = nout[l];
     }
@@ -570,6 +511,10 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
     } else {
         PA_REQUIRE(false, "pa_mlp_chain: unknown mode %d", mode);
     }
+    if (wp16) {   // fp16-operand variant (mlp_chain_f16.hip): same tiling decisions, its own LDS geometry
+        PA_REQUIRE(is_pooled || (split ? RTv != 8 : RTv == 2), "pa_mlp_chain(fp16): tiling variant not built");
+        return pa_chain16_launch(a, mode, is_pooled, split, RTv, scratch, st);
+    }
     a.wave_floats = ((R * a.lds_stride + scratch + 3) / 4) * 4;
     if (ep_floats > a.wave_floats) a.wave_floats = ep_floats;
     const size_t per_wave = (size_t)a.wave_floats * 4;
@@ -641,6 +586,38 @@ PA_API int pa_fp_chain_premul(int nlayers, const float *const *wt, const float *
 {
     return chain_dispatch(MODE_FPX, 0, nlayers, wt, wpk, bias, kpad, nout, rows, c2, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0,
                           g, idx3, w3, skip, n_unknown, m_known, c2, c1, out, ldo, 1, nullptr, 0, stream, wskip, bias0);
+}
+
+// ---- fp16-operand variants (BASELINE configs[4], opt-in): same arguments, wp16[l] = pa_pack_weights_f16 of layer l -----------
+PA_API int pa_mlp_chain_f16(int mode, int pooled, int nlayers, const float *const *wt, const void *const *wp16, const float *const *bias,
+                            const int *kpad, const int *nout, long rows, int k0,
+                            const float *x, int ldx,
+                            const float *xyz, const float *feat, const int *center_idx, const int *nbr_idx, int n_src, int m_ctr, int ns, int c_feat,
+                            const float *known, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2, int c1,
+                            float *out, int ldo, pa_stream_t stream)
+{
+    PA_REQUIRE(wp16, "pa_mlp_chain_f16: null wp16");
+    return chain_dispatch(mode, pooled, nlayers, wt, nullptr, bias, kpad, nout, rows, k0, x, ldx, xyz, feat, center_idx, nbr_idx, n_src, m_ctr, ns, c_feat,
+                          known, idx3, w3, skip, n_unknown, m_known, c2, c1, out, ldo, 1, nullptr, 0, stream, nullptr, nullptr, wp16);
+}
+
+PA_API int pa_linear_f16(long rows, int k, int n, const float *x, int ldx, const float *wt, const void *wp16, const float *bias, int relu,
+                         const float *residual, int ldr, float *out, int ldo, pa_stream_t stream)
+{
+    PA_REQUIRE(wp16, "pa_linear_f16: null wp16");
+    PA_REQUIRE(residual == nullptr || ldr >= n, "pa_linear_f16: residual row stride %d < n=%d", ldr, n);
+    const int kpad = (k + 3) / 4 * 4;
+    return chain_dispatch(0, 0, 1, &wt, nullptr, &bias, &kpad, &n, rows, k, x, ldx, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0,
+                          nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, out, ldo, relu, residual, ldr, stream, nullptr, nullptr, &wp16);
+}
+
+PA_API int pa_fp_chain_premul_f16(int nlayers, const float *const *wt, const void *const *wp16, const float *const *bias, const int *kpad,
+                                  const int *nout, long rows, const float *g, const int *idx3, const float *w3, const float *skip, int n_unknown,
+                                  int m_known, int c2, int c1, const float *wskip, const float *bias0, float *out, int ldo, pa_stream_t stream)
+{
+    PA_REQUIRE(wp16, "pa_fp_chain_premul_f16: null wp16");
+    return chain_dispatch(MODE_FPX, 0, nlayers, wt, nullptr, bias, kpad, nout, rows, c2, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0,
+                          g, idx3, w3, skip, n_unknown, m_known, c2, c1, out, ldo, 1, nullptr, 0, stream, wskip, bias0, wp16);
 }
 
 namespace {

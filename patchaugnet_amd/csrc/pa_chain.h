@@ -8,6 +8,8 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 struct PaLayer {
     const float *wt;    // [kpad][n], K-major, rows >= k are zero
     const float *wp;    // optional fragment-major packing of the same matrix (pa_pack_weights), n % 64 == 0; null = use wt
+    const _Float16 *wp16;  // fp16 path: fragment-major fp16 packing (pa_pack_weights_f16), K padded to k32
+    int k32;               // fp16 path: K rounded up to 32
     const float *bias;  // [n]
     int kpad;           // multiple of 4
     int n;              // multiple of 16
@@ -264,6 +266,69 @@ __device__ __forceinline__ void chain_prologue(T *act, float *scratch, const PaC
                 const long p = row0 + r;
                 act[r * stride + C2 + ch] = (p < a.rows && ch < C1) ? a.skip[p * C1 + ch] : 0.f;
             }
+        }
+    }
+}
+
+// ---- epilogues of the operand-swapped layout (weights = MFMA A operand): a lane holds channels 16ct + 4(l/16) + r of point 16rt + l%16
+// last layer, plain: out = residual + act(acc + bias), 16-byte row segments (VEC: out / residual rows are 16-byte aligned)
+template <int RT, int NC, bool VEC>
+__device__ __forceinline__ void store_rows(float *__restrict__ out, int ldo, long row0, long rows, const PaLayer &L, int c0, int lane,
+                                            floatx4 (&acc)[RT][NC], int relu, const float *__restrict__ residual, int ldr)
+{
+    const float floor_v = relu ? 0.f : -INFINITY;
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) {
+        const int col = (c0 + ct) * 16 + (lane >> 4) * 4;
+        const float4 bias = *reinterpret_cast<const float4 *>(L.bias + col);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const long row = row0 + rt * 16 + (lane & 15);
+            if (row >= rows) continue;
+            float4 v = make_float4(fmaxf(acc[rt][ct][0] + bias.x, floor_v), fmaxf(acc[rt][ct][1] + bias.y, floor_v),
+                                   fmaxf(acc[rt][ct][2] + bias.z, floor_v), fmaxf(acc[rt][ct][3] + bias.w, floor_v));
+            if (VEC) {
+                if (residual) {
+                    const float4 rr = *reinterpret_cast<const float4 *>(residual + row * ldr + col);
+                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                }
+                *reinterpret_cast<float4 *>(out + row * ldo + col) = v;
+            } else {
+                float *o = out + row * ldo + col;
+                const float *rr = residual ? residual + row * ldr + col : nullptr;
+                o[0] = v.x + (rr ? rr[0] : 0.f); o[1] = v.y + (rr ? rr[1] : 0.f); o[2] = v.z + (rr ? rr[2] : 0.f); o[3] = v.w + (rr ? rr[3] : 0.f);
+            }
+        }
+    }
+}
+
+// last layer, pooled: rows are neighbour-major (row = slot*4 + group), so a lane's point 16rt + l%16 belongs to group l%4: the max
+// over a group's neighbours is a max across row tiles (registers) and across the lanes l%16 = g, g+4, g+8, g+12 (two DPP row
+// rotations); then bias + ReLU (both monotone, so the order is exact) and one 16-byte store per group and channel quad.
+template <int RT, int NC, bool VEC>
+__device__ __forceinline__ void store_pooled(float *__restrict__ out, int ldo, long group0, long groups, const PaLayer &L, int c0, int lane,
+                                              floatx4 (&acc)[RT][NC])
+{
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) {
+        floatx4 m = acc[0][ct];
+#pragma unroll
+        for (int rt = 1; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m[r] = fmaxf(m[r], acc[rt][ct][r]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            m[r] = fmaxf(m[r], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m[r]), 0x120 + 4, 0xf, 0xf, true)));   // row_ror:4
+            m[r] = fmaxf(m[r], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m[r]), 0x120 + 8, 0xf, 0xf, true)));   // row_ror:8
+        }
+        const int g = lane & 15;
+        if (g < 4 && group0 + g < groups) {
+            const int col = (c0 + ct) * 16 + (lane >> 4) * 4;
+            const float4 bias = *reinterpret_cast<const float4 *>(L.bias + col);
+            const float4 v = make_float4(fmaxf(m[0] + bias.x, 0.f), fmaxf(m[1] + bias.y, 0.f), fmaxf(m[2] + bias.z, 0.f), fmaxf(m[3] + bias.w, 0.f));
+            float *o = out + (group0 + g) * ldo + col;
+            if (VEC) *reinterpret_cast<float4 *>(o) = v;
+            else { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
         }
     }
 }

@@ -55,16 +55,32 @@ def pack_weights(wt):
     return wp
 
 
-class _Chain:
-    """Host-side descriptor of one pa_mlp_chain call (pointer arrays are built once)."""
+def pack_weights_f16(wt):
+    """K-major (kpad, n) fp32 device tensor -> fp16 fragment packing for the fp16 chain kernels (pa_pack_weights_f16)."""
+    kpad, n = wt.shape
+    wp = torch.empty(_lib.lib().pa_pack_weights_f16_halfs(kpad, n), dtype=torch.float16, device=wt.device)
+    call("pa_pack_weights_f16", kpad, n, ptr(wt), ptr(wp))
+    return wp
 
-    def __init__(self, layers):
+
+class _Chain:
+    """Host-side descriptor of one pa_mlp_chain call (pointer arrays are built once).  f16=True selects the fp16-operand
+    kernels (fp32 accumulation and outputs; BASELINE configs[4])."""
+
+    def __init__(self, layers, f16=False):
+        self.f16 = f16
         self.layers = layers
         n = len(layers)
         self.n = n
         self.wt = (ctypes.c_void_p * n)(*[l[0].data_ptr() for l in layers])
         self.packed = [pack_weights(l[0]) for l in layers]
         self.wpk = (ctypes.c_void_p * n)(*[(p.data_ptr() if p is not None else None) for p in self.packed])
+        if f16:
+            if any(l[4] % 32 for l in layers[:-1]):
+                raise ValueError("fp16 chain kernels need hidden widths that are multiples of 32")
+            self.packed16 = [pack_weights_f16(l[0]) for l in layers]
+            self.wpk = (ctypes.c_void_p * n)(*[p.data_ptr() for p in self.packed16])       # same argument slot, fp16 entry points
+        self._fn = "pa_mlp_chain_f16" if f16 else "pa_mlp_chain_packed"
         self.bias = (ctypes.c_void_p * n)(*[l[1].data_ptr() for l in layers])
         self.kpad = (ctypes.c_int * n)(*[l[3] for l in layers])
         self.nout = (ctypes.c_int * n)(*[l[4] for l in layers])
@@ -81,7 +97,7 @@ class _Chain:
         m, ns = nbr_idx.shape[1], nbr_idx.shape[2]
         groups = B * m
         out = torch.empty((groups if pooled else groups * ns, self.n_last), dtype=torch.float32, device=xyz.device)
-        call("pa_mlp_chain_packed", 1, 1 if pooled else 0, *self._common(), groups, self.k0, None, 0,
+        call(self._fn, 1, 1 if pooled else 0, *self._common(), groups, self.k0, None, 0,
              ptr(xyz), ptr(feat), ptr(center_idx), ptr(nbr_idx), n_src, m, ns, c_feat,
              None, None, None, None, 0, 0, 0, 0, ptr(out), self.n_last)
         return out
@@ -89,7 +105,7 @@ class _Chain:
     def fp(self, known_feat, idx3, w3, skip, B, n_unknown, m_known, c2, c1):
         rows = B * n_unknown
         out = torch.empty((rows, self.n_last), dtype=torch.float32, device=known_feat.device)
-        call("pa_mlp_chain_packed", 2, 0, *self._common(), rows, self.k0, None, 0,
+        call(self._fn, 2, 0, *self._common(), rows, self.k0, None, 0,
              None, None, None, None, 0, 0, 0, 0,
              ptr(known_feat), ptr(idx3), ptr(w3), ptr(skip), n_unknown, m_known, c2, c1, ptr(out), self.n_last)
         return out
@@ -104,30 +120,30 @@ class _Chain:
             rest = self.layers[1:]
             m = len(rest)
             self._premul = {
-                "w1a": w1a, "w1a_p": pack_weights(w1a), "zero": torch.zeros(n0, dtype=torch.float32, device=dev),
+                "w1a": w1a, "w1a_p": pack_weights_f16(w1a) if self.f16 else pack_weights(w1a), "zero": torch.zeros(n0, dtype=torch.float32, device=dev),
                 "wskip": wt0[c2:c2 + c1].contiguous(), "bias0": b0, "n0": n0, "m": m,
                 "wt": (ctypes.c_void_p * m)(*[l[0].data_ptr() for l in rest]),
-                "wpk": (ctypes.c_void_p * m)(*[(p.data_ptr() if p is not None else None) for p in self.packed[1:]]),
+                "wpk": (ctypes.c_void_p * m)(*[(p.data_ptr() if p is not None else None) for p in (self.packed16 if self.f16 else self.packed)[1:]]),
                 "bias": (ctypes.c_void_p * m)(*[l[1].data_ptr() for l in rest]),
                 "kpad": (ctypes.c_int * m)(*[l[3] for l in rest]), "nout": (ctypes.c_int * m)(*[l[4] for l in rest]),
             }
         pm = self._premul
         g = torch.empty((B * m_known, pm["n0"]), dtype=torch.float32, device=dev)
-        call("pa_linear", B * m_known, c2, pm["n0"], ptr(known_feat), c2, ptr(pm["w1a"]), ptr(pm["w1a_p"]), ptr(pm["zero"]), 0, None, 0,
-             ptr(g), pm["n0"])
+        call("pa_linear_f16" if self.f16 else "pa_linear", B * m_known, c2, pm["n0"], ptr(known_feat), c2, ptr(pm["w1a"]), ptr(pm["w1a_p"]),
+             ptr(pm["zero"]), 0, None, 0, ptr(g), pm["n0"])
         if mark is not None:
             mark()
         rows = B * n_unknown
         out = torch.empty((rows, self.n_last), dtype=torch.float32, device=dev)
         cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
-        call("pa_fp_chain_premul", pm["m"], cast(pm["wt"]), cast(pm["wpk"]), cast(pm["bias"]), cast(pm["kpad"]), cast(pm["nout"]), rows,
+        call("pa_fp_chain_premul_f16" if self.f16 else "pa_fp_chain_premul", pm["m"], cast(pm["wt"]), cast(pm["wpk"]), cast(pm["bias"]), cast(pm["kpad"]), cast(pm["nout"]), rows,
              ptr(g), ptr(idx3), ptr(w3), ptr(skip), n_unknown, m_known, pm["n0"], c1, ptr(pm["wskip"]), ptr(pm["bias0"]), ptr(out), self.n_last)
         return out
 
     def plain(self, x):
         rows, k = x.shape
         out = torch.empty((rows, self.n_last), dtype=torch.float32, device=x.device)
-        call("pa_mlp_chain_packed", 0, 0, *self._common(), rows, self.k0, ptr(x), k,
+        call(self._fn, 0, 0, *self._common(), rows, self.k0, ptr(x), k,
              None, None, None, None, 0, 0, 0, 0, None, None, None, None, 0, 0, 0, 0, ptr(out), self.n_last)
         return out
 
@@ -299,9 +315,15 @@ class PatchAugNetEngine:
         self.sampling, self.knn = list(cfg["SAMPLING"]), list(cfg["KNN"])
         self.use_origin = cfg.get("USE_ORIGIN_PC_IN_FP", True)
         bb = model.backbone
+        # "f32" (default): exact fp32 MFMA.  "f16": the shared-MLP chains run on fp16 MFMA with fp32 accumulation (model.mlp_dtype or
+        # PA_ENGINE_MLP_DTYPE); sampling, grouping indices, attention, NetVLAD and the heads stay fp32.
+        self.mlp_dtype = getattr(model, "mlp_dtype", None) or os.environ.get("PA_ENGINE_MLP_DTYPE", "f32")
+        if self.mlp_dtype not in ("f32", "f16"):
+            raise ValueError("mlp_dtype must be 'f32' or 'f16'")
+        f16 = self.mlp_dtype == "f16"
         with torch.no_grad():
-            self.sa = [_Chain(fold_shared_mlp(m.mlps[0], self.device)) for m in bb.SA_modules]
-            self.fp = [_Chain(fold_shared_mlp(m.mlp, self.device)) for m in bb.FP_modules]
+            self.sa = [_Chain(fold_shared_mlp(m.mlps[0], self.device), f16) for m in bb.SA_modules]
+            self.fp = [_Chain(fold_shared_mlp(m.mlp, self.device), f16) for m in bb.FP_modules]
             self.attn = [_Attn(m.sas[0], self.device) if hasattr(m, "sas") else None for m in bb.SA_modules]
         self.agg = model.aggregation
         agg = self.agg
@@ -332,7 +354,7 @@ class PatchAugNetEngine:
     @staticmethod
     def _params_key(model):
         p = next(model.parameters())
-        return (p.device, p.data_ptr(), p._version)
+        return (p.device, p.data_ptr(), p._version, getattr(model, "mlp_dtype", None))
 
     def matches(self, model, x):
         return x.device == self.device and self._key == self._params_key(model)

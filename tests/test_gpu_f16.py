@@ -1,0 +1,90 @@
+"""fp16-operand chain kernels (mlp_chain_f16.hip; BASELINE.json configs[4] "fp16 MFMA MLP path"): fp32 accumulation and outputs,
+fp16 weights / activations inside the kernel.  Tolerance per SURVEY.md section 8: cosine >= 0.999 on descriptors; indices exact."""
+import numpy as np
+import pytest
+import torch
+
+from patchaugnet_amd import configs
+from tests._util import golden, seeded_sd_from_table
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("rows,k,n,relu,res", [(1000, 64, 128, 0, False), (77, 259, 256, 1, True), (4096, 512, 1024, 0, False), (33, 20, 16, 1, False),
+                                               (131072, 256, 256, 1, False)])
+def test_pa_linear_f16(rows, k, n, relu, res):
+    from patchaugnet_amd._lib import call, ptr
+    from patchaugnet_amd.engine import pack_weights_f16
+    x = torch.randn(rows, k, device="cuda")
+    w = torch.randn(n, k, device="cuda") / k ** 0.5
+    bias = torch.randn(n, device="cuda")
+    r = torch.randn(rows, n, device="cuda") if res else None
+    kpad = (k + 3) // 4 * 4
+    wt = torch.zeros(kpad, n, device="cuda")
+    wt[:k] = w.t()
+    out = torch.empty(rows, n, device="cuda")
+    call("pa_linear_f16", rows, k, n, ptr(x), k, ptr(wt), ptr(pack_weights_f16(wt)), ptr(bias), relu, ptr(r), n if res else 0, ptr(out), n)
+    # reference with the same operand rounding: fp16(x) . fp16(w) accumulated exactly, fp32 bias
+    ref = x.half().double() @ w.half().double().t() + bias.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    if res:
+        ref = ref + r.double()
+    err = (out.double() - ref).abs().max().item()
+    assert err <= 1e-4 * max(ref.abs().max().item(), 1.0), err          # only the fp32 accumulation order differs
+    full = x.double() @ w.double().t() + bias.double()                   # and against unrounded operands: fp16 rounding level
+    if relu:
+        full = full.clamp_min(0)
+    if res:
+        full = full + r.double()
+    assert (out.double() - full).abs().max().item() <= 4e-3 * max(full.abs().max().item(), 1.0)
+
+
+def _cos(a, b):
+    return (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+
+
+@pytest.mark.parametrize("tag", ["small", "full"])
+def test_patch_aug_net_f16_mlp_path(tag):
+    from patchaugnet_amd import patch_aug_net
+    g = golden("patch_aug_net")
+    cfg = configs.patch_aug_net_config()
+    if tag == "small":
+        cfg = configs.scaled_config(cfg, 512)
+    m = patch_aug_net.Network(param=cfg, use_a2a_recon=True, use_l2_norm=True)
+    m.load_state_dict(seeded_sd_from_table("patch_aug_net"), strict=True)
+    m = m.cuda().eval()
+    m.mlp_dtype = "f16"
+    x = torch.from_numpy(g[f"{tag}_x"]).cuda()
+    with torch.no_grad():
+        desc, fp, cidx = m(x)
+        assert m._engine.mlp_dtype == "f16"
+        m.mlp_dtype = "f32"
+        d32, _, _ = m(x)                                       # the engine is rebuilt for the other dtype
+        assert m._engine.mlp_dtype == "f32"
+    for i in range(3):
+        assert np.array_equal(cidx[i].cpu().numpy(), g[f"{tag}_center_idx{i}"])      # sampling is untouched by the MLP dtype
+    d = desc.cpu().numpy()
+    assert np.isfinite(d).all()
+    assert _cos(d, g[f"{tag}_desc"]).min() >= 0.999
+    assert np.abs(d - g[f"{tag}_desc"]).max() <= 5e-3
+    assert np.abs(d32.cpu().numpy() - g[f"{tag}_desc"]).max() <= 1e-4
+
+
+@pytest.mark.parametrize("tag", ["small", "full"])
+def test_pptnet_f16_mlp_path(tag):
+    """BASELINE.json configs[4]: PPT-Net with the fp16 MFMA MLP path."""
+    from patchaugnet_amd import pptnet
+    g = golden("pptnet")
+    cfg = configs.pptnet_config()
+    if tag == "small":
+        cfg = configs.scaled_config(cfg, 1024)
+    m = pptnet.Network(param=cfg, use_normalize=True)
+    m.load_state_dict(seeded_sd_from_table("pptnet"), strict=True)
+    m = m.cuda().eval()
+    m.mlp_dtype = "f16"
+    with torch.no_grad():
+        d, fp, cidx = m(torch.from_numpy(g[f"{tag}_x"]).cuda())
+    for i in range(4):
+        assert np.array_equal(cidx[i].cpu().numpy(), g[f"{tag}_center_idx{i}"])
+    assert _cos(d.cpu().numpy(), g[f"{tag}_desc_l2"]).min() >= 0.999
