@@ -519,7 +519,10 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
     if (ep_floats > a.wave_floats) a.wave_floats = ep_floats;
     const size_t per_wave = (size_t)a.wave_floats * 4;
     PA_REQUIRE(per_wave <= 156 * 1024, "pa_mlp_chain: one tile needs %zu B of LDS (> 156 KiB); reduce K", per_wave);
-    int wpw = (!is_pooled && !split && RTv == 1) ? 8 : 4;
+    // waves per workgroup of the wave-private tilings.  Smaller workgroups leave LDS granules in which OTHER kernels' workgroups
+    // (kNN: 70 KB, 3-NN, FPS) can become resident next to a chain workgroup when several streams are in flight.
+    static const int wpw_env = getenv("PA_CHAIN_WPW") ? atoi(getenv("PA_CHAIN_WPW")) : 0;
+    int wpw = (!is_pooled && !split && RTv == 1) ? 8 : (wpw_env > 0 ? wpw_env : 4);
     while (wpw > 1 && wpw * per_wave > 156 * 1024) wpw >>= 1;
     const long ntiles = is_pooled ? (rows + 3) / 4 : (total_rows + R - 1) / R;
 
