@@ -18,6 +18,31 @@ for S in default 1; do
 done
 head -8 gpurun_out/${TAG}_kernel_stats_streams_1.csv | cut -c1-160
 cd /tmp
+# MFMA utilisation of the MFMA-bound kernels: SQ_VALU_MFMA_BUSY_CYCLES (sum over SIMDs) / (kernel cycles x 1024 SIMDs), kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs
+rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmc_mfma
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES -d $GRAFT_REPO_ROOT/gpurun_out/pmc_mfma -o pmc -- python $GRAFT_REPO_ROOT/tools/pmc_target.py > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_mfma.log 2>&1
+python $GRAFT_REPO_ROOT/tools/pmc_summary.py $(ls $GRAFT_REPO_ROOT/gpurun_out/pmc_mfma/*results.db | head -1) > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_mfma.txt 2>&1
+rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmc_mfma
+python - <<'PY'
+import os, re, collections
+root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+tag = [f for f in os.listdir(root + "/gpurun_out") if f.endswith("_pmc_mfma.txt")][-1]
+vals = collections.defaultdict(dict)
+for line in open(root + "/gpurun_out/" + tag):
+    m = re.match(r"(.*?)\s+(SQ_\w+|GRBM_\w+)\s+n=\s*\d+ avg=([0-9.]+)", line)
+    if m:
+        vals[m.group(1).strip()][m.group(2)] = float(m.group(3))
+out = []
+for k, v in vals.items():
+    if v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) > 0 and v.get("GRBM_GUI_ACTIVE", 0) > 0:
+        util = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] / 8 * 1024)
+        out.append((util, k))
+with open(root + "/gpurun_out/" + tag.replace("_pmc_mfma.txt", "_mfma_util.txt"), "w") as f:
+    f.write("MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), averages per kernel over tools/pmc_target.py\n")
+    for util, k in sorted(out, reverse=True):
+        f.write(f"{util:6.1%}  {k[:150]}\n")
+        print(f"{util:6.1%}  {k[:110]}")
+PY
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmc_$C
   timeout 300 rocprofv3 --kernel-trace --pmc $C -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$C -o pmc -- python $GRAFT_REPO_ROOT/tools/pmc_target.py > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_$C.log 2>&1
