@@ -13,6 +13,7 @@
 #include <stdlib.h>
 
 #include "pa_common.h"
+#include "pa_cellsort.h"
 
 namespace {
 
@@ -98,34 +99,6 @@ __global__ __launch_bounds__(256) void knn_wave_kernel(int n, int m, int k, int 
 // distance, so equal-distance candidates with a lower index are still seen.  The order inside a cell depends on LDS atomics
 // and varies between runs; the selected (distance, index) keys do not.  Points with non-finite coordinates can never be
 // selected (their distance is never < a finite or infinite best) and are left out of the chunks.
-constexpr int KG_CELLS = 512;
-
-__device__ __forceinline__ u32 kg_spread3(u32 v)  // 3 bits -> every third bit
-{
-    return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4);
-}
-
-__device__ __forceinline__ u64 kg_shfl_xor_u64(u64 v, int m)
-{
-    const u32 lo = (u32)__shfl_xor((int)(u32)v, m), hi = (u32)__shfl_xor((int)(u32)(v >> 32), m);
-    return ((u64)hi << 32) | lo;
-}
-
-__device__ __forceinline__ u64 kg_wave_min_u64(u64 v) { return ~pa_wave_max_u64(~v); }
-
-__device__ __forceinline__ float kg_wave_min_f(float v)
-{
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) v = fminf(v, __shfl_xor(v, s));
-    return v;
-}
-__device__ __forceinline__ float kg_wave_max_f(float v)
-{
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) v = fmaxf(v, __shfl_xor(v, s));
-    return v;
-}
-
 // ascending bitonic sort of one u64 key per lane across the wavefront
 __device__ __forceinline__ u64 kg_sort64(u64 key, int lane)
 {
@@ -156,122 +129,8 @@ __global__ __launch_bounds__(NT, NT / 128) void knn_grid_kernel(int n, int m, in
     constexpr int NW = NT / 64;
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *xyz = xyz_all + (size_t)b * n * 3;
-
-    // ---- 1. cloud bounding box over the finite points
-    float px[PTS], py[PTS], pz[PTS];
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-    for (int u = 0; u < PTS; ++u) {
-        const int i = tid + u * NT;
-        if (i < n) {
-            px[u] = xyz[i * 3 + 0]; py[u] = xyz[i * 3 + 1]; pz[u] = xyz[i * 3 + 2];
-            if (isfinite(px[u]) && isfinite(py[u]) && isfinite(pz[u])) {
-                lo[0] = fminf(lo[0], px[u]); hi[0] = fmaxf(hi[0], px[u]);
-                lo[1] = fminf(lo[1], py[u]); hi[1] = fmaxf(hi[1], py[u]);
-                lo[2] = fminf(lo[2], pz[u]); hi[2] = fmaxf(hi[2], pz[u]);
-            }
-        }
-    }
-    for (int c = tid; c <= KG_CELLS; c += NT) cnt[c] = 0;
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        lo[t] = kg_wave_min_f(lo[t]);
-        hi[t] = kg_wave_max_f(hi[t]);
-        if (lane == 0) { red[wave * 6 + t] = lo[t]; red[wave * 6 + 3 + t] = hi[t]; }
-    }
-    __syncthreads();
-    float scale[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        lo[t] = red[t];
-        hi[t] = red[3 + t];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) { lo[t] = fminf(lo[t], red[w * 6 + t]); hi[t] = fmaxf(hi[t], red[w * 6 + 3 + t]); }
-        const float ext = hi[t] - lo[t];
-        scale[t] = (ext > 0.f && isfinite(ext)) ? 8.0f / ext : 0.f;
-    }
-    // ---- 2. Morton cell of every point, histogram
-    int cell[PTS];
-#pragma unroll
-    for (int u = 0; u < PTS; ++u) {
-        const int i = tid + u * NT;
-        cell[u] = -1;
-        if (i < n) {
-            cell[u] = KG_CELLS;                                                  // non-finite points: last bin, never a candidate
-            if (isfinite(px[u]) && isfinite(py[u]) && isfinite(pz[u])) {
-                const u32 cx = (u32)min(max((int)((px[u] - lo[0]) * scale[0]), 0), 7);
-                const u32 cy = (u32)min(max((int)((py[u] - lo[1]) * scale[1]), 0), 7);
-                const u32 cz = (u32)min(max((int)((pz[u] - lo[2]) * scale[2]), 0), 7);
-                cell[u] = (int)(kg_spread3(cx) | (kg_spread3(cy) << 1) | (kg_spread3(cz) << 2));
-            }
-            atomicAdd(&cnt[cell[u]], 1);
-        }
-    }
-    __syncthreads();
-    // ---- 3. exclusive scan of the 513 bins (wave 0, 9 bins per lane), scatter
-    if (wave == 0) {
-        int v[9], sum = 0;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int c = lane * 9 + t;
-            v[t] = c <= KG_CELLS ? cnt[c] : 0;
-            sum += v[t];
-        }
-        int incl = sum;
-#pragma unroll
-        for (int s = 1; s < 64; s <<= 1) {
-            const int o = __shfl_up(incl, s);
-            if (lane >= s) incl += o;
-        }
-        int run = incl - sum;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int c = lane * 9 + t;
-            if (c <= KG_CELLS) cnt[c] = run;
-            run += v[t];
-        }
-    }
-    __syncthreads();
-    const int n_valid = cnt[KG_CELLS];                                           // start of the non-finite bin == number of finite points
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < PTS; ++u) {
-        const int i = tid + u * NT;
-        if (i < n && cell[u] < KG_CELLS) {
-            const int pos = atomicAdd(&cnt[cell[u]], 1);
-            sorted[pos] = make_float4(px[u], py[u], pz[u], __int_as_float(i));
-        }
-    }
-    __syncthreads();
-    // ---- 4. chunk bounding boxes: four threads per chunk, 16 points each, combined inside the quad
-    const int nchunks = (n_valid + 63) >> 6;
-    {
-        const int c = tid >> 2, part = tid & 3;
-        float bl[3] = {INFINITY, INFINITY, INFINITY}, bh[3] = {-INFINITY, -INFINITY, -INFINITY};
-        if (c < nchunks) {
-#pragma unroll 4
-            for (int j = 0; j < 16; ++j) {
-                const int i = c * 64 + part * 16 + j;
-                if (i < n_valid) {
-                    const float4 p = sorted[i];
-                    bl[0] = fminf(bl[0], p.x); bh[0] = fmaxf(bh[0], p.x);
-                    bl[1] = fminf(bl[1], p.y); bh[1] = fmaxf(bh[1], p.y);
-                    bl[2] = fminf(bl[2], p.z); bh[2] = fmaxf(bh[2], p.z);
-                }
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            bl[t] = fminf(bl[t], __shfl_xor(bl[t], 1)); bh[t] = fmaxf(bh[t], __shfl_xor(bh[t], 1));
-            bl[t] = fminf(bl[t], __shfl_xor(bl[t], 2)); bh[t] = fmaxf(bh[t], __shfl_xor(bh[t], 2));
-        }
-        if (c < nchunks && part == 0) {
-            float *bx = box + c * 8;
-            bx[0] = bl[0]; bx[1] = bl[1]; bx[2] = bl[2]; bx[3] = bh[0]; bx[4] = bh[1]; bx[5] = bh[2];
-        }
-    }
-    __syncthreads();
-
+    int nchunks;
+    const int n_valid = cell_sort_cloud<PTS, NT>(n, xyz, sorted, box, cnt, red, &nchunks);
     const long long t_pro = DBG ? (long long)__builtin_readcyclecounter() : 0;
     // ---- 5. queries
     const int q_begin = blockIdx.x * q_per_block;
@@ -382,8 +241,7 @@ __global__ __launch_bounds__(256) void knn_select_kernel(int n, int m, int k, co
 static long long *g_knn_dbg = nullptr;
 PA_API void pa_knn_debug_buffer(long long *buf) { g_knn_dbg = buf; }   // profiling hook (6 int64), NULL = off
 
-PA_API int pa_knnquery(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx, float *dist2,
-                       pa_stream_t stream)
+PA_API int pa_knnquery(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx, float *dist2, pa_stream_t stream)
 {
     PA_REQUIRE(b > 0 && n > 0 && m > 0 && nsample > 0, "pa_knnquery: b=%d n=%d m=%d nsample=%d must be positive", b, n, m, nsample);
     PA_REQUIRE(xyz && new_xyz && idx && dist2, "pa_knnquery: null pointer");
