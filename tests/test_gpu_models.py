@@ -151,3 +151,23 @@ def test_fused_engine_is_batch_size_invariant(model_name):
         for lo, hi in ((0, 1), (5, 8), (20, 52), (60, 100)):
             part = m(x[lo:hi].contiguous(), return_feat=False)
             assert torch.equal(part, full[lo:hi]), (lo, hi, (part - full[lo:hi]).abs().max().item())
+
+
+@pytest.mark.parametrize("npts,sampling", [(2048, [512, 64, 16]), (8192, [2048, 256, 32]), (3000, [700, 100, 20])])
+def test_fused_engine_matches_module_path_at_other_cloud_sizes(npts, sampling):
+    """The engine is not specialised to 4096 points: other sizes (the pruned kNN's lower bound 2048, clouds above its 4096 limit,
+    a size that is no multiple of anything) give the module path's descriptors and bit-identical centre indices."""
+    from patchaugnet_amd.weights import synthetic_submaps
+    cfg = configs.patch_aug_net_config()
+    cfg["NUM_POINTS"], cfg["SAMPLING"], cfg["MAX_SAMPLES"] = npts, sampling, [sampling[1], sampling[0], npts]
+    m = _pan(cfg)
+    x = torch.cat([synthetic_submaps(2, npts, 41, "uniform"), synthetic_submaps(1, npts, 42, "street")]).cuda()
+    with torch.no_grad():
+        torch.manual_seed(3)
+        d_mod, fp_mod, c_mod = m(x, use_engine=False)
+        d_eng, fp_eng, c_eng = m(x, use_engine=True)
+    for a, b in zip(c_eng, c_mod):
+        assert torch.equal(a, b)
+    _check_desc(d_eng, d_mod.cpu().numpy())
+    for a, b in zip(fp_eng, fp_mod):
+        assert (a - b).abs().max().item() <= 2e-4 * max(b.abs().max().item(), 1.0)
