@@ -146,7 +146,9 @@ int pa_mlp_chain(int mode, int pooled, int nlayers, const float *const *wt, cons
  * pa_mlp_chain up to fp32 summation order; (n_unknown/m_known) x fewer first-layer FLOPs. */
 int pa_fp_chain_premul(int nlayers, const float *const *wt, const float *const *wpk, const float *const *bias, const int *kpad, const int *nout,
                        long rows, const float *g, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2,
-                       int c1, const float *wskip, const float *bias0, float *out, int ldo, pa_stream_t stream);
+                       int c1, const float *wskip, const float *wskip_p, const float *bias0, float *out, int ldo, pa_stream_t stream);
+/*   c1 > 4 (coarser levels, skip = encoder features, c1 % 4 == 0, nlayers <= 2): the first layer stays in the chain as a c1-wide
+ *   contraction over the skip channels (wskip, optional packed copy wskip_p) whose output gets the interpolated term added. */
 
 /* ---- fp16-operand variants of the chain kernels (opt-in; BASELINE.json configs[4] "fp16 MFMA MLP path") ---------------------
  * Same fusion and fp32 inputs / outputs; inside the kernel activations are held as fp16 in LDS, weights are fp16 fragments
@@ -165,7 +167,8 @@ int pa_linear_f16(long rows, int k, int n, const float *x, int ldx, const float 
                   const float *residual, int ldr, float *out, int ldo, pa_stream_t stream);
 int pa_fp_chain_premul_f16(int nlayers, const float *const *wt, const void *const *wp16, const float *const *bias, const int *kpad,
                            const int *nout, long rows, const float *g, const int *idx3, const float *w3, const float *skip, int n_unknown,
-                           int m_known, int c2, int c1, const float *wskip, const float *bias0, float *out, int ldo, pa_stream_t stream);
+                           int m_known, int c2, int c1, const float *wskip, const void *wskip16, const float *bias0, float *out, int ldo,
+                           pa_stream_t stream);   /* wskip16: pa_pack_weights_f16 of wskip, needed when c1 > 4 */
 
 /* One dense layer on point-major rows (the chain kernel's plain mode with a selectable epilogue):
  * out[r][:] = residual[r][:] + act(x[r][:k] . Wt + bias), act = ReLU if relu != 0 else identity; residual may be NULL.

@@ -46,8 +46,8 @@ _SIGS = {
     "pa_pack_weights_f16": "iipp",
     "pa_mlp_chain_f16": "iiippppplipippppiiiippppiiiipi",
     "pa_linear_f16": "liipipppipipi",
-    "pa_fp_chain_premul_f16": "ippppplppppiiiipppi",
-    "pa_fp_chain_premul": "ippppplppppiiiipppi",
+    "pa_fp_chain_premul_f16": "ippppplppppiiiippppi",
+    "pa_fp_chain_premul": "ippppplppppiiiippppi",
     "pa_mlp_chain_packed": "iiippppplipippppiiiippppiiiipi",
     "pa_sa_attention": "iiipppp",
     "pa_netvlad": "iiiippppppii",

@@ -156,7 +156,7 @@ __device__ __forceinline__ void gemm_chunk(const float *__restrict__ act, int st
 // plain-row kernels, where hipcc 7.2 turns the operand-swapped loop's loop-carried vmcnt(7) into vmcnt(0) (the weight prefetch then
 // no longer overlaps the MFMAs: 45 instead of 38 cycles per MFMA at fp0).
 // hidden layer: bias + ReLU, written back in place as the next layer's A tile
-template <int RT, int NC>
+template <int RT, int NC, bool ADD>
 __device__ __forceinline__ void store_hidden_nat(float *act, int stride, const PaLayer &L, int c0, int lane, floatx4 (&acc)[RT][NC])
 {
 #pragma unroll
@@ -168,7 +168,8 @@ __device__ __forceinline__ void store_hidden_nat(float *act, int stride, const P
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = rt * 16 + (lane >> 4) * 4 + r;
-                act[row * stride + col] = fmaxf(acc[rt][ct][r] + bias, 0.f);
+                float *d = act + row * stride + col;
+                *d = fmaxf(acc[rt][ct][r] + bias + (ADD ? *d : 0.f), 0.f);
             }
     }
 }
@@ -216,7 +217,7 @@ __device__ __forceinline__ void stage_rows_lds_nat(float *act, int ostride, cons
 }
 
 // hidden layer: bias + ReLU, written back in place as the next layer's activation tile (row stride is even: 8-byte stores)
-template <int RT, int NC>
+template <int RT, int NC, bool ADD>
 __device__ __forceinline__ void store_hidden(float *act, int stride, const PaLayer &L, int c0, int lane, floatx4 (&acc)[RT][NC])
 {
 #pragma unroll
@@ -225,15 +226,11 @@ __device__ __forceinline__ void store_hidden(float *act, int stride, const PaLay
         const float4 bias = *reinterpret_cast<const float4 *>(L.bias + col);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-#ifdef PA_HIDDEN_SCALAR
-            float *d = act + (rt * 16 + (lane & 15)) * stride + col;
-            d[0] = fmaxf(acc[rt][ct][0] + bias.x, 0.f); d[1] = fmaxf(acc[rt][ct][1] + bias.y, 0.f);
-            d[2] = fmaxf(acc[rt][ct][2] + bias.z, 0.f); d[3] = fmaxf(acc[rt][ct][3] + bias.w, 0.f);
-#else
             float2 *d = reinterpret_cast<float2 *>(act + (rt * 16 + (lane & 15)) * stride + col);
-            d[0] = make_float2(fmaxf(acc[rt][ct][0] + bias.x, 0.f), fmaxf(acc[rt][ct][1] + bias.y, 0.f));
-            d[1] = make_float2(fmaxf(acc[rt][ct][2] + bias.z, 0.f), fmaxf(acc[rt][ct][3] + bias.w, 0.f));
-#endif
+            float2 lo = make_float2(0.f, 0.f), hi = make_float2(0.f, 0.f);
+            if (ADD) { lo = d[0]; hi = d[1]; }   // folded first layer: the interpolated term sits where the result goes
+            d[0] = make_float2(fmaxf(acc[rt][ct][0] + bias.x + lo.x, 0.f), fmaxf(acc[rt][ct][1] + bias.y + lo.y, 0.f));
+            d[1] = make_float2(fmaxf(acc[rt][ct][2] + bias.z + hi.x, 0.f), fmaxf(acc[rt][ct][3] + bias.w + hi.y, 0.f));
         }
     }
 }
@@ -283,11 +280,15 @@ __device__ __forceinline__ void run_layer_chunks(float *act, const PaChain &a, i
     const bool last = (l == a.nlayers - 1);
     for (int c0 = c_begin; c0 < c_end; c0 += NC) {
         floatx4 acc[RT][NC];
-        gemm_chunk<RT, NC, (WPT == 1 ? 2 : (RT * NC >= 16 ? 4 : 8)), SWAP>(act, a.lds_stride, L, c0, lane, acc);
+        const bool fold = MODE == MODE_FP && l == 0 && a.fold0;     // layer 0 contracts the skip columns only and adds the interpolated term
+        gemm_chunk<RT, NC, (WPT == 1 ? 2 : (RT * NC >= 16 ? 4 : 8)), SWAP>(fold ? act + a.c2 : act, a.lds_stride, L, c0, lane, acc);
         if (!last) {
             tile_sync<WPT>();  // every A read of this layer has landed before its rows are overwritten (single chunk per wave: host-checked)
-            if (SWAP) store_hidden<RT, NC>(act, a.lds_stride, L, c0, lane, acc);
-            else store_hidden_nat<RT, NC>(act, a.lds_stride, L, c0, lane, acc);
+            if (fold) {
+                if (SWAP) store_hidden<RT, NC, true>(act, a.lds_stride, L, c0, lane, acc);
+                else store_hidden_nat<RT, NC, true>(act, a.lds_stride, L, c0, lane, acc);
+            } else if (SWAP) store_hidden<RT, NC, false>(act, a.lds_stride, L, c0, lane, acc);
+            else store_hidden_nat<RT, NC, false>(act, a.lds_stride, L, c0, lane, acc);
         } else if (POOLED) {
             if (a.vec_out) store_pooled<RT, NC, true>(a.out, a.ldo, tile * 4, a.rows, L, c0, lane, acc);
             else store_pooled<RT, NC, false>(a.out, a.ldo, tile * 4, a.rows, L, c0, lane, acc);
@@ -331,7 +332,7 @@ __global__ __launch_bounds__((!POOLED && WPT == 1 && RT == 1) ? 512 : 256, (POOL
     float *act = smem + (WPT == 1 ? (size_t)wave * a.wave_floats : (size_t)0);
     const int tid = WPT == 1 ? lane : (int)threadIdx.x;  // prologue work is spread over the tile's owner(s)
     const int stride = a.lds_stride;
-    const int k0pad = a.L[0].kpad;
+    const int k0pad = (MODE == MODE_FP && a.fold0) ? a.c2 + a.L[0].kpad : a.L[0].kpad;
 #define PA_STAMP(i) do { if (a.dbg && tile < 512 && lane == 0 && (WPT == 1 || wave == 0)) a.dbg[tile * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
     PA_STAMP(0);
 
@@ -404,7 +405,7 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
                           const float *xyz, const float *feat, const int *center_idx, const int *nbr_idx, int n_src, int m_ctr, int ns, int c_feat,
                           const float *known, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2, int c1,
                           float *out, int ldo, int relu_last, const float *residual, int ldr, pa_stream_t stream,
-                          const float *wskip = nullptr, const float *bias0 = nullptr, const void *const *wp16 = nullptr)
+                          const float *wskip = nullptr, const float *bias0 = nullptr, const void *const *wp16 = nullptr, int fold0 = 0)
 {
     PA_REQUIRE(nlayers >= 1 && nlayers <= 3, "pa_mlp_chain: nlayers=%d must be 1..3", nlayers);
     PA_REQUIRE(rows > 0 && k0 > 0 && out, "pa_mlp_chain: rows/k0 must be positive and out non-null");
@@ -423,6 +424,11 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
         if (kpad[l] > maxk) maxk = kpad[l];
         kin = nout[l];
     }
+    if (fold0) {   // MODE_FP with a folded first layer: the tile holds [interpolated term (c2) | skip channels (kpad[0])]
+        PA_REQUIRE(mode == MODE_FP && nlayers >= 2 && c2 == nout[0] && k0 == c1, "pa_fp_chain_premul: folded first layer needs >= 2 layers, c2 == nout[0]");
+        if (c2 + kpad[0] > maxk) maxk = c2 + kpad[0];
+    }
+    a.fold0 = fold0;
     a.rows = rows; a.k0 = k0; a.lds_stride = maxk + 2;
     a.x = x; a.ldx = ldx;
     a.xyz = xyz; a.feat = feat; a.center_idx = center_idx; a.nbr_idx = nbr_idx; a.n_src = n_src; a.m_ctr = m_ctr; a.ns = ns; a.c_feat = c_feat;
@@ -500,7 +506,7 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
         scratch = 2 * R;
     } else if (mode == MODE_FP) {
         PA_REQUIRE(known && idx3 && w3 && n_unknown > 0 && m_known > 0 && c2 > 0 && c1 >= 0 && (c1 == 0 || skip), "pa_mlp_chain: FP mode arguments");
-        PA_REQUIRE(c2 % 4 == 0 && k0 == c2 + c1, "pa_mlp_chain: FP mode needs c2 %% 4 == 0 and k0 == c2 + c1");
+        PA_REQUIRE(c2 % 4 == 0 && (fold0 ? k0 == c1 : k0 == c2 + c1), "pa_mlp_chain: FP mode needs c2 %% 4 == 0 and k0 == c2 + c1");
         PA_REQUIRE(rows % n_unknown == 0, "pa_mlp_chain: FP rows=%ld must be B*n", rows);
         scratch = 6 * R;
     } else if (mode == MODE_FPX) {
@@ -583,12 +589,33 @@ PA_API int pa_linear(long rows, int k, int n, const float *x, int ldx, const flo
 // g = known features already multiplied by W1a (one pa_linear over the B*m known rows instead of a 259-wide layer over the B*n
 // unknown rows, n/m = 4 at fp0); this kernel interpolates g, adds the skip term on the VALU (c1 <= 4 channels: xyz) and the bias,
 // applies ReLU, and runs the REMAINING layers (wt/wpk/bias/kpad/nout describe layers 2..) on the MFMA pipe.
+// c1 <= 4 (the finest level: skip = xyz) is the case above.  c1 > 4 (coarser levels: skip = encoder features): the first layer stays in
+// the chain as a c1-wide contraction over the skip channels whose output gets the interpolated term added; it is built here from wskip
+// (c1 x c2 K-major, c1 % 4 == 0, optional packed copy) and bias0, in front of the caller's nlayers (<= 2) remaining layers.
+static int fp_premul_dispatch(int nlayers, const float *const *wt, const float *const *wpk, const void *const *wp16, const float *const *bias,
+                              const int *kpad, const int *nout, long rows, const float *g, const int *idx3, const float *w3, const float *skip,
+                              int n_unknown, int m_known, int c2, int c1, const float *wskip, const float *wskip_p, const void *wskip16,
+                              const float *bias0, float *out, int ldo, pa_stream_t stream)
+{
+    if (c1 <= 4)
+        return chain_dispatch(MODE_FPX, 0, nlayers, wt, wpk, bias, kpad, nout, rows, c2, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0,
+                              g, idx3, w3, skip, n_unknown, m_known, c2, c1, out, ldo, 1, nullptr, 0, stream, wskip, bias0, wp16);
+    PA_REQUIRE(nlayers >= 1 && nlayers <= 2 && c1 % 4 == 0 && wskip && bias0, "pa_fp_chain_premul: c1=%d > 4 needs c1 %% 4 == 0 and at most 2 remaining layers", c1);
+    const float *wt2[3] = {wskip, wt[0], nlayers > 1 ? wt[1] : nullptr};
+    const float *wp2[3] = {wskip_p, wpk ? wpk[0] : nullptr, (wpk && nlayers > 1) ? wpk[1] : nullptr};
+    const void *w162[3] = {wskip16, wp16 ? wp16[0] : nullptr, (wp16 && nlayers > 1) ? wp16[1] : nullptr};
+    const float *b2[3] = {bias0, bias[0], nlayers > 1 ? bias[1] : nullptr};
+    const int k2[3] = {c1, kpad[0], nlayers > 1 ? kpad[1] : 0}, n2[3] = {c2, nout[0], nlayers > 1 ? nout[1] : 0};
+    return chain_dispatch(MODE_FP, 0, nlayers + 1, wt2, wp2, b2, k2, n2, rows, c1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0,
+                          g, idx3, w3, skip, n_unknown, m_known, c2, c1, out, ldo, 1, nullptr, 0, stream, nullptr, nullptr, wp16 ? w162 : nullptr, 1);
+}
+
 PA_API int pa_fp_chain_premul(int nlayers, const float *const *wt, const float *const *wpk, const float *const *bias, const int *kpad, const int *nout,
                               long rows, const float *g, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2,
-                              int c1, const float *wskip, const float *bias0, float *out, int ldo, pa_stream_t stream)
+                              int c1, const float *wskip, const float *wskip_p, const float *bias0, float *out, int ldo, pa_stream_t stream)
 {
-    return chain_dispatch(MODE_FPX, 0, nlayers, wt, wpk, bias, kpad, nout, rows, c2, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0,
-                          g, idx3, w3, skip, n_unknown, m_known, c2, c1, out, ldo, 1, nullptr, 0, stream, wskip, bias0);
+    return fp_premul_dispatch(nlayers, wt, wpk, nullptr, bias, kpad, nout, rows, g, idx3, w3, skip, n_unknown, m_known, c2, c1, wskip, wskip_p, nullptr,
+                              bias0, out, ldo, stream);
 }
 
 // ---- fp16-operand variants (BASELINE configs[4], opt-in): same arguments, wp16[l] = pa_pack_weights_f16 of layer l -----------
@@ -616,11 +643,13 @@ PA_API int pa_linear_f16(long rows, int k, int n, const float *x, int ldx, const
 
 PA_API int pa_fp_chain_premul_f16(int nlayers, const float *const *wt, const void *const *wp16, const float *const *bias, const int *kpad,
                                   const int *nout, long rows, const float *g, const int *idx3, const float *w3, const float *skip, int n_unknown,
-                                  int m_known, int c2, int c1, const float *wskip, const float *bias0, float *out, int ldo, pa_stream_t stream)
+                                  int m_known, int c2, int c1, const float *wskip, const void *wskip16, const float *bias0, float *out, int ldo,
+                                  pa_stream_t stream)
 {
     PA_REQUIRE(wp16, "pa_fp_chain_premul_f16: null wp16");
-    return chain_dispatch(MODE_FPX, 0, nlayers, wt, nullptr, bias, kpad, nout, rows, c2, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0,
-                          g, idx3, w3, skip, n_unknown, m_known, c2, c1, out, ldo, 1, nullptr, 0, stream, wskip, bias0, wp16);
+    PA_REQUIRE(c1 <= 4 || wskip16, "pa_fp_chain_premul_f16: c1 > 4 needs the fp16 packing of wskip");
+    return fp_premul_dispatch(nlayers, wt, nullptr, wp16, bias, kpad, nout, rows, g, idx3, w3, skip, n_unknown, m_known, c2, c1, wskip, nullptr, wskip16,
+                              bias0, out, ldo, stream);
 }
 
 namespace {

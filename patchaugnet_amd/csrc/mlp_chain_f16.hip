@@ -69,7 +69,7 @@ __device__ __forceinline__ void gemm16(const _Float16 *__restrict__ act, int str
 }
 
 // hidden layer: bias + ReLU in fp32, rounded to fp16, written back in place (four consecutive channels = one 8-byte store)
-template <int RT, int NC>
+template <int RT, int NC, bool ADD>
 __device__ __forceinline__ void store_hidden16(_Float16 *act, int stride, const PaLayer &L, int c0, int lane, floatx4 (&acc)[RT][NC])
 {
 #pragma unroll
@@ -77,9 +77,17 @@ __device__ __forceinline__ void store_hidden16(_Float16 *act, int stride, const 
         const int col = (c0 + ct) * 16 + (lane >> 4) * 4;
         const float4 bias = *reinterpret_cast<const float4 *>(L.bias + col);
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-            pa_store4(act + (rt * 16 + (lane & 15)) * stride + col, fmaxf(acc[rt][ct][0] + bias.x, 0.f), fmaxf(acc[rt][ct][1] + bias.y, 0.f),
-                      fmaxf(acc[rt][ct][2] + bias.z, 0.f), fmaxf(acc[rt][ct][3] + bias.w, 0.f));
+        for (int rt = 0; rt < RT; ++rt) {
+            _Float16 *d = act + (rt * 16 + (lane & 15)) * stride + col;
+            float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
+            if (ADD) {   // folded first layer: the interpolated term sits where the result goes
+                typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+                const half4 h = *reinterpret_cast<const half4 *>(d);
+                e0 = (float)h[0]; e1 = (float)h[1]; e2 = (float)h[2]; e3 = (float)h[3];
+            }
+            pa_store4(d, fmaxf(acc[rt][ct][0] + bias.x + e0, 0.f), fmaxf(acc[rt][ct][1] + bias.y + e1, 0.f),
+                      fmaxf(acc[rt][ct][2] + bias.z + e2, 0.f), fmaxf(acc[rt][ct][3] + bias.w + e3, 0.f));
+        }
     }
 }
 
@@ -90,10 +98,12 @@ __device__ __forceinline__ void run_layer16(_Float16 *act, const PaChain &a, int
     const bool last = (l == a.nlayers - 1);
     for (int c0 = c_begin; c0 < c_end; c0 += NC) {
         floatx4 acc[RT][NC];
-        gemm16<RT, NC>(act, a.lds_stride, L, c0, lane, acc);
+        const bool fold = MODE == MODE_FP && l == 0 && a.fold0;
+        gemm16<RT, NC>(fold ? act + a.c2 : act, a.lds_stride, L, c0, lane, acc);
         if (!last) {
             tile_sync<WPT>();  // every read of this layer's input has landed before its rows are overwritten (single chunk per wave: host-checked)
-            store_hidden16<RT, NC>(act, a.lds_stride, L, c0, lane, acc);
+            if (fold) store_hidden16<RT, NC, true>(act, a.lds_stride, L, c0, lane, acc);
+            else store_hidden16<RT, NC, false>(act, a.lds_stride, L, c0, lane, acc);
         } else if (POOLED) {
             if (a.vec_out) store_pooled<RT, NC, true>(a.out, a.ldo, tile * 4, a.rows, L, c0, lane, acc);
             else store_pooled<RT, NC, false>(a.out, a.ldo, tile * 4, a.rows, L, c0, lane, acc);
@@ -122,7 +132,7 @@ __global__ __launch_bounds__(256, (POOLED && RT <= 5) ? 2 : 1) void chain16_kern
     const int tid = WPT == 1 ? lane : (int)threadIdx.x;
     const int stride = a.lds_stride;
     float *scratch = reinterpret_cast<float *>(act + (size_t)R * stride);
-    chain_prologue<_Float16, R, MODE, POOLED, WPT>(act, scratch, a, tile, tid, lane, stride, a.L[0].k32);
+    chain_prologue<_Float16, R, MODE, POOLED, WPT>(act, scratch, a, tile, tid, lane, stride, (MODE == MODE_FP && a.fold0) ? a.c2 + a.L[0].k32 : a.L[0].k32);
     tile_sync<WPT>();
     for (int l = 0; l < a.nlayers; ++l) {
         const int nct = a.L[l].n >> 4;
@@ -180,7 +190,8 @@ int pa_chain16_launch(PaChain &a, int mode, bool is_pooled, bool split, int RTv,
         if (a.L[l].k32 > maxk) maxk = a.L[l].k32;
         PA_REQUIRE(l + 1 == a.nlayers || a.L[l].n % 32 == 0, "fp16 chain: hidden width %d must be a multiple of 32", a.L[l].n);
     }
-    PA_REQUIRE(mode != MODE_FPX || a.c2 % 32 == 0, "fp16 chain: pre-multiplied width %d must be a multiple of 32", a.c2);
+    PA_REQUIRE((mode != MODE_FPX && !a.fold0) || a.c2 % 32 == 0, "fp16 chain: pre-multiplied width %d must be a multiple of 32", a.c2);
+    if (a.fold0 && a.c2 + a.L[0].k32 > maxk) maxk = a.c2 + a.L[0].k32;
     const int R = RTv * 16;
     a.lds_stride = maxk + 8;                                   // halfs; row pitch is a multiple of 16 bytes, 16 rows hit all 64 banks
     const size_t tile_bytes = (size_t)R * a.lds_stride * 2;

@@ -49,6 +49,9 @@ struct PaChain {
     long long *dbg;          // profiling only: per-tile s_memtime stamps at phase boundaries (null in production)
     int xcd_remap;           // != 0: contiguous tile ranges per XCD (see chain_kernel)
     int ep_stride;           // > 0: the last layer's tile is staged through LDS (row stride ep_stride floats) and leaves as whole rows
+    int fold0;               // MODE_FP only, != 0: `known` holds features already multiplied by the first layer's interpolated-part weights;
+                             //   layer 0 then contracts only the c1 skip channels (tile columns c2 ..) and ADDS the interpolated term it finds in
+                             //   columns 0 .. c2-1 before bias and ReLU (linearity of interpolation; pa_fp_chain_premul with c1 > 4)
     int vec_out;             // != 0: out (and residual) rows are 16-byte aligned -> 16-byte stores
 };
 

@@ -122,12 +122,15 @@ class _Chain:
             self._premul = {
                 "w1a": w1a, "w1a_p": pack_weights_f16(w1a) if self.f16 else pack_weights(w1a), "zero": torch.zeros(n0, dtype=torch.float32, device=dev),
                 "wskip": wt0[c2:c2 + c1].contiguous(), "bias0": b0, "n0": n0, "m": m,
+                "wskip_p": None,
                 "wt": (ctypes.c_void_p * m)(*[l[0].data_ptr() for l in rest]),
                 "wpk": (ctypes.c_void_p * m)(*[(p.data_ptr() if p is not None else None) for p in (self.packed16 if self.f16 else self.packed)[1:]]),
                 "bias": (ctypes.c_void_p * m)(*[l[1].data_ptr() for l in rest]),
                 "kpad": (ctypes.c_int * m)(*[l[3] for l in rest]), "nout": (ctypes.c_int * m)(*[l[4] for l in rest]),
             }
         pm = self._premul
+        if c1 > 4 and pm["wskip_p"] is None:      # coarser levels: the skip part of the first layer is an MFMA layer of its own
+            pm["wskip_p"] = pack_weights_f16(pm["wskip"]) if self.f16 else pack_weights(pm["wskip"])
         g = torch.empty((B * m_known, pm["n0"]), dtype=torch.float32, device=dev)
         call("pa_linear_f16" if self.f16 else "pa_linear", B * m_known, c2, pm["n0"], ptr(known_feat), c2, ptr(pm["w1a"]), ptr(pm["w1a_p"]),
              ptr(pm["zero"]), 0, None, 0, ptr(g), pm["n0"])
@@ -137,7 +140,8 @@ class _Chain:
         out = torch.empty((rows, self.n_last), dtype=torch.float32, device=dev)
         cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
         call("pa_fp_chain_premul_f16" if self.f16 else "pa_fp_chain_premul", pm["m"], cast(pm["wt"]), cast(pm["wpk"]), cast(pm["bias"]), cast(pm["kpad"]), cast(pm["nout"]), rows,
-             ptr(g), ptr(idx3), ptr(w3), ptr(skip), n_unknown, m_known, pm["n0"], c1, ptr(pm["wskip"]), ptr(pm["bias0"]), ptr(out), self.n_last)
+             ptr(g), ptr(idx3), ptr(w3), ptr(skip), n_unknown, m_known, pm["n0"], c1, ptr(pm["wskip"]), ptr(pm["wskip_p"]), ptr(pm["bias0"]),
+             ptr(out), self.n_last)
         return out
 
     def plain(self, x):
@@ -404,7 +408,9 @@ class PatchAugNetEngine:
             known_feat = l_feat[i]
             c2 = known_feat.shape[-1]
             c1 = skip.shape[-1] if skip is not None else 0
-            if self.premul and 1 <= c1 <= 4 and chain.n >= 2 and n_u >= 2 * m_k and c2 % 4 == 0 and chain.layers[0][4] % 16 == 0:
+            # c1 <= 4 (xyz skip): always; wider skips only when there are enough rows to amortise the extra pre-multiply launch
+            fold_ok = 1 <= c1 <= 4 or (c1 % 4 == 0 and chain.n <= 3 and B * n_u >= 16384 and (not chain.f16 or chain.layers[0][4] % 32 == 0))
+            if self.premul and fold_ok and chain.n >= 2 and n_u >= 2 * m_k and c2 % 4 == 0 and chain.layers[0][4] % 16 == 0:
                 y = chain.fp_premul(known_feat.contiguous(), idx3, w3, skip.contiguous(), B, n_u, m_k, c2, c1,
                                     mark=lambda k=nfp + i: self._mark(f"fp{k}.premul"))
             else:
