@@ -276,6 +276,8 @@ def main():
         if not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, {k: v.cpu() for k, v in sd.items()}, a.cpu_batch, a.points)
     print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
