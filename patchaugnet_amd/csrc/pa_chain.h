@@ -94,10 +94,27 @@ __device__ __forceinline__ void chain_prologue(T *act, float *scratch, const PaC
     // ---------------------------------------------------------------- prologue: build the A tile of layer 0
     if (MODE == MODE_PLAIN) {
         const long row0 = tile * R;
-        for (int q = tid; q < R * k0pad; q += NTH) {
-            const int r = q / k0pad, ch = q - r * k0pad;
-            const long row = row0 + r;
-            act[r * stride + ch] = (row < a.rows && ch < a.k0) ? a.x[row * a.ldx + ch] : 0.f;
+        if ((a.k0 & 3) == 0 && (a.ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0) {
+            // aligned rows: 16-byte loads, four activations per store (no per-element division)
+            const int qpr = a.k0 >> 2;
+            for (int q = tid; q < R * qpr; q += NTH) {
+                const int r = q / qpr, part = q - r * qpr;
+                const long row = row0 + r;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < a.rows) v = *reinterpret_cast<const float4 *>(a.x + row * a.ldx + part * 4);
+                pa_store4(act + r * stride + part * 4, v.x, v.y, v.z, v.w);
+            }
+            const int tail = k0pad - a.k0;   // fp16 path: K is padded to 32
+            for (int q = tid; q < R * tail; q += NTH) {
+                const int r = q / tail, ch = q - r * tail;
+                act[r * stride + a.k0 + ch] = 0.f;
+            }
+        } else {
+            for (int q = tid; q < R * k0pad; q += NTH) {
+                const int r = q / k0pad, ch = q - r * k0pad;
+                const long row = row0 + r;
+                act[r * stride + ch] = (row < a.rows && ch < a.k0) ? a.x[row * a.ldx + ch] : 0.f;
+            }
         }
     } else if (MODE == MODE_SA) {
         int *src = reinterpret_cast<int *>(scratch);  // [R] source point (global row), -1 = padding row
