@@ -354,18 +354,41 @@ class KNNQuery(Function):
 knnquery = KNNQuery.apply
 
 
-def knnquery_naive(nsample, xyz, new_xyz=None):
-    """pointops.py:366-404 (torch sort of the full distance matrix; kept for API parity)."""
-    new_xyz = xyz if new_xyz is None else new_xyz
-    dist = (new_xyz.unsqueeze(2) - xyz.unsqueeze(1)).pow(2).sum(dim=3)
-    return torch.sort(dist, dim=2)[1][:, :, :nsample].int()
+class KNNQueryNaive(Function):
+    """pointops.py:367-404 -- the reference sorts the full (b, m, n) distance matrix with torch.sort (unstable among equal distances)
+    and keeps the first nsample columns; the HIP kNN returns exactly that set in (distance, index) order without the matrix."""
+
+    @staticmethod
+    def forward(ctx, nsample, xyz, new_xyz=None):
+        idx, _ = knnquery_with_dist(nsample, xyz, new_xyz)
+        ctx.mark_non_differentiable(idx)
+        return idx
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None, None
 
 
-def knnquery_exclude(nsample, xyz, new_xyz=None):
-    """pointops.py:436-473 (neighbours 1..nsample, i.e. excluding the closest)."""
-    new_xyz = xyz if new_xyz is None else new_xyz
-    dist = (new_xyz.unsqueeze(2) - xyz.unsqueeze(1)).pow(2).sum(dim=3)
-    return torch.sort(dist, dim=2)[1][:, :, 1:nsample + 1].int()
+knnquery_naive = KNNQueryNaive.apply
+
+
+class KNNQueryExclude(Function):
+    """pointops.py:436-473 -- columns 1 .. nsample of the sorted distance matrix, i.e. the nsample nearest EXCLUDING the closest
+    (the point itself when new_xyz is xyz)."""
+
+    @staticmethod
+    def forward(ctx, nsample, xyz, new_xyz=None):
+        idx, _ = knnquery_with_dist(nsample + 1, xyz, new_xyz)
+        idx = idx[:, :, 1:].contiguous()
+        ctx.mark_non_differentiable(idx)
+        return idx
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None, None
+
+
+knnquery_exclude = KNNQueryExclude.apply
 
 
 def _neighbours(radius, nsample, xyz, new_xyz):

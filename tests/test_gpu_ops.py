@@ -228,3 +228,15 @@ def test_three_nn_weights_form(b, n, m):
     r = 1.0 / (torch.sqrt(torch.from_numpy(rd)) + 1e-8)       # patch_aug_net.py:351-353
     ref = r / torch.sum(r, dim=2, keepdim=True)
     assert torch.allclose(w.cpu(), ref, rtol=1e-6, atol=1e-9)
+
+
+def test_knnquery_naive_and_exclude_match_the_reference_definition():
+    """pointops.py:367-404 / :436-473: first nsample columns (resp. columns 1..nsample) of the row-sorted distance matrix."""
+    from patchaugnet_amd import pointops
+    x = torch.rand(3, 500, 3, device="cuda")
+    q = torch.rand(3, 70, 3, device="cuda")
+    dist = (q.unsqueeze(2) - x.unsqueeze(1)).pow(2).sum(dim=3)
+    order = torch.sort(dist, dim=2, stable=True)[1]
+    assert torch.equal(pointops.knnquery_naive(9, x, q).long(), order[:, :, :9])
+    assert torch.equal(pointops.knnquery_exclude(9, x, q).long(), order[:, :, 1:10])
+    assert torch.equal(pointops.knnquery_exclude(4, x).long()[:, :, 0] != torch.arange(500, device="cuda"), torch.ones(3, 500, dtype=torch.bool, device="cuda"))
