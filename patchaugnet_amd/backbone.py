@@ -32,7 +32,19 @@ class SALayer(nn.Module):
         self.trans_conv = nn.Conv1d(channels, channels, 1)
         self.after_norm = nn.BatchNorm1d(channels)
 
+    def _fused(self, x):
+        """eval + no_grad on the MI355X: pa_linear + pa_sa_attention + pa_linear (csrc/attention.hip), no (B, gp, N, N) tensor."""
+        from .engine import _Attn
+        key = (x.device, self.k_conv.weight.data_ptr(), self.k_conv.weight._version)
+        if getattr(self, "_attn_key", None) != key:
+            self._attn, self._attn_key = _Attn(self, x.device), key
+        bs, ch, n = x.shape
+        xm = x.transpose(1, 2).contiguous().view(bs * n, ch)
+        return self._attn.run(xm, bs, n).view(bs, n, ch).transpose(1, 2).contiguous()
+
     def forward(self, x):
+        if x.is_cuda and not self.training and not torch.is_grad_enabled() and x.shape[1] in (64, 128, 256, 512):
+            return self._fused(x)
         bs, ch, n = x.shape
         y = self.k_conv(x).reshape(bs, self.gp, ch // self.gp, n)
         energy = torch.matmul(y.permute(0, 1, 3, 2), y).sum(dim=1)

@@ -408,8 +408,9 @@ class PatchAugNetEngine:
             known_feat = l_feat[i]
             c2 = known_feat.shape[-1]
             c1 = skip.shape[-1] if skip is not None else 0
-            # c1 <= 4 (xyz skip): always; wider skips only when there are enough rows to amortise the extra pre-multiply launch
-            fold_ok = 1 <= c1 <= 4 or (c1 % 4 == 0 and chain.n <= 3 and B * n_u >= 16384 and (not chain.f16 or chain.layers[0][4] % 32 == 0))
+            # c1 <= 4 (xyz skip): always; wider skips only at levels with enough points per cloud to amortise the extra pre-multiply
+            # launch (a per-level rule, NOT a function of the batch size: results must not depend on how clouds are batched)
+            fold_ok = 1 <= c1 <= 4 or (c1 % 4 == 0 and chain.n <= 3 and n_u >= 512 and (not chain.f16 or chain.layers[0][4] % 32 == 0))
             if self.premul and fold_ok and chain.n >= 2 and n_u >= 2 * m_k and c2 % 4 == 0 and chain.layers[0][4] % 16 == 0:
                 y = chain.fp_premul(known_feat.contiguous(), idx3, w3, skip.contiguous(), B, n_u, m_k, c2, c1,
                                     mark=lambda k=nfp + i: self._mark(f"fp{k}.premul"))

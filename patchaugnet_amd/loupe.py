@@ -13,6 +13,11 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .backbone import SALayer
+
+GroupSALayer = SALayer      # patch_aug_net/models/loupe.py:69-114 -- the same grouped self-attention as pptnet.py's SA_Layer (disabled in
+                            # the shipped PatchAugNet config, patch_aug_net.py:239; kept so code that names it keeps importing)
+
 
 class GatingContext(nn.Module):
     """loupe.py:332-361 -- x * sigmoid(BN(x @ W))."""

@@ -10,9 +10,11 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import loupe as lp
-from .backbone import PyramidBackbone
+from .backbone import PyramidBackbone, SALayer
 
-__all__ = ["Network"]
+SA_Layer = SALayer          # the reference's class name (pptnet.py:246)
+
+__all__ = ["Network", "SA_Layer"]
 
 
 class Network(nn.Module):

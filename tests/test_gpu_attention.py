@@ -26,7 +26,14 @@ def test_sa_layer_fused_vs_oracle(b, n, c):
         ref = models_cpu.sa_layer(sd, "s", x, 8)                                          # (B, C, N)
         xm = x.transpose(1, 2).contiguous().view(b * n, c).cuda()
         got = _Attn(sa, xm.device).run(xm, b, n).view(b, n, c).transpose(1, 2).cpu()
-        mod = sa.cuda()(x.cuda()).cpu()                                                   # torch module path on the GPU
+        sa = sa.cuda()
+        mod = sa(x.cuda()).cpu()                                                          # the module itself: fused HIP path under no_grad
+    mod_t = sa.train(False)
+    with torch.enable_grad():
+        mod_torch = sa(x.cuda()).detach().cpu()                                           # autograd path: torch dense ops
+    assert (mod_torch - ref).abs().max().item() <= 2e-5 * max(ref.abs().max().item(), 1.0)
+    with torch.no_grad():
+        pass
     scale = ref.abs().max().item()
     assert (got - ref).abs().max().item() <= 2e-5 * max(scale, 1.0), (got - ref).abs().max().item()
     assert (mod - ref).abs().max().item() <= 2e-5 * max(scale, 1.0)
