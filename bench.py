@@ -151,21 +151,25 @@ def pcie_inclusive(model, a, pipe):
         if i >= 0:
             host_d[i].copy_(d, non_blocking=True)
 
+    rates = []
     with torch.no_grad():
         pipe.begin()
         for i in range(nbuf):
             pipe.submit(one, -1 - i)
         pipe.end()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        pipe.begin()
-        for i in range(a.steps):
-            pipe.submit(one, i)
-        pipe.end()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    return {"value": a.steps * a.batch / dt, "unit": "submaps/s", "ms_per_step": dt / a.steps * 1e3,
-            "note": "host pinned fp32 batch -> H2D -> extraction -> D2H descriptors, all inside the timed region (never the headline value)"}
+        for _ in range(3):      # the host-buffer path shows occasional slow repetitions (DMA/host jitter): report the median of 3
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pipe.begin()
+            for i in range(a.steps):
+                pipe.submit(one, i)
+            pipe.end()
+            torch.cuda.synchronize()
+            rates.append(a.steps * a.batch / (time.perf_counter() - t0))
+    med = sorted(rates)[1]
+    return {"value": med, "unit": "submaps/s", "ms_per_step": a.batch / med * 1e3, "repetitions": [round(r, 1) for r in rates],
+            "note": "host pinned fp32 batch -> H2D -> extraction -> D2H descriptors, all inside the timed region; median of 3 repetitions of "
+                    "the K steps (never the headline value)"}
 
 
 def main():
