@@ -26,8 +26,9 @@ def run_model(model, queries, positives, negatives, other_neg, nn_dict=None, num
     returns {'global_desc': (q, pos, neg, other) split along dim 1, 'patch_recon': dict or None}."""
     device = device or next(model.parameters()).device
     q = _as_tensor(queries)
-    feed = torch.cat((q, _as_tensor(positives), _as_tensor(negatives), _as_tensor(other_neg)), 1).view((-1, 1, num_points, 3))
-    feed = feed.to(device, non_blocking=True).requires_grad_(require_grad)
+    # the four groups go to the device first and are concatenated there (a host-side cat spins the ATen thread pool, hostcpu.py)
+    feed = torch.cat([_as_tensor(t).to(device, non_blocking=True) for t in (q, positives, negatives, other_neg)], 1)
+    feed = feed.view((-1, 1, num_points, 3)).requires_grad_(require_grad)
     with torch.set_grad_enabled(require_grad):
         out = model(feed, nn_dict, return_feat=False) if nn_dict is not None else model(feed, return_feat=False)
     desc, recon = out if nn_dict is not None else (out, None)

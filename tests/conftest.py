@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # size ATen / the oracle's OpenMP pool to the container's CPU grant, not the machine's core count (patchaugnet_amd/hostcpu.py)
+    from patchaugnet_amd.hostcpu import limit_host_threads
+    limit_host_threads()
 
 
 def _has_gpu():

@@ -58,6 +58,8 @@ def extraction_rate(model, batch, kind, streams=3, steps=None):
 
 
 def main():
+    from patchaugnet_amd.hostcpu import limit_host_threads
+    limit_host_threads()
     torch.cuda.set_device(0)
     res = {"device": torch.cuda.get_device_name(0)}
     model = patch_aug_net.Network(param=configs.patch_aug_net_config(), use_a2a_recon=True, use_l2_norm=True)
