@@ -146,6 +146,80 @@ __global__ __launch_bounds__(GT) void interp_backward_kernel(int c, int n, int m
     atomicAdd(gp + id[2], g * w[2]);
 }
 
+// Backward scatters through LDS (K3 / K6 / K11 / K15): a workgroup owns CT channel rows of one cloud's grad_points (CT * dst_len
+// floats <= 64 KiB), accumulates every source element into them with LDS atomics (ds_add_f32) and adds the finished rows to
+// global memory once.  The reference issues one global atomicAdd per (channel, source element)
+// (interpolation_cuda_kernel.cu:198-230, grouping_cuda_kernel.cu:33-52, sampling_cuda_kernel.cu:21-36); here global traffic is
+// grad_out read once + grad_points read-modify-written once.  W3 = the three weighted neighbours of the interpolation backward.
+// When b * c / CT alone cannot fill the chip the source range is split over blockIdx.x and the partial rows are added atomically.
+template <int CT, bool W3>
+__global__ __launch_bounds__(256) void lds_scatter_kernel(int c, int dst_len, int src_len, int per_split, const float *__restrict__ grad_out,
+                                                            const int *__restrict__ idx, const float *__restrict__ weight,
+                                                            float *__restrict__ grad_points)
+{
+    extern __shared__ float acc[];
+    const int b = blockIdx.z, c0 = blockIdx.y * CT, tid = threadIdx.x;
+    const int ct = min(CT, c - c0);
+    for (int i = tid; i < CT * dst_len; i += 256) acc[i] = 0.f;
+    __syncthreads();
+    const int t0 = blockIdx.x * per_split, t1 = min(src_len, t0 + per_split);
+    const float *g = grad_out + ((size_t)b * c + c0) * src_len;
+    for (int t = t0 + tid; t < t1; t += 256) {
+        if (W3) {
+            const int *id = idx + ((size_t)b * src_len + t) * 3;
+            const float *w = weight + ((size_t)b * src_len + t) * 3;
+            const int i0 = id[0], i1 = id[1], i2 = id[2];
+            const float w0 = w[0], w1 = w[1], w2 = w[2];
+#pragma unroll
+            for (int r = 0; r < CT; ++r) {
+                if (r < ct) {
+                    const float v = g[(size_t)r * src_len + t];
+                    atomicAdd(acc + r * dst_len + i0, v * w0);
+                    atomicAdd(acc + r * dst_len + i1, v * w1);
+                    atomicAdd(acc + r * dst_len + i2, v * w2);
+                }
+            }
+        } else {
+            const int i0 = idx[(size_t)b * src_len + t];
+#pragma unroll
+            for (int r = 0; r < CT; ++r)
+                if (r < ct) atomicAdd(acc + r * dst_len + i0, g[(size_t)r * src_len + t]);
+        }
+    }
+    __syncthreads();
+    float *gp = grad_points + ((size_t)b * c + c0) * dst_len;
+    if (gridDim.x == 1) {
+        for (int i = tid; i < ct * dst_len; i += 256) gp[i] += acc[i];
+    } else {
+        for (int i = tid; i < ct * dst_len; i += 256)
+            if (acc[i] != 0.f) atomicAdd(gp + i, acc[i]);
+    }
+}
+
+template <bool W3>
+bool launch_lds_scatter(int b, int c, int dst_len, int src_len, const float *grad_out, const int *idx, const float *weight, float *grad_points,
+                        hipStream_t st)
+{
+    if ((size_t)dst_len * 4 > 64 * 1024 || getenv("PA_SCATTER_GLOBAL_ATOMICS")) return false;   // rows do not fit: caller uses the global-atomic kernel
+    int ct = 16;
+    while (ct > 1 && ((size_t)ct * dst_len * 4 > 64 * 1024 || ct > c)) ct >>= 1;
+    const int row_blocks = pa_div_up(c, ct) * b;
+    int splits = 1;
+    if (row_blocks < 512) splits = max(1, min(pa_div_up(512, row_blocks), src_len / 1024));
+    const int per_split = pa_div_up(pa_div_up(src_len, splits), 256) * 256;
+    splits = pa_div_up(src_len, per_split);
+    const dim3 grid(splits, pa_div_up(c, ct), b);
+    const size_t lds = (size_t)ct * dst_len * 4;
+    switch (ct) {
+        case 16: hipLaunchKernelGGL((lds_scatter_kernel<16, W3>), grid, dim3(256), lds, st, c, dst_len, src_len, per_split, grad_out, idx, weight, grad_points); break;
+        case 8: hipLaunchKernelGGL((lds_scatter_kernel<8, W3>), grid, dim3(256), lds, st, c, dst_len, src_len, per_split, grad_out, idx, weight, grad_points); break;
+        case 4: hipLaunchKernelGGL((lds_scatter_kernel<4, W3>), grid, dim3(256), lds, st, c, dst_len, src_len, per_split, grad_out, idx, weight, grad_points); break;
+        case 2: hipLaunchKernelGGL((lds_scatter_kernel<2, W3>), grid, dim3(256), lds, st, c, dst_len, src_len, per_split, grad_out, idx, weight, grad_points); break;
+        default: hipLaunchKernelGGL((lds_scatter_kernel<1, W3>), grid, dim3(256), lds, st, c, dst_len, src_len, per_split, grad_out, idx, weight, grad_points); break;
+    }
+    return true;
+}
+
 // pick the channel tile so CT rows fit in 32 KiB of LDS (>= 4 workgroups per CU: one stages while others gather and
 // stream out) and the column split so that the launch has >= ~1024 workgroups whenever the problem is big enough
 struct GatherPlan { int ct; int cols_per_block; int col_blocks; size_t lds; };
@@ -212,7 +286,8 @@ int scatter_add(const char *name, int b, int c, int n, int mk, const float *grad
     PA_REQUIRE(b > 0 && c > 0 && n > 0 && mk > 0, "%s: sizes must be positive", name);
     PA_REQUIRE(grad_out && idx && grad_points, "%s: null pointer", name);
     PA_REQUIRE(b <= 65535 && c <= 65535, "%s: b=%d / c=%d exceed the grid limits", name, b, c);
-    hipLaunchKernelGGL(scatter_add_kernel, dim3(pa_div_up(mk, GT), c, b), dim3(GT), 0, st, c, n, mk, grad_out, idx, grad_points);
+    if (!launch_lds_scatter<false>(b, c, n, mk, grad_out, idx, nullptr, grad_points, st))
+        hipLaunchKernelGGL(scatter_add_kernel, dim3(pa_div_up(mk, GT), c, b), dim3(GT), 0, st, c, n, mk, grad_out, idx, grad_points);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { pa_set_error("%s: launch failed: %s", name, hipGetErrorString(e)); return (int)e; }
     return PA_OK;
@@ -289,7 +364,8 @@ PA_API int pa_interpolation_backward(int b, int c, int n, int m, const float *gr
     PA_REQUIRE(b > 0 && c > 0 && m > 0 && n > 0, "pa_interpolation_backward: sizes must be positive");
     PA_REQUIRE(grad_out && idx && weight && grad_points, "pa_interpolation_backward: null pointer");
     PA_REQUIRE(b <= 65535 && c <= 65535, "pa_interpolation_backward: b=%d / c=%d exceed the grid limits", b, c);
-    hipLaunchKernelGGL(interp_backward_kernel, dim3(pa_div_up(n, GT), c, b), dim3(GT), 0, (hipStream_t)stream, c, n, m, grad_out, idx, weight, grad_points);
+    if (!launch_lds_scatter<true>(b, c, m, n, grad_out, idx, weight, grad_points, (hipStream_t)stream))
+        hipLaunchKernelGGL(interp_backward_kernel, dim3(pa_div_up(n, GT), c, b), dim3(GT), 0, (hipStream_t)stream, c, n, m, grad_out, idx, weight, grad_points);
     PA_CHECK_LAUNCH("pa_interpolation_backward");
     return PA_OK;
 }

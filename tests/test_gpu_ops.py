@@ -151,6 +151,33 @@ def test_backward_ops(P):
     assert np.allclose(f.grad.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
 
 
+# (b, c, n source points, m centres, k): model shapes (LDS rows, one block per channel tile), a small b*c (source range split
+# across workgroups + atomic merge), and n too large for the LDS rows (global-atomic kernel)
+@pytest.mark.parametrize("b,c,n,m,k", [(3, 256, 1024, 4096, 20), (2, 64, 4096, 1024, 20), (1, 3, 4096, 1024, 20), (1, 5, 20000, 700, 4),
+                                       (2, 19, 333, 77, 3)])
+def test_backward_ops_at_scale(P, b, c, n, m, k):
+    """K3 / K6 / K11 backward scatters vs the oracle (float sums in a different order: tolerance, not bit-exact)."""
+    k = min(k, 8) if b * c * m * k > 4e7 else k
+    f = torch.randn(b, c, n, device="cuda", requires_grad=True)
+    idx = dev(RNG.integers(0, n, (b, m, k), dtype=np.int32))
+    go = torch.randn(b, c, m, k, device="cuda")
+    P.grouping(f, idx).backward(go)
+    ref = o.grouping_backward(go.cpu().numpy(), idx.cpu().numpy(), n)
+    assert np.allclose(f.grad.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+    f.grad = None
+    i1 = dev(RNG.integers(0, n, (b, m), dtype=np.int32))
+    g1 = torch.randn(b, c, m, device="cuda")
+    P.gathering(f, i1).backward(g1)
+    assert np.allclose(f.grad.cpu().numpy(), o.gathering_backward(g1.cpu().numpy(), i1.cpu().numpy(), n), rtol=1e-4, atol=1e-4)
+    f.grad = None
+    i3 = dev(RNG.integers(0, n, (b, m, 3), dtype=np.int32))          # m "unknown" points interpolated from the n known ones
+    w = torch.rand(b, m, 3, device="cuda")
+    g3 = torch.randn(b, c, m, device="cuda")
+    P.interpolation(f, i3, w).backward(g3)
+    ref = o.interpolation_backward(g3.cpu().numpy(), i3.cpu().numpy(), w.cpu().numpy(), n)
+    assert np.allclose(f.grad.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("n,m,r,k", [(4096, 1024, 0.2, 32), (200, 20, 0.5, 8), (3000, 300, 0.05, 16), (100, 10, 1e-4, 4)])
 def test_ballquery_bit_exact(P, n, m, r, k):
     x = cloud(2, n)

@@ -3,6 +3,8 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from patchaugnet_amd.hostcpu import limit_host_threads
+limit_host_threads()
 from patchaugnet_amd import configs, patch_aug_net
 from patchaugnet_amd.train import training_step
 from patchaugnet_amd.weights import seeded_state_dict

@@ -1,6 +1,8 @@
 import os, sys, time, gc
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from patchaugnet_amd.hostcpu import limit_host_threads
+limit_host_threads()
 from patchaugnet_amd import configs, patch_aug_net, losses
 from patchaugnet_amd.train import run_model, DEFAULTS as args
 from patchaugnet_amd.weights import seeded_state_dict
