@@ -26,11 +26,15 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+// exp on the transcendental unit: v_exp_f32(x * log2 e), ~2 ulp; both passes use the same function, so the soft-max rows stay
+// normalised exactly as computed.  exp(-inf) = 0.
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
 template <int C>
 struct AttnCfg {
     static constexpr int TJ = C <= 128 ? 64 : (C == 256 ? 32 : 16);   // rows of Y / V per LDS tile
-    static constexpr int YS = C + 2;                                  // conflict-free A-fragment reads (row l%16, k = k0 + l/16)
-    static constexpr int VS = C + 4;                                  // conflict-free reads of V[4g + r][c0 + l%16]
+    static constexpr int YS = C + 4;                                  // 16-byte A-fragment reads: row l%16 at float 16q + 4(l/16) -> bank 4(row + g + 4q), conflict-free
+    static constexpr int VS = C + 4;                                  // 16-byte reads of V[4g + r][64u + 4(l%16) ..]: 16 lanes of a phase cover 64 banks
 };
 
 template <int C, int PASS>
@@ -50,11 +54,13 @@ __global__ __launch_bounds__(256) void sa_attn_kernel(int n, const float *__rest
     const float *yv = yv_all + (size_t)b * n * (2 * C);
     const float *stats = stats_all + (size_t)b * n * 2;
 
-    float yb[KS];                                      // own points as the B operand: B[k = 4ks + l/16][j = l%16] = Y[j0 + l%16][k]
+    // Own points as the B operand.  The contraction index is permuted the same way on both operands so that a lane's four
+    // consecutive k-steps read ONE float4: MFMA (q, s) contracts k = 16q + 4(l/16) + s, i.e. B[slot l/16][j = l%16] = Y[j0 + l%16][16q + 4(l/16) + s].
+    float4 yb[KS / 4];
     if (active) {
-        const float *p = yv + (size_t)min(j0 + (lane & 15), n - 1) * (2 * C) + (lane >> 4);
+        const float *p = yv + (size_t)min(j0 + (lane & 15), n - 1) * (2 * C) + (lane >> 4) * 4;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) yb[ks] = p[ks * 4];
+        for (int q = 0; q < KS / 4; ++q) yb[q] = *reinterpret_cast<const float4 *>(p + q * 16);
     }
     float m_run = -INFINITY, l_run = 0.f, s_run = 0.f;
     floatx4 o[PASS == 2 ? CT : 1];
@@ -68,9 +74,7 @@ __global__ __launch_bounds__(256) void sa_attn_kernel(int n, const float *__rest
             const int r = q / Q, part = q - r * Q;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (t0 + r < n) v = *reinterpret_cast<const float4 *>(yv + (size_t)(t0 + r) * (2 * C) + part * 4);
-            float2 *d = reinterpret_cast<float2 *>(Ys + r * YS + part * 4);
-            d[0] = make_float2(v.x, v.y);
-            d[1] = make_float2(v.z, v.w);
+            *reinterpret_cast<float4 *>(Ys + r * YS + part * 4) = v;
             if (PASS == 2) {
                 float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (t0 + r < n) w = *reinterpret_cast<const float4 *>(yv + (size_t)(t0 + r) * (2 * C) + C + part * 4);
@@ -87,9 +91,15 @@ __global__ __launch_bounds__(256) void sa_attn_kernel(int n, const float *__rest
             const int nit = (min(TJ, n - t0) + 15) >> 4;
             for (int it = 0; it < nit; ++it) {
                 floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
-                const float *ap = Ys + (it * 16 + (lane & 15)) * YS + (lane >> 4);
+                const float *ap = Ys + (it * 16 + (lane & 15)) * YS + (lane >> 4) * 4;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[ks * 4], yb[ks], acc, 0, 0, 0);
+                for (int q = 0; q < KS / 4; ++q) {
+                    const float4 a = *reinterpret_cast<const float4 *>(ap + q * 16);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, yb[q].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, yb[q].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, yb[q].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, yb[q].w, acc, 0, 0, 0);
+                }
                 // acc[r] = e(i = t0 + 16it + 4(l/16) + r, j = j0 + l%16)
                 if (PASS == 1) {
                     const int ig = t0 + it * 16 + (lane >> 4) * 4;
@@ -99,20 +109,30 @@ __global__ __launch_bounds__(256) void sa_attn_kernel(int n, const float *__rest
                     const float mt = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
                     const float mn = fmaxf(m_run, mt);
                     if (mn > -INFINITY) {
-                        l_run = l_run * expf(m_run - mn) + ((expf(acc[0] - mn) + expf(acc[1] - mn)) + (expf(acc[2] - mn) + expf(acc[3] - mn)));
+                        l_run = l_run * fexp(m_run - mn) + ((fexp(acc[0] - mn) + fexp(acc[1] - mn)) + (fexp(acc[2] - mn) + fexp(acc[3] - mn)));
                         m_run = mn;
                     }
                 } else {
                     const int ib = it * 16 + (lane >> 4) * 4;
+                    const float4 mi = *reinterpret_cast<const float4 *>(Ms + ib), li = *reinterpret_cast<const float4 *>(Ms + TJ + ib);
                     float p[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) p[r] = expf(acc[r] - Ms[ib + r]) * Ms[TJ + ib + r];
+                    p[0] = fexp(acc[0] - mi.x) * li.x;
+                    p[1] = fexp(acc[1] - mi.y) * li.y;
+                    p[2] = fexp(acc[2] - mi.z) * li.z;
+                    p[3] = fexp(acc[3] - mi.w) * li.w;
                     s_run += (p[0] + p[1]) + (p[2] + p[3]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float *vp = Vs + (ib + r) * VS + (lane & 15);   // A[c = 16ct + l%16][slot g = l/16] = V[i = 16it + 4g + r][c]
+                        // A[row m = l%16][slot g = l/16] = V[i = 16it + 4g + r][chan(ct, m)], chan(ct, m) = 64(ct/4) + 4m + ct%4: one float4 per four ct
+                        const float *vp = Vs + (ib + r) * VS + (lane & 15) * 4;
 #pragma unroll
-                        for (int ct = 0; ct < CT; ++ct) o[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[ct * 16], p[r], o[ct], 0, 0, 0);
+                        for (int u = 0; u < CT / 4; ++u) {
+                            const float4 a = *reinterpret_cast<const float4 *>(vp + u * 64);
+                            o[4 * u + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, p[r], o[4 * u + 0], 0, 0, 0);
+                            o[4 * u + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, p[r], o[4 * u + 1], 0, 0, 0);
+                            o[4 * u + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, p[r], o[4 * u + 2], 0, 0, 0);
+                            o[4 * u + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, p[r], o[4 * u + 3], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -127,7 +147,7 @@ __global__ __launch_bounds__(256) void sa_attn_kernel(int n, const float *__rest
         for (int sft = 16; sft < 64; sft <<= 1) {
             const float mo = __shfl_xor(m_run, sft), lo = __shfl_xor(l_run, sft);
             const float mn = fmaxf(m_run, mo);
-            l_run = mn > -INFINITY ? l_run * expf(m_run - mn) + lo * expf(mo - mn) : 0.f;
+            l_run = mn > -INFINITY ? l_run * fexp(m_run - mn) + lo * fexp(mo - mn) : 0.f;
             m_run = mn;
         }
         if (lane < 16 && j0 + lane < n) {
@@ -144,15 +164,18 @@ __global__ __launch_bounds__(256) void sa_attn_kernel(int n, const float *__rest
         const float *xr = x_all + row * C;
         float *dr = d_all + row * C;
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            const int c = ct * 16 + (lane >> 4) * 4;                           // o[ct][rr]: channel c + rr, point j = l%16
-            const float4 xv = *reinterpret_cast<const float4 *>(xr + c);
-            float4 d;
-            d.x = xv.x - o[ct][0] / den;
-            d.y = xv.y - o[ct][1] / den;
-            d.z = xv.z - o[ct][2] / den;
-            d.w = xv.w - o[ct][3] / den;
-            *reinterpret_cast<float4 *>(dr + c) = d;
+        for (int u = 0; u < CT / 4; ++u) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int c = u * 64 + (lane >> 4) * 16 + rr * 4;              // o[4u + e][rr]: channel chan(4u + e, 4(l/16) + rr) = c + e, point j = l%16
+                const float4 xv = *reinterpret_cast<const float4 *>(xr + c);
+                float4 d;
+                d.x = xv.x - o[4 * u + 0][rr] / den;
+                d.y = xv.y - o[4 * u + 1][rr] / den;
+                d.z = xv.z - o[4 * u + 2][rr] / den;
+                d.w = xv.w - o[4 * u + 3][rr] / den;
+                *reinterpret_cast<float4 *>(dr + c) = d;
+            }
         }
     }
 }
