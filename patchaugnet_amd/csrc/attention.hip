@@ -67,26 +67,44 @@ __global__ __launch_bounds__(256) void sa_attn_kernel(int n, const float *__rest
 #pragma unroll
     for (int ct = 0; ct < (PASS == 2 ? CT : 1); ++ct) o[ct] = (floatx4){0.f, 0.f, 0.f, 0.f};
 
-    for (int t0 = 0; t0 < n; t0 += TJ) {
-        // ---- stage rows t0 .. t0+TJ-1 of Y (and V, m, 1/l) -------------------------------------------------------
-        constexpr int Q = C / 4;
-        for (int q = tid; q < TJ * Q; q += 256) {
-            const int r = q / Q, part = q - r * Q;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t0 + r < n) v = *reinterpret_cast<const float4 *>(yv + (size_t)(t0 + r) * (2 * C) + part * 4);
-            *reinterpret_cast<float4 *>(Ys + r * YS + part * 4) = v;
-            if (PASS == 2) {
-                float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (t0 + r < n) w = *reinterpret_cast<const float4 *>(yv + (size_t)(t0 + r) * (2 * C) + C + part * 4);
-                *reinterpret_cast<float4 *>(Vs + r * VS + part * 4) = w;
-            }
+    // Tiles are fetched one step ahead into registers (global latency hides under the previous tile's MFMAs) and dropped into LDS
+    // between the two barriers.
+    constexpr int Q = C / 4, NPF = TJ * Q / 256;
+    static_assert(TJ * Q % 256 == 0, "tile must split evenly over the workgroup");
+    float4 py[NPF], pv[PASS == 2 ? NPF : 1];
+    float pm = 0.f, pl = 0.f;
+    auto fetch = [&](int t0) {
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int q = tid + u * 256, r = q / Q, part = q - r * Q;
+            const bool ok = t0 + r < n;
+            const float *src = yv + (size_t)(t0 + r) * (2 * C) + part * 4;
+            py[u] = ok ? *reinterpret_cast<const float4 *>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (PASS == 2) pv[u] = ok ? *reinterpret_cast<const float4 *>(src + C) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (PASS == 2 && tid < TJ) {
             const bool ok = t0 + tid < n;
-            Ms[tid] = ok ? stats[(size_t)(t0 + tid) * 2] : 0.f;
-            Ms[TJ + tid] = ok ? stats[(size_t)(t0 + tid) * 2 + 1] : 0.f;
+            pm = ok ? stats[(size_t)(t0 + tid) * 2] : 0.f;
+            pl = ok ? stats[(size_t)(t0 + tid) * 2 + 1] : 0.f;
+        }
+    };
+    constexpr bool PF = C <= 256;          // C = 512 (N = 16 in PPT-Net: a single tile) has no registers to spare for the look-ahead
+    if (PF) fetch(0);
+    for (int t0 = 0; t0 < n; t0 += TJ) {
+        if (!PF) fetch(t0);
+        // ---- rows t0 .. t0+TJ-1 of Y (and V, m, 1/l): registers -> LDS ---------------------------------------------
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int q = tid + u * 256, r = q / Q, part = q - r * Q;
+            *reinterpret_cast<float4 *>(Ys + r * YS + part * 4) = py[u];
+            if (PASS == 2) *reinterpret_cast<float4 *>(Vs + r * VS + part * 4) = pv[u];
+        }
+        if (PASS == 2 && tid < TJ) {
+            Ms[tid] = pm;
+            Ms[TJ + tid] = pl;
         }
         __syncthreads();
+        if (PF && t0 + TJ < n) fetch(t0 + TJ);
         if (active) {
             const int nit = (min(TJ, n - t0) + 15) >> 4;
             for (int it = 0; it < nit; ++it) {
