@@ -107,8 +107,8 @@ __device__ __forceinline__ void gemm_chunk(const float *__restrict__ act, int st
             }
         }
     } else {
-        const float *wp = L.wt + (size_t)(lane >> 4) * L.n + c0 * 16 + (lane & 15);
-        const size_t wstep = (size_t)4 * L.n;
+        const float *wp = L.wt + (size_t)(lane >> 4) * L.ldw + c0 * 16 + (lane & 15);
+        const size_t wstep = (size_t)4 * L.ldw;
 #pragma unroll
         for (int u = 0; u < PD; ++u) {
             const int k = min(u, last);
@@ -273,10 +273,10 @@ __device__ __forceinline__ void copy_rows_out(const float *act, int ostride, int
 }
 
 template <int RT, int NC, int MODE, bool POOLED, int WPT>
-__device__ __forceinline__ void run_layer_chunks(float *act, const PaChain &a, int l, long tile, int lane, int c_begin, int c_end)
+__device__ __forceinline__ void run_layer_chunks(float *act, const PaChain &a, const PaLayer &L, float *out, const float *residual, int l, long tile,
+                                                 int lane, int c_begin, int c_end)
 {
     constexpr bool SWAP = POOLED || WPT > 1;   // see the note above store_hidden_nat
-    const PaLayer &L = a.L[l];
     const bool last = (l == a.nlayers - 1);
     for (int c0 = c_begin; c0 < c_end; c0 += NC) {
         floatx4 acc[RT][NC];
@@ -290,24 +290,24 @@ __device__ __forceinline__ void run_layer_chunks(float *act, const PaChain &a, i
             } else if (SWAP) store_hidden<RT, NC, false>(act, a.lds_stride, L, c0, lane, acc);
             else store_hidden_nat<RT, NC, false>(act, a.lds_stride, L, c0, lane, acc);
         } else if (POOLED) {
-            if (a.vec_out) store_pooled<RT, NC, true>(a.out, a.ldo, tile * 4, a.rows, L, c0, lane, acc);
-            else store_pooled<RT, NC, false>(a.out, a.ldo, tile * 4, a.rows, L, c0, lane, acc);
+            if (a.vec_out) store_pooled<RT, NC, true>(out, a.ldo, tile * 4, a.rows, L, c0, lane, acc);
+            else store_pooled<RT, NC, false>(out, a.ldo, tile * 4, a.rows, L, c0, lane, acc);
         } else if (a.ep_stride > 0) {   // host guarantees a single chunk per wave here
             tile_sync<WPT>();           // every A read of the last layer has landed: the activation tile is dead
             if (SWAP) stage_rows_lds<RT, NC>(act, a.ep_stride, L, c0, lane, acc, a.relu_last);
             else stage_rows_lds_nat<RT, NC>(act, a.ep_stride, L, c0, lane, acc, a.relu_last);
         } else {
             const long total_rows = (MODE == MODE_SA) ? a.rows * a.ns : a.rows;
-            if (!SWAP) store_rows_nat<RT, NC>(a.out, a.ldo, tile * (RT * 16), total_rows, L, c0, lane, acc, a.relu_last, a.residual, a.ldr);
-            else if (a.vec_out) store_rows<RT, NC, true>(a.out, a.ldo, tile * (RT * 16), total_rows, L, c0, lane, acc, a.relu_last, a.residual, a.ldr);
-            else store_rows<RT, NC, false>(a.out, a.ldo, tile * (RT * 16), total_rows, L, c0, lane, acc, a.relu_last, a.residual, a.ldr);
+            if (!SWAP) store_rows_nat<RT, NC>(out, a.ldo, tile * (RT * 16), total_rows, L, c0, lane, acc, a.relu_last, residual, a.ldr);
+            else if (a.vec_out) store_rows<RT, NC, true>(out, a.ldo, tile * (RT * 16), total_rows, L, c0, lane, acc, a.relu_last, residual, a.ldr);
+            else store_rows<RT, NC, false>(out, a.ldo, tile * (RT * 16), total_rows, L, c0, lane, acc, a.relu_last, residual, a.ldr);
         }
     }
     if (!last) tile_sync<WPT>();
     else if (!POOLED && a.ep_stride > 0) {
         tile_sync<WPT>();
         const long total_rows = (MODE == MODE_SA) ? a.rows * a.ns : a.rows;
-        copy_rows_out<RT * 16>(act, a.ep_stride, L.n, a.out, a.ldo, tile * (RT * 16), total_rows, a.residual, a.ldr,
+        copy_rows_out<RT * 16>(act, a.ep_stride, L.n, out, a.ldo, tile * (RT * 16), total_rows, residual, a.ldr,
                                WPT == 1 ? lane : (int)threadIdx.x, WPT * 64);
     }
 }
@@ -342,14 +342,18 @@ __global__ __launch_bounds__((!POOLED && WPT == 1 && RT == 1) ? 512 : 256, (POOL
 
     // ---------------------------------------------------------------- layers
     for (int l = 0; l < a.nlayers; ++l) {
-        const int nct = a.L[l].n >> 4;
+        PaLayer L = a.L[l];
+        float *out = a.out;
+        const float *residual = a.residual;
+        if (MODE == MODE_PLAIN && WPT == 4) pa_col_slice(a, L, out, residual);
+        const int nct = L.n >> 4;
         const int per = WPT == 1 ? nct : nct / WPT;          // column tiles this wave computes (host: nct % WPT == 0)
         const int cb = WPT == 1 ? 0 : wave * per, ce = cb + per;
-        if (NCMAX >= 16 && per % 16 == 0) run_layer_chunks<RT, (NCMAX >= 16 ? 16 : NCMAX), MODE, POOLED, WPT>(act, a, l, tile, lane, cb, ce);
-        else if (NCMAX >= 8 && per % 8 == 0) run_layer_chunks<RT, (NCMAX >= 8 ? 8 : NCMAX), MODE, POOLED, WPT>(act, a, l, tile, lane, cb, ce);
-        else if (NCMAX >= 4 && per % 4 == 0) run_layer_chunks<RT, (NCMAX >= 4 ? 4 : NCMAX), MODE, POOLED, WPT>(act, a, l, tile, lane, cb, ce);
-        else if (per % 2 == 0) run_layer_chunks<RT, 2, MODE, POOLED, WPT>(act, a, l, tile, lane, cb, ce);
-        else run_layer_chunks<RT, 1, MODE, POOLED, WPT>(act, a, l, tile, lane, cb, ce);
+        if (NCMAX >= 16 && per % 16 == 0) run_layer_chunks<RT, (NCMAX >= 16 ? 16 : NCMAX), MODE, POOLED, WPT>(act, a, L, out, residual, l, tile, lane, cb, ce);
+        else if (NCMAX >= 8 && per % 8 == 0) run_layer_chunks<RT, (NCMAX >= 8 ? 8 : NCMAX), MODE, POOLED, WPT>(act, a, L, out, residual, l, tile, lane, cb, ce);
+        else if (NCMAX >= 4 && per % 4 == 0) run_layer_chunks<RT, (NCMAX >= 4 ? 4 : NCMAX), MODE, POOLED, WPT>(act, a, L, out, residual, l, tile, lane, cb, ce);
+        else if (per % 2 == 0) run_layer_chunks<RT, 2, MODE, POOLED, WPT>(act, a, L, out, residual, l, tile, lane, cb, ce);
+        else run_layer_chunks<RT, 1, MODE, POOLED, WPT>(act, a, L, out, residual, l, tile, lane, cb, ce);
         PA_STAMP(2 + l);
     }
 #undef PA_STAMP
@@ -375,7 +379,7 @@ int launch_chain(const PaChain &a, int waves_per_wg, long ntiles, hipStream_t st
     auto kern = chain_kernel<RT, NCMAX, MODE, POOLED, WPT>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (WPT == 1) hipLaunchKernelGGL(kern, dim3(pa_div_up(ntiles, waves_per_wg)), dim3(64 * waves_per_wg), lds, st, a);
-    else hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(kern, dim3(ntiles, a.col_slices > 1 ? a.col_slices : 1), dim3(256), lds, st, a);
     return 0;
 }
 
@@ -405,7 +409,7 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
                           const float *xyz, const float *feat, const int *center_idx, const int *nbr_idx, int n_src, int m_ctr, int ns, int c_feat,
                           const float *known, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2, int c1,
                           float *out, int ldo, int relu_last, const float *residual, int ldr, pa_stream_t stream,
-                          const float *wskip = nullptr, const float *bias0 = nullptr, const void *const *wp16 = nullptr, int fold0 = 0)
+                          const float *wskip = nullptr, const float *bias0 = nullptr, const void *const *wp16 = nullptr, int fold0 = 0, int col_slices = 1)
 {
     PA_REQUIRE(nlayers >= 1 && nlayers <= 3, "pa_mlp_chain: nlayers=%d must be 1..3", nlayers);
     PA_REQUIRE(rows > 0 && k0 > 0 && out, "pa_mlp_chain: rows/k0 must be positive and out non-null");
@@ -417,7 +421,7 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
         PA_REQUIRE(wt[l] && bias[l], "pa_mlp_chain: null weights for layer %d", l);
         PA_REQUIRE(kpad[l] % 4 == 0 && kpad[l] >= kin && kpad[l] < kin + 4, "pa_mlp_chain: layer %d kpad=%d must be k=%d rounded up to 4", l, kpad[l], kin);
         PA_REQUIRE(nout[l] % 16 == 0 && nout[l] > 0, "pa_mlp_chain: layer %d n=%d must be a positive multiple of 16", l, nout[l]);
-        a.L[l].wt = wt[l]; a.L[l].bias = bias[l]; a.L[l].kpad = kpad[l]; a.L[l].n = nout[l];
+        a.L[l].wt = wt[l]; a.L[l].bias = bias[l]; a.L[l].kpad = kpad[l]; a.L[l].n = nout[l]; a.L[l].ldw = nout[l];
         static const bool no_packed = getenv("PA_CHAIN_NO_PACKED") != nullptr;   // A/B knob
         a.L[l].wp = (!no_packed && wpk && wpk[l] && nout[l] % 64 == 0) ? wpk[l] : nullptr;
         a.L[l].wp16 = wp16 ? reinterpret_cast<const _Float16 *>(wp16[l]) : nullptr;
@@ -437,6 +441,12 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
     a.out = out; a.ldo = ldo;
     a.relu_last = relu_last; a.residual = residual; a.ldr = ldr;
     a.dbg = g_chain_dbg;
+    if (col_slices > 1) {   // pa_linear over few rows: nout[0] is the slice width
+        PA_REQUIRE(nlayers == 1 && mode == MODE_PLAIN && nout[0] % 64 == 0 && (a.L[0].wp || a.L[0].wp16), "pa_linear: column slices need one packed layer");
+        a.col_slices = col_slices; a.slice_n = nout[0];
+        a.wp_slice = (long)nout[0] * kpad[0];
+        a.L[0].ldw = nout[0] * col_slices;
+    }
     static const bool no_xcd = getenv("PA_CHAIN_NO_XCD_REMAP") != nullptr;   // A/B knob
     a.xcd_remap = no_xcd ? 0 : 1;
     hipStream_t st = (hipStream_t)stream;
@@ -473,6 +483,7 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
         const long tp = (rows + 3) / 4;
         if (can_split && tp < 2048 && RTv == 5) split = true;
     }
+    PA_REQUIRE(col_slices <= 1 || split, "pa_linear: column slices are built for the shared-tile (few rows) variant");
     const int R = RTv * 16;
     const int ncmax = split ? 8 : (is_pooled ? 4 : 16);
     if (!split)
@@ -573,6 +584,19 @@ PA_API int pa_mlp_chain_packed(int mode, int pooled, int nlayers, const float *c
                           known, idx3, w3, skip, n_unknown, m_known, c2, c1, out, ldo, 1, nullptr, 0, stream);
 }
 
+// Column slices for a single layer over few rows: with 16-row tiles a (512 x 512) @ (512 x 1024) layer is 32 workgroups, each streaming
+// the whole 2 MB weight matrix through one CU; slicing the outputs over gridDim.y spreads that stream over the chip.
+static int linear_col_slices(long rows, int n, bool packed)
+{
+    static const long target = getenv("PA_LINEAR_SLICE_BLOCKS") ? atol(getenv("PA_LINEAR_SLICE_BLOCKS")) : 512;
+    static const int min_n = getenv("PA_LINEAR_SLICE_MIN") ? atoi(getenv("PA_LINEAR_SLICE_MIN")) : 128;
+    const long t16 = (rows + 15) / 16;
+    if (!packed || t16 >= 512 || n % 64 != 0) return 1;
+    int s = 1;
+    while (t16 * s < target && n % (2 * s) == 0 && (n / (2 * s)) % 64 == 0 && n / (2 * s) >= min_n) s *= 2;
+    return s;
+}
+
 // One dense layer on point-major rows: out = residual + act(x Wt + bias); wt K-major (kpad x n), kpad = k rounded up to 4;
 // wpk: optional packed copy of wt (NULL = none).
 PA_API int pa_linear(long rows, int k, int n, const float *x, int ldx, const float *wt, const float *wpk, const float *bias, int relu,
@@ -580,8 +604,11 @@ PA_API int pa_linear(long rows, int k, int n, const float *x, int ldx, const flo
 {
     PA_REQUIRE(residual == nullptr || ldr >= n, "pa_linear: residual row stride %d < n=%d", ldr, n);
     const int kpad = (k + 3) / 4 * 4;
-    return chain_dispatch(0, 0, 1, &wt, &wpk, &bias, &kpad, &n, rows, k, x, ldx, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0,
-                          nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, out, ldo, relu, residual, ldr, stream);
+    static const bool no_packed = getenv("PA_CHAIN_NO_PACKED") != nullptr;
+    const int slices = linear_col_slices(rows, n, wpk != nullptr && !no_packed);
+    const int ns = n / slices;
+    return chain_dispatch(0, 0, 1, &wt, &wpk, &bias, &kpad, &ns, rows, k, x, ldx, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0,
+                          nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, out, ldo, relu, residual, ldr, stream, nullptr, nullptr, nullptr, 0, slices);
 }
 
 // Feature propagation with the first layer folded into the prologue.  Interpolation is linear, so
@@ -637,8 +664,10 @@ PA_API int pa_linear_f16(long rows, int k, int n, const float *x, int ldx, const
     PA_REQUIRE(wp16, "pa_linear_f16: null wp16");
     PA_REQUIRE(residual == nullptr || ldr >= n, "pa_linear_f16: residual row stride %d < n=%d", ldr, n);
     const int kpad = (k + 3) / 4 * 4;
-    return chain_dispatch(0, 0, 1, &wt, nullptr, &bias, &kpad, &n, rows, k, x, ldx, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0,
-                          nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, out, ldo, relu, residual, ldr, stream, nullptr, nullptr, &wp16);
+    const int slices = linear_col_slices(rows, n, true);
+    const int ns = n / slices;
+    return chain_dispatch(0, 0, 1, &wt, nullptr, &bias, &kpad, &ns, rows, k, x, ldx, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0,
+                          nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, out, ldo, relu, residual, ldr, stream, nullptr, nullptr, &wp16, 0, slices);
 }
 
 PA_API int pa_fp_chain_premul_f16(int nlayers, const float *const *wt, const void *const *wp16, const float *const *bias, const int *kpad,

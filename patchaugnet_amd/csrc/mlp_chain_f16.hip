@@ -92,9 +92,9 @@ __device__ __forceinline__ void store_hidden16(_Float16 *act, int stride, const 
 }
 
 template <int RT, int NC, int MODE, bool POOLED, int WPT>
-__device__ __forceinline__ void run_layer16(_Float16 *act, const PaChain &a, int l, long tile, int lane, int c_begin, int c_end)
+__device__ __forceinline__ void run_layer16(_Float16 *act, const PaChain &a, const PaLayer &L, float *out, const float *residual, int l, long tile,
+                                            int lane, int c_begin, int c_end)
 {
-    const PaLayer &L = a.L[l];
     const bool last = (l == a.nlayers - 1);
     for (int c0 = c_begin; c0 < c_end; c0 += NC) {
         floatx4 acc[RT][NC];
@@ -105,12 +105,12 @@ __device__ __forceinline__ void run_layer16(_Float16 *act, const PaChain &a, int
             if (fold) store_hidden16<RT, NC, true>(act, a.lds_stride, L, c0, lane, acc);
             else store_hidden16<RT, NC, false>(act, a.lds_stride, L, c0, lane, acc);
         } else if (POOLED) {
-            if (a.vec_out) store_pooled<RT, NC, true>(a.out, a.ldo, tile * 4, a.rows, L, c0, lane, acc);
-            else store_pooled<RT, NC, false>(a.out, a.ldo, tile * 4, a.rows, L, c0, lane, acc);
+            if (a.vec_out) store_pooled<RT, NC, true>(out, a.ldo, tile * 4, a.rows, L, c0, lane, acc);
+            else store_pooled<RT, NC, false>(out, a.ldo, tile * 4, a.rows, L, c0, lane, acc);
         } else {
             const long total_rows = (MODE == MODE_SA) ? a.rows * a.ns : a.rows;
-            if (a.vec_out) store_rows<RT, NC, true>(a.out, a.ldo, tile * (RT * 16), total_rows, L, c0, lane, acc, a.relu_last, a.residual, a.ldr);
-            else store_rows<RT, NC, false>(a.out, a.ldo, tile * (RT * 16), total_rows, L, c0, lane, acc, a.relu_last, a.residual, a.ldr);
+            if (a.vec_out) store_rows<RT, NC, true>(out, a.ldo, tile * (RT * 16), total_rows, L, c0, lane, acc, a.relu_last, residual, a.ldr);
+            else store_rows<RT, NC, false>(out, a.ldo, tile * (RT * 16), total_rows, L, c0, lane, acc, a.relu_last, residual, a.ldr);
         }
     }
     if (!last) tile_sync<WPT>();
@@ -135,14 +135,18 @@ __global__ __launch_bounds__(256, (POOLED && RT <= 5) ? 2 : 1) void chain16_kern
     chain_prologue<_Float16, R, MODE, POOLED, WPT>(act, scratch, a, tile, tid, lane, stride, (MODE == MODE_FP && a.fold0) ? a.c2 + a.L[0].k32 : a.L[0].k32);
     tile_sync<WPT>();
     for (int l = 0; l < a.nlayers; ++l) {
-        const int nct = a.L[l].n >> 4;
+        PaLayer L = a.L[l];
+        float *out = a.out;
+        const float *residual = a.residual;
+        if (MODE == MODE_PLAIN && WPT == 4) pa_col_slice(a, L, out, residual);
+        const int nct = L.n >> 4;
         const int per = WPT == 1 ? nct : nct / WPT;
         const int cb = WPT == 1 ? 0 : wave * per, ce = cb + per;
-        if (NCMAX >= 16 && per % 16 == 0) run_layer16<RT, (NCMAX >= 16 ? 16 : NCMAX), MODE, POOLED, WPT>(act, a, l, tile, lane, cb, ce);
-        else if (NCMAX >= 8 && per % 8 == 0) run_layer16<RT, (NCMAX >= 8 ? 8 : NCMAX), MODE, POOLED, WPT>(act, a, l, tile, lane, cb, ce);
-        else if (NCMAX >= 4 && per % 4 == 0) run_layer16<RT, (NCMAX >= 4 ? 4 : NCMAX), MODE, POOLED, WPT>(act, a, l, tile, lane, cb, ce);
-        else if (per % 2 == 0) run_layer16<RT, 2, MODE, POOLED, WPT>(act, a, l, tile, lane, cb, ce);
-        else run_layer16<RT, 1, MODE, POOLED, WPT>(act, a, l, tile, lane, cb, ce);
+        if (NCMAX >= 16 && per % 16 == 0) run_layer16<RT, (NCMAX >= 16 ? 16 : NCMAX), MODE, POOLED, WPT>(act, a, L, out, residual, l, tile, lane, cb, ce);
+        else if (NCMAX >= 8 && per % 8 == 0) run_layer16<RT, (NCMAX >= 8 ? 8 : NCMAX), MODE, POOLED, WPT>(act, a, L, out, residual, l, tile, lane, cb, ce);
+        else if (NCMAX >= 4 && per % 4 == 0) run_layer16<RT, (NCMAX >= 4 ? 4 : NCMAX), MODE, POOLED, WPT>(act, a, L, out, residual, l, tile, lane, cb, ce);
+        else if (per % 2 == 0) run_layer16<RT, 2, MODE, POOLED, WPT>(act, a, L, out, residual, l, tile, lane, cb, ce);
+        else run_layer16<RT, 1, MODE, POOLED, WPT>(act, a, L, out, residual, l, tile, lane, cb, ce);
     }
 }
 
@@ -153,7 +157,7 @@ void launch16(const PaChain &a, int waves_per_wg, long ntiles, hipStream_t st)
     auto kern = chain16_kernel<RT, NCMAX, MODE, POOLED, WPT>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (WPT == 1) hipLaunchKernelGGL(kern, dim3(pa_div_up(ntiles, waves_per_wg)), dim3(64 * waves_per_wg), lds, st, a);
-    else hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(kern, dim3(ntiles, a.col_slices > 1 ? a.col_slices : 1), dim3(256), lds, st, a);
 }
 
 template <int MODE>
@@ -192,6 +196,7 @@ int pa_chain16_launch(PaChain &a, int mode, bool is_pooled, bool split, int RTv,
     }
     PA_REQUIRE((mode != MODE_FPX && !a.fold0) || a.c2 % 32 == 0, "fp16 chain: pre-multiplied width %d must be a multiple of 32", a.c2);
     if (a.fold0 && a.c2 + a.L[0].k32 > maxk) maxk = a.c2 + a.L[0].k32;
+    if (a.col_slices > 1) a.wp16_slice = (long)a.slice_n * a.L[0].k32;
     const int R = RTv * 16;
     a.lds_stride = maxk + 8;                                   // halfs; row pitch is a multiple of 16 bytes, 16 rows hit all 64 banks
     const size_t tile_bytes = (size_t)R * a.lds_stride * 2;

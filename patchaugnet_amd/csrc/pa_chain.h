@@ -13,6 +13,7 @@ struct PaLayer {
     const float *bias;  // [n]
     int kpad;           // multiple of 4
     int n;              // multiple of 16
+    int ldw;            // row stride of wt in floats (= n, or the full width when this launch computes a column slice)
 };
 
 struct PaChain {
@@ -53,11 +54,31 @@ struct PaChain {
                              //   layer 0 then contracts only the c1 skip channels (tile columns c2 ..) and ADDS the interpolated term it finds in
                              //   columns 0 .. c2-1 before bias and ReLU (linearity of interpolation; pa_fp_chain_premul with c1 > 4)
     int vec_out;             // != 0: out (and residual) rows are 16-byte aligned -> 16-byte stores
+    // Single-layer launches over few rows (pa_linear): gridDim.y column slices of slice_n outputs each, so that a 512-row layer fills
+    // the chip instead of 32 workgroups streaming the whole weight matrix each.  L[0].n == slice_n; slice y shifts the packed weights,
+    // bias, out and residual (packed layouts are column-group-major, so a slice is a contiguous range).
+    int col_slices, slice_n;
+    long wp_slice, wp16_slice;   // packed fp32 floats / fp16 halfs per slice
 };
 
 namespace {
 
 enum { MODE_PLAIN = 0, MODE_SA = 1, MODE_FP = 2, MODE_FPX = 3 };
+
+// Column slice y = blockIdx.y of a single-layer launch: shifted copies of the layer descriptor and of the output / residual pointers.
+// (The kernel argument itself is never written: a modified by-value argument would be demoted to scratch memory.)
+__device__ __forceinline__ void pa_col_slice(const PaChain &a, PaLayer &L, float *&out, const float *&residual)
+{
+    if (a.col_slices > 1) {
+        const int y = blockIdx.y;
+        L.wt += y * a.slice_n;
+        if (L.wp) L.wp += (size_t)y * a.wp_slice;
+        if (L.wp16) L.wp16 += (size_t)y * a.wp16_slice;
+        L.bias += y * a.slice_n;
+        out += y * a.slice_n;
+        if (residual) residual += y * a.slice_n;
+    }
+}
 
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 

@@ -39,7 +39,8 @@ def test_sa_layer_fused_vs_oracle(b, n, c):
     assert (mod - ref).abs().max().item() <= 2e-5 * max(scale, 1.0)
 
 
-@pytest.mark.parametrize("rows,k,n,relu,res", [(1000, 64, 128, 0, False), (77, 259, 256, 1, True), (4096, 512, 1024, 0, False), (33, 20, 16, 1, False)])
+@pytest.mark.parametrize("rows,k,n,relu,res", [(1000, 64, 128, 0, False), (77, 259, 256, 1, True), (4096, 512, 1024, 0, False), (33, 20, 16, 1, False),
+                                               (512, 512, 1024, 0, False), (512, 512, 512, 1, True), (2048, 256, 512, 0, True), (100, 128, 256, 1, True)])
 def test_pa_linear(rows, k, n, relu, res):
     from patchaugnet_amd._lib import call, ptr
     x = torch.randn(rows, k, device="cuda")

@@ -11,6 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("rows,k,n,relu,res", [(1000, 64, 128, 0, False), (77, 259, 256, 1, True), (4096, 512, 1024, 0, False), (33, 20, 16, 1, False),
+                                               (512, 512, 1024, 0, False), (512, 512, 512, 1, True), (2048, 256, 512, 0, True), (100, 128, 256, 1, True),
                                                (131072, 256, 256, 1, False)])
 def test_pa_linear_f16(rows, k, n, relu, res):
     from patchaugnet_amd._lib import call, ptr
