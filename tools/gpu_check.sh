@@ -9,6 +9,22 @@ timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_tests.log 2>
 tail -5 gpurun_out/${TAG}_tests.log
 timeout 600 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"
 cat gpurun_out/${TAG}_bench.json
+# the other BASELINE configurations: PPT-Net (fp32 and the fp16 MLP path = configs[4]), PatchAugNet fp16 MLP path, section-8(d) sweep
+timeout 300 python bench.py --model pptnet --no-cpu-baseline > gpurun_out/${TAG}_bench_pptnet_f32.json 2>> gpurun_out/${TAG}_bench.err
+timeout 300 python bench.py --model pptnet --mlp-dtype f16 --no-cpu-baseline > gpurun_out/${TAG}_bench_pptnet_f16.json 2>> gpurun_out/${TAG}_bench.err
+timeout 300 python bench.py --mlp-dtype f16 --no-cpu-baseline > gpurun_out/${TAG}_bench_patchaugnet_f16.json 2>> gpurun_out/${TAG}_bench.err
+timeout 600 python tools/config_sweep.py > gpurun_out/${TAG}_config_sweep.json 2>> gpurun_out/${TAG}_bench.err
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/*_bench_*.json")):
+    try:
+        l = json.loads(open(f).read().strip().splitlines()[-1]); print(f, round(l["value"]), l["unit"])
+    except Exception as ex:
+        print(f, "unreadable", ex)
+PY
+rm -rf gpurun_out/${TAG}_prof
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_prof -o ${TAG} -- python bench.py --model pptnet --mlp-dtype f16 --streams 1 --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-pass > gpurun_out/${TAG}_prof_ppt.log 2>&1; echo "rocprof(ppt) rc=$?"
+python tools/rocprof_summary.py $(ls gpurun_out/${TAG}_prof/*results.db | head -1) gpurun_out/${TAG}_kernel_stats_pptnet_f16_streams_1.csv
 for S in default 1; do
   rm -rf gpurun_out/${TAG}_prof
   EXTRA=""; [ "$S" = "1" ] && EXTRA="--streams 1"
