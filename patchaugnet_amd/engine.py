@@ -87,6 +87,15 @@ class _Chain:
         self.k0 = layers[0][2]
         self.n_last = layers[-1][4]
         self.hidden_ok_pooled = all(l[4] <= 64 for l in layers[:-1])
+        # the shared-tile pooled kernel (four waves split the columns of one 4-group tile) also takes hidden widths 64 / 128 / 256
+        self._split_widths_ok = all(l[4] in (64, 128, 256) for l in layers[:-1]) and layers[-1][4] % 64 == 0
+
+    def pooled_ok(self, groups, ns):
+        """Can the pooled (max over the ns neighbours inside the kernel) variant run this level?  Narrow hidden layers: always; wide ones
+        only through the shared-tile variant, which mlp_chain.hip selects for 17 <= ns <= 20 and fewer than 2048 four-group tiles."""
+        tiles = (groups + 3) // 4
+        # fp32: below ~256 tiles the 16-row unpooled tiling (5x the workgroups) wins; both give the same bits (tests/test_gpu_chain.py)
+        return self.hidden_ok_pooled or (self._split_widths_ok and 17 <= ns <= 20 and (0 if self.f16 else 256) <= tiles < 2048)
 
     def _common(self):
         return (self.n, ctypes.cast(self.wt, ctypes.c_void_p), ctypes.cast(self.wpk, ctypes.c_void_p), ctypes.cast(self.bias, ctypes.c_void_p),
@@ -379,7 +388,7 @@ class PatchAugNetEngine:
             call("pa_knnquery", B, n, m, ns, ptr(src), ptr(new_xyz), ptr(nbr), ptr(d2))
             self._mark(f"sa{i}.knn")
             feat = l_feat[i]
-            if chain.hidden_ok_pooled:
+            if chain.pooled_ok(B * m, ns):
                 y = chain.sa(src, feat, cidx, nbr, c_feat, pooled=True)                      # (B*m, C')
             else:  # wide hidden layers: rows in group order, then the max over each group's ns rows
                 full = chain.sa(src, feat, cidx, nbr, c_feat, pooled=False)                  # (B*m*ns, C')

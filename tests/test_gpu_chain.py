@@ -91,6 +91,33 @@ def test_sa_unpooled_then_rowgroup_max(B, n, m, ns, C, dims):
     assert torch.equal(pooled.cpu(), got.view(B * m, ns, -1).max(dim=1)[0].cpu())
 
 
+@pytest.mark.parametrize("f16", [False, True])
+@pytest.mark.parametrize("B,n,m,ns,C,dims", [(32, 256, 64, 20, 256, [259, 256, 256, 512]), (70, 128, 16, 20, 256, [259, 256, 256, 512]),
+                                              (20, 256, 64, 20, 128, [131, 128, 128, 256]), (65, 64, 16, 18, 61, [64, 64, 256, 128])])
+def test_sa_pooled_wide_hidden_equals_unpooled(B, n, m, ns, C, dims, f16):
+    """Wide hidden layers: the shared-tile pooled kernel (the engine picks it for 256 <= four-group tiles < 2048; any count below 2048
+    on the fp16 path) must give the same bits as the unpooled kernel followed by pa_rowgroup_max (what other batch sizes run) --
+    results may not depend on the batch size."""
+    from patchaugnet_amd import _lib
+    from patchaugnet_amd.engine import _Chain
+    ref, eng = make_layers(dims, seed=11)
+    xyz, feat, cidx, nbr = sa_inputs(B, n, m, ns, C, seed=5)
+    chain = _Chain(eng, f16=f16)
+    assert chain.pooled_ok(B * m, ns) and not chain.hidden_ok_pooled
+    assert not chain.pooled_ok(8192, ns) and chain.pooled_ok(8, ns) == f16
+    args = (xyz.cuda(), feat.cuda().contiguous(), cidx.cuda(), nbr.cuda(), C)
+    got = chain.sa(*args, pooled=True)
+    full = chain.sa(*args, pooled=False)
+    two_step = torch.empty(B * m, dims[-1], device="cuda")
+    _lib.call("pa_rowgroup_max", B * m, ns, dims[-1], _lib.ptr(full), _lib.ptr(two_step))
+    assert torch.equal(got, two_step)
+    if f16:
+        return
+    rows = sa_rows_ref(xyz, feat, cidx, nbr).double()
+    exp = mlp_ref(rows, [(w.float().double(), b.float().double()) for w, b in ref]).max(dim=2)[0].reshape(B * m, -1)
+    close(got, exp)
+
+
 @pytest.mark.parametrize("B,n,m,c2,c1,dims", [(2, 128, 16, 512, 256, [768, 256, 256]), (2, 1024, 128, 256, 64, [320, 256, 256]),
                                                (2, 4096, 1024, 256, 3, [259, 256, 256, 256]), (1, 50, 7, 8, 0, [8, 16]), (1, 33, 9, 4, 5, [9, 32, 16])])
 def test_fp_interpolate(B, n, m, c2, c1, dims):
