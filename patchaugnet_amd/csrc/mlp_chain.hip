@@ -466,7 +466,8 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
     static const long split_below = getenv("PA_CHAIN_SPLIT_BELOW") ? atol(getenv("PA_CHAIN_SPLIT_BELOW")) : 2048;   // tuning knob
     if (!is_pooled) {
         const long t32 = (total_rows + 31) / 32;
-        if (can_split && t32 < split_below) { split = true; RTv = t32 >= 512 ? 2 : 1; }
+        static const long rt2_above = getenv("PA_CHAIN_SPLIT_RT2_ABOVE") ? atol(getenv("PA_CHAIN_SPLIT_RT2_ABOVE")) : 512;          // tuning knob
+        if (can_split && t32 < split_below) { split = true; RTv = t32 >= rt2_above ? 2 : 1; }
         // Many rows and every layer exactly 256 wide: 128-row tiles shared by the four waves, each wave owning 64 output columns.
         // A wave then pulls only ITS quarter of each weight matrix (1 KB per k-step instead of 4 KB four times per CU).
         // (kept selectable for experiments; with packed weights the wave-private tiling is faster at every size measured: default off)

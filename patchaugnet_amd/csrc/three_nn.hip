@@ -22,12 +22,30 @@ __device__ __forceinline__ void stage_tile(float4 *s, const float *__restrict__ 
     for (int i = tid; i < count; i += nt) s[i] = make_float4(src[i * 3 + 0], src[i * 3 + 1], src[i * 3 + 2], 0.f);
 }
 
+// one candidate against the running (d2 asc, index asc) top three: the strict compares of the reference
+// (interpolation_cuda_kernel.cu:156-170), a tie keeps the earlier index.
+__device__ __forceinline__ void top3_insert(float d, int gi, float &b1, float &b2, float &b3, int &i1, int &i2, int &i3)
+{
+    const bool c1 = d < b1, c2 = d < b2, c3 = d < b3;
+    b3 = c2 ? b2 : (c3 ? d : b3);
+    i3 = c2 ? i2 : (c3 ? gi : i3);
+    b2 = c1 ? b1 : (c2 ? d : b2);
+    i2 = c1 ? i1 : (c2 ? gi : i2);
+    b1 = c1 ? d : b1;
+    i1 = c1 ? gi : i1;
+}
+
+// K9.  The brute-force scan is VALU-issue bound (4096 x 1024 pairs per cloud at the finest level, ~21 instructions per pair).
+// Candidates are staged in PAIRS ({x0,x1,y0,y1 | z0,z1,-,-}: 32-byte LDS records, every lane reads the same record: broadcast) and the
+// loop is unrolled over 4 records: 89.8 -> 80.2 us at (32, 4096, 1024).  Measured and rejected on gfx950 (tools/probes/tnn_time.py):
+// v_pk_add/mul_f32 for the two distances (no gain: the packed fp32 ops issue at half rate) and v_med3_f32 for the value updates
+// (101 us: slower than the compare/select chain it replaces).
 template <bool WEIGHTS>
 __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float *__restrict__ unknown_all,
                                                          const float *__restrict__ known_all, float *__restrict__ dist2_all,
                                                          int *__restrict__ idx_all)
 {
-    __shared__ float4 s[TILE];
+    __shared__ float4 s[TILE];                       // TILE / 2 pair records of two float4
     const int b = blockIdx.y, tid = threadIdx.x;
     const int pt = blockIdx.x * 256 + tid;
     const float *known = known_all + (size_t)b * m * 3;
@@ -41,20 +59,23 @@ __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float
     int i1 = 0, i2 = 0, i3 = 0;
     for (int base = 0; base < m; base += TILE) {
         const int cnt = min(TILE, m - base);
+        const int pairs = (cnt + 1) >> 1;
         __syncthreads();
-        stage_tile(s, known + (size_t)base * 3, cnt, tid, 256);
+        for (int p = tid; p < pairs; p += 256) {     // a missing second candidate sits at +inf: its distance is +inf and never admitted
+            const float *a = known + (size_t)(base + 2 * p) * 3;
+            const bool two = 2 * p + 1 < cnt;
+            s[2 * p] = make_float4(a[0], two ? a[3] : inf, a[1], two ? a[4] : inf);
+            s[2 * p + 1] = make_float4(a[2], two ? a[5] : inf, 0.f, 0.f);
+        }
         __syncthreads();
-        for (int k = 0; k < cnt; ++k) {
-            const float4 p = s[k];
-            const float d = (ux - p.x) * (ux - p.x) + (uy - p.y) * (uy - p.y) + (uz - p.z) * (uz - p.z);  // :155
-            const int gi = base + k;
-            const bool c1 = d < b1, c2 = d < b2, c3 = d < b3;
-            b3 = c2 ? b2 : (c3 ? d : b3);
-            i3 = c2 ? i2 : (c3 ? gi : i3);
-            b2 = c1 ? b1 : (c2 ? d : b2);
-            i2 = c1 ? i1 : (c2 ? gi : i2);
-            b1 = c1 ? d : b1;
-            i1 = c1 ? gi : i1;
+#pragma unroll 4
+        for (int p = 0; p < pairs; ++p) {
+            const float4 q0 = s[2 * p], q1 = s[2 * p + 1];
+            const float d0 = (ux - q0.x) * (ux - q0.x) + (uy - q0.z) * (uy - q0.z) + (uz - q1.x) * (uz - q1.x);  // :155
+            const float d1 = (ux - q0.y) * (ux - q0.y) + (uy - q0.w) * (uy - q0.w) + (uz - q1.y) * (uz - q1.y);
+            const int gi = base + 2 * p;
+            top3_insert(d0, gi, b1, b2, b3, i1, i2, i3);
+            top3_insert(d1, gi + 1, b1, b2, b3, i1, i2, i3);
         }
     }
     if (pt < n) {
