@@ -183,7 +183,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     from patchaugnet_amd.hostcpu import limit_host_threads
-    limit_host_threads()     # host-side torch ops sized by os.cpu_count() overrun the cgroup CPU quota and get the process throttled
+    # host-side torch ops sized by os.cpu_count() overrun the cgroup CPU quota and get the process throttled; N ranks share the grant
+    from patchaugnet_amd.hostcpu import cpu_budget
+    limit_host_threads(max(1, cpu_budget() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))))
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
