@@ -37,7 +37,7 @@ def parse():
     p.add_argument("--model", choices=["patch_aug_net", "pptnet"], default="patch_aug_net", help="pptnet = BASELINE.json configs[4]")
     p.add_argument("--mlp-dtype", choices=["f32", "f16"], default="f32",
                    help="f16: shared-MLP chains on fp16 MFMA (fp32 accumulate; cosine >= 0.999 contract) -- not the headline configuration")
-    p.add_argument("--streams", type=int, default=3, help="HIP streams the consecutive steps are issued on (1 = strictly sequential)")
+    p.add_argument("--streams", type=int, default=4, help="HIP streams the consecutive steps are issued on (1 = strictly sequential)")
     return p.parse_args()
 
 

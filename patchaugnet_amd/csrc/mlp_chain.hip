@@ -315,7 +315,7 @@ __device__ __forceinline__ void run_layer_chunks(float *act, const PaChain &a, c
 // Pooled wave-private kernels (the set-abstraction levels) are gather-latency bound in their prologue: keep two waves per SIMD
 // (<= 256 registers) there; the plain row kernels trade occupancy for their 128 accumulator registers.
 template <int RT, int NCMAX, int MODE, bool POOLED, int WPT>
-__global__ __launch_bounds__((!POOLED && WPT == 1 && RT == 1) ? 512 : 256, (POOLED && RT <= 5) ? 2 : 1) void chain_kernel(PaChain a)
+__global__ __launch_bounds__(256, (POOLED && RT <= 5) ? 2 : 1) void chain_kernel(PaChain a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int R = RT * 16;
@@ -386,9 +386,7 @@ int launch_chain(const PaChain &a, int waves_per_wg, long ntiles, hipStream_t st
 template <int MODE>
 void launch_rows(const PaChain &a, int rt, bool split, int wpw, long ntiles, hipStream_t st)
 {
-    if (!split && rt == 1) launch_chain<1, 16, MODE, false, 1>(a, wpw, ntiles, st);   // 16-row wave tiles, 8 waves per workgroup (2 per SIMD)
-    else if (!split) launch_chain<2, 16, MODE, false, 1>(a, wpw, ntiles, st);
-    else if (rt == 8) launch_chain<8, 4, MODE, false, 4>(a, 4, ntiles, st);
+    if (!split) launch_chain<2, 16, MODE, false, 1>(a, wpw, ntiles, st);
     else if (rt == 2) launch_chain<2, 8, MODE, false, 4>(a, 4, ntiles, st);
     else launch_chain<1, 8, MODE, false, 4>(a, 4, ntiles, st);
 }
@@ -468,18 +466,8 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
         const long t32 = (total_rows + 31) / 32;
         static const long rt2_above = getenv("PA_CHAIN_SPLIT_RT2_ABOVE") ? atol(getenv("PA_CHAIN_SPLIT_RT2_ABOVE")) : 512;          // tuning knob
         if (can_split && t32 < split_below) { split = true; RTv = t32 >= rt2_above ? 2 : 1; }
-        // Many rows and every layer exactly 256 wide: 128-row tiles shared by the four waves, each wave owning 64 output columns.
-        // A wave then pulls only ITS quarter of each weight matrix (1 KB per k-step instead of 4 KB four times per CU).
-        // (kept selectable for experiments; with packed weights the wave-private tiling is faster at every size measured: default off)
-        static const long big_above = getenv("PA_CHAIN_BIG_ABOVE") ? atol(getenv("PA_CHAIN_BIG_ABOVE")) : (1L << 60);
-        bool all256 = true;
-        for (int l = 0; l < nlayers; ++l) all256 = all256 && nout[l] == 256;
-        if (!split && all256 && total_rows >= big_above && (size_t)128 * (maxk + 2) * 4 <= 150 * 1024) { split = true; RTv = 8; }
-        // Wave-private tiles of 16 rows with EIGHT waves per workgroup: two waves per SIMD fill each other's issue gaps (every
-        // non-MFMA instruction costs a lone wave ~6-7 matrix-pipe cycles) and one wave's gather prologue / store epilogue runs under
-        // the other's MFMA loop.  Needs 8 x 16 x (K+2) x 4 bytes of LDS.
-        static const long rt1_above = getenv("PA_CHAIN_RT1_ABOVE") ? atol(getenv("PA_CHAIN_RT1_ABOVE")) : (1L << 60);
-        if (!split && total_rows >= rt1_above && (size_t)8 * (16 * (maxk + 2) + 160) * 4 <= 156 * 1024) RTv = 1;
+        // Measured and dropped (round 1): 128-row tiles shared by four waves for all-256-wide chains (slower than wave-private tiles
+        // once the weights are packed) and 16-row wave-private tiles with eight waves per workgroup (no gain over 32-row tiles).
     } else {
         const long tp = (rows + 3) / 4;
         if (can_split && tp < 2048 && RTv == 5) split = true;
@@ -540,7 +528,7 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
     // waves per workgroup of the wave-private tilings.  Smaller workgroups leave LDS granules in which OTHER kernels' workgroups
     // (kNN: 70 KB, 3-NN, FPS) can become resident next to a chain workgroup when several streams are in flight.
     static const int wpw_env = getenv("PA_CHAIN_WPW") ? atoi(getenv("PA_CHAIN_WPW")) : 0;
-    int wpw = (!is_pooled && !split && RTv == 1) ? 8 : (wpw_env > 0 ? wpw_env : 4);
+    int wpw = wpw_env > 0 ? wpw_env : 4;
     while (wpw > 1 && wpw * per_wave > 156 * 1024) wpw >>= 1;
     const long ntiles = is_pooled ? (rows + 3) / 4 : (total_rows + R - 1) / R;
 

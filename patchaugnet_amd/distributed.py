@@ -39,7 +39,7 @@ def all_gather_descriptors(local, n_total):
 
 
 @torch.no_grad()
-def extract_dataset(model, load_batch, n_total, batch_size=32, n_streams=3, dim=256, device=None):
+def extract_dataset(model, load_batch, n_total, batch_size=32, n_streams=4, dim=256, device=None):
     """Descriptors of records 0..n_total-1 on every rank.
 
     load_batch(lo, hi) -> (hi - lo, 1, N, 3) fp32 tensor on the compute device (the caller owns file I/O / H2D);

@@ -10,9 +10,30 @@ HIP streams: batch i+1's sampling overlaps batch i's MFMA work.  Results are ide
 import torch
 
 
+_PRIMED = set()
+
+
+def _prime_stream_queues(device):
+    """ROCm 7.2 binds a HIP stream to one of the process's 4 hardware queues when the stream is first used.  Measured on MI355X
+    (tools/probes/small_batch.py): four pipeline streams that are the FIRST streams of the process sustain 23.0 k submaps/s, the same
+    four streams created after a few other streams have run anything sustain 29.5 k (they then spread one per hardware queue instead
+    of crowding next to the default stream).  So a handful of throw-away pool streams run one tiny kernel each before the pipeline's
+    own streams are taken.  Pure scheduling: no effect on results.  PA_STREAM_PRIME=0 disables it."""
+    import os
+    key = (device.type, device.index)
+    if key in _PRIMED or os.environ.get("PA_STREAM_PRIME", "1") == "0":
+        return
+    _PRIMED.add(key)
+    for _ in range(4):
+        with torch.cuda.stream(torch.cuda.Stream(device=device)):
+            torch.zeros(8, device=device).add_(1)
+    torch.cuda.synchronize(device)
+
+
 class StreamPipeline:
     def __init__(self, n_streams=2, device=None):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        _prime_stream_queues(self.device)
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(max(1, n_streams))]
         self._i = 0
 
@@ -37,7 +58,7 @@ class StreamPipeline:
 
 
 @torch.no_grad()
-def extract_descriptors(model, batches, n_streams=3, out=None):
+def extract_descriptors(model, batches, n_streams=4, out=None):
     """batches: iterable of (B,1,N,3) device tensors -> (sum B, 256) descriptors in input order."""
     batches = list(batches)
     total = sum(b.shape[0] for b in batches)

@@ -29,7 +29,7 @@ def timed(fn, iters, warm=3):
     return (time.perf_counter() - t0) / iters
 
 
-def extraction_rate(model, batch, kind, streams=3, steps=None):
+def extraction_rate(model, batch, kind, streams=4, steps=None):
     x = synthetic_submaps(batch, 4096, seed=1234, kind=kind).cuda()
     steps = steps or max(12, min(100, 3200 // batch))
     out = torch.empty(steps, batch, 256, device="cuda")
