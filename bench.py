@@ -37,6 +37,7 @@ def parse():
     p.add_argument("--model", choices=["patch_aug_net", "pptnet"], default="patch_aug_net", help="pptnet = BASELINE.json configs[4]")
     p.add_argument("--mlp-dtype", choices=["f32", "f16"], default="f32",
                    help="f16: shared-MLP chains on fp16 MFMA (fp32 accumulate; cosine >= 0.999 contract) -- not the headline configuration")
+    p.add_argument("--no-graphs", action="store_true", help="issue every step's launches from Python instead of replaying one captured hipGraph per stream")
     p.add_argument("--streams", type=int, default=4, help="HIP streams the consecutive steps are issued on (1 = strictly sequential)")
     return p.parse_args()
 
@@ -147,24 +148,32 @@ def pcie_inclusive(model, a, pipe):
     host_x = [synthetic_submaps(a.batch, a.points, seed=77 + i).pin_memory() for i in range(nbuf)]
     host_d = torch.empty(a.steps, a.batch, 256).pin_memory()
 
+    graphed = hasattr(pipe, "run")          # GraphedExtractor: the pinned batch is copied straight into the slot's static input buffer
+
     def one(i):
         xd = host_x[(i if i >= 0 else -1 - i) % nbuf].to("cuda", non_blocking=True)
         d = model(xd, return_feat=False)
         if i >= 0:
             host_d[i].copy_(d, non_blocking=True)
 
+    def submit(i):
+        if graphed:
+            pipe.run(host_x[(i if i >= 0 else -1 - i) % nbuf], out=host_d[i] if i >= 0 else None)
+        else:
+            pipe.submit(one, i)
+
     rates = []
     with torch.no_grad():
         pipe.begin()
         for i in range(nbuf):
-            pipe.submit(one, -1 - i)
+            submit(-1 - i)
         pipe.end()
         for rep in range(4):    # repetition 0 is warm-up (first D2H into the fresh pinned result pages); then the median of 3
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             pipe.begin()
             for i in range(a.steps):
-                pipe.submit(one, i)
+                submit(i)
             pipe.end()
             torch.cuda.synchronize()
             if rep > 0:
@@ -213,8 +222,28 @@ def main():
     x = synthetic_submaps(a.batch, a.points, seed=1234 + rank).cuda()
     descs = torch.empty(a.steps, a.batch, 256, device="cuda")
 
-    from patchaugnet_amd.extract import StreamPipeline
-    pipe = StreamPipeline(a.streams)
+    from patchaugnet_amd.extract import GraphedExtractor, StreamPipeline
+    use_graphs = not a.no_graphs and not a.module_path
+    if use_graphs:
+        # one captured hipGraph of the step per stream (same kernels, same arguments, bit-identical descriptors: tests/test_gpu_extract.py);
+        # a replay costs the host 0.03 ms instead of 0.30 ms of Python launches
+        class _Graphed:
+            def __init__(self):
+                self.gx = GraphedExtractor(model, tuple(x.shape), a.streams)
+            def begin(self):
+                self.gx.begin()
+            def end(self):
+                self.gx.end()
+            def submit(self, fn, i):
+                self.gx.run(x, out=descs[i] if i >= 0 else None)
+        try:
+            pipe = _Graphed()
+        except Exception as ex:      # capture refused (driver / allocator state): same kernels issued from Python instead
+            print(f"bench.py: hipGraph capture failed ({ex!r}); falling back to python launches", file=sys.stderr)
+            use_graphs = False
+            torch.cuda.synchronize()
+    if not use_graphs:
+        pipe = StreamPipeline(a.streams)
 
     def one(i):
         d = model(x, return_feat=False)
@@ -263,7 +292,8 @@ def main():
                                 f"PPT-Net inference, {a.points}-pt synthetic submaps, batch={a.batch} per MI355X (BASELINE.json configs[4])"),
                    "batch_per_gpu": a.batch, "points": a.points,
                    "path": "fused HIP engine" if model.fused_eval else "HIP point ops + torch dense ops (module path)",
-                   "weights": "key-seeded random init", "parallelism": f"dp{world}", "streams": a.streams},
+                   "weights": "key-seeded random init", "parallelism": f"dp{world}", "streams": a.streams,
+                   "launch": "hipGraph replay per stream" if use_graphs else "python launches"},
     }
     if world == 1 and (a.model != "patch_aug_net" or a.mlp_dtype != "f32"):   # non-headline configurations: stage times only
         try:
@@ -281,7 +311,7 @@ def main():
             except Exception as ex:  # attribution is diagnostics; never lose the bench line over it
                 line["kernels"]["stages_ms"] = {"error": repr(ex)}
         try:
-            line["pcie_inclusive"] = pcie_inclusive(model, a, pipe)
+            line["pcie_inclusive"] = pcie_inclusive(model, a, pipe.gx if use_graphs else pipe)
         except Exception as ex:
             line["pcie_inclusive"] = {"error": repr(ex)}
         if not a.no_cpu_baseline:

@@ -119,13 +119,21 @@ def ptr(t):
     return _P(t.data_ptr()) if t is not None else _P(0)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream_ptr():
+    """hipStream_t of torch's current stream on the current device.  torch.cuda.current_stream() costs ~8 us of Python per call (device
+    index resolution); the raw accessors are two C calls -- with ~45 launches per step that is a third of the host's issue time."""
+    if _raw_stream is not None and _cur_device is not None:
+        return _P(_raw_stream(_cur_device()))
     return _P(torch.cuda.current_stream().cuda_stream)
 
 
 def call(name, *args, stream=None):
     """Invoke an entry point on the current torch stream; raise on a non-zero return."""
-    l = lib()
+    l = _lib or lib()
     rc = getattr(l, name)(*args, stream if stream is not None else stream_ptr())
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {l.pa_last_error().decode()}")
