@@ -39,12 +39,14 @@ def all_gather_descriptors(local, n_total):
 
 
 @torch.no_grad()
-def extract_dataset(model, load_batch, n_total, batch_size=32, n_streams=4, dim=256, device=None):
+def extract_dataset(model, load_batch, n_total, batch_size=32, n_streams=4, dim=256, device=None, graphs=False):
     """Descriptors of records 0..n_total-1 on every rank.
 
     load_batch(lo, hi) -> (hi - lo, 1, N, 3) fp32 tensor on the compute device (the caller owns file I/O / H2D);
     model(x, return_feat=False) -> (B, dim).  Batches of this rank's shard are issued round-robin on `n_streams` HIP streams
-    (patchaugnet_amd/extract.py); n_streams = 0 runs them inline on the current stream (CPU stand-ins in tests)."""
+    (patchaugnet_amd/extract.py); n_streams = 0 runs them inline on the current stream (CPU stand-ins in tests).  graphs=True replays
+    one captured hipGraph per stream for the full-size batches (extract.GraphedExtractor); load_batch may then return pinned host
+    tensors, which are copied straight into the graph's static input buffer."""
     _, rank, world = dist_info()
     lo, hi = shard_bounds(n_total, rank, world)
     if device is None:
@@ -55,9 +57,18 @@ def extract_dataset(model, load_batch, n_total, batch_size=32, n_streams=4, dim=
         from .extract import StreamPipeline
         pipe = StreamPipeline(n_streams, device)
         pipe.begin()
+    gx = None
     for b0 in range(lo, hi, batch_size):
         b1 = min(b0 + batch_size, hi)
         dst = local[b0 - lo:b1 - lo]
+        if graphs and pipe is not None and b1 - b0 == batch_size and hi - lo >= 2 * n_streams * batch_size:
+            x = load_batch(b0, b1)
+            if gx is None:
+                from .extract import GraphedExtractor
+                gx = GraphedExtractor(model, tuple(x.shape), n_streams, device)
+                gx.begin()
+            gx.run(x, out=dst)
+            continue
 
         def step(b0=b0, b1=b1, dst=dst):
             dst.copy_(model(load_batch(b0, b1), return_feat=False))
@@ -67,4 +78,6 @@ def extract_dataset(model, load_batch, n_total, batch_size=32, n_streams=4, dim=
             step()
     if pipe is not None:
         pipe.end()
+    if gx is not None:
+        gx.end()
     return all_gather_descriptors(local, n_total)

@@ -47,3 +47,21 @@ def test_graphed_extractor_slots_and_host_input():
     torch.cuda.synchronize()
     for i in range(6):
         assert torch.equal(out[i], ref[i]), i
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_extract_dataset_single_rank(graphs):
+    """distributed.extract_dataset on one rank (no process group): full batches through the pipeline / graphs, ragged tail eagerly."""
+    from patchaugnet_amd.distributed import extract_dataset
+    m = _model("patch_aug_net")
+    x = synthetic_submaps(70, 4096, 41)
+    xd = x.cuda()
+    with torch.no_grad():
+        ref = torch.cat([m(xd[i:i + 8].contiguous(), return_feat=False) for i in range(0, 70, 8)])
+    load = (lambda lo, hi: x[lo:hi].contiguous().pin_memory()) if graphs else (lambda lo, hi: xd[lo:hi].contiguous())
+    if not graphs:
+        got = extract_dataset(m, load, 70, batch_size=8, n_streams=4)
+    else:                                                                   # pinned host batches; the ragged tail needs a device tensor
+        got = extract_dataset(m, lambda lo, hi: load(lo, hi) if hi - lo == 8 else xd[lo:hi].contiguous(), 70, batch_size=8, n_streams=4, graphs=True)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
