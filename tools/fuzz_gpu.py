@@ -1,0 +1,239 @@
+#!/usr/bin/env python
+"""Randomised shape fuzzing of the HIP ops against the CPU oracle / fp64 torch (run on the GPU box; not part of the test suite).
+    python tools/fuzz_gpu.py [seconds per op family, default 20]
+Index outputs and pure gathers must be bit-exact; GEMM-based ops within 2e-5 relative of an fp64 reference."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from patchaugnet_amd.hostcpu import limit_host_threads
+limit_host_threads()
+from oracle import oracle_ops as o
+from patchaugnet_amd import pointops as P, _lib
+from patchaugnet_amd._lib import call, ptr
+from patchaugnet_amd.engine import pack_weights
+
+BUDGET = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
+rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "2026")))
+
+
+def cloud(b, n):
+    kind = rng.integers(0, 4)
+    x = (rng.random((b, n, 3), dtype=np.float32) * 2 - 1).astype(np.float32)
+    if kind == 1:
+        x = (np.round(x * rng.integers(2, 9)) / 8).astype(np.float32)
+    elif kind == 2 and n > 4:
+        k = max(n // 8, 1)
+        x[:, rng.choice(n, k, replace=False)] = x[:, rng.choice(n, k, replace=False)]
+    elif kind == 3:
+        x[..., 2] = 0.0          # planar
+    return x
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def logint(lo, hi):
+    return int(np.exp(rng.uniform(np.log(lo), np.log(hi + 1))))
+
+
+def run(name, fn):
+    t0, cases = time.time(), 0
+    while time.time() - t0 < BUDGET:
+        desc = fn()
+        cases += 1
+        if desc is not None:
+            print(f"FAIL {name}: {desc}", flush=True)
+            return False
+    print(f"ok   {name}: {cases} random cases", flush=True)
+    return True
+
+
+def f_fps():
+    b, n = int(rng.integers(1, 4)), logint(1, 6000)
+    m = int(rng.integers(1, min(n, 1200) + 1))
+    x = cloud(b, n)
+    if not np.array_equal(P.furthestsampling(dev(x), m).cpu().numpy(), o.furthestsampling(x, m)):
+        return f"b={b} n={n} m={m}"
+
+
+def f_knn():
+    b, n, m = int(rng.integers(1, 4)), logint(1, 5000), logint(1, 1100)
+    k = int(rng.integers(1, 65))
+    x, q = cloud(b, n), cloud(b, m)
+    if rng.random() < 0.5:
+        mm = min(m, n)
+        q[:, :mm] = x[:, :mm]
+    ref = o.knnquery(k, x, q)
+    got = P.knnquery(k, dev(x), dev(q)).cpu().numpy()
+    if not np.array_equal(got, ref[0] if isinstance(ref, tuple) else ref):
+        return f"b={b} n={n} m={m} k={k}"
+
+
+def f_3nn():
+    b, n, m = int(rng.integers(1, 4)), logint(1, 5000), logint(1, 3000)
+    u, kn = cloud(b, n), cloud(b, m)
+    rd, ri = o.nearestneighbor(u, kn)
+    gd, gi = P.nearestneighbor(dev(u), dev(kn))
+    if not (np.array_equal(gi.cpu().numpy(), ri) and np.array_equal(gd.cpu().numpy(), np.sqrt(rd))):
+        return f"b={b} n={n} m={m}"
+
+
+def f_gather():
+    b, c, n, m, k = int(rng.integers(1, 4)), logint(1, 300), logint(1, 20000), logint(1, 600), int(rng.integers(1, 33))
+    if b * c * m * k > 3e7:
+        return None
+    f = rng.standard_normal((b, c, n)).astype(np.float32)
+    idx = rng.integers(0, n, (b, m, k), dtype=np.int32)
+    if not np.array_equal(P.grouping(dev(f), dev(idx)).cpu().numpy(), o.grouping_forward(f, idx)):
+        return f"grouping b={b} c={c} n={n} m={m} k={k}"
+    i1 = rng.integers(0, n, (b, m), dtype=np.int32)
+    if not np.array_equal(P.gathering(dev(f), dev(i1)).cpu().numpy(), o.gathering_forward(f, i1)):
+        return f"gathering b={b} c={c} n={n} m={m}"
+    i3 = rng.integers(0, n, (b, m, 3), dtype=np.int32)
+    w = rng.random((b, m, 3), dtype=np.float32)
+    if not np.array_equal(P.interpolation(dev(f), dev(i3), dev(w)).cpu().numpy(), o.interpolation_forward(f, i3, w)):
+        return f"interpolation b={b} c={c} n={n} m={m}"
+
+
+def f_backward():
+    b, c, n, m, k = int(rng.integers(1, 4)), logint(1, 300), logint(1, 20000), logint(1, 600), int(rng.integers(1, 21))
+    if b * c * m * k > 2e7:
+        return None
+    f = torch.randn(b, c, n, device="cuda", requires_grad=True)
+    idx = dev(rng.integers(0, n, (b, m, k), dtype=np.int32))
+    go = torch.randn(b, c, m, k, device="cuda")
+    P.grouping(f, idx).backward(go)
+    tol = 1e-4 + 4e-6 * (m * k / n)        # fp32 sums of ~m*k/n addends per bin in a different order than the oracle
+    if not np.allclose(f.grad.cpu().numpy(), o.grouping_backward(go.cpu().numpy(), idx.cpu().numpy(), n), rtol=1e-4, atol=tol):
+        return f"grouping_backward b={b} c={c} n={n} m={m} k={k}"
+    f.grad = None
+    i3 = dev(rng.integers(0, n, (b, m, 3), dtype=np.int32))
+    w = torch.rand(b, m, 3, device="cuda")
+    g3 = torch.randn(b, c, m, device="cuda")
+    P.interpolation(f, i3, w).backward(g3)
+    if not np.allclose(f.grad.cpu().numpy(), o.interpolation_backward(g3.cpu().numpy(), i3.cpu().numpy(), w.cpu().numpy(), n), rtol=1e-4, atol=tol):
+        return f"interpolation_backward b={b} c={c} n={n} m={m}"
+
+
+def f_linear():
+    rows, k, n = logint(1, 5000), logint(1, 600), 16 * int(rng.integers(1, 65))
+    relu, res, packed = int(rng.integers(0, 2)), bool(rng.integers(0, 2)), n % 64 == 0 and bool(rng.integers(0, 2))
+    x = torch.randn(rows, k, device="cuda")
+    w = torch.randn(n, k, device="cuda") / k ** 0.5
+    bias = torch.randn(n, device="cuda")
+    r = torch.randn(rows, n, device="cuda") if res else None
+    kpad = (k + 3) // 4 * 4
+    wt = torch.zeros(kpad, n, device="cuda")
+    wt[:k] = w.t()
+    out = torch.empty(rows, n, device="cuda")
+    call("pa_linear", rows, k, n, ptr(x), k, ptr(wt), ptr(pack_weights(wt)) if packed else None, ptr(bias), relu, ptr(r), n if res else 0, ptr(out), n)
+    ref = x.double() @ w.double().t() + bias.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    if res:
+        ref = ref + r.double()
+    err = (out.double() - ref).abs().max().item()
+    if not err <= 2e-5 * max(ref.abs().max().item(), 1.0):
+        return f"rows={rows} k={k} n={n} relu={relu} res={res} packed={packed} err={err}"
+
+
+def f_attention():
+    from patchaugnet_amd import backbone
+    from patchaugnet_amd.engine import _Attn
+    from oracle import models_cpu
+    b, n, c = int(rng.integers(1, 4)), logint(1, 1100), int(rng.choice([64, 128, 256, 512]))
+    if n * c > 300000:
+        n = max(1, 300000 // c)
+    torch.manual_seed(int(rng.integers(0, 1 << 30)))
+    sa = backbone.SALayer(c, 8).eval()
+    for p in sa.parameters():
+        p.data.mul_(0.5)
+    x = torch.randn(b, c, n)
+    sd = {"s." + k: v for k, v in sa.state_dict().items()}
+    with torch.no_grad():
+        ref = models_cpu.sa_layer(sd, "s", x, 8)
+        xm = x.transpose(1, 2).contiguous().view(b * n, c).cuda()
+        got = _Attn(sa, xm.device).run(xm, b, n).view(b, n, c).transpose(1, 2).cpu()
+    err = (got - ref).abs().max().item()
+    if not err <= 5e-5 * max(ref.abs().max().item(), 1.0):
+        return f"b={b} n={n} c={c} err={err}"
+
+
+def _chain_dims(k0, pooled):
+    """Random legal widths: hidden layers 16*2^j (single chunk), <= 64 when pooled wave-private, last layer a multiple of 16."""
+    nl = int(rng.integers(1, 4))
+    hid_choices = [16, 32, 64] if pooled else [16, 32, 64, 128, 256]
+    dims = [k0] + [int(rng.choice(hid_choices)) for _ in range(nl - 1)] + [16 * int(rng.integers(1, 33))]
+    return dims
+
+
+def f_chain_sa():
+    from tests.test_gpu_chain import make_layers, mlp_ref, sa_inputs, sa_rows_ref
+    from patchaugnet_amd.engine import _Chain
+    B, n, ns = int(rng.integers(1, 4)), logint(2, 3000), int(rng.choice([13, 16, 17, 20, 29, 32]))
+    m, C = logint(1, min(n, 400)), int(rng.choice([3, 5, 8, 61, 64, 128]))
+    pooled = bool(rng.integers(0, 2))
+    if not pooled:
+        ns = int(rng.integers(1, 33))
+    if B * m * ns * C > 4e6:
+        return None
+    dims = _chain_dims(3 + C, pooled)
+    seed = int(rng.integers(0, 1 << 30))
+    ref, eng = make_layers(dims, seed=seed)
+    xyz, feat, cidx, nbr = sa_inputs(B, n, m, ns, C, seed=seed + 1)
+    rows = sa_rows_ref(xyz, feat, cidx, nbr).double()
+    full = mlp_ref(rows, [(w.float().double(), b.float().double()) for w, b in ref])
+    exp = full.max(dim=2)[0].reshape(B * m, -1) if pooled else full.reshape(B * m * ns, -1)
+    got = _Chain(eng).sa(xyz.cuda(), feat.cuda().contiguous(), cidx.cuda(), nbr.cuda(), C, pooled=pooled)
+    err = (got.double().cpu() - exp).abs().max().item()
+    if not err <= 2e-5 * (exp.abs().max().item() + 1e-12):
+        return f"B={B} n={n} m={m} ns={ns} C={C} dims={dims} pooled={pooled} err={err}"
+
+
+def f_chain_fp():
+    from tests.test_gpu_chain import make_layers, mlp_ref
+    from patchaugnet_amd.engine import _Chain
+    B, n, m = int(rng.integers(1, 4)), logint(1, 5000), logint(1, 1200)
+    c2, c1 = 4 * int(rng.integers(1, 129)), int(rng.choice([0, 3, 4, 5, 64, 256]))
+    if B * n * (c2 + c1) > 6e6:
+        return None
+    dims = _chain_dims(c2 + c1, False)
+    seed = int(rng.integers(0, 1 << 30))
+    ref, eng = make_layers(dims, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    known = torch.randn(B, m, c2, generator=g)
+    skip = torch.randn(B, n, c1, generator=g) if c1 else None
+    idx3 = torch.randint(0, m, (B, n, 3), generator=g).int()
+    w3 = torch.rand(B, n, 3, generator=g)
+    w3 = w3 / w3.sum(-1, keepdim=True)
+    bi = torch.arange(B)[:, None]
+    f = [known[bi, idx3[:, :, t].long()] for t in range(3)]
+    interp = (w3[..., 0:1] * f[0] + w3[..., 1:2] * f[1]) + w3[..., 2:3] * f[2]
+    rows = torch.cat([interp, skip], dim=-1) if c1 else interp
+    exp = mlp_ref(rows.double(), [(w.float().double(), b.float().double()) for w, b in ref]).reshape(B * n, -1)
+    got = _Chain(eng).fp(known.cuda(), idx3.cuda(), w3.cuda().contiguous(), skip.cuda() if c1 else None, B, n, m, c2, c1)
+    err = (got.double().cpu() - exp).abs().max().item()
+    if not err <= 2e-5 * (exp.abs().max().item() + 1e-12):
+        return f"B={B} n={n} m={m} c2={c2} c1={c1} dims={dims} err={err}"
+
+
+if __name__ == "__main__":
+    ok = True
+    fams = (("fps", f_fps), ("knn", f_knn), ("3nn", f_3nn), ("gather", f_gather), ("backward", f_backward), ("linear", f_linear),
+            ("attention", f_attention), ("chain_sa", f_chain_sa), ("chain_fp", f_chain_fp))
+    only = os.environ.get("FUZZ_ONLY")
+    for name, fn in fams:
+        if only and name not in only.split(","):
+            continue
+        try:
+            ok = run(name, fn) and ok
+        except Exception as ex:
+            print(f"EXC  {name}: {ex!r}", flush=True)
+            ok = False
+    sys.exit(0 if ok else 1)
