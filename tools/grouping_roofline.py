@@ -1,3 +1,5 @@
+#!/usr/bin/env python
+"""Print the K5 grouping micro-benchmark (bench.grouping_roofline) alone: python tools/grouping_roofline.py"""
 import sys, os, json
 sys.path.insert(0, os.getcwd())
 import torch
