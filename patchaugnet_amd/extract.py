@@ -82,7 +82,7 @@ class GraphedExtractor:
                         model(x, return_feat=False)
                 cur.wait_stream(st)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=st):
+                with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may poll events
                     y = model(x, return_feat=False)
                 self.slots.append((g, x, y, st))
         torch.cuda.synchronize(self.device)
