@@ -440,7 +440,8 @@ class PatchAugNetEngine:
         vlad = torch.matmul(act.transpose(1, 2), x).transpose(1, 2) - a
         return F.normalize(vlad, dim=1, p=2)
 
-    def forward(self, x):
+    def forward(self, x, views=True):
+        """-> desc (B, 256), (fp_features views, level-0 centre indices); views=False skips the index mapping (descriptor-only callers)."""
         xyz = x.squeeze(1).contiguous()
         self._mark("start")
         l_feat, l_c = self.backbone(xyz)
@@ -457,7 +458,7 @@ class PatchAugNetEngine:
             self._mark("vlad")
             desc = self.head.run(v) if self.ppt else self.afa.run_rows(v)
             self._mark("afa")
-            return desc, self._views(feats, l_c)
+            return desc, (self._views(feats, l_c) if views else (None, None))
         v = torch.cat([self._vlad(vl, f) for vl, f in zip(agg.vlads, feats)], dim=-1)       # (B, 256, sum K)
         self._mark("vlad")
         if agg.aggregation_type == 2:
@@ -469,7 +470,7 @@ class PatchAugNetEngine:
         if agg.gating:
             desc = agg.context_gating(desc)
         self._mark("afa")
-        return desc, self._views(feats, l_c)
+        return desc, (self._views(feats, l_c) if views else (None, None))
 
     @staticmethod
     def _views(feats, l_c):

@@ -61,11 +61,11 @@ class Network(nn.Module):
         self.fused_eval = True       # eval()+no_grad() forwards run the fused HIP engine; set False for the module path
 
     # ---- fused inference engine (eval + no_grad) ----------------------------------------------------------------
-    def _fused(self, x):
+    def _fused(self, x, views=True):
         from .engine import PatchAugNetEngine
         if self._engine is None or not self._engine.matches(self, x):
             self._engine = PatchAugNetEngine(self, x.device)
-        return self._engine.forward(x)
+        return self._engine.forward(x, views=views)
 
     def train(self, mode=True):
         self._engine = None            # parameters may change: rebuild folded weights at the next eval forward
@@ -81,7 +81,7 @@ class Network(nn.Module):
             use_engine = self.fused_eval and not self.training and not torch.is_grad_enabled() and nn_dict is None
         fused = use_engine
         if fused:
-            desc, (fp_features, center_idx) = self._fused(x)
+            desc, (fp_features, center_idx) = self._fused(x, views=return_feat)
             return (desc, fp_features, center_idx) if return_feat else desc
         xyz = x.squeeze(1)
         res = self.backbone(xyz)

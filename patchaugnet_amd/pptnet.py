@@ -50,7 +50,7 @@ class Network(nn.Module):
             from .engine import PatchAugNetEngine
             if self._engine is None or not self._engine.matches(self, x):
                 self._engine = PatchAugNetEngine(self, x.device)
-            d, (fp, cidx) = self._engine.forward(x)
+            d, (fp, cidx) = self._engine.forward(x, views=return_feat)
             return (d, fp, cidx) if return_feat else d
         res = self.backbone(x.squeeze(1))
         fp = res["fp_features"]
