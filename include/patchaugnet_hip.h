@@ -65,7 +65,9 @@ int pa_gathering_backward(int b, int c, int n, int m, const float *grad_out, con
 int pa_knnquery(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx, float *dist2, pa_stream_t stream);
 
 /* ---- K5/K6/K8: grouping  (grouping_cuda_kernel.h:16-19, .cu:28-46, :60-74; grouping_int .cu:33-49)
- * forward: out[b,c,j,s] = points[b,c,idx[b,j,s]] */
+ * forward: out[b,c,j,s] = points[b,c,idx[b,j,s]]
+ * backward (here and for gathering / interpolation): ACCUMULATES into grad_points, which the caller zero-fills as the reference's
+ * wrappers do; like the reference's atomicAdd, the order of the float additions is not fixed. */
 int pa_grouping_forward(int b, int c, int n, int m, int nsample, const float *points, const int *idx, float *out, pa_stream_t stream);
 int pa_grouping_backward(int b, int c, int n, int m, int nsample, const float *grad_out, const int *idx, float *grad_points, pa_stream_t stream);
 int pa_grouping_int_forward(int b, int c, int n, int m, int nsample, const int64_t *points, const int *idx, int64_t *out, pa_stream_t stream);
