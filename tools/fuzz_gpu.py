@@ -223,10 +223,52 @@ def f_chain_fp():
         return f"B={B} n={n} m={m} c2={c2} c1={c1} dims={dims} err={err}"
 
 
+def _seed_module(m, seed):
+    from patchaugnet_amd.weights import seeded_state_dict
+    m.load_state_dict(seeded_state_dict(m.state_dict(), seed=seed))
+    return m.cuda().eval()
+
+
+def f_netvlad():
+    from patchaugnet_amd import loupe
+    from patchaugnet_amd.engine import _Vlad
+    b, n, k = int(rng.integers(1, 5)), logint(1, 5000), int(rng.integers(1, 65))
+    v = _seed_module(loupe.NetVLADBase(256, n, k, 256, gating=False), seed=int(rng.integers(0, 1 << 30)))
+    x = torch.randn(b, n, 256, device="cuda") * 0.7
+    pad_l, pad_r = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+    with torch.no_grad():
+        ref = v(x.transpose(1, 2).unsqueeze(-1))
+        out = torch.full((b, 256, pad_l + k + pad_r), 7.0, device="cuda")
+        _Vlad(v, x.device).run(x, out, pad_l + k + pad_r, pad_l)
+        out_t = torch.full((b, pad_l + k + pad_r, 256), 7.0, device="cuda")
+        _Vlad(v, x.device).run(x, out_t, pad_l + k + pad_r, pad_l, rows=True)
+    got = out[:, :, pad_l:pad_l + k]
+    err = (got - ref).abs().max().item()
+    clean = torch.all(out[:, :, :pad_l] == 7.0) and torch.all(out[:, :, pad_l + k:] == 7.0) and torch.all(out_t[:, :pad_l] == 7.0) and torch.all(out_t[:, pad_l + k:] == 7.0)
+    if not (err <= 3e-5 and clean and torch.equal(out_t[:, pad_l:pad_l + k].transpose(1, 2), got)):
+        return f"b={b} n={n} k={k} pads=({pad_l},{pad_r}) err={err} clean={bool(clean)}"
+
+
+def f_afa():
+    from patchaugnet_amd import loupe
+    from patchaugnet_amd.engine import _Afa
+    b, ktot = logint(1, 150), int(rng.integers(1, 130))
+    afa = _seed_module(loupe.AdaptiveFeatureAggregator(256, ktot, 256), seed=int(rng.integers(0, 1 << 30)))
+    v = torch.nn.functional.normalize(torch.randn(b, 256, ktot, device="cuda"), dim=1)
+    with torch.no_grad():
+        ref = afa(v).squeeze(-1)
+        eng = _Afa(afa, v.device)
+        got = eng.run(v.contiguous())
+        got_rows = eng.run_rows(v.transpose(1, 2).contiguous())
+    e1, e2 = (got - ref).abs().max().item(), (got_rows - ref).abs().max().item()
+    if not (e1 <= 3e-5 and e2 <= 3e-5):
+        return f"b={b} ktot={ktot} err={e1} err_rows={e2}"
+
+
 if __name__ == "__main__":
     ok = True
     fams = (("fps", f_fps), ("knn", f_knn), ("3nn", f_3nn), ("gather", f_gather), ("backward", f_backward), ("linear", f_linear),
-            ("attention", f_attention), ("chain_sa", f_chain_sa), ("chain_fp", f_chain_fp))
+            ("attention", f_attention), ("chain_sa", f_chain_sa), ("chain_fp", f_chain_fp), ("netvlad", f_netvlad), ("afa", f_afa))
     only = os.environ.get("FUZZ_ONLY")
     for name, fn in fams:
         if only and name not in only.split(","):
