@@ -87,8 +87,13 @@ class GraphedExtractor:
                 self.slots.append((g, x, y, st))
         torch.cuda.synchronize(self.device)
         self._i = 0
+        self._model = model
+        self._engine = getattr(model, "_engine", None)      # the graphs point at THIS engine's folded / packed weight buffers
 
     def begin(self):
+        if getattr(self._model, "_engine", None) is not self._engine or self._model.training:
+            raise RuntimeError("GraphedExtractor: the model's weights or mode changed after capture (load_state_dict / train()); "
+                               "build a new GraphedExtractor")
         cur = torch.cuda.current_stream(self.device)
         for _, _, _, st in self.slots:
             st.wait_stream(cur)

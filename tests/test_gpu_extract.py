@@ -65,3 +65,14 @@ def test_extract_dataset_single_rank(graphs):
         got = extract_dataset(m, lambda lo, hi: load(lo, hi) if hi - lo == 8 else xd[lo:hi].contiguous(), 70, batch_size=8, n_streams=4, graphs=True)
     torch.cuda.synchronize()
     assert torch.equal(got, ref)
+
+
+def test_graphed_extractor_refuses_stale_weights():
+    from patchaugnet_amd.extract import GraphedExtractor
+    m = _model("patch_aug_net")
+    gx = GraphedExtractor(m, (2, 1, 4096, 3), n_streams=1)
+    gx.begin(); gx.end()
+    m.load_state_dict(seeded_state_dict(m.state_dict(), seed=99))           # new weights: the captured graphs still point at the old buffers
+    m.eval()
+    with pytest.raises(RuntimeError, match="changed after capture"):
+        gx.begin()
