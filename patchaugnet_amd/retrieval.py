@@ -85,6 +85,43 @@ def pair_recall_precision(found, query_indices, positives, num_database, top_k=2
     return recall, precision, one_percent_recall, num_evaluated - one_percent_retrieved, threshold, states, num_evaluated, num_database
 
 
+def pair_recall_precision_fast(found, query_indices, positives, num_database, top_k=25, total=None):
+    """pair_recall_precision with the per-query loops as array operations (same 8-tuple, same integers).
+
+    A (query row, retrieved index) pair is a true positive iff its code ``row * total + index`` is among the codes of the positive
+    lists; everything else is cumulative sums over boolean matrices.  ``total`` = number of records in the dataset (any bound above
+    the largest index)."""
+    threshold = one_percent_threshold(num_database)
+    found = np.asarray(found, dtype=np.int64)
+    query_indices = np.asarray(query_indices, dtype=np.int64)
+    keep = np.array([bool(positives.get(int(q))) for q in query_indices], dtype=bool)     # queries without positives are not evaluated
+    found, query_indices = found[keep], query_indices[keep]
+    ne = int(len(query_indices))
+    recall, precision = np.zeros(top_k), np.zeros(top_k)
+    if ne == 0:
+        return recall, precision, 0.0, 0, threshold, [], 0, num_database
+    if total is None:
+        total = int(max(found.max(initial=0), query_indices.max(initial=0), max(max(v) for v in positives.values() if v))) + 1
+    rows = np.concatenate([np.full(len(positives[int(q)]), i, dtype=np.int64) for i, q in enumerate(query_indices)])
+    cols = np.concatenate([np.asarray(positives[int(q)], dtype=np.int64) for q in query_indices])
+    pos_codes = np.unique(rows * total + cols)
+    codes = np.arange(ne, dtype=np.int64)[:, None] * total + found
+    is_tp = np.isin(codes, pos_codes)                                                    # (ne, k)
+    counted = is_tp[:, :top_k] & (found[:, :top_k] != query_indices[:, None])            # :1064-1065 the query itself is skipped
+    kk = counted.shape[1]
+    precision[:kk] = counted.sum(0)
+    any_hit = counted.any(1)
+    first = counted.argmax(1)[any_hit]
+    np.add.at(recall, first, 1)
+    in_threshold = is_tp[:, :threshold].any(1)
+    one_percent_retrieved = int(in_threshold.sum())
+    states = np.where(is_tp[:, 0], 0, np.where(in_threshold, 1, 2)).tolist()
+    one_percent_recall = (one_percent_retrieved / float(ne)) * 100
+    recall = (np.cumsum(recall) / float(ne)) * 100
+    precision = (np.cumsum(precision) / float(ne)) * 100 / np.arange(1, top_k + 1, 1)
+    return recall, precision, one_percent_recall, ne - one_percent_retrieved, threshold, states, ne, num_database
+
+
 def _dist_info():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
@@ -102,32 +139,36 @@ def get_recall_precision(global_descs, records_size_list, tuples, top_k=25, skip
     dist, rank, world = _dist_info()
     sample_indices = indices_in_dataset(records_size_list)
     ntrips = len(records_size_list)
+    total = int(sum(records_size_list))
     mine = {}
     for r in range(ntrips):
         db_idx = sample_indices[r]
-        database = None
-        for q in range(ntrips):
-            if skip_trip_itself and q == r:
-                continue
-            if query_trips is not None and q not in query_trips:
-                continue
-            if (q * ntrips + r) % world != rank:
-                continue
-            if database is None:
-                database = global_descs[int(db_idx[0]):int(db_idx[-1]) + 1]
-            q_idx = sample_indices[q]
+        qs = [q for q in range(ntrips)
+              if not (skip_trip_itself and q == r) and (query_trips is None or q in query_trips) and (q * ntrips + r) % world == rank]
+        if not qs:
+            continue
+        k = real_top_k(len(db_idx), top_k)
+        # every evaluated query of every owned query trip against this reference trip: ONE kNN launch and one device -> host copy
+        evaluated = {}
+        for q in qs:
             pos = tuples.get((q, r), {})
-            evaluated = np.array([i for i in q_idx if pos.get(int(i))], dtype=np.int64)
-            k = real_top_k(len(db_idx), top_k)
-            if len(evaluated) == 0:
+            evaluated[q] = np.array([i for i in sample_indices[q] if pos.get(int(i))], dtype=np.int64)
+        all_q = np.concatenate([evaluated[q] for q in qs]) if qs else np.zeros(0, dtype=np.int64)
+        found_all = np.zeros((0, k), dtype=np.int64)
+        if len(all_q):
+            database = global_descs[int(db_idx[0]):int(db_idx[-1]) + 1]
+            sel = torch.as_tensor(all_q, device=global_descs.device)
+            found_all = db_idx[knn(database, global_descs.index_select(0, sel), min(k, len(db_idx))).cpu().numpy()]
+        off = 0
+        for q in qs:
+            ne = len(evaluated[q])
+            found = found_all[off:off + ne]
+            off += ne
+            if ne == 0:
                 found = np.zeros((0, k), dtype=np.int64)
-            else:
-                sel = torch.as_tensor(evaluated, device=global_descs.device)
-                found = knn(database, global_descs.index_select(0, sel), min(k, len(db_idx)))
-                found = db_idx[found.cpu().numpy()]
-                if q == r and not skip_trip_itself:        # `add_one_more`: the first hit is the query itself (:1058-1060)
-                    found = found[:, 1:]
-            mine[q, r] = pair_recall_precision(found, evaluated, pos, len(db_idx), top_k)
+            elif q == r and not skip_trip_itself:          # `add_one_more`: the first hit is the query itself (:1058-1060)
+                found = found[:, 1:]
+            mine[q, r] = pair_recall_precision_fast(found, evaluated[q], tuples.get((q, r), {}), len(db_idx), top_k, total=total)
     if dist is None:
         return mine
     parts = [None] * world

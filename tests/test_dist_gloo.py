@@ -40,8 +40,11 @@ def _clouds(lo, hi):
 
 
 def _numpy_knn(database, queries, k):
-    d = ((queries.double()[:, None, :] - database.double()[None, :, :]) ** 2).sum(-1).numpy()
-    return torch.from_numpy(np.lexsort((np.broadcast_to(np.arange(d.shape[1]), d.shape), d), axis=1)[:, :k].copy())
+    out = []
+    for lo in range(0, queries.shape[0], 64):                    # 64 queries at a time: the (nq, nd, dim) float64 cube stays small
+        d = ((queries[lo:lo + 64].double()[:, None, :] - database.double()[None, :, :]) ** 2).sum(-1).numpy()
+        out.append(np.lexsort((np.broadcast_to(np.arange(d.shape[1]), d.shape), d), axis=1)[:, :k])
+    return torch.from_numpy(np.concatenate(out).copy() if out else np.zeros((0, k), dtype=np.int64))
 
 
 def _worker(rank, world, port, n_total, ret):
