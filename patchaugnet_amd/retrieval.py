@@ -13,6 +13,8 @@ brute force anyway).  Here all queries of a trip pair go through ONE brute-force
 ``torch.distributed`` initialised the query trips are dealt round-robin to the ranks and the small index blocks are gathered.
 Only the integer bookkeeping (which of the k hits is a true positive) stays on the host.
 """
+import itertools
+
 import numpy as np
 import torch
 
@@ -102,8 +104,10 @@ def pair_recall_precision_fast(found, query_indices, positives, num_database, to
         return recall, precision, 0.0, 0, threshold, [], 0, num_database
     if total is None:
         total = int(max(found.max(initial=0), query_indices.max(initial=0), max(max(v) for v in positives.values() if v))) + 1
-    rows = np.concatenate([np.full(len(positives[int(q)]), i, dtype=np.int64) for i, q in enumerate(query_indices)])
-    cols = np.concatenate([np.asarray(positives[int(q)], dtype=np.int64) for q in query_indices])
+    lists = [positives[int(q)] for q in query_indices]
+    lens = np.fromiter((len(l) for l in lists), dtype=np.int64, count=ne)
+    rows = np.repeat(np.arange(ne, dtype=np.int64), lens)
+    cols = np.fromiter(itertools.chain.from_iterable(lists), dtype=np.int64, count=int(lens.sum()))
     pos_codes = np.unique(rows * total + cols)
     codes = np.arange(ne, dtype=np.int64)[:, None] * total + found
     is_tp = np.isin(codes, pos_codes)                                                    # (ne, k)
