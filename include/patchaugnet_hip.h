@@ -152,6 +152,17 @@ int pa_fp_chain_premul(int nlayers, const float *const *wt, const float *const *
 /*   c1 > 4 (coarser levels, skip = encoder features, c1 % 4 == 0, nlayers <= 2): the first layer stays in the chain as a c1-wide
  *   contraction over the skip channels (wskip, optional packed copy wskip_p) whose output gets the interpolated term added. */
 
+/* EXPERIMENTAL, not used by default.  Finest feature-propagation level with register-resident activations (fpx_reg.hip):
+ * pa_fp_chain_premul for 1 <= c1 <= 4 and exactly
+ * two remaining 256 -> 256 layers (patch_aug_net.py:350-362 at the 4096-point level), computed with operand-swapped MFMAs so that a
+ * layer's accumulators are the next layer's B operand (no LDS tile, 16-point waves, two to three per SIMD).  g (b*m_known, 256);
+ * wp2 / wp3: the two layers' K-major (256 x 256) weights in the k-permuted packing
+ *     wp[((q*16 + ot)*64 + l)*4 + s] = Wt[16q + 4(l/16) + s][16 ot + l%16],  q, ot in 0..15, l in 0..63, s in 0..3.
+ * Contracts the channels in a different order than pa_fp_chain_premul: same values to fp32 rounding, not the same bits. */
+int pa_fpx256(long rows, const float *g, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c1,
+              const float *wskip, const float *bias0, const float *wp2, const float *b2, const float *wp3, const float *b3,
+              float *out, int ldo, pa_stream_t stream);
+
 /* ---- fp16-operand variants of the chain kernels (opt-in; BASELINE.json configs[4] "fp16 MFMA MLP path") ---------------------
  * Same fusion and fp32 inputs / outputs; inside the kernel activations are held as fp16 in LDS, weights are fp16 fragments
  * (pa_pack_weights_f16: wp16[(((ct*ceil(kpad/32) + ks)*64 + l)*8 + e] = wt[(32ks + 8(l/16) + e)*n + 16ct + l%16], zero past kpad;

@@ -55,6 +55,20 @@ def pack_weights(wt):
     return wp
 
 
+def pack_weights_kperm(wt):
+    """K-major (256, 256) fp32 weights -> the k-permuted packing of pa_fpx256 (fpx_reg.hip):
+    wp[((q*16 + ot)*64 + l)*4 + s] = wt[16q + 4(l//16) + s, 16 ot + l%16]."""
+    assert tuple(wt.shape) == (256, 256)
+    dev = wt.device
+    q = torch.arange(16, device=dev).view(16, 1, 1, 1)
+    ot = torch.arange(16, device=dev).view(1, 16, 1, 1)
+    l = torch.arange(64, device=dev).view(1, 1, 64, 1)
+    sidx = torch.arange(4, device=dev).view(1, 1, 1, 4)
+    k = 16 * q + 4 * (l // 16) + sidx
+    n = 16 * ot + l % 16
+    return wt[k.expand(16, 16, 64, 4), n.expand(16, 16, 64, 4)].contiguous().view(-1)
+
+
 def pack_weights_f16(wt):
     """K-major (kpad, n) fp32 device tensor -> fp16 fragment packing for the fp16 chain kernels (pa_pack_weights_f16)."""
     kpad, n = wt.shape
@@ -147,6 +161,16 @@ class _Chain:
             mark()
         rows = B * n_unknown
         out = torch.empty((rows, self.n_last), dtype=torch.float32, device=dev)
+        rest = self.layers[1:]
+        if (not self.f16 and c1 <= 4 and pm["n0"] == 256 and len(rest) == 2 and all(l[2] == 256 and l[4] == 256 for l in rest)
+                and os.environ.get("PA_ENGINE_FPX_REG", "0") == "1"):
+            # experimental register-resident variant (fpx_reg.hip, opt-in: slower than the LDS-tiled kernel so far); a function of the
+            # layer shapes and the environment only, never of the batch size
+            if "kperm" not in pm:
+                pm["kperm"] = [pack_weights_kperm(l[0]) for l in rest]
+            call("pa_fpx256", rows, ptr(g), ptr(idx3), ptr(w3), ptr(skip), n_unknown, m_known, c1, ptr(pm["wskip"]), ptr(pm["bias0"]),
+                 ptr(pm["kperm"][0]), ptr(rest[0][1]), ptr(pm["kperm"][1]), ptr(rest[1][1]), ptr(out), self.n_last)
+            return out
         cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
         call("pa_fp_chain_premul_f16" if self.f16 else "pa_fp_chain_premul", pm["m"], cast(pm["wt"]), cast(pm["wpk"]), cast(pm["bias"]), cast(pm["kpad"]), cast(pm["nout"]), rows,
              ptr(g), ptr(idx3), ptr(w3), ptr(skip), n_unknown, m_known, pm["n0"], c1, ptr(pm["wskip"]), ptr(pm["wskip_p"]), ptr(pm["bias0"]),

@@ -136,3 +136,26 @@ def test_fp_interpolate(B, n, m, c2, c1, dims):
     exp = mlp_ref(rows.double(), [(w.float().double(), b.float().double()) for w, b in ref]).reshape(B * n, -1)
     got = _Chain(eng).fp(known.cuda(), idx3.cuda(), w3.cuda().contiguous(), skip.cuda() if c1 else None, B, n, m, c2, c1)
     close(got, exp)
+
+
+def test_register_resident_fpx_variant_matches_shipped_kernel(monkeypatch):
+    """fpx_reg.hip (opt-in experiment: activations in registers, operand-swapped MFMA, k-permuted weights) computes the same finest FP level
+    as the shipped LDS-tiled kernel up to the order of the fp32 additions."""
+    from patchaugnet_amd.engine import _Chain
+    B, n, m, c2, c1, dims = 3, 4096, 1024, 256, 3, [259, 256, 256, 256]
+    ref, eng = make_layers(dims, seed=5)
+    g = torch.Generator().manual_seed(9)
+    known = torch.randn(B, m, c2, generator=g).cuda()
+    skip = torch.randn(B, n, c1, generator=g).cuda()
+    idx3 = torch.randint(0, m, (B, n, 3), generator=g).int().cuda()
+    w3 = torch.rand(B, n, 3, generator=g)
+    w3 = (w3 / w3.sum(-1, keepdim=True)).cuda().contiguous()
+    monkeypatch.setenv("PA_ENGINE_FPX_REG", "0")
+    a = _Chain(eng).fp_premul(known, idx3, w3, skip, B, n, m, c2, c1)
+    monkeypatch.setenv("PA_ENGINE_FPX_REG", "1")
+    b = _Chain(eng).fp_premul(known, idx3, w3, skip, B, n, m, c2, c1)
+    close(b, a.double(), rtol=2e-5)                                        # different summation order: equal to rounding, not bit for bit
+    tail = _Chain(eng).fp_premul(known[:1], idx3[:1, :1000].contiguous(), w3[:1, :1000].contiguous(), skip[:1, :1000].contiguous(), 1, 1000, m, c2, c1)
+    monkeypatch.setenv("PA_ENGINE_FPX_REG", "0")
+    tail_ref = _Chain(eng).fp_premul(known[:1], idx3[:1, :1000].contiguous(), w3[:1, :1000].contiguous(), skip[:1, :1000].contiguous(), 1, 1000, m, c2, c1)
+    close(tail, tail_ref.double(), rtol=2e-5)                              # rows not a multiple of the 64-point workgroup tile
