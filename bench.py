@@ -26,7 +26,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32-input MFMA peak (same guide)
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--steps", type=int, default=100)
     p.add_argument("--warmup", type=int, default=10)
     p.add_argument("--batch", type=int, default=32)
     p.add_argument("--points", type=int, default=4096)
