@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Randomised shape fuzzing of the HIP ops against the CPU oracle / fp64 torch (run on the GPU box; not part of the test suite).
-    python tools/fuzz_gpu.py [seconds per op family, default 20]
+    python tests/fuzz_gpu.py [seconds per op family, default 20]
 Index outputs and pure gathers must be bit-exact; GEMM-based ops within 2e-5 relative of an fp64 reference."""
 import os
 import sys
