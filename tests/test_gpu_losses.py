@@ -111,3 +111,17 @@ def test_emd_backward_matches_oracle():
     g = (0.5 / np.sqrt(d) / d.size).astype(np.float32)
     ref = o.emd_backward(a, c, g, ass.cpu().numpy())
     assert np.allclose(x1.grad.cpu().numpy(), ref, rtol=1e-5, atol=1e-9)
+
+
+def test_batched_hard_negative_mining_equals_per_query_path():
+    """retrieval.get_hard_negatives_batch (one padded batch on the device) returns what the per-query kNN launches return."""
+    from patchaugnet_amd import retrieval
+    g = torch.Generator().manual_seed(4)
+    ref = torch.nn.functional.normalize(torch.randn(3000, 256, generator=g), dim=1).cuda()
+    rng = np.random.default_rng(1)
+    negs = [rng.choice(3000, int(rng.integers(5, 700)), replace=False).tolist() for _ in range(150)]
+    negs[3] = negs[3][:4]                                                    # fewer negatives than requested -> []
+    qs = ref[:150] + 0.01
+    got = retrieval.get_hard_negatives_batch(qs, ref, negs, num_hard_neg=10, chunk=64)
+    exp = [retrieval.get_hard_negatives(q, ref, n, 10) for q, n in zip(qs, negs)]
+    assert got == exp and got[3] == []
