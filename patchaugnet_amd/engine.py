@@ -466,6 +466,12 @@ class PatchAugNetEngine:
 
     def forward(self, x, views=True):
         """-> desc (B, 256), (fp_features views, level-0 centre indices); views=False skips the index mapping (descriptor-only callers)."""
+        if x.device.index is not None and x.device.index != torch.cuda.current_device():
+            with torch.cuda.device(x.device):        # the C ABI launches on the CURRENT device's stream: follow the tensor
+                return self._forward(x, views)
+        return self._forward(x, views)
+
+    def _forward(self, x, views):
         xyz = x.squeeze(1).contiguous()
         self._mark("start")
         l_feat, l_c = self.backbone(xyz)
