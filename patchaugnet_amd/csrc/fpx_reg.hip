@@ -16,7 +16,9 @@
 // Status (round 1, MI355X, 131 072 rows): bit-for-bit deterministic and within the 1e-4 descriptor tolerance, but 0.41 ms against
 // 0.35 ms for the LDS-tiled kernel.  Even without gathers and stores the layer pipeline runs at 55 % of the MFMA rate: hipcc sinks the
 // next chunk's global fetch to the end of the chunk (latency exposed before every barrier) and issues the LDS fragment reads only four
-// MFMAs ahead.  Needs explicit software pipelining (sched_group_barrier or inline asm) before it can replace the shipped kernel.
+// MFMAs ahead.  One workgroup per CU (LDS-padded launch) takes 0.57 ms, two take 0.44 ms: a lone wave reaches 39 % of the MFMA rate
+// and the second wave per SIMD hides only part of its stalls.  Needs explicit software pipelining (sched_group_barrier or inline asm)
+// before it can replace the shipped kernel.
 #include "pa_common.h"
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
