@@ -18,7 +18,9 @@
 // next chunk's global fetch to the end of the chunk (latency exposed before every barrier) and issues the LDS fragment reads only four
 // MFMAs ahead.  One workgroup per CU (LDS-padded launch) takes 0.57 ms, two take 0.44 ms: a lone wave reaches 39 % of the MFMA rate
 // and the second wave per SIMD hides only part of its stalls.  Needs explicit software pipelining (sched_group_barrier or inline asm)
-// before it can replace the shipped kernel.
+// before it can replace the shipped kernel.  Tried in source and undone by the machine scheduler: a three-deep stage with the fragments of
+// chunk c + 1 read into a second register set during chunk c (one wave per SIMD, 16 x float4 ahead) -- the emitted code reads every
+// fragment immediately before the four MFMAs that consume it, with s_waitcnt lgkmcnt(0) in between (0.73 ms).
 #include "pa_common.h"
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
