@@ -155,7 +155,7 @@ int pa_fp_chain_premul(int nlayers, const float *const *wt, const float *const *
 /* EXPERIMENTAL, not used by default.  Finest feature-propagation level with register-resident activations (fpx_reg.hip):
  * pa_fp_chain_premul for 1 <= c1 <= 4 and exactly
  * two remaining 256 -> 256 layers (patch_aug_net.py:350-362 at the 4096-point level), computed with operand-swapped MFMAs so that a
- * layer's accumulators are the next layer's B operand (no LDS tile, 16-point waves, two to three per SIMD).  g (b*m_known, 256);
+ * layer's accumulators are the next layer's B operand (no activation tile in LDS; weights through a shared LDS stage; 16-point waves).  g (b*m_known, 256);
  * wp2 / wp3: the two layers' K-major (256 x 256) weights in the k-permuted packing
  *     wp[((q*16 + ot)*64 + l)*4 + s] = Wt[16q + 4(l/16) + s][16 ot + l%16],  q, ot in 0..15, l in 0..63, s in 0..3.
  * Contracts the channels in a different order than pa_fp_chain_premul: same values to fp32 rounding, not the same bits. */

@@ -10,17 +10,17 @@
 // layer's output is produced in the same layout by the interpolation prologue.  The weights are packed so that the four k-steps
 // r = 0..3 of one (input-channel tile q, output tile ot) pair are ONE 16-byte fragment:
 //     wp[((q * 16 + ot) * 64 + l) * 4 + s] = Wt[16 q + 4 (l/16) + s][16 ot + l%16]          (pa_fpx256 in the header)
-// and travel global -> registers -> a double-buffered 2 x 16 KB LDS stage shared by the workgroup's four 16-point waves (each wave
-// streaming its own copy from L2 put half of the CU's L1 bandwidth on weights: 0.44-0.54 ms).  ~190 live registers: two waves per SIMD.
+// Weight pipeline: chunk = the 16 output tiles of 16 input channels (16 KB).  Chunk C + 2 goes global -> LDS without registers
+// (global_load_lds_dwordx4) into a three-deep stage shared by the workgroup's four 16-point waves; a wave reads the eight fragments of
+// the next half-chunk from the stage while the 32 MFMAs of the current half-chunk issue; s_waitcnt vmcnt(0) + one barrier per chunk.
+// ~200 live registers: two waves per SIMD, so one wave's gather prologue / store epilogue runs under another's MFMAs.
 //
-// Status (round 1, MI355X, 131 072 rows): bit-for-bit deterministic and within the 1e-4 descriptor tolerance, but 0.41 ms against
-// 0.35 ms for the LDS-tiled kernel.  Even without gathers and stores the layer pipeline runs at 55 % of the MFMA rate: hipcc sinks the
-// next chunk's global fetch to the end of the chunk (latency exposed before every barrier) and issues the LDS fragment reads only four
-// MFMAs ahead.  One workgroup per CU (LDS-padded launch) takes 0.57 ms, two take 0.44 ms: a lone wave reaches 39 % of the MFMA rate
-// and the second wave per SIMD hides only part of its stalls.  Needs explicit software pipelining (sched_group_barrier or inline asm)
-// before it can replace the shipped kernel.  Tried in source and undone by the machine scheduler: a three-deep stage with the fragments of
-// chunk c + 1 read into a second register set during chunk c (one wave per SIMD, 16 x float4 ahead) -- the emitted code reads every
-// fragment immediately before the four MFMAs that consume it, with s_waitcnt lgkmcnt(0) in between (0.73 ms).
+// Status (round 1, MI355X, 131 072 rows): 0.355 ms = the shipped kernel's time (0.35-0.36 ms), deterministic, within the 1e-4
+// descriptor tolerance (it contracts the channels in a different order, so not the same bits).  History: each wave streaming its own
+// weights from L2 0.44-0.54 ms (half of the CU's L1 bandwidth on weights); LDS stage filled through registers 0.41-0.43 ms (hipcc sank
+// the fetch to the end of the chunk and, with a deeper register look-ahead, spilled it to scratch behind s_waitcnt vmcnt(0));
+// sched_group_barrier patterns made it worse (the scheduler pairs every DS read with the MFMAs that consume it).  Left to do before it
+// can replace the shipped kernel: two chunks per barrier, the 22 spilled registers of the two-waves-per-SIMD build, epilogue through LDS.
 #include "pa_common.h"
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
@@ -40,48 +40,84 @@ struct FpxArgs {
     int ldo, n_unknown, m_known, c1, xcd_remap;
 };
 
-// 64 MFMAs of one weight chunk q (16 output tiles x 4 k-steps) from the LDS stage: acc[ot] += W^T fragment * h_q.s
-__device__ __forceinline__ void fpx_chunk(const float4 *__restrict__ stage, const floatx4 &hq, floatx4 (&acc)[16], int lane)
+// 64 MFMAs of weight chunk c in two halves of eight output tiles.  Half A runs from wa[8] (read during the previous chunk) while the
+// eight fragments of half B are read from this chunk's stage into wb[8]; half B runs while half A of chunk c + 1 is read into wa[8].
+// Eight independent accumulators per half: no MFMA waits on its predecessor; a fragment has >= 32 MFMAs to arrive.
+__device__ __forceinline__ void fpx_chunk(const float4 *__restrict__ cur_stage, const float4 *__restrict__ next_stage, bool have_next,
+                                          const floatx4 &hq, float4 (&wa)[8], float4 (&wb)[8], floatx4 (&acc)[16], int lane)
 {
 #pragma unroll
-    for (int o4 = 0; o4 < 16; o4 += 4) {                                  // four output tiles in flight: no MFMA waits on the one before it
-        float4 w[4];
+    for (int ot = 0; ot < 8; ++ot) {
+        wb[ot] = cur_stage[(8 + ot) * 64 + lane];
+        acc[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ot].x, hq[0], acc[ot], 0, 0, 0);
+    }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) w[u] = stage[(o4 + u) * 64 + lane];
+    for (int ot = 0; ot < 8; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ot].y, hq[1], acc[ot], 0, 0, 0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[o4 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u].x, hq[0], acc[o4 + u], 0, 0, 0);
+    for (int ot = 0; ot < 8; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ot].z, hq[2], acc[ot], 0, 0, 0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[o4 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u].y, hq[1], acc[o4 + u], 0, 0, 0);
+    for (int ot = 0; ot < 8; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ot].w, hq[3], acc[ot], 0, 0, 0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[o4 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u].z, hq[2], acc[o4 + u], 0, 0, 0);
+    for (int ot = 0; ot < 8; ++ot) {
+        if (have_next) wa[ot] = next_stage[ot * 64 + lane];
+        acc[8 + ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[ot].x, hq[0], acc[8 + ot], 0, 0, 0);
+    }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[o4 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u].w, hq[3], acc[o4 + u], 0, 0, 0);
+    for (int ot = 0; ot < 8; ++ot) acc[8 + ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[ot].y, hq[1], acc[8 + ot], 0, 0, 0);
+#pragma unroll
+    for (int ot = 0; ot < 8; ++ot) acc[8 + ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[ot].z, hq[2], acc[8 + ot], 0, 0, 0);
+#pragma unroll
+    for (int ot = 0; ot < 8; ++ot) acc[8 + ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[ot].w, hq[3], acc[8 + ot], 0, 0, 0);
+}
+
+// global -> LDS without registers (global_load_lds_dwordx4: lane l of the wave writes 16 bytes at M0 + 16 l)
+__device__ __forceinline__ void fpx_fetch_chunk(const float *wp, int chunk, float4 *stage_buf, int tid, int lane, int wave)
+{
+    const float4 *src = reinterpret_cast<const float4 *>(wp) + (size_t)chunk * 1024 + tid;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + u * 256),
+                                         (void __attribute__((address_space(3))) *)(stage_buf + u * 256 + wave * 64), 16, 0, 0);
+}
+
+// iteration C of the 32-chunk pipeline as a compile-time recursion (every register array index must be a constant).  Chunk C + 2 is
+// fetched straight into stage[(C + 2) % 3] while chunk C (second half) and chunk C + 1 (first half) are read; vmcnt(0) + barrier at the end.
+template <int C>
+__device__ __forceinline__ void fpx_pipeline(const FpxArgs &a, float4 *stage, floatx4 (&h)[16], float4 (&wa)[8], float4 (&wb)[8], floatx4 (&acc)[16],
+                                             int tid, int lane, int wave, int gq)
+{
+    if constexpr (C < 32) {
+        if constexpr (C + 2 < 32) fpx_fetch_chunk(C + 2 < 16 ? a.wp2 : a.wp3, (C + 2) & 15, stage + ((C + 2) % 3) * 1024, tid, lane, wave);
+        fpx_chunk(stage + (C % 3) * 1024, stage + ((C + 1) % 3) * 1024, C + 1 < 32, h[C & 15], wa, wb, acc, lane);
+        if constexpr (C == 15) {
+#pragma unroll
+            for (int ot = 0; ot < 16; ++ot) {
+                const float4 bz = *reinterpret_cast<const float4 *>(a.b2 + ot * 16 + gq * 4);
+                h[ot] = (floatx4){fmaxf(acc[ot][0] + bz.x, 0.f), fmaxf(acc[ot][1] + bz.y, 0.f), fmaxf(acc[ot][2] + bz.z, 0.f), fmaxf(acc[ot][3] + bz.w, 0.f)};
+                acc[ot] = (floatx4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        if constexpr (C + 2 < 32) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        fpx_pipeline<C + 1>(a, stage, h, wa, wb, acc, tid, lane, wave, gq);
     }
 }
 
 __global__ __launch_bounds__(256, 2) void fpx_reg_kernel(FpxArgs a)
 {
-    // weight stage: 2 x 16 KB (one chunk = the 16 output tiles of 16 input channels), shared by the four waves of the workgroup:
-    // every wave streaming its own copy of the 256 KB matrix would put half of the CU's L1 bandwidth on weight traffic
     extern __shared__ __attribute__((aligned(16))) float fpx_lds[];
-    float4 *stage = reinterpret_cast<float4 *>(fpx_lds);                 // [2][1024]
+    float4 *stage = reinterpret_cast<float4 *>(fpx_lds);                 // [3][1024]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long nblk = gridDim.x;
     const long blk = (a.xcd_remap && (nblk & 7) == 0) ? (long)(blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3) : (long)blockIdx.x;
     const long tile = blk * 4 + wave;
     const long row = tile * 16 + (lane & 15);
-    const long rowc = row < a.rows ? row : a.rows - 1;                    // lanes past the end compute on a clamped row and store nothing
+    const long rowc = row < a.rows ? row : a.rows - 1;
     const int gq = lane >> 4;
-
-    // chunk 0 of the first layer goes to the stage while the prologue gathers
-    float4 pre[4];
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(a.wp2);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) pre[u] = src[tid + u * 256];
-    }
-
-    // ---- first layer: bias + skip . Wskip + interpolation of the pre-multiplied coarse features, ReLU (same fmaf chain as pa_chain.h)
+    fpx_fetch_chunk(a.wp2, 0, stage, tid, lane, wave);
+    fpx_fetch_chunk(a.wp2, 1, stage + 1024, tid, lane, wave);
     const long cloud = rowc / a.n_unknown;
     const float4 *g4[3];
     float wj[3];
@@ -95,55 +131,39 @@ __global__ __launch_bounds__(256, 2) void fpx_reg_kernel(FpxArgs a)
     for (int t = 0; t < 4; ++t) sv[t] = t < a.c1 ? a.skip[rowc * a.c1 + t] : 0.f;
     floatx4 h[16], acc[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int c = q * 16 + gq * 4;
-        const float4 bz = *reinterpret_cast<const float4 *>(a.bias0 + c);
-        float v[4] = {bz.x, bz.y, bz.z, bz.w};
+    for (int q4 = 0; q4 < 16; q4 += 4) {                                 // twelve gathers issued, then consumed
+        float4 f[4][3];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (t < a.c1) {
-                const float4 wv = *reinterpret_cast<const float4 *>(a.wskip + (size_t)t * 256 + c);
-                v[0] = fmaf(sv[t], wv.x, v[0]); v[1] = fmaf(sv[t], wv.y, v[1]); v[2] = fmaf(sv[t], wv.z, v[2]); v[3] = fmaf(sv[t], wv.w, v[3]);
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) f[u][t] = g4[t][(q4 + u) * 4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = (q4 + u) * 16 + gq * 4;
+            const float4 bz = *reinterpret_cast<const float4 *>(a.bias0 + c);
+            float v[4] = {bz.x, bz.y, bz.z, bz.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t < a.c1) {
+                    const float4 wv = *reinterpret_cast<const float4 *>(a.wskip + (size_t)t * 256 + c);
+                    v[0] = fmaf(sv[t], wv.x, v[0]); v[1] = fmaf(sv[t], wv.y, v[1]); v[2] = fmaf(sv[t], wv.z, v[2]); v[3] = fmaf(sv[t], wv.w, v[3]);
+                }
             }
-        }
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const float4 f = g4[t][q * 4];
-            v[0] = fmaf(wj[t], f.x, v[0]); v[1] = fmaf(wj[t], f.y, v[1]); v[2] = fmaf(wj[t], f.z, v[2]); v[3] = fmaf(wj[t], f.w, v[3]);
+            for (int t = 0; t < 3; ++t) {
+                v[0] = fmaf(wj[t], f[u][t].x, v[0]); v[1] = fmaf(wj[t], f[u][t].y, v[1]); v[2] = fmaf(wj[t], f[u][t].z, v[2]); v[3] = fmaf(wj[t], f[u][t].w, v[3]);
+            }
+            h[q4 + u] = (floatx4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
         }
-        h[q] = (floatx4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
-        if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);           // at most twelve 16-byte gathers in flight
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) stage[tid + u * 256] = pre[u];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-
-    // ---- two 256 -> 256 layers as one pipeline of 32 weight chunks: chunk c is read from stage[c & 1] while chunk c + 1 travels
-    // global -> registers -> stage[(c + 1) & 1]; one barrier per chunk.  The accumulators of layer 1 (bias + ReLU) ARE layer 2's B operands.
+    float4 wa[8], wb[8];
+#pragma unroll
+    for (int ot = 0; ot < 8; ++ot) wa[ot] = stage[ot * 64 + lane];
 #pragma unroll
     for (int ot = 0; ot < 16; ++ot) acc[ot] = (floatx4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < 32; ++c) {
-        if (c + 1 < 32) {
-            const float4 *src = reinterpret_cast<const float4 *>(c + 1 < 16 ? a.wp2 : a.wp3) + (size_t)((c + 1) & 15) * 1024;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) pre[u] = src[tid + u * 256];
-        }
-        fpx_chunk(stage + (c & 1) * 1024, h[c & 15], acc, lane);
-        if (c == 15) {                                                   // layer boundary: h <- relu(acc + b2), in place of the consumed inputs
-#pragma unroll
-            for (int ot = 0; ot < 16; ++ot) {
-                const float4 bz = *reinterpret_cast<const float4 *>(a.b2 + ot * 16 + gq * 4);
-                h[ot] = (floatx4){fmaxf(acc[ot][0] + bz.x, 0.f), fmaxf(acc[ot][1] + bz.y, 0.f), fmaxf(acc[ot][2] + bz.z, 0.f), fmaxf(acc[ot][3] + bz.w, 0.f)};
-                acc[ot] = (floatx4){0.f, 0.f, 0.f, 0.f};
-            }
-        }
-        if (c + 1 < 32) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) stage[((c + 1) & 1) * 1024 + tid + u * 256] = pre[u];
-            __syncthreads();
-        }
-    }
+    fpx_pipeline<0>(a, stage, h, wa, wb, acc, tid, lane, wave, gq);
     if (row < a.rows) {
         float *o = a.out + (size_t)row * a.ldo + gq * 4;
 #pragma unroll
@@ -171,7 +191,7 @@ PA_API int pa_fpx256(long rows, const float *g, const int *idx3, const float *w3
     a.xcd_remap = no_xcd ? 0 : 1;
     static const int pad_kb = getenv("PA_FPX_LDS_PAD") ? atoi(getenv("PA_FPX_LDS_PAD")) : 0;   // tuning knob: extra LDS per workgroup steers co-residency
     const long nblk = (rows + 63) / 64;
-    const size_t lds = (size_t)(32 + pad_kb) * 1024;
+    const size_t lds = (size_t)(48 + pad_kb) * 1024;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fpx_reg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(fpx_reg_kernel, dim3(nblk), dim3(256), lds, (hipStream_t)stream, a);
     PA_CHECK_LAUNCH("pa_fpx256");
