@@ -20,7 +20,9 @@
 // weights from L2 0.44-0.54 ms (half of the CU's L1 bandwidth on weights); LDS stage filled through registers 0.41-0.43 ms (hipcc sank
 // the fetch to the end of the chunk and, with a deeper register look-ahead, spilled it to scratch behind s_waitcnt vmcnt(0));
 // sched_group_barrier patterns made it worse (the scheduler pairs every DS read with the MFMAs that consume it).  Left to do before it
-// can replace the shipped kernel: two chunks per barrier, the 22 spilled registers of the two-waves-per-SIMD build, epilogue through LDS.
+// can replace the shipped kernel: the layer pipeline alone (no gathers, no stores) takes 0.32 ms = 69 % of the MFMA rate, gathers and
+// stores add 0.02 ms each; 32 KB chunks with one barrier per 128 MFMAs were no faster (0.368 ms).  Open: why two waves per SIMD fed from
+// LDS a half-chunk ahead stop at 69 %, the 22 spilled registers of the two-waves build, an LDS-staged epilogue.
 #include "pa_common.h"
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
