@@ -4,9 +4,12 @@
     python bench.py --gpus N --steps K --warmup W
 
 A step = one pass of the hot path over one batch of 32 synthetic 4096-point submaps already resident in HBM:
-(B,1,4096,3) fp32 on device -> (B,256) fp32 descriptors on device.  N > 1: one process per GPU (torchrun), every
-rank extracts its own shard (weak scaling, no data-path collective), and the timed region ends with ONE RCCL
-all-gather of every rank's descriptors (the exchange the retrieval step needs).  Rank 0 prints one JSON line.
+(B,1,4096,3) fp32 on device -> (B,256) fp32 descriptors on device.  N > 1: one process per GPU -- either launched by
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the
+environment) or, when WORLD_SIZE is not set, by this script itself (one child process per GPU, MASTER_ADDR=127.0.0.1) --
+every rank extracts its own shard (weak scaling, no data-path collective), and the timed region ends with ONE RCCL
+all-gather of every rank's descriptors (the exchange the retrieval step needs).  Rank 0 prints one JSON line.  Asking for more
+GPUs than the box has is an error, never a silent 1-GPU run.
 """
 import argparse
 import json
@@ -33,6 +36,7 @@ def parse():
     p.add_argument("--module-path", action="store_true", help="force the unfused module path instead of the fused engine")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-pass", action="store_true")
+    p.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic (it is then null)")
     p.add_argument("--cpu-batch", type=int, default=8)
     p.add_argument("--model", choices=["patch_aug_net", "pptnet"], default="patch_aug_net", help="pptnet = BASELINE.json configs[4]")
     p.add_argument("--mlp-dtype", choices=["f32", "f16"], default="f32",
@@ -79,7 +83,7 @@ def stage_pass(model, x, iters=5):
         return profiling.stage_times(model, x, iters)
 
 
-def dominant_kernel_roofline(st, cfg, batch, points, grouping):
+def dominant_kernel_roofline(st, cfg, batch, points, grouping, pmc=None, pmc_note=None):
     """Roofline of the kernel that owns the most CU-time in a step.
 
     Stage times come from HIP events on the launch stream (patchaugnet_amd/profiling.py).  CU-time = duration x share of the
@@ -105,19 +109,66 @@ def dominant_kernel_roofline(st, cfg, batch, points, grouping):
     cu_time = {k: v * (min(batch, 256) / 256.0 if k.endswith(".fps") else 1.0) for k, v in st.items() if k != "total"}
     owner = max(cu_time, key=cu_time.get)
     mc = grouping["micro_c64"]
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(pmc):   # HBM bytes per launch from rocprofv3 PMC passes of this kernel at this shape (profiles/)
-        traffic = json.load(open(pmc)).get("chain_fp0_bytes_per_launch")
+    traffic = pmc["dominant"]["bytes_per_launch"] if pmc and "dominant" in pmc else None     # measured in this run, or null
+    g_traffic = pmc["grouping"]["bytes_per_launch"] if pmc and "grouping" in pmc else None
     return {
         "roofline": {"kernel": kname,
                      "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
-                     "traffic": traffic, "algorithmic_flops_per_launch": flops, "ms_per_launch": ms, "cu_time_owner": owner},
+                     "traffic": traffic, "traffic_source": pmc_note, "algorithmic_flops_per_launch": flops, "ms_per_launch": ms, "cu_time_owner": owner},
         "roofline_grouping": {"kernel": "group_lds_kernel (pa_grouping_forward, K5)", "bound": "hbm", "achieved": mc["GBps"], "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": mc["GBps"] / HBM_PEAK_GBS,
-                              "traffic": json.load(open(pmc)).get("grouping_bytes_per_launch") if os.path.exists(pmc) else None, "shape": mc["shape"],
+                              "traffic": g_traffic, "shape": mc["shape"],
                               "algorithmic_bytes_per_launch": mc["algorithmic_bytes"], "ms_per_launch": mc["ms"]},
     }
+
+
+DOMINANT_KERNEL_RE = r"chain_kernel<2, 16, 3, false, 1>"     # fp0 feature-propagation chain (pa_fp_chain_premul); update with the kernel
+GROUPING_KERNEL_RE = r"group_lds_kernel<4>"
+
+
+def measure_traffic(batch, points):
+    """HBM bytes per launch of the dominant kernel and of the graded gather, measured NOW: two rocprofv3 passes (FETCH_SIZE and
+    WRITE_SIZE cannot share a pass on gfx950: MI355X_MICROARCH.md, PMC slots) over tools/pmc_target.py, which runs the same engine
+    steps at the same shape in a child process.  Correction per the guide's HBM section: the counters are KiB; FETCH_SIZE reports
+    half the bytes of a wide (16 B/lane) coalesced read, which is how both kernels read, so it is doubled; WRITE_SIZE as reported.
+    Returns ({...}, note); any failure gives (None, reason) -- the bench line then carries traffic = null, never a stale constant."""
+    import re
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "bench.py itself runs under rocprofv3: nested counter passes skipped"
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="pa_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable, os.path.join(ROOT, "tools", "pmc_target.py"),
+                   "--batch", str(batch), "--points", str(points)]
+            res = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
+            dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith("results.db")]
+            if res.returncode != 0 or not dbs:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {res.returncode}): {res.stdout[-300:]}"
+            c = sqlite3.connect(dbs[0])
+            for name, avg, n in c.execute("select kernel_name, avg(value), count(*) from counters_collection where counter_name = ? group by kernel_name", (counter,)):
+                for tag, rx in (("dominant", DOMINANT_KERNEL_RE), ("grouping", GROUPING_KERNEL_RE)):
+                    if re.search(rx, name):
+                        out.setdefault(tag, {})[counter] = avg * 1024.0
+                        out[tag]["launches_sampled"] = n
+    except Exception as ex:
+        return None, f"PMC pass failed: {ex!r}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    res = {}
+    for tag, v in out.items():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            res[tag] = {"bytes_per_launch": 2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"], "FETCH_SIZE_bytes_raw": v["FETCH_SIZE"], "WRITE_SIZE_bytes": v["WRITE_SIZE"],
+                        "launches_sampled": v["launches_sampled"]}
+    return (res or None), "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/pmc_target.py in this run; FETCH_SIZE x2 (gfx950, 16-B reads), KiB -> bytes"
 
 
 def cpu_baseline(cfg, sd, batch, points):
@@ -184,13 +235,45 @@ def pcie_inclusive(model, a, pipe):
                     "the K steps after one warm-up repetition (never the headline value)"}
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` with no launcher around it: start one child per GPU (rank i on GPU i) with the torchrun environment
+    contract and wait for them.  Rank 0's stdout (the JSON line) is this process's stdout."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} requested but this box has {have} visible GPU(s); refusing to print a {have}-GPU number "
+                         f"as an {a.gpus}-GPU one")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    if rc:
+        raise SystemExit(f"bench.py: a rank exited with status {rc}")
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        return self_launch(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} does not match WORLD_SIZE={world} of the launcher")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    if torch.cuda.device_count() <= local:
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local} but only {torch.cuda.device_count()} are visible")
     from patchaugnet_amd.hostcpu import limit_host_threads
     # host-side torch ops sized by os.cpu_count() overrun the cgroup CPU quota and get the process throttled; N ranks share the grant
     from patchaugnet_amd.hostcpu import cpu_budget
@@ -266,9 +349,15 @@ def main():
         for i in range(a.steps):
             pipe.submit(one, i)
         pipe.end()
-        if dist is not None:   # the one exchange step: every rank's descriptors to every rank
+        ag_ms = None
+        if dist is not None:   # the one exchange step: every rank's descriptors to every rank (its own duration is reported beside the total)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             dist.all_gather_into_tensor(gathered, descs.view(-1, 256))
+            e1.record()
         torch.cuda.synchronize()
+        if dist is not None:
+            ag_ms = e0.elapsed_time(e1)
         if dist is not None:
             dist.barrier()
         dt = time.perf_counter() - t0
@@ -295,6 +384,8 @@ def main():
                    "weights": "key-seeded random init", "parallelism": f"dp{world}", "streams": a.streams,
                    "launch": "hipGraph replay per stream" if use_graphs else "python launches"},
     }
+    if ag_ms is not None:
+        line["all_gather_ms"] = ag_ms      # rank 0's view of the one RCCL collective that ends the timed region
     if world == 1 and (a.model != "patch_aug_net" or a.mlp_dtype != "f32"):   # non-headline configurations: stage times only
         try:
             line["kernels"] = {"stages_ms": stage_pass(model, x)}
@@ -307,7 +398,8 @@ def main():
             try:
                 st = stage_pass(model, x)
                 line["kernels"]["stages_ms"] = st
-                line.update(dominant_kernel_roofline(st, cfg, a.batch, a.points, g))
+                pmc, note = (None, "--no-pmc") if a.no_pmc else measure_traffic(a.batch, a.points)
+                line.update(dominant_kernel_roofline(st, cfg, a.batch, a.points, g, pmc, note))
             except Exception as ex:  # attribution is diagnostics; never lose the bench line over it
                 line["kernels"]["stages_ms"] = {"error": repr(ex)}
         try:

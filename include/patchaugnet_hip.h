@@ -253,6 +253,11 @@ long pa_fc_scratch_floats(int b, int kdim, int nout);
 int pa_fc(int b, int kdim, int nout, const float *y, const float *fc_wt, const float *fc_bias, const float *scale, const float *shift,
           int l2norm, const float *gate_x, float *scratch, float *out, pa_stream_t stream);
 
+/* Max-pool head (SpatialPyramidNetVLAD aggregation_type 3, place_recognition/patch_aug_net/models/loupe.py:304-306):
+ * out[b][c] = max over the ktot clusters of vt[b][k][c] (cluster-major rows from pa_netvlad_rows), then F.normalize when l2norm != 0.
+ * c must be 256. */
+int pa_vlad_maxpool(int b, int ktot, int c, const float *vt, int l2norm, float *out, pa_stream_t stream);
+
 /* ---- the reference's launcher names (group 2) -------------------------------------------------*/
 void furthestsampling_cuda_launcher(int b, int n, int m, const float *dataset, float *temp, int *idxs);
 void gathering_forward_cuda_launcher(int b, int c, int n, int m, const float *points, const int *idx, float *out);
@@ -267,7 +272,9 @@ void nearestneighbor_cuda_launcher(int b, int n, int m, const float *unknown, co
 void nearestneighbor_cuda_launcher_fast(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx);
 void interpolation_forward_cuda_launcher(int b, int c, int m, int n, const float *points, const int *idx, const float *weight, float *out);
 void interpolation_forward_cuda_launcher_fast(int b, int c, int m, int n, const float *points, const int *idx, const float *weight, float *out);
-void interpolation_backward_cuda_launcher(int b, int n, int c, int m, const float *grad_out, const int *idx, const float *weight, float *grad_points);
+/* the reference DECLARES this one as (b, n, c, m) (interpolation_cuda_kernel.h:23) but its only caller passes (b, c, n, m)
+ * (interpolation_cuda.cpp:62): the declared NAMES n/c are swapped there; positions are what link, and the names here say what they carry */
+void interpolation_backward_cuda_launcher(int b, int c, int n, int m, const float *grad_out, const int *idx, const float *weight, float *grad_points);
 void ballquery_cuda_launcher(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int *idx);
 void ballquery_cuda_launcher_fast(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int *idx, pa_stream_t stream);
 void featuredistribute_cuda_launcher(int b, int n, int m, const float *max_xyz, const float *xyz, int *distribute_idx, pa_stream_t stream);

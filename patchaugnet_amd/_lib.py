@@ -58,6 +58,7 @@ _SIGS = {
     "pa_netvlad_rows": "iiiipppppppii",
     "pa_afa_rows": "iiiippppppppipp",
     "pa_fc": "iiipppppippp",
+    "pa_vlad_maxpool": "iiipip",
 }
 _T = {"i": _I, "f": _F, "p": _P, "l": ctypes.c_long}
 

@@ -35,12 +35,21 @@ class SALayer(nn.Module):
     def _fused(self, x):
         """eval + no_grad on the MI355X: pa_linear + pa_sa_attention + pa_linear (csrc/attention.hip), no (B, gp, N, N) tensor."""
         from .engine import _Attn
-        key = (x.device, self.k_conv.weight.data_ptr(), self.k_conv.weight._version)
-        if getattr(self, "_attn_key", None) != key:
-            self._attn, self._attn_key = _Attn(self, x.device), key
-        bs, ch, n = x.shape
-        xm = x.transpose(1, 2).contiguous().view(bs * n, ch)
-        return self._attn.run(xm, bs, n).view(bs, n, ch).transpose(1, 2).contiguous()
+        ts = (self.k_conv.weight, self.v_conv.weight, self.v_conv.bias, self.trans_conv.weight, self.trans_conv.bias, self.after_norm.weight,
+              self.after_norm.bias, self.after_norm.running_mean, self.after_norm.running_var)
+        key = (x.device,) + tuple((t.data_ptr(), t._version) for t in ts)
+        with torch.cuda.device(x.device):     # the C ABI launches on the CURRENT device's stream: follow the tensor
+            if getattr(self, "_attn_key", None) != key:
+                self._attn, self._attn_key = _Attn(self, x.device), key
+            bs, ch, n = x.shape
+            xm = x.transpose(1, 2).contiguous().view(bs * n, ch)
+            return self._attn.run(xm, bs, n).view(bs, n, ch).transpose(1, 2).contiguous()
+
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st.pop("_attn", None)                  # folded copies hold device buffers bound to this module's current weights
+        st.pop("_attn_key", None)
+        return st
 
     def forward(self, x):
         if x.is_cuda and not self.training and not torch.is_grad_enabled() and x.shape[1] in (64, 128, 256, 512):

@@ -224,11 +224,9 @@ PA_API int pa_emd_forward(int b, int n, int m, const float *xyz1, const float *x
     PA_REQUIRE(xyz1 && xyz2 && dist && assignment && price && assignment_inv && bid && bid_increments && max_increments && max_idx,
                "pa_emd_forward: null pointer");
     const size_t lds_bytes = (size_t)n * 16 + (size_t)n * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
+    {   // the opt-in is a per-DEVICE attribute of the function: set it on every call (a process may drive several GPUs)
         hipError_t e = hipFuncSetAttribute((const void *)emd_auction_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         if (e != hipSuccess) { pa_set_error("pa_emd_forward: cannot raise the LDS limit: %s", hipGetErrorString(e)); return (int)e; }
-        attr_set = true;
     }
     hipLaunchKernelGGL(emd_auction_kernel, dim3(b), dim3(EMD_THREADS), lds_bytes, (hipStream_t)stream, n, xyz1, xyz2, dist, assignment, price,
                        assignment_inv, bid, bid_increments, max_increments, max_idx, eps, iters);

@@ -610,3 +610,33 @@ PA_API int pa_afa_rows(int b, int c, int ktot, int nout, const float *vt, const 
     PA_CHECK_LAUNCH("pa_afa_rows");
     return PA_OK;
 }
+
+namespace {
+// grid B x 256 threads (= channels): max over the cluster rows, optional L2 normalisation over the 256 channels
+__global__ __launch_bounds__(256) void vlad_maxpool_kernel(int ktot, const float *__restrict__ vt_all, int l2norm, float *__restrict__ out)
+{
+    __shared__ float red[4];
+    const int b = blockIdx.x, c = threadIdx.x;
+    const float *vt = vt_all + (size_t)b * ktot * VC;
+    float m = vt[c];
+    for (int k = 1; k < ktot; ++k) m = fmaxf(m, vt[(size_t)k * VC + c]);
+    if (l2norm) {
+        float ss = m * m;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) ss += __shfl_xor(ss, o);
+        if ((c & 63) == 0) red[c >> 6] = ss;
+        __syncthreads();
+        m = m / fmaxf(sqrtf((red[0] + red[1]) + (red[2] + red[3])), 1e-12f);
+    }
+    out[(size_t)b * VC + c] = m;
+}
+}  // namespace
+
+PA_API int pa_vlad_maxpool(int b, int ktot, int c, const float *vt, int l2norm, float *out, pa_stream_t stream)
+{
+    PA_REQUIRE(b > 0 && ktot > 0 && vt && out, "pa_vlad_maxpool: bad arguments");
+    if (c != VC) { pa_set_error("pa_vlad_maxpool: built for 256 channels (got c=%d)", c); return PA_EUNSUPPORTED; }
+    hipLaunchKernelGGL(vlad_maxpool_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, ktot, vt, l2norm, out);
+    PA_CHECK_LAUNCH("pa_vlad_maxpool");
+    return PA_OK;
+}

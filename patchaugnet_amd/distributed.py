@@ -54,7 +54,8 @@ def extract_dataset(model, load_batch, n_total, batch_size=32, n_streams=4, dim=
     local = torch.empty((hi - lo, dim), dtype=torch.float32, device=device)
     pipe = None
     if n_streams > 0:
-        from .extract import StreamPipeline
+        from .extract import StreamPipeline, _prepare
+        _prepare(model, device)         # engine built on the caller's stream before the pipeline streams fork from it
         pipe = StreamPipeline(n_streams, device)
         pipe.begin()
     gx = None

@@ -19,7 +19,6 @@ import ctypes
 import os
 
 import torch
-import torch.nn.functional as F
 
 from . import _lib
 from ._lib import call, ptr
@@ -133,27 +132,37 @@ class _Chain:
              ptr(known_feat), ptr(idx3), ptr(w3), ptr(skip), n_unknown, m_known, c2, c1, ptr(out), self.n_last)
         return out
 
+    def build_premul(self, c2, c1, kperm=False):
+        """Split and pack the first layer for pa_fp_chain_premul ONCE, at engine construction (on the constructing stream): nothing is
+        packed lazily in the hot path, so pipeline streams never race a pack kernel issued on another stream."""
+        wt0, b0, _, _, n0 = self.layers[0]
+        dev = wt0.device
+        w1a = wt0[:c2].contiguous()
+        rest = self.layers[1:]
+        m = len(rest)
+        pk = lambda w: pack_weights_f16(w) if self.f16 else pack_weights(w)
+        wskip = wt0[c2:c2 + c1].contiguous()
+        self._premul = {
+            "c2": c2, "c1": c1,
+            "w1a": w1a, "w1a_p": pk(w1a), "zero": torch.zeros(n0, dtype=torch.float32, device=dev),
+            "wskip": wskip, "bias0": b0, "n0": n0, "m": m,
+            # coarser levels (c1 > 4): the skip part of the first layer is an MFMA layer of its own
+            "wskip_p": pk(wskip) if (c1 > 4 and c1 % 4 == 0 and (self.f16 or n0 % 64 == 0)) else None,
+            "wt": (ctypes.c_void_p * m)(*[l[0].data_ptr() for l in rest]),
+            "wpk": (ctypes.c_void_p * m)(*[(p.data_ptr() if p is not None else None) for p in (self.packed16 if self.f16 else self.packed)[1:]]),
+            "bias": (ctypes.c_void_p * m)(*[l[1].data_ptr() for l in rest]),
+            "kpad": (ctypes.c_int * m)(*[l[3] for l in rest]), "nout": (ctypes.c_int * m)(*[l[4] for l in rest]),
+        }
+        if kperm and not self.f16 and m == 2 and all(l[2] == 256 and l[4] == 256 for l in rest):
+            self._premul["kperm"] = [pack_weights_kperm(l[0]) for l in rest]
+
     def fp_premul(self, known_feat, idx3, w3, skip, B, n_unknown, m_known, c2, c1, mark=None):
         """Finest feature-propagation level: the first layer is applied to the m_known coarse points BEFORE interpolation
         (pa_fp_chain_premul; interpolation is linear), the skip (xyz) term is added in the kernel's prologue."""
         dev = known_feat.device
-        if not hasattr(self, "_premul"):
-            wt0, b0, _, _, n0 = self.layers[0]
-            w1a = wt0[:c2].contiguous()
-            rest = self.layers[1:]
-            m = len(rest)
-            self._premul = {
-                "w1a": w1a, "w1a_p": pack_weights_f16(w1a) if self.f16 else pack_weights(w1a), "zero": torch.zeros(n0, dtype=torch.float32, device=dev),
-                "wskip": wt0[c2:c2 + c1].contiguous(), "bias0": b0, "n0": n0, "m": m,
-                "wskip_p": None,
-                "wt": (ctypes.c_void_p * m)(*[l[0].data_ptr() for l in rest]),
-                "wpk": (ctypes.c_void_p * m)(*[(p.data_ptr() if p is not None else None) for p in (self.packed16 if self.f16 else self.packed)[1:]]),
-                "bias": (ctypes.c_void_p * m)(*[l[1].data_ptr() for l in rest]),
-                "kpad": (ctypes.c_int * m)(*[l[3] for l in rest]), "nout": (ctypes.c_int * m)(*[l[4] for l in rest]),
-            }
+        if getattr(self, "_premul", None) is None or (self._premul["c2"], self._premul["c1"]) != (c2, c1):
+            raise RuntimeError("fp_premul: build_premul(c2, c1) was not run for this level at engine construction")
         pm = self._premul
-        if c1 > 4 and pm["wskip_p"] is None:      # coarser levels: the skip part of the first layer is an MFMA layer of its own
-            pm["wskip_p"] = pack_weights_f16(pm["wskip"]) if self.f16 else pack_weights(pm["wskip"])
         g = torch.empty((B * m_known, pm["n0"]), dtype=torch.float32, device=dev)
         call("pa_linear_f16" if self.f16 else "pa_linear", B * m_known, c2, pm["n0"], ptr(known_feat), c2, ptr(pm["w1a"]), ptr(pm["w1a_p"]),
              ptr(pm["zero"]), 0, None, 0, ptr(g), pm["n0"])
@@ -163,11 +172,9 @@ class _Chain:
         out = torch.empty((rows, self.n_last), dtype=torch.float32, device=dev)
         rest = self.layers[1:]
         if (not self.f16 and c1 <= 4 and pm["n0"] == 256 and len(rest) == 2 and all(l[2] == 256 and l[4] == 256 for l in rest)
-                and os.environ.get("PA_ENGINE_FPX_REG", "0") == "1"):
+                and "kperm" in pm):
             # experimental register-resident variant (fpx_reg.hip, opt-in: slower than the LDS-tiled kernel so far); a function of the
             # layer shapes and the environment only, never of the batch size
-            if "kperm" not in pm:
-                pm["kperm"] = [pack_weights_kperm(l[0]) for l in rest]
             call("pa_fpx256", rows, ptr(g), ptr(idx3), ptr(w3), ptr(skip), n_unknown, m_known, c1, ptr(pm["wskip"]), ptr(pm["bias0"]),
                  ptr(pm["kperm"][0]), ptr(rest[0][1]), ptr(pm["kperm"][1]), ptr(rest[1][1]), ptr(out), self.n_last)
             return out
@@ -301,44 +308,59 @@ class _Attn:
         return out
 
 
-class _PptHead:
-    """PPT-Net head after the pyramid VLADs (pptnet_origin/models/loupe.py:94-105): flat concat -> hidden_weights -> bn2 ->
-    context gating.  The VLAD kernel writes cluster-major rows (B, sum K, 256), so the FC weight rows are permuted once from
-    the reference's per-scale C-major flattening (off_i + c*K_i + k) to (koff_i + k)*256 + c."""
+class _FcHead:
+    """Fully connected aggregation head on the cluster-major VLAD rows (B, sum K, 256): FC -> BatchNorm1d (eval) [-> L2 normalise].
 
-    def __init__(self, agg, ks, use_normalize, device):
+    per_scale=True : PPT-Net (pptnet_origin/models/loupe.py:94-105): every scale is flattened C-major on its own and the blocks are
+                     concatenated, so the reference's FC row of (scale i, channel c, cluster k) is off_i + c*K_i + k;
+    per_scale=False: PatchAugNet aggregation_type 0 (patch_aug_net/models/loupe.py:298-300): the concatenated (B, C, sum K) tensor is
+                     flattened C-major, row c*sum K + koff_i + k.
+    Either way the rows are permuted ONCE to the kernel's order (koff_i + k)*256 + c."""
+
+    def __init__(self, hidden_weights, bn, ks, per_scale, l2, device):
         c, ktot = 256, sum(ks)
-        hw = agg.hidden_weights.detach()
+        hw = hidden_weights.detach()
         perm = torch.empty(c * ktot, dtype=torch.long)
         off, koff = 0, 0
         for k in ks:
             cc, kk = torch.meshgrid(torch.arange(c), torch.arange(k), indexing="ij")
-            perm[((koff + kk) * c + cc).flatten()] = (off + cc * k + kk).flatten()
+            src = (off + cc * k + kk) if per_scale else (cc * ktot + koff + kk)
+            perm[((koff + kk) * c + cc).flatten()] = src.flatten()
             off += c * k
             koff += k
         self.fc_wt = hw[perm.to(hw.device)].float().contiguous().to(device)                 # (256*ktot, nout) K-major
-        scale, shift = fold_bn1d(agg.bn2)
+        scale, shift = fold_bn1d(bn)
         self.scale, self.shift = scale.float().contiguous().to(device), shift.float().contiguous().to(device)
         self.nout = hw.shape[1]
-        self.gating = agg.gating
-        if self.gating:
-            g = agg.context_gating
-            self.g_wt = g.gating_weights.detach().float().contiguous().to(device)          # (dim, dim): x @ W, already K-major
-            gs, gh = fold_bn1d(g.bn1)
-            self.g_scale, self.g_shift = gs.float().contiguous().to(device), gh.float().contiguous().to(device)
-        self.l2 = 1 if use_normalize else 0
+        if self.nout % 16:
+            raise ValueError("fused FC head needs an output width that is a multiple of 16")
+        self.l2 = l2
 
     def run(self, v):
         b, kdim, dev = v.shape[0], v.shape[1] * v.shape[2], v.device
         scratch = torch.empty(_lib.lib().pa_fc_scratch_floats(b, kdim, self.nout), dtype=torch.float32, device=dev)
         h = torch.empty((b, self.nout), dtype=torch.float32, device=dev)
-        call("pa_fc", b, kdim, self.nout, ptr(v), ptr(self.fc_wt), None, ptr(self.scale), ptr(self.shift),
-             0 if self.gating else self.l2, None, ptr(scratch), ptr(h))
-        if not self.gating:
-            return h
+        call("pa_fc", b, kdim, self.nout, ptr(v), ptr(self.fc_wt), None, ptr(self.scale), ptr(self.shift), self.l2, None, ptr(scratch), ptr(h))
+        return h
+
+
+class _Gate:
+    """GatingContext (loupe.py:332-361): x * sigmoid(BN(x @ W)) [-> L2 normalise], one pa_fc launch pair."""
+
+    def __init__(self, g, l2, device):
+        self.g_wt = g.gating_weights.detach().float().contiguous().to(device)               # (dim, dim): x @ W, already K-major
+        gs, gh = fold_bn1d(g.bn1)
+        self.g_scale, self.g_shift = gs.float().contiguous().to(device), gh.float().contiguous().to(device)
+        self.dim = self.g_wt.shape[0]
+        if self.dim % 16:
+            raise ValueError("fused context gating needs a width that is a multiple of 16")
+        self.l2 = l2
+
+    def run(self, h):
+        b, dev = h.shape[0], h.device
+        scratch = torch.empty(_lib.lib().pa_fc_scratch_floats(b, self.dim, self.dim), dtype=torch.float32, device=dev)
         out = torch.empty_like(h)
-        call("pa_fc", b, self.nout, self.nout, ptr(h), ptr(self.g_wt), None, ptr(self.g_scale), ptr(self.g_shift), self.l2, ptr(h),
-             ptr(scratch), ptr(out))
+        call("pa_fc", b, self.dim, self.dim, ptr(h), ptr(self.g_wt), None, ptr(self.g_scale), ptr(self.g_shift), self.l2, ptr(h), ptr(scratch), ptr(out))
         return out
 
 
@@ -366,21 +388,47 @@ class PatchAugNetEngine:
         agg = self.agg
         self.ppt = hasattr(agg, "vlad0")
         vl = [getattr(agg, f"vlad{i}") for i in range(4)] if self.ppt else list(agg.vlads)
-        ok = all(v.feature_size == 256 and v.cluster_size <= 64 for v in vl) and sum(v.cluster_size for v in vl) <= 256
-        if self.ppt:
-            self.fused_head = ok and agg.hidden_weights.shape[1] % 16 == 0
-        else:
-            self.fused_head = ok and agg.aggregation_type == 2 and not agg.gating and agg.afa.fc.out_features % 16 == 0
-        if self.fused_head:
-            with torch.no_grad():
-                self.vlads = [_Vlad(v, self.device) for v in vl]
-                if self.ppt:
-                    self.head = _PptHead(agg, [v.cluster_size for v in vl], model.use_normalize, self.device)
-                else:
+        if not (all(v.feature_size == 256 and v.cluster_size <= 64 for v in vl) and sum(v.cluster_size for v in vl) <= 256):
+            # no PyTorch fallback in the product path: shapes the HIP head kernels are not built for are refused, loudly
+            raise ValueError("fused engine: the NetVLAD / aggregation kernels are built for 256-wide features, <= 64 clusters per scale and "
+                             "<= 256 clusters in total; set model.fused_eval = False to run the autograd module path instead")
+        ks = [v.cluster_size for v in vl]
+        with torch.no_grad():
+            self.vlads = [_Vlad(v, self.device) for v in vl]
+            self.afa = self.head = self.gate = None
+            if self.ppt:
+                self.head_kind = "fc"
+                self.head = _FcHead(agg.hidden_weights, agg.bn2, ks, per_scale=True, l2=0 if agg.gating else (1 if model.use_normalize else 0), device=self.device)
+                if agg.gating:
+                    self.gate = _Gate(agg.context_gating, l2=1 if model.use_normalize else 0, device=self.device)
+            else:
+                if agg.aggregation_type == 2:
+                    if len(agg.afa.mlpa.mlps) != 1 or agg.afa.fc.out_features % 16:
+                        raise ValueError("fused APFA head supports the single-conv attention layer and an output width that is a multiple of 16")
+                    self.head_kind = "afa"
                     self.afa = _Afa(agg.afa, self.device)
-        elif self.ppt:
-            raise ValueError("PPT-Net fused engine needs 256-wide features and <= 64 clusters per scale")
-        self.premul = os.environ.get("PA_ENGINE_NO_PREMUL") is None     # fold the finest FP level's first layer into its prologue
+                elif agg.aggregation_type == 0:       # loupe.py:298-300: FC over the C-major flattening of (B, C, sum K), BN, L2 normalise
+                    self.head_kind = "fc"
+                    self.head = _FcHead(agg.hidden_weights, agg.bn, ks, per_scale=False, l2=1, device=self.device)
+                else:                                 # loupe.py:304-306: max over the clusters, L2 normalise
+                    self.head_kind = "max"
+                if agg.gating:                        # loupe.py:308-309, applied after the normalisation
+                    self.gate = _Gate(agg.context_gating, l2=0, device=self.device)
+        self.premul = os.environ.get("PA_ENGINE_NO_PREMUL") is None     # fold the FP levels' first layer through the interpolation
+        # Channel counts of every FP level are fixed by the architecture: known = the level above (coarsest: the last SA level), skip = the
+        # encoder features of the same level (finest: xyz).  The first-layer split of pa_fp_chain_premul is packed HERE, never in a forward.
+        nfp = len(self.fp)
+        self._fold_static = []
+        with torch.no_grad():
+            for j, chain in enumerate(self.fp):
+                c2 = self.fp[j + 1].n_last if j + 1 < nfp else self.sa[-1].n_last
+                c1 = (3 if self.use_origin else 0) if j == 0 else self.sa[j - 1].n_last
+                ok = (1 <= c1 <= 4 or (c1 > 4 and c1 % 4 == 0 and chain.n <= 3 and (not chain.f16 or chain.layers[0][4] % 32 == 0)))
+                ok = bool(self.premul and ok and chain.n >= 2 and c2 % 4 == 0 and chain.layers[0][4] % 16 == 0 and chain.layers[0][2] == c2 + c1)
+                self._fold_static.append(ok)
+                if ok:
+                    chain.build_premul(c2, c1, kperm=os.environ.get("PA_ENGINE_FPX_REG", "0") == "1")
+        self._tensors = list(model.parameters()) + list(model.buffers())
         self._key = self._params_key(model)
         self.timer = None     # optional profiling.StageTimer: per-stage HIP-event marks (bench.py kernel attribution)
 
@@ -388,13 +436,25 @@ class PatchAugNetEngine:
         if self.timer is not None:
             self.timer.mark(name)
 
-    @staticmethod
-    def _params_key(model):
-        p = next(model.parameters())
-        return (p.device, p.data_ptr(), p._version, getattr(model, "mlp_dtype", None))
+    def _params_key(model_or_self, model=None):
+        """Identity + version of EVERY parameter and buffer (partial load_state_dict, p.data.copy_(), edited BatchNorm statistics all
+        bump a tensor's _version or move its storage); ~30 us per forward."""
+        if model is None:                              # called as a static helper on a model without an engine
+            model = model_or_self
+            ts = list(model.parameters()) + list(model.buffers())
+        else:
+            ts = model_or_self._tensors
+        ver = ptrs = 0
+        for t in ts:
+            ver += t._version
+            ptrs ^= t.data_ptr()
+        return (ts[0].device, len(ts), ver, ptrs, getattr(model, "mlp_dtype", None))
 
     def matches(self, model, x):
         return x.device == self.device and self._key == self._params_key(model)
+
+    def stale(self, model):
+        return self._key != self._params_key(model)
 
     def backbone(self, xyz):
         """xyz (B, N, 3) -> point-major features per level + level-0 centre indices."""
@@ -443,8 +503,7 @@ class PatchAugNetEngine:
             c1 = skip.shape[-1] if skip is not None else 0
             # c1 <= 4 (xyz skip): always; wider skips only at levels with enough points per cloud to amortise the extra pre-multiply
             # launch (a per-level rule, NOT a function of the batch size: results must not depend on how clouds are batched)
-            fold_ok = 1 <= c1 <= 4 or (c1 % 4 == 0 and chain.n <= 3 and n_u >= 512 and (not chain.f16 or chain.layers[0][4] % 32 == 0))
-            if self.premul and fold_ok and chain.n >= 2 and n_u >= 2 * m_k and c2 % 4 == 0 and chain.layers[0][4] % 16 == 0:
+            if self._fold_static[nfp + i] and (c1 <= 4 or n_u >= 512) and n_u >= 2 * m_k:
                 y = chain.fp_premul(known_feat.contiguous(), idx3, w3, skip.contiguous(), B, n_u, m_k, c2, c1,
                                     mark=lambda k=nfp + i: self._mark(f"fp{k}.premul"))
             else:
@@ -452,17 +511,6 @@ class PatchAugNetEngine:
             self._mark(f"fp{nfp + i}.chain")
             l_feat[i - 1] = y.view(B, n_u, chain.n_last)
         return l_feat, l_c
-
-    @staticmethod
-    def _vlad(v, x):
-        """loupe.py:191-222 on point-major x (B, N, C) -- exactly the layout the reference transposes into."""
-        act = torch.matmul(x, v.cluster_weights)
-        act = F.batch_norm(act.view(-1, v.cluster_size), v.bn1.running_mean, v.bn1.running_var, v.bn1.weight, v.bn1.bias,
-                           False, 0.0, v.bn1.eps).view(x.shape[0], -1, v.cluster_size)
-        act = torch.softmax(act, dim=-1)
-        a = act.sum(-2, keepdim=True) * v.cluster_weights2
-        vlad = torch.matmul(act.transpose(1, 2), x).transpose(1, 2) - a
-        return F.normalize(vlad, dim=1, p=2)
 
     def forward(self, x, views=True):
         """-> desc (B, 256), (fp_features views, level-0 centre indices); views=False skips the index mapping (descriptor-only callers)."""
@@ -477,28 +525,22 @@ class PatchAugNetEngine:
         l_feat, l_c = self.backbone(xyz)
         nfp = len(self.fp)
         feats = [l_feat[j] for j in range(nfp - 1, -1, -1)]                                   # coarse -> fine, (B, N_i, 256)
-        agg = self.agg
-        if self.fused_head:
-            ktot = sum(v.k for v in self.vlads)
-            v = torch.empty((x.shape[0], ktot, 256), dtype=torch.float32, device=self.device)     # cluster-major rows
-            koff = 0
-            for vl, f in zip(self.vlads, feats):
-                vl.run(f.contiguous(), v, ktot, koff, rows=True)
-                koff += vl.k
-            self._mark("vlad")
-            desc = self.head.run(v) if self.ppt else self.afa.run_rows(v)
-            self._mark("afa")
-            return desc, (self._views(feats, l_c) if views else (None, None))
-        v = torch.cat([self._vlad(vl, f) for vl, f in zip(agg.vlads, feats)], dim=-1)       # (B, 256, sum K)
+        ktot = sum(v.k for v in self.vlads)
+        v = torch.empty((x.shape[0], ktot, 256), dtype=torch.float32, device=self.device)     # cluster-major rows
+        koff = 0
+        for vl, f in zip(self.vlads, feats):
+            vl.run(f.contiguous(), v, ktot, koff, rows=True)
+            koff += vl.k
         self._mark("vlad")
-        if agg.aggregation_type == 2:
-            desc = agg.afa(v).squeeze(-1)
-        elif agg.aggregation_type == 0:
-            desc = F.normalize(agg.bn(torch.matmul(v.flatten(1), agg.hidden_weights)))
+        if self.head_kind == "afa":
+            desc = self.afa.run_rows(v)
+        elif self.head_kind == "fc":
+            desc = self.head.run(v)
         else:
-            desc = F.normalize(v.max(dim=2)[0])
-        if agg.gating:
-            desc = agg.context_gating(desc)
+            desc = torch.empty((x.shape[0], 256), dtype=torch.float32, device=self.device)
+            call("pa_vlad_maxpool", x.shape[0], ktot, 256, ptr(v), 1, ptr(desc))
+        if self.gate is not None:
+            desc = self.gate.run(desc)
         self._mark("afa")
         return desc, (self._views(feats, l_c) if views else (None, None))
 
@@ -508,3 +550,19 @@ class PatchAugNetEngine:
         for i in range(1, len(l_c)):
             c_o.append(torch.gather(c_o[i - 1], -1, l_c[i].long()))
         return [f.transpose(1, 2).unsqueeze(-1) for f in feats], c_o                         # (B, 256, N_i, 1) views
+
+
+def engine_for(model, device):
+    """The model's fused engine for `device`, (re)built when absent or stale.  Construction runs under a device guard: the C ABI
+    launches on the CURRENT device's stream, so packing kernels for a model on cuda:1 must not be issued while cuda:0 is current."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("the fused engine runs on the MI355X only (got %s); there is no CPU path" % device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    eng = getattr(model, "_engine", None)
+    if eng is None or eng.device != device or eng._key != eng._params_key(model):
+        with torch.cuda.device(device):
+            eng = PatchAugNetEngine(model, device)
+        model._engine = eng
+    return eng

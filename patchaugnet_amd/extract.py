@@ -30,6 +30,16 @@ def _prime_stream_queues(device):
     torch.cuda.synchronize(device)
 
 
+def _prepare(model, device):
+    """Build the model's fused engine (folded + packed weights) on the CALLER's current stream before any pipeline stream touches it:
+    a lazily built engine would enqueue its pack kernels on whichever pipeline stream runs the first batch, and the other streams would
+    read the packed buffers with nothing ordering them after those kernels."""
+    prep = getattr(model, "prepare", None)
+    if prep is not None and not getattr(model, "training", False) and getattr(model, "fused_eval", True):
+        with torch.cuda.device(device):
+            prep(device)
+
+
 class StreamPipeline:
     def __init__(self, n_streams=2, device=None):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -72,6 +82,7 @@ class GraphedExtractor:
         _prime_stream_queues(self.device)
         self.slots = []
         cur = torch.cuda.current_stream(self.device)
+        _prepare(model, self.device)                   # BatchNorm folding / weight packing on the caller's stream, before any slot stream runs
         with torch.no_grad():
             for _ in range(max(1, n_streams)):
                 st = torch.cuda.Stream(device=self.device)
@@ -91,7 +102,8 @@ class GraphedExtractor:
         self._engine = getattr(model, "_engine", None)      # the graphs point at THIS engine's folded / packed weight buffers
 
     def begin(self):
-        if getattr(self._model, "_engine", None) is not self._engine or self._model.training:
+        eng = getattr(self._model, "_engine", None)
+        if eng is not self._engine or self._model.training or (eng is not None and eng.stale(self._model)):
             raise RuntimeError("GraphedExtractor: the model's weights or mode changed after capture (load_state_dict / train()); "
                                "build a new GraphedExtractor")
         cur = torch.cuda.current_stream(self.device)
@@ -126,6 +138,7 @@ def extract_descriptors(model, batches, n_streams=4, out=None, graphs=False):
     if out is None:
         out = torch.empty(total, 256, device=dev)
     shape = tuple(batches[0].shape)
+    _prepare(model, dev)
     gx = GraphedExtractor(model, shape, n_streams, dev) if graphs and sum(tuple(b.shape) == shape for b in batches) >= 2 * n_streams else None
     pipe = StreamPipeline(n_streams, dev)
     pipe.begin()

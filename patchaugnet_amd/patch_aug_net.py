@@ -62,10 +62,20 @@ class Network(nn.Module):
 
     # ---- fused inference engine (eval + no_grad) ----------------------------------------------------------------
     def _fused(self, x, views=True):
-        from .engine import PatchAugNetEngine
-        if self._engine is None or not self._engine.matches(self, x):
-            self._engine = PatchAugNetEngine(self, x.device)
-        return self._engine.forward(x, views=views)
+        from .engine import engine_for
+        return engine_for(self, x.device).forward(x, views=views)
+
+    def prepare(self, device=None):
+        """Build the fused engine (BatchNorm folding, weight packing) NOW, on the caller's current stream of `device`.  Callers that
+        issue forwards on several streams (extract.StreamPipeline, GraphedExtractor) do this first, so no pack kernel is ever
+        enqueued from inside a pipelined forward."""
+        from .engine import engine_for
+        dev = torch.device(device) if device is not None else next(self.parameters()).device
+        return engine_for(self, dev)
+
+    def invalidate_engine(self):
+        """Drop the folded / packed weight copies (they are rebuilt at the next eval forward)."""
+        self._engine = None
 
     def train(self, mode=True):
         self._engine = None            # parameters may change: rebuild folded weights at the next eval forward
@@ -74,6 +84,12 @@ class Network(nn.Module):
     def load_state_dict(self, *a, **k):
         self._engine = None
         return super().load_state_dict(*a, **k)
+
+    def __getstate__(self):
+        """The engine holds ctypes pointer arrays into device buffers: never copied or pickled (copy.deepcopy / torch.save of the module)."""
+        st = self.__dict__.copy()
+        st["_engine"] = None
+        return st
 
     def forward(self, x, nn_dict=None, return_feat=True, use_engine=None):
         """x: (B, 1, N, 3)."""

@@ -35,6 +35,15 @@ class Network(nn.Module):
         self._engine = None
         self.fused_eval = True       # eval()+no_grad() forwards run the fused HIP engine; set False for the module path
 
+    def prepare(self, device=None):
+        """Build the fused engine now, on the caller's current stream (see patch_aug_net.Network.prepare)."""
+        from .engine import engine_for
+        dev = torch.device(device) if device is not None else next(self.parameters()).device
+        return engine_for(self, dev)
+
+    def invalidate_engine(self):
+        self._engine = None
+
     def train(self, mode=True):
         self._engine = None
         return super().train(mode)
@@ -43,14 +52,17 @@ class Network(nn.Module):
         self._engine = None
         return super().load_state_dict(*a, **k)
 
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st["_engine"] = None               # ctypes pointer arrays: never copied or pickled
+        return st
+
     def forward(self, x, return_feat=True, use_engine=None):
         if use_engine is None:
             use_engine = self.fused_eval and not self.training and not torch.is_grad_enabled()
         if use_engine:
-            from .engine import PatchAugNetEngine
-            if self._engine is None or not self._engine.matches(self, x):
-                self._engine = PatchAugNetEngine(self, x.device)
-            d, (fp, cidx) = self._engine.forward(x, views=return_feat)
+            from .engine import engine_for
+            d, (fp, cidx) = engine_for(self, x.device).forward(x, views=return_feat)
             return (d, fp, cidx) if return_feat else d
         res = self.backbone(x.squeeze(1))
         fp = res["fp_features"]

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Randomised shape fuzzing of the HIP ops against the CPU oracle / fp64 torch (run on the GPU box; not part of the test suite).
+"""Randomised shape fuzzing of the HIP ops against the CPU oracle / fp64 torch.  A bounded slice (a few seconds per family, fixed seed) is
+collected by `pytest -m gpu` through tests/test_gpu_fuzz.py; longer campaigns are run by hand on the GPU box:
     python tests/fuzz_gpu.py [seconds per op family, default 20]
 Index outputs and pure gathers must be bit-exact; GEMM-based ops within 2e-5 relative of an fp64 reference."""
 import os
@@ -17,8 +18,13 @@ from patchaugnet_amd import pointops as P, _lib
 from patchaugnet_amd._lib import call, ptr
 from patchaugnet_amd.engine import pack_weights
 
-BUDGET = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
+BUDGET = 20.0            # seconds per family; the command line / tests/test_gpu_fuzz.py override it
 rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "2026")))
+
+
+def reseed(seed):
+    global rng
+    rng = np.random.default_rng(seed)
 
 
 def cloud(b, n):
@@ -42,9 +48,9 @@ def logint(lo, hi):
     return int(np.exp(rng.uniform(np.log(lo), np.log(hi + 1))))
 
 
-def run(name, fn):
+def run(name, fn, budget=None):
     t0, cases = time.time(), 0
-    while time.time() - t0 < BUDGET:
+    while time.time() - t0 < (BUDGET if budget is None else budget):
         desc = fn()
         cases += 1
         if desc is not None:
@@ -265,10 +271,14 @@ def f_afa():
         return f"b={b} ktot={ktot} err={e1} err_rows={e2}"
 
 
-if __name__ == "__main__":
-    ok = True
-    fams = (("fps", f_fps), ("knn", f_knn), ("3nn", f_3nn), ("gather", f_gather), ("backward", f_backward), ("linear", f_linear),
+FAMILIES = (("fps", f_fps), ("knn", f_knn), ("3nn", f_3nn), ("gather", f_gather), ("backward", f_backward), ("linear", f_linear),
             ("attention", f_attention), ("chain_sa", f_chain_sa), ("chain_fp", f_chain_fp), ("netvlad", f_netvlad), ("afa", f_afa))
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        BUDGET = float(sys.argv[1])
+    ok = True
+    fams = FAMILIES
     only = os.environ.get("FUZZ_ONLY")
     for name, fn in fams:
         if only and name not in only.split(","):

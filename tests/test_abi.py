@@ -109,3 +109,13 @@ def test_reference_op_layer_imports_against_the_mirrors():
     from patchaugnet_amd import pointops_cuda
     used = set(re.findall(r"pointops_cuda\.(\w+)\(", open("/root/reference/libs/pointops/functions/pointops.py").read()))
     assert used and not (used - set(dir(pointops_cuda)))
+
+
+def test_bench_refuses_gpu_counts_it_cannot_honour():
+    """`python bench.py --gpus 2` on a box without two GPUs must fail loudly, never print a 1-GPU line (N-rank self-launch of bench.py)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(max(torch.cuda.device_count(), 1) + 1)],
+                         capture_output=True, text=True, env=env)
+    assert out.returncode != 0 and "refusing" in out.stderr and '"n_gpus"' not in out.stdout
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=dict(env, WORLD_SIZE="1", RANK="0"))
+    assert out.returncode != 0 and "does not match WORLD_SIZE" in out.stderr

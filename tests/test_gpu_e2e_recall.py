@@ -1,0 +1,75 @@
+"""End-to-end Recall parity (north_star: Recall@1 within 0.1 % of the reference).
+
+clouds -> descriptors -> retrieval -> Recall@N, product against reference:
+  product  : distributed.extract_dataset (fused HIP engine, 4 streams) -> retrieval.get_recall_precision (HIP brute-force kNN)
+  reference: oracle/models_cpu descriptors -> the REFERENCE's SceneDataSet.get_recall_precision (place_recognition/evaluate.py:167-237,
+             datasets/scene_dataset.py:1016-1099), run in the build container by oracle/gen_e2e_golden.py and committed as
+             tests/golden/e2e_recall.npz together with the oracle descriptors.
+Tolerance: |delta Recall@N| <= 0.1 percentage points for every N, every trip pair, and on the evaluate.py average; descriptors
+<= 1e-4 max-abs (the fp32 MFMA contract of SURVEY.md section 8).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gen_e2e_golden as g
+from oracle import recall_cpu
+from tests._util import golden
+
+
+def _fixture():
+    z = golden("e2e_recall")
+    sizes = [int(v) for v in z["sizes"]]
+    assert sizes == g.SIZES and int(z["seed"]) == g.SEED
+    return z, sizes
+
+
+def _check_inputs(z, x, full=True):
+    assert np.array_equal(x[0, 0, :8].numpy(), z["cloud_head"])
+    if full:
+        assert np.allclose([x.double().sum().item(), x.double().abs().sum().item()], z["cloud_checksum"], rtol=0, atol=1e-6)
+
+
+def test_fixture_recall_is_what_the_oracle_bookkeeping_gives():
+    """CPU: the committed reference numbers follow from the committed oracle descriptors through oracle/recall_cpu (restatement pinned
+    to the reference run), and the clouds re-made from the seed are the generator's."""
+    z, sizes = _fixture()
+    _check_inputs(z, g.clouds(0, 2), full=False)
+    tuples = g.positives(g.trip_positions())
+    res = recall_cpu.get_recall_precision(z["oracle_desc"], sizes, tuples, top_k=int(z["top_k"]), skip_trip_itself=True)
+    for i, k in enumerate(map(tuple, z["pairs"])):
+        assert np.array_equal(res[k][0], z["recall"][i]) and np.array_equal(res[k][1], z["precision"][i])
+        assert res[k][2] == z["opr"][i] and res[k][6] == z["num_eval"][i]
+    ave = recall_cpu.average(res, int(z["top_k"]))
+    assert 10.0 < ave[0][0] < 90.0, "Recall@1 should sit in its sensitive mid range for this fixture"
+
+
+@pytest.mark.gpu
+def test_recall_from_hip_descriptors_matches_reference_within_0p1_percent():
+    from patchaugnet_amd import configs, distributed, patch_aug_net, retrieval
+    from patchaugnet_amd.weights import seeded_state_dict
+    z, sizes = _fixture()
+    n = sum(sizes)
+    x = g.clouds(0, n)
+    _check_inputs(z, x)
+    cfg = configs.patch_aug_net_config()
+    model = patch_aug_net.Network(param=cfg, use_a2a_recon=True, use_l2_norm=True)
+    model.load_state_dict(seeded_state_dict(model.state_dict()))
+    model = model.cuda().eval()                                   # a COLD model: the pipeline must build the engine before it forks streams
+    xd = x.cuda()
+    desc = distributed.extract_dataset(model, lambda lo, hi: xd[lo:hi], n, batch_size=16, n_streams=4)
+    torch.cuda.synchronize()
+    err = (desc.cpu() - torch.from_numpy(z["oracle_desc"])).abs().max().item()
+    assert err <= 1e-4, f"descriptor max|diff| vs the oracle {err:.3e}"
+    tuples = g.positives(g.trip_positions())
+    top_k = int(z["top_k"])
+    res = retrieval.get_recall_precision(desc, sizes, tuples, top_k=top_k, skip_trip_itself=True)
+    worst = 0.0
+    for i, k in enumerate(map(tuple, z["pairs"])):
+        assert res[k][6] == z["num_eval"][i]
+        worst = max(worst, float(np.abs(np.asarray(res[k][0]) - z["recall"][i]).max()), abs(res[k][2] - float(z["opr"][i])))
+    assert worst <= 0.1, f"per-pair Recall@N differs by {worst:.3f} percentage points"
+    ave = retrieval.average(res, top_k)
+    ref = (z["recall"].mean(0), z["precision"].mean(0), float(z["opr"].mean()))
+    assert abs(ave[0][0] - ref[0][0]) <= 0.1 and abs(ave[0][4] - ref[0][4]) <= 0.1, (ave[0][:5], ref[0][:5])
+    assert np.abs(ave[0] - ref[0]).max() <= 0.1 and abs(ave[2] - ref[2]) <= 0.1

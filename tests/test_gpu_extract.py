@@ -76,3 +76,89 @@ def test_graphed_extractor_refuses_stale_weights():
     m.eval()
     with pytest.raises(RuntimeError, match="changed after capture"):
         gx.begin()
+
+
+@pytest.mark.parametrize("name", ["patch_aug_net", "pptnet"])
+def test_pipeline_on_a_cold_model(name):
+    """A model that has never run: extract_descriptors must build the engine (BatchNorm folding, weight packing) on the caller's stream
+    BEFORE the pipeline streams fork, otherwise batches 2..4 read packed buffers that the pack kernels on stream 1 may not have
+    written yet.  The cold run must equal a warm run of the same model bit for bit."""
+    from patchaugnet_amd.extract import extract_descriptors
+    x = synthetic_submaps(40, 4096, 51).cuda()
+    batches = [x[i:i + 4].contiguous() for i in range(0, 40, 4)]
+    cold = _model(name)
+    assert cold._engine is None
+    got = extract_descriptors(cold, batches, n_streams=4)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = torch.cat([cold(b, return_feat=False) for b in batches])
+    assert torch.equal(got, ref)
+    for ch in cold._engine.fp:                              # nothing is packed lazily any more
+        assert not cold._engine._fold_static[cold._engine.fp.index(ch)] or ch._premul is not None
+
+
+def test_engine_notices_partial_weight_updates_and_survives_deepcopy():
+    """Partial load_state_dict, in-place parameter edits and edited BatchNorm statistics all invalidate the folded / packed copies; a
+    module that has run the engine can still be deep-copied and pickled (the engine itself is never copied)."""
+    import copy
+    import io
+    m = _model("patch_aug_net")
+    x = synthetic_submaps(3, 4096, 61).cuda()
+    with torch.no_grad():
+        d0 = m(x, return_feat=False).clone()
+        e0 = m._engine
+        assert torch.equal(m(x, return_feat=False), d0) and m._engine is e0           # unchanged weights: same engine
+        m.aggregation.load_state_dict(seeded_state_dict(m.aggregation.state_dict(), seed=5))      # submodule load: Network.load_state_dict is not called
+        d1 = m(x, return_feat=False).clone()
+        assert m._engine is not e0 and not torch.equal(d1, d0)
+        m.backbone.SA_modules[1].mlps[0].layer1.bn.bn.running_var.mul_(1.5)           # BatchNorm statistics edited in place
+        d2 = m(x, return_feat=False).clone()
+        assert not torch.equal(d2, d1)
+        m.backbone.FP_modules[0].mlp.layer2.conv.weight.data.mul_(0.9)               # .data edit
+        m.invalidate_engine()                                                         # (a .data write bumps no version counter: the explicit hook)
+        d3 = m(x, return_feat=False).clone()
+        assert not torch.equal(d3, d2)
+        ref = m(x, return_feat=False, use_engine=False)
+        assert (d3 - ref).abs().max().item() <= 1e-4
+        m2 = copy.deepcopy(m)
+        torch.save(m, io.BytesIO())
+        assert m2._engine is None and torch.equal(m2(x, return_feat=False), d3)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_model_on_a_device_that_is_not_current():
+    x = synthetic_submaps(2, 4096, 71)
+    m0 = _model("patch_aug_net")
+    with torch.no_grad():
+        ref = m0(x.cuda(0), return_feat=False).cpu()
+        m1 = _model("patch_aug_net").to("cuda:1")
+        torch.cuda.set_device(0)
+        got = m1(x.to("cuda:1"), return_feat=False)                                   # engine built and run under a device guard
+        torch.cuda.synchronize(1)
+    assert torch.equal(got.cpu(), ref)
+
+
+def test_graph_capture_next_to_a_live_rccl_group():
+    """hipGraph capture + replay while an RCCL process group (world size 1 on this GPU) has collectives in flight: its watchdog thread
+    polls events during capture (capture_error_mode thread_local).  Own process: a process group cannot be re-initialised in pytest's."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "probes", "graph_nccl.py")], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("trial")]
+    assert len(lines) == 3 and all(l.endswith("ok True True") for l in lines), out.stdout
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode != 0 and "refusing" in out.stderr and '"n_gpus"' not in out.stdout

@@ -1,5 +1,5 @@
-"""pa_netvlad / pa_afa (fused NetVLAD scale, adaptive feature aggregator) against the torch module path
-(patchaugnet_amd/loupe.py, itself pinned to the reference by the golden model tests).  fp32 tolerance."""
+"""pa_netvlad / pa_afa / the FC, max-pool and gated heads against the CPU oracle (oracle/models_cpu.py: netvlad_base,
+adaptive_feature_aggregator, spvlad_aggregate) and the torch module path (patchaugnet_amd/loupe.py).  fp32 tolerance."""
 import numpy as np
 import pytest
 import torch
@@ -29,6 +29,10 @@ def test_netvlad_scale(b, n, k):
     assert torch.all(out[:, :, :3] == 7.0) and torch.all(out[:, :, 3 + k:] == 7.0)       # neighbours of the block untouched
     err = (got - ref).abs().max().item()
     assert err <= 2e-5, err
+    from oracle import models_cpu
+    sd = {"v." + kk: t.cpu() for kk, t in v.state_dict().items()}
+    orc = models_cpu.netvlad_base(sd, "v", x.cpu().transpose(1, 2).unsqueeze(-1), n, 256, k)          # loupe.py:191-222 restated on the CPU
+    assert (got.cpu() - orc).abs().max().item() <= 2e-5
     assert torch.equal(out_t[:, 3:3 + k].transpose(1, 2), got) and torch.all(out_t[:, :3] == 7.0) and torch.all(out_t[:, 3 + k:] == 7.0)
 
 
@@ -46,3 +50,43 @@ def test_afa(b, ktot):
     err = (got - ref).abs().max().item()
     assert err <= 2e-5, err
     assert (got_rows - ref).abs().max().item() <= 2e-5
+    from oracle import models_cpu
+    orc = models_cpu.adaptive_feature_aggregator({"a." + kk: t.cpu() for kk, t in afa.state_dict().items()}, "a", v.cpu())
+    assert (got.cpu() - orc).abs().max().item() <= 2e-5 and (got_rows.cpu() - orc).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("agg_type,gating", [(0, False), (0, True), (2, True), (3, False), (3, True)])
+def test_other_aggregation_heads_run_on_hip_kernels(agg_type, gating):
+    """SpatialPyramidNetVLAD aggregation types 0 (FC) and 3 (max-pool) and context gating (loupe.py:289-326) go through the HIP head
+    kernels of the fused engine (no torch fallback): whole-model descriptors against the CPU oracle and the module path."""
+    from oracle import models_cpu
+    from patchaugnet_amd import configs, patch_aug_net
+    from patchaugnet_amd.weights import seeded_state_dict, synthetic_submaps
+    cfg = configs.scaled_config(configs.patch_aug_net_config(), 512)
+    cfg["AGGREGATION_TYPE"], cfg["GATING"] = agg_type, gating
+    m = patch_aug_net.Network(param=cfg, use_a2a_recon=False, use_l2_norm=True)
+    sd = seeded_state_dict(m.state_dict(), seed=40 + agg_type)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    x = synthetic_submaps(5, 512, seed=3)
+    with torch.no_grad():
+        torch.manual_seed(0)
+        d_eng = m(x.cuda(), return_feat=False)
+        kind = m._engine.head_kind
+        torch.manual_seed(0)
+        d_mod = m(x.cuda(), return_feat=False, use_engine=False)
+        torch.manual_seed(0)
+        d_orc = models_cpu.patch_aug_net_forward(sd, cfg, x, return_feat=False)
+    assert kind == {0: "fc", 2: "afa", 3: "max"}[agg_type] and (m._engine.gate is not None) == gating
+    assert (d_eng.cpu() - d_orc).abs().max().item() <= 1e-4
+    assert (d_eng - d_mod).abs().max().item() <= 1e-4
+
+
+def test_unsupported_head_shape_raises_instead_of_falling_back():
+    from patchaugnet_amd import configs, patch_aug_net
+    from patchaugnet_amd.weights import synthetic_submaps
+    cfg = configs.scaled_config(configs.patch_aug_net_config(), 512)
+    cfg["CLUSTER_SIZE"] = [4, 16, 80]                           # more clusters per scale than the NetVLAD kernel is built for
+    m = patch_aug_net.Network(param=cfg, use_a2a_recon=False, use_l2_norm=True).cuda().eval()
+    with torch.no_grad(), pytest.raises(ValueError, match="fused engine"):
+        m(synthetic_submaps(2, 512, seed=1).cuda(), return_feat=False)

@@ -53,3 +53,25 @@ def test_pptnet_matches_reference_vectors(tag):
     for i in range(4):
         assert np.array_equal(cidx[i].numpy(), g[f"{tag}_center_idx{i}"])
         assert np.allclose(samples(fp[i]), g[f"{tag}_fp{i}_samples"], atol=1e-5)
+
+
+@pytest.mark.parametrize("agg_type,gating", [(0, False), (0, True), (2, False), (2, True), (3, False), (3, True)])
+def test_aggregation_heads_match_reference_vectors(agg_type, gating):
+    """oracle.models_cpu.netvlad_base + spvlad_aggregate against the reference's SpatialPyramidNetVLAD for every aggregation type the
+    product's HIP heads cover (tests/golden/heads.npz, oracle/gen_head_golden.py)."""
+    from oracle.gen_head_golden import KS, NS, features
+    from patchaugnet_amd import loupe
+    from patchaugnet_amd.weights import seeded_state_dict
+    g = golden("heads")
+    agg = loupe.SpatialPyramidNetVLAD([256] * 3, NS, KS, [256] * 3, gating=gating, aggregation_type=agg_type)
+    sd = seeded_state_dict(agg.state_dict(), seed=100 + agg_type)
+    assert sorted(sd.keys()) == g[f"type{agg_type}_gating{int(gating)}_keys"].tolist()        # same parameter names as the reference class
+    feats = features()
+    sdp = {"a." + k: v for k, v in sd.items()}
+    with torch.no_grad():
+        v = torch.cat([models_cpu.netvlad_base(sdp, f"a.vlads.{i}", feats[i], NS[i], 256, KS[i]) for i in range(3)], dim=-1)
+        d = models_cpu.spvlad_aggregate(sdp, "a", v, agg_type, gating)
+        agg.load_state_dict(sd)
+        d_mod = agg.eval()(feats)                                                              # the product's module path too
+    ref = g[f"type{agg_type}_gating{int(gating)}"]
+    assert np.abs(d.numpy() - ref).max() <= 1e-6 and np.abs(d_mod.numpy() - ref).max() <= 1e-6

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
 """Workload for the rocprofv3 --pmc passes: 3 engine steps at the bench shape (B=32, 4096 pts) + the K5 micro-benchmark."""
+import argparse
 import os
 import sys
 
@@ -9,11 +10,15 @@ import torch
 from patchaugnet_amd import _lib, configs, patch_aug_net
 from patchaugnet_amd.weights import seeded_state_dict, synthetic_submaps
 
-cfg = configs.patch_aug_net_config()
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--points", type=int, default=4096)
+args = ap.parse_args()
+cfg = configs.patch_aug_net_config() if args.points == 4096 else configs.scaled_config(configs.patch_aug_net_config(), args.points)
 model = patch_aug_net.Network(param=cfg, use_a2a_recon=True, use_l2_norm=True)
 model.load_state_dict(seeded_state_dict(model.state_dict()))
 model = model.cuda().eval()
-x = synthetic_submaps(32, 4096, seed=1234).cuda()
+x = synthetic_submaps(args.batch, args.points, seed=1234).cuda()
 with torch.no_grad():
     for _ in range(3):
         model(x, return_feat=False)
