@@ -70,19 +70,58 @@ __device__ __forceinline__ void gemm_chunk(const float *__restrict__ act, int st
     int ks = 0;
     if ((NC % 4 == 0) && L.wp != nullptr) {
         constexpr int NQ = NC / 4 > 0 ? NC / 4 : 1;
-        const float4 *wq = reinterpret_cast<const float4 *>(L.wp) + (size_t)(c0 >> 2) * ksteps * 64 + lane;
-        const size_t gstep = (size_t)ksteps * 64;   // float4s between consecutive 64-column groups
+        // Packed weights through a buffer descriptor: the per-lane part of the address (lane and 64-column group) is a loop-invariant
+        // 32-bit VGPR offset, the k-step is a SCALAR offset, so a weight fetch costs one VMEM instruction and no VALU address math
+        // (flat 64-bit addressing cost a v_lshl_add_u64 per load: ~1 extra vector instruction per 8 MFMAs in a stream where every
+        // non-MFMA issue delays the matrix pipe).  The descriptor base must be provably wave-uniform: c0 depends on the wave id in the
+        // shared-tile variants, which the compiler treats as divergent, hence the readfirstlane.
+        const int c0u = __builtin_amdgcn_readfirstlane(c0);
+        const float *wbase = L.wp + (size_t)(c0u >> 2) * ksteps * 256;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wbase), 0, 0x7fffffff, 0x00020000);
+        unsigned voff[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) voff[q] = ((unsigned)q * (unsigned)ksteps * 64u + (unsigned)lane) * 16u;
+        auto load_b = [&](int u, int k) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[q], k * 1024, 0);
+                bq[u][4 * q] = __uint_as_float(v.x); bq[u][4 * q + 1] = __uint_as_float(v.y);
+                bq[u][4 * q + 2] = __uint_as_float(v.z); bq[u][4 * q + 3] = __uint_as_float(v.w);
+            }
+        };
 #pragma unroll
         for (int u = 0; u < PD; ++u) {
             const int k = min(u, last);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const float4 v = wq[q * gstep + (size_t)k * 64];
-                bq[u][4 * q] = v.x; bq[u][4 * q + 1] = v.y; bq[u][4 * q + 2] = v.z; bq[u][4 * q + 3] = v.w;
-            }
+            load_b(u, k);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) aq[u][rt] = ap[rt * 16 * stride + k * 4];
         }
+        // main loop: every refill is in range, so no clamps -- LDS reads become base + immediate offset, weight loads base + scalar offset
+        for (; ks + 2 * PD <= ksteps; ks += PD) {
+#pragma unroll
+            for (int u = 0; u < PD; ++u) {
+                const int nx = ks + u + PD;
+                float an[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) an[rt] = ap[rt * 16 * stride + nx * 4];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt)
+                            acc[rt][4 * q + c] = mfma_ab<SWAP>(aq[u][rt], bq[u][4 * q + c], acc[rt][4 * q + c]);
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[q], nx * 1024, 0);
+                    bq[u][4 * q] = __uint_as_float(v.x); bq[u][4 * q + 1] = __uint_as_float(v.y);
+                    bq[u][4 * q + 2] = __uint_as_float(v.z); bq[u][4 * q + 3] = __uint_as_float(v.w);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * RT, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) aq[u][rt] = an[rt];
+            }
+        }
+        // last full ring pass: refills beyond the end are clamped to the last k-step (loaded, never used)
         for (; ks + PD <= ksteps; ks += PD) {
 #pragma unroll
             for (int u = 0; u < PD; ++u) {
@@ -97,8 +136,9 @@ __device__ __forceinline__ void gemm_chunk(const float *__restrict__ act, int st
 #pragma unroll
                         for (int rt = 0; rt < RT; ++rt)
                             acc[rt][4 * q + c] = mfma_ab<SWAP>(aq[u][rt], bq[u][4 * q + c], acc[rt][4 * q + c]);
-                    const float4 v = wq[q * gstep + (size_t)nx * 64];
-                    bq[u][4 * q] = v.x; bq[u][4 * q + 1] = v.y; bq[u][4 * q + 2] = v.z; bq[u][4 * q + 3] = v.w;
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[q], nx * 1024, 0);
+                    bq[u][4 * q] = __uint_as_float(v.x); bq[u][4 * q + 1] = __uint_as_float(v.y);
+                    bq[u][4 * q + 2] = __uint_as_float(v.z); bq[u][4 * q + 3] = __uint_as_float(v.w);
                     __builtin_amdgcn_sched_group_barrier(0x008, 4 * RT, 0);
                     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }

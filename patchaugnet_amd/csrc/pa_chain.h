@@ -4,6 +4,7 @@
 #include "pa_common.h"
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct PaLayer {
     const float *wt;    // [kpad][n], K-major, rows >= k are zero
@@ -223,18 +224,22 @@ __device__ __forceinline__ void chain_prologue(T *act, float *scratch, const PaC
 #pragma unroll
             for (int t = 0; t < 4; ++t)
                 wv[t] = t < C1 ? *reinterpret_cast<const float4 *>(a.wskip + (size_t)t * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int r0 = 0; r0 < R; r0 += 4) {
-                float4 f[4][3];
-                float w[4][3];
+            // eight rows per trip: 24 independent 16-byte gathers in flight per lane (the coarse features of a batch live in the Infinity
+            // Cache / L2, ~1-2 us away; a wave-private tile has nobody else to hide that latency, so the trip count IS the prologue time:
+            // 4 trips instead of 8 for a 32-row tile).  The accumulators are not live yet, so the 96 extra registers are free here.
+            constexpr int U = (R % 8 == 0) ? 8 : 4;
+            for (int r0 = 0; r0 < R; r0 += U) {
+                float4 f[U][3];
+                float w[U][3];
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < U; ++u)
 #pragma unroll
                     for (int t = 0; t < 3; ++t) {
                         w[u][t] = wt[(r0 + u) * 3 + t];
                         f[u][t] = k4[(unsigned)nb[(r0 + u) * 3 + t] * 64u + (unsigned)lane];
                     }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < U; ++u) {
                     const float *s4 = sk + (r0 + u) * 4;
                     const float sx = s4[0], sy = s4[1], sz = s4[2], sw = s4[3];
                     // fixed fmaf order (bias, skip channels, then the three interpolation terms): the generic path below uses the same

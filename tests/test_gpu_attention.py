@@ -69,7 +69,7 @@ def test_pa_linear(rows, k, n, relu, res):
 def test_ppt_head_fc_and_gating(b, norm):
     """pptnet_origin/models/loupe.py:94-105 -- flat concat -> hidden_weights -> bn2 -> context gating (any batch size)."""
     from patchaugnet_amd import loupe
-    from patchaugnet_amd.engine import _PptHead
+    from patchaugnet_amd.engine import _FcHead, _Gate
     ks = [1, 4, 16, 64]
     agg = _seed_module(loupe.SpatialPyramidNetVLAD4([256] * 4, [64, 256, 1024, 4096], ks, [256] * 4, gating=True), seed=b).cuda()
     vl = [torch.nn.functional.normalize(torch.randn(b, 256, k, device="cuda"), dim=1) for k in ks]
@@ -79,5 +79,7 @@ def test_ppt_head_fc_and_gating(b, norm):
         ref = agg.context_gating(ref)
         if norm:
             ref = torch.nn.functional.normalize(ref)
-        got = _PptHead(agg, ks, norm, flat.device).run(torch.cat(vl, dim=-1).transpose(1, 2).contiguous())   # (B, 85, 256) rows of the VLAD kernel
+        rows = torch.cat(vl, dim=-1).transpose(1, 2).contiguous()                          # (B, 85, 256) rows of the VLAD kernel
+        h = _FcHead(agg.hidden_weights, agg.bn2, ks, per_scale=True, l2=0, device=flat.device).run(rows)
+        got = _Gate(agg.context_gating, l2=1 if norm else 0, device=flat.device).run(h)
     assert (got - ref).abs().max().item() <= 3e-5 * max(ref.abs().max().item(), 1.0)

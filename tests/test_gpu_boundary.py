@@ -28,6 +28,15 @@ def p(t):
     return P(t.data_ptr())
 
 
+_ALIVE = []
+
+
+def _keep(t):
+    """Hold a device tensor until the test ends: raw pointers handed to the C ABI do not keep their tensor alive."""
+    _ALIVE.append(t)
+    return t
+
+
 def zeros(*s, dt=torch.float32):
     return torch.zeros(*s, dtype=dt, device="cuda")
 
@@ -73,7 +82,7 @@ def test_group2_launchers_execute_and_match_the_oracle(lib):
     assert np.array_equal(out.cpu().numpy(), o.gathering_forward(f, cidx))
     g = RNG.standard_normal((b, c, m)).astype(np.float32)
     gp = zeros(b, c, n)
-    _sig(lib.gathering_backward_cuda_launcher, "iiiippp")(b, c, n, m, p(dev(g)), p(idx), p(gp))
+    _sig(lib.gathering_backward_cuda_launcher, "iiiippp")(b, c, n, m, p(_keep(dev(g))), p(idx), p(gp))
     torch.cuda.synchronize()
     assert np.allclose(gp.cpu().numpy(), o.gathering_backward(g, cidx, n), atol=1e-6)
 
@@ -92,13 +101,13 @@ def test_group2_launchers_execute_and_match_the_oracle(lib):
         assert np.array_equal(go.cpu().numpy(), o.grouping_forward(f, ri)), name
     gg = RNG.standard_normal((b, c, m, k)).astype(np.float32)
     gp = zeros(b, c, n)
-    _sig(lib.grouping_backward_cuda_launcher, "iiiiippp")(b, c, n, m, k, p(dev(gg)), p(kidx), p(gp))
+    _sig(lib.grouping_backward_cuda_launcher, "iiiiippp")(b, c, n, m, k, p(_keep(dev(gg))), p(kidx), p(gp))
     torch.cuda.synchronize()
     assert np.allclose(gp.cpu().numpy(), o.grouping_backward(gg, ri, n), atol=1e-5)
     fi = RNG.integers(-2**40, 2**40, (b, 3, n), dtype=np.int64)
     for name in ("grouping_int_forward_cuda_launcher", "grouping_int_forward_cuda_launcher_fast"):
         gi = zeros(b, 3, m, k, dt=torch.int64)
-        _sig(getattr(lib, name), "iiiiippp")(b, 3, n, m, k, p(dev(fi)), p(kidx), p(gi))
+        _sig(getattr(lib, name), "iiiiippp")(b, 3, n, m, k, p(_keep(dev(fi))), p(kidx), p(gi))
         torch.cuda.synchronize()
         assert np.array_equal(gi.cpu().numpy(), o.grouping_int_forward(fi, ri)), name
 
@@ -112,14 +121,15 @@ def test_group2_launchers_execute_and_match_the_oracle(lib):
     fk = RNG.standard_normal((b, c, m)).astype(np.float32)
     w = RNG.random((b, n, 3), dtype=np.float32)
     w /= w.sum(-1, keepdims=True)
+    FK, W = dev(fk), dev(w)                      # named: a temporary would be freed (and its block re-used) before the launch reads it
     for name in ("interpolation_forward_cuda_launcher", "interpolation_forward_cuda_launcher_fast"):
         io = zeros(b, c, n)
-        _sig(getattr(lib, name), "iiiipppp")(b, c, m, n, p(dev(fk)), p(i3), p(dev(w)), p(io))
+        _sig(getattr(lib, name), "iiiipppp")(b, c, m, n, p(FK), p(i3), p(W), p(io))
         torch.cuda.synchronize()
         assert np.array_equal(io.cpu().numpy(), o.interpolation_forward(fk, ri3, w)), name
     gi_ = RNG.standard_normal((b, c, n)).astype(np.float32)
-    gk = zeros(b, c, m)
-    _sig(lib.interpolation_backward_cuda_launcher, "iiiipppp")(b, c, n, m, p(dev(gi_)), p(i3), p(dev(w)), p(gk))     # positions (b, c, n, m)
+    gk, GI = zeros(b, c, m), dev(gi_)
+    _sig(lib.interpolation_backward_cuda_launcher, "iiiipppp")(b, c, n, m, p(GI), p(i3), p(W), p(gk))     # positions (b, c, n, m)
     torch.cuda.synchronize()
     assert np.allclose(gk.cpu().numpy(), o.interpolation_backward(gi_, ri3, w, m), atol=1e-4)
 
@@ -146,7 +156,7 @@ def test_group2_launchers_execute_and_match_the_oracle(lib):
     assert np.array_equal(fo.cpu().numpy(), o.gathering_forward(f, rdi))
     gf = RNG.standard_normal((b, c, m)).astype(np.float32)
     gm = zeros(b, c, n)
-    _sig(lib.featuregather_backward_cuda_launcher, "iiiipppp")(b, n, m, c, p(dev(gf)), p(di), p(gm), P(S))
+    _sig(lib.featuregather_backward_cuda_launcher, "iiiipppp")(b, n, m, c, p(_keep(dev(gf))), p(di), p(gm), P(S))
     torch.cuda.synchronize()
     assert np.allclose(gm.cpu().numpy(), o.gathering_backward(gf, rdi, n), atol=1e-6)
 

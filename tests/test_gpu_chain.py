@@ -150,12 +150,13 @@ def test_register_resident_fpx_variant_matches_shipped_kernel(monkeypatch):
     idx3 = torch.randint(0, m, (B, n, 3), generator=g).int().cuda()
     w3 = torch.rand(B, n, 3, generator=g)
     w3 = (w3 / w3.sum(-1, keepdim=True)).cuda().contiguous()
-    monkeypatch.setenv("PA_ENGINE_FPX_REG", "0")
-    a = _Chain(eng).fp_premul(known, idx3, w3, skip, B, n, m, c2, c1)
-    monkeypatch.setenv("PA_ENGINE_FPX_REG", "1")
-    b = _Chain(eng).fp_premul(known, idx3, w3, skip, B, n, m, c2, c1)
+    def chain(kperm):                       # the first-layer split is packed at construction time (engine.build_premul), never in a forward
+        ch = _Chain(eng)
+        ch.build_premul(c2, c1, kperm=kperm)
+        return ch
+    a = chain(False).fp_premul(known, idx3, w3, skip, B, n, m, c2, c1)
+    b = chain(True).fp_premul(known, idx3, w3, skip, B, n, m, c2, c1)
     close(b, a.double(), rtol=2e-5)                                        # different summation order: equal to rounding, not bit for bit
-    tail = _Chain(eng).fp_premul(known[:1], idx3[:1, :1000].contiguous(), w3[:1, :1000].contiguous(), skip[:1, :1000].contiguous(), 1, 1000, m, c2, c1)
-    monkeypatch.setenv("PA_ENGINE_FPX_REG", "0")
-    tail_ref = _Chain(eng).fp_premul(known[:1], idx3[:1, :1000].contiguous(), w3[:1, :1000].contiguous(), skip[:1, :1000].contiguous(), 1, 1000, m, c2, c1)
+    tail = chain(True).fp_premul(known[:1], idx3[:1, :1000].contiguous(), w3[:1, :1000].contiguous(), skip[:1, :1000].contiguous(), 1, 1000, m, c2, c1)
+    tail_ref = chain(False).fp_premul(known[:1], idx3[:1, :1000].contiguous(), w3[:1, :1000].contiguous(), skip[:1, :1000].contiguous(), 1, 1000, m, c2, c1)
     close(tail, tail_ref.double(), rtol=2e-5)                              # rows not a multiple of the 64-point workgroup tile
