@@ -258,6 +258,37 @@ int pa_fc(int b, int kdim, int nout, const float *y, const float *fc_wt, const f
  * c must be 256. */
 int pa_vlad_maxpool(int b, int ktot, int c, const float *vt, int l2norm, float *out, pa_stream_t stream);
 
+/* ---- Training-mode dense path (MFMA, fp32): building blocks of the hand-written forward / backward of SharedMLP in train() mode
+ * (utils/model_util/pt_util.py:16-41, :98-152: conv 1x1 -> BatchNorm with batch statistics -> ReLU) and of PointNetDecoder
+ * (place_recognition/patch_aug_net/models/pointnet_autoencoder.py:85-111), as the training step drives them
+ * (place_recognition/train_place_recognition.py:142-169, :386-392).  Activations are CHANNEL-MAJOR (B, C, P) like the reference's.
+ * Per-channel parameter block p: 7 rows of nch floats -- 0 scale = gamma*rstd, 1 shift = beta - mean*scale, 2 mean, 3 rstd (pa_bn_finalize),
+ * 4 mean(mask g), 5 mean(mask g * xhat), 6 gamma*rstd (pa_bn_bwd_finalize).
+ * pa_tgemm_nn: C_b (M x N) = [beta*C_b +] act(A_b (M x K) . f(B_b) (K x N) + bias[m]); B, C n-contiguous; A(m,k) = A[m*lda + k] when
+ *   a_kcontig else A[k*lda + m]; sAb = 0 shares A over the batch.  f acts per k (the channel): bmode 0 identity, 1 relu(x*p0 + p1),
+ *   2 / 3 the BatchNorm(+ReLU mask for 2) input gradient built from B = gradient w.r.t. the activation and baux = raw layer output.
+ *   act 0 none / 1 tanh.  stats: 2*M doubles receiving (accumulating) the per-row sum and sum of squares of the stored values, or NULL.
+ * pa_tgemm_kk: C (M x N) += sum over batch and k of fA(A_b)(m,k) * fB(B_b)(n,k), both operands k-contiguous (weight gradients: k runs
+ *   over the points); amode 0 / 2 / 3 per row m, bmode 0 / 1 per row n; partial tiles are combined with fp32 atomics, so C must be
+ *   zero-filled (or hold the value to add to); per_batch != 0 writes C_b = C + b*sCb instead of summing over the batch. */
+int pa_tgemm_nn(int batch, int M, int N, int K, const float *A, long sAb, int lda, int a_kcontig,
+                const float *B, long sBb, int ldb, int bmode, const float *baux, const float *bp,
+                float *C, long sCb, int ldc, int beta, const float *bias, int act, double *stats, pa_stream_t stream);
+int pa_tgemm_kk(int batch, int M, int N, long K, const float *A, long sAb, int lda, int amode, const float *aaux, const float *ap,
+                const float *B, long sBb, int ldb, int bmode, const float *bp,
+                float *C, long sCb, int ldc, int per_batch, pa_stream_t stream);
+/* BatchNorm (training): statistics -> rows 0..3 of p, running statistics updated in place (momentum, unbiased variance) when given. */
+int pa_bn_finalize(int nch, double count, const double *stats, const float *gamma, const float *beta, float eps, float momentum,
+                   float *running_mean, float *running_var, float *p, pa_stream_t stream);
+/* sums (2*C doubles, zero-filled) += per-channel sum of mask(g) and of mask(g)*xhat over g, y (B, C, P); relu != 0: mask = BN(y) > 0. */
+int pa_bn_bwd_reduce(int B, int C, long P, const float *g, const float *y, const float *p, int relu, double *sums, pa_stream_t stream);
+/* rows 4..6 of p from the sums; dgamma / dbeta (nch floats) written when given. */
+int pa_bn_bwd_finalize(int nch, double count, const double *sums, float *p, float *dgamma, float *dbeta, pa_stream_t stream);
+/* out = [relu](y*scale + shift) over (B, C, P); pool > 0: max over groups of `pool` consecutive points (patch_aug_net.py:236) ->
+ * out (B, C, P/pool) and arg (int8 winning slot, first maximum).  pa_maxpool_bwd scatters a pooled gradient back: rows = B*C. */
+int pa_bn_apply(int B, int C, long P, int pool, int relu, const float *y, const float *p, float *out, signed char *arg, pa_stream_t stream);
+int pa_maxpool_bwd(int rows, long Pout, int pool, const float *gp, const signed char *arg, float *g, pa_stream_t stream);
+
 /* ---- the reference's launcher names (group 2) -------------------------------------------------*/
 void furthestsampling_cuda_launcher(int b, int n, int m, const float *dataset, float *temp, int *idxs);
 void gathering_forward_cuda_launcher(int b, int c, int n, int m, const float *points, const int *idx, float *out);

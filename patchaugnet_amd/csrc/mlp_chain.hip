@@ -354,8 +354,10 @@ __device__ __forceinline__ void run_layer_chunks(float *act, const PaChain &a, c
 
 // Pooled wave-private kernels (the set-abstraction levels) are gather-latency bound in their prologue: keep two waves per SIMD
 // (<= 256 registers) there; the plain row kernels trade occupancy for their 128 accumulator registers.
+// The 16-row wave-private variant (RT == 1, unpooled) runs EIGHT waves per workgroup, two per SIMD: while one wave of a SIMD gathers its
+// next tile or stores its last one, the other keeps the matrix pipe busy.
 template <int RT, int NCMAX, int MODE, bool POOLED, int WPT>
-__global__ __launch_bounds__(256, (POOLED && RT <= 5) ? 2 : 1) void chain_kernel(PaChain a)
+__global__ __launch_bounds__((RT == 1 && WPT == 1 && !POOLED) ? 512 : 256, (POOLED && RT <= 5) || (RT == 1 && WPT == 1) ? 2 : 1) void chain_kernel(PaChain a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int R = RT * 16;
@@ -375,6 +377,12 @@ __global__ __launch_bounds__(256, (POOLED && RT <= 5) ? 2 : 1) void chain_kernel
     const int k0pad = (MODE == MODE_FP && a.fold0) ? a.c2 + a.L[0].kpad : a.L[0].kpad;
 #define PA_STAMP(i) do { if (a.dbg && tile < 512 && lane == 0 && (WPT == 1 || wave == 0)) a.dbg[tile * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
     PA_STAMP(0);
+    // Two waves share each SIMD in the eight-wave variant and every tile costs the same, so without help both would sit in their
+    // prologue / epilogue at the same moments and leave the matrix pipe idle together.  Delaying the second wave of each SIMD by about
+    // half a tile once, at the start, puts the pair in anti-phase for the rest of the launch: one gathers or stores while the other
+    // multiplies.  Pure scheduling; results unchanged.
+    if (RT == 1 && WPT == 1 && !POOLED && wave >= 4)
+        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
 
     chain_prologue<float, R, MODE, POOLED, WPT>(act, act + R * stride, a, tile, tid, lane, stride, k0pad);
     tile_sync<WPT>();
@@ -426,7 +434,10 @@ int launch_chain(const PaChain &a, int waves_per_wg, long ntiles, hipStream_t st
 template <int MODE>
 void launch_rows(const PaChain &a, int rt, bool split, int wpw, long ntiles, hipStream_t st)
 {
-    if (!split) launch_chain<2, 16, MODE, false, 1>(a, wpw, ntiles, st);
+    if (!split && rt == 1) {
+        if (MODE == MODE_FPX) launch_chain<1, 16, MODE_FPX, false, 1>(a, wpw, ntiles, st);     // only instantiated where it is used
+        else launch_chain<2, 16, MODE, false, 1>(a, wpw, ntiles, st);
+    } else if (!split) launch_chain<2, 16, MODE, false, 1>(a, wpw, ntiles, st);
     else if (rt == 2) launch_chain<2, 8, MODE, false, 4>(a, 4, ntiles, st);
     else launch_chain<1, 8, MODE, false, 4>(a, 4, ntiles, st);
 }
@@ -512,6 +523,12 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
         const long tp = (rows + 3) / 4;
         if (can_split && tp < 2048 && RTv == 5) split = true;
     }
+    // Finest FP level (and any other wave-private FPX launch): 16-row tiles with EIGHT waves per workgroup, two per SIMD -- with the lean
+    // buffer-load k-loop the partner wave's MFMAs fill the slots one wave leaves while it gathers / stores (0.332 -> 0.307 ms at B = 32).
+    static const bool fpx_rt2 = getenv("PA_CHAIN_FPX_RT2") != nullptr;   // A/B knob: the former 32-row, one-wave-per-SIMD tiling
+    static const int stagger_env = getenv("PA_CHAIN_STAGGER") ? atoi(getenv("PA_CHAIN_STAGGER")) : 0;
+    const bool rt1 = !fpx_rt2 && mode == MODE_FPX && !split && !is_pooled && !wp16;
+    if (rt1) { RTv = 1; a.stagger = stagger_env; }
     PA_REQUIRE(col_slices <= 1 || split, "pa_linear: column slices are built for the shared-tile (few rows) variant");
     const int R = RTv * 16;
     const int ncmax = split ? 8 : (is_pooled ? 4 : 16);
@@ -568,7 +585,7 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
     // waves per workgroup of the wave-private tilings.  Smaller workgroups leave LDS granules in which OTHER kernels' workgroups
     // (kNN: 70 KB, 3-NN, FPS) can become resident next to a chain workgroup when several streams are in flight.
     static const int wpw_env = getenv("PA_CHAIN_WPW") ? atoi(getenv("PA_CHAIN_WPW")) : 0;
-    int wpw = wpw_env > 0 ? wpw_env : 4;
+    int wpw = wpw_env > 0 ? wpw_env : (rt1 ? 8 : 4);
     while (wpw > 1 && wpw * per_wave > 156 * 1024) wpw >>= 1;
     const long ntiles = is_pooled ? (rows + 3) / 4 : (total_rows + R - 1) / R;
 

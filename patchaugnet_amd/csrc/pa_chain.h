@@ -60,6 +60,7 @@ struct PaChain {
     // bias, out and residual (packed layouts are column-group-major, so a slice is a contiguous range).
     int col_slices, slice_n;
     long wp_slice, wp16_slice;   // packed fp32 floats / fp16 halfs per slice
+    int stagger;                 // eight-wave wave-private variant: waves 4..7 (the second wave of every SIMD) start this many x 8128 cycles late
 };
 
 namespace {

@@ -1,0 +1,653 @@
+// Training-mode dense path on the MFMA pipe (gfx950, exact fp32 MFMA): the building blocks of the hand-written forward AND backward of
+//   pt_util.SharedMLP in train() mode   utils/model_util/pt_util.py:16-41, :98-152   (1x1 conv without bias -> BatchNorm(batch statistics) -> ReLU)
+//   PointNetDecoder                     place_recognition/patch_aug_net/models/pointnet_autoencoder.py:85-111 (Linear + BatchNorm1d + ReLU, x2; Linear + tanh)
+// as driven by the training step (place_recognition/train_place_recognition.py:142-169, :386-392).  The reference runs every layer as
+// cuDNN/cuBLAS conv + a BatchNorm kernel + a ReLU kernel (and their three backward kernels), each a full pass over the activation.
+//
+// MI355X plan.  Activations stay in the reference's CHANNEL-MAJOR layout (B, C, P) (P = points, or m*k grouped points), so a 1x1 conv is,
+// per cloud, Y (O x P) = W (O x C) . X (C x P): the big operand is read in whole contiguous rows.  BatchNorm in train mode needs global
+// statistics between layers, so a layer is one launch, but everything elementwise rides inside the GEMMs:
+//   * forward  (tgemm_nn): the B-operand loader applies the PREVIOUS layer's BatchNorm + ReLU on the fly (per-channel scale/shift), the
+//     epilogue accumulates this layer's per-channel sum / sum of squares (fp64 atomics) -- the normalised activation is never written;
+//   * backward dX (tgemm_nn): the B-operand loader turns (dZ, raw Y) into the BatchNorm/ReLU input gradient on the fly
+//         dY = (mask(dZ) - mean(mask dZ) - xhat * mean(mask dZ * xhat)) * gamma * rstd ,
+//   * backward dW (tgemm_kk): both operands are built on the fly (dY as above, the layer input as BN+ReLU of the previous raw output) and
+//     contracted over all points of all clouds with split-K partial tiles combined by fp32 atomics;
+//   * two thin HBM-bound passes remain per layer: the statistics finalize (a few hundred channels) and the dZ reduction that BatchNorm's
+//     backward needs before any dY can be formed.
+// Kernels are LDS-tiled (BM x 128 x 16, register-staged double buffer, one barrier per k-tile), v_mfma_f32_16x16x4_f32.
+#include <string.h>
+
+#include "pa_common.h"
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ operand transforms
+enum { TF_NONE = 0, TF_AFFINE_RELU = 1, TF_BN_BWD_RELU = 2, TF_BN_BWD = 3 };
+
+struct TOp {
+    int mode;
+    const float *aux;   // modes 2/3: the layer's raw (pre-BatchNorm) output, same layout as the operand
+    const float *p;     // per-channel parameters, SoA p[j * nch + ch]: mode 1: j = 0 scale, 1 shift;
+                        // modes 2/3: 0 scale (gamma*rstd), 1 shift, 2 mean, 3 rstd, 4 mean(mask g), 5 mean(mask g * xhat), 6 gamma*rstd
+    int nch;
+};
+
+struct ChanP { float v[7]; };
+
+template <int MODE>
+__device__ __forceinline__ ChanP load_chan(const TOp &t, int ch, bool live)
+{
+    ChanP c;
+    constexpr int NP = MODE == TF_NONE ? 0 : (MODE == TF_AFFINE_RELU ? 2 : 7);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) c.v[j] = (j < NP && live) ? t.p[(size_t)j * t.nch + ch] : 0.f;
+    return c;
+}
+
+template <int MODE>
+__device__ __forceinline__ float tf_apply(float g, float y, const ChanP &c)
+{
+    if (MODE == TF_NONE) return g;
+    if (MODE == TF_AFFINE_RELU) return fmaxf(fmaf(g, c.v[0], c.v[1]), 0.f);
+    const float z = fmaf(y, c.v[0], c.v[1]);
+    const float gm = (MODE == TF_BN_BWD || z > 0.f) ? g : 0.f;
+    const float xhat = (y - c.v[2]) * c.v[3];
+    return (gm - c.v[4] - xhat * c.v[5]) * c.v[6];
+}
+
+// ------------------------------------------------------------------------------------------------ tgemm_nn
+// C_b (M x N) = [beta * C_b +] act( A_b (M x K) . f(B_b) (K x N) + bias[m] ),   B and C n-contiguous, f = per-k (channel) transform.
+struct NNArgs {
+    int M, N, K;
+    const float *A; long sAb; int lda;   // A_KCONTIG: A(m,k) = A[m*lda + k]; else A(m,k) = A[k*lda + m].  sAb = 0: shared by the batch
+    const float *B; long sBb; int ldb;
+    TOp tb;
+    float *C; long sCb; int ldc;
+    int beta;
+    const float *bias;                   // per m, or null
+    int act;                             // 0 none, 1 tanh
+    double *stats;                       // [2*M]: sum and sum of squares of the stored values per row m over (batch, n); or null
+    int vecA, vecB;                      // 16-byte loads allowed (alignment / divisibility checked on the host)
+};
+
+constexpr int NN_BN = 128, NN_BK = 16;
+
+template <int BM, bool A_KCONTIG, int BMODE>
+__global__ __launch_bounds__(256) void tgemm_nn_kernel(NNArgs a)
+{
+    constexpr int SA = BM + 16, SB = NN_BN + 16;          // row strides = 16 mod 32 floats: conflict-free fragment reads (rows k, k+1 per 32-lane half)
+    constexpr int WM = BM == 128 ? 2 : 1, WN = 4 / WM;     // wave grid
+    constexpr int MT = BM / WM / 16, NT = NN_BN / WN / 16; // 16x16 tiles per wave
+    constexpr int AE = BM * NN_BK / 256;                   // A elements staged per thread (4 or 8)
+    __shared__ __attribute__((aligned(16))) float As[2][NN_BK * SA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][NN_BK * SB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int n0 = blockIdx.x * NN_BN, m0 = blockIdx.y * BM, b = blockIdx.z;
+    const float *A = a.A + (size_t)b * a.sAb;
+    const float *B = a.B + (size_t)b * a.sBb;
+    const float *B2 = (BMODE >= TF_BN_BWD_RELU) ? a.tb.aux + (size_t)b * a.sBb : nullptr;
+    float *C = a.C + (size_t)b * a.sCb;
+
+    floatx4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+
+    float ra[AE];
+    float rb[8];
+    // B staging: thread -> rows kb, kb + 8; 4 consecutive columns nb4
+    const int kb = tid >> 5, nb4 = (tid & 31) * 4;
+    auto fetch = [&](int k0) {
+        // ---- A tile
+        if (A_KCONTIG) {                                   // 4 consecutive k per load: m = q / 4, k4 = (q % 4) * 4
+#pragma unroll
+            for (int u = 0; u < AE / 4; ++u) {
+                const int q = tid + u * 256, m = q >> 2, k4 = (q & 3) * 4;
+                const int gm = m0 + m, gk = k0 + k4;
+                const float *src = A + (size_t)gm * a.lda + gk;
+                if (gm < a.M && gk + 3 < a.K && a.vecA) {
+                    const float4 v = *reinterpret_cast<const float4 *>(src);
+                    ra[u * 4] = v.x; ra[u * 4 + 1] = v.y; ra[u * 4 + 2] = v.z; ra[u * 4 + 3] = v.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ra[u * 4 + e] = (gm < a.M && gk + e < a.K) ? src[e] : 0.f;
+                }
+            }
+        } else {                                           // 4 consecutive m per load: k = q / (BM/4), m4 = (q % (BM/4)) * 4
+#pragma unroll
+            for (int u = 0; u < AE / 4; ++u) {
+                const int q = tid + u * 256, k = q / (BM / 4), m4 = (q % (BM / 4)) * 4;
+                const int gm = m0 + m4, gk = k0 + k;
+                const float *src = A + (size_t)gk * a.lda + gm;
+                if (gk < a.K && gm + 3 < a.M && a.vecA) {
+                    const float4 v = *reinterpret_cast<const float4 *>(src);
+                    ra[u * 4] = v.x; ra[u * 4 + 1] = v.y; ra[u * 4 + 2] = v.z; ra[u * 4 + 3] = v.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ra[u * 4 + e] = (gk < a.K && gm + e < a.M) ? src[e] : 0.f;
+                }
+            }
+        }
+        // ---- B tile (transform applied here, in registers)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int gk = k0 + kb + h * 8, gn = n0 + nb4;
+            const bool klive = gk < a.K;
+            const ChanP cp = load_chan<BMODE>(a.tb, gk, klive);
+            float g[4], y[4] = {0.f, 0.f, 0.f, 0.f};
+            const float *src = B + (size_t)gk * a.ldb + gn;
+            if (klive && gn + 3 < a.N && a.vecB) {
+                const float4 v = *reinterpret_cast<const float4 *>(src);
+                g[0] = v.x; g[1] = v.y; g[2] = v.z; g[3] = v.w;
+                if (BMODE >= TF_BN_BWD_RELU) {
+                    const float4 w = *reinterpret_cast<const float4 *>(B2 + (size_t)gk * a.ldb + gn);
+                    y[0] = w.x; y[1] = w.y; y[2] = w.z; y[3] = w.w;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool live = klive && gn + e < a.N;
+                    g[e] = live ? src[e] : 0.f;
+                    if (BMODE >= TF_BN_BWD_RELU) y[e] = live ? B2[(size_t)gk * a.ldb + gn + e] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rb[h * 4 + e] = (klive && gn + e < a.N) ? tf_apply<BMODE>(g[e], y[e], cp) : 0.f;
+        }
+    };
+    auto stash = [&](int buf) {
+        float *as = As[buf], *bs = Bs[buf];
+        if (A_KCONTIG) {
+#pragma unroll
+            for (int u = 0; u < AE / 4; ++u) {
+                const int q = tid + u * 256, m = q >> 2, k4 = (q & 3) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) as[(k4 + e) * SA + m] = ra[u * 4 + e];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < AE / 4; ++u) {
+                const int q = tid + u * 256, k = q / (BM / 4), m4 = (q % (BM / 4)) * 4;
+                *reinterpret_cast<float4 *>(as + k * SA + m4) = make_float4(ra[u * 4], ra[u * 4 + 1], ra[u * 4 + 2], ra[u * 4 + 3]);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            *reinterpret_cast<float4 *>(bs + (kb + h * 8) * SB + nb4) = make_float4(rb[h * 4], rb[h * 4 + 1], rb[h * 4 + 2], rb[h * 4 + 3]);
+    };
+
+    const int nk = (a.K + NN_BK - 1) / NN_BK;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) fetch((kt + 1) * NN_BK);
+        const float *as = As[cur] + (lane >> 4) * SA + wm * (BM / WM) + (lane & 15);
+        const float *bs = Bs[cur] + (lane >> 4) * SB + wn * (NN_BN / WN) + (lane & 15);
+#pragma unroll
+        for (int ks = 0; ks < NN_BK / 4; ++ks) {
+            float af[MT], bf[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = as[ks * 4 * SA + i * 16];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bf[j] = bs[ks * 4 * SB + j * 16];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) stash(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout: column n = l % 16, row m = 4 * (l / 16) + r
+    float s1[MT][4], s2[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gm = m0 + wm * (BM / WM) + i * 16 + (lane >> 4) * 4 + r;
+            const float bias = (a.bias && gm < a.M) ? a.bias[gm] : 0.f;
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int gn = n0 + wn * (NN_BN / WN) + j * 16 + (lane & 15);
+                if (gm < a.M && gn < a.N) {
+                    float v = acc[i][j][r] + bias;
+                    if (a.act == 1) v = tanhf(v);
+                    float *dst = C + (size_t)gm * a.ldc + gn;
+                    if (a.beta) v += *dst;
+                    *dst = v;
+                    t1 += v;
+                    t2 += v * v;
+                }
+            }
+            s1[i][r] = t1;
+            s2[i][r] = t2;
+        }
+    if (a.stats) {   // per-row sums over this workgroup's columns: 16 lanes of a DPP row share a row m
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t1 = s1[i][r], t2 = s2[i][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { t1 += __shfl_xor(t1, o); t2 += __shfl_xor(t2, o); }
+                const int gm = m0 + wm * (BM / WM) + i * 16 + (lane >> 4) * 4 + r;
+                if ((lane & 15) == 0 && gm < a.M) {
+                    atomicAdd(a.stats + gm, (double)t1);
+                    atomicAdd(a.stats + a.M + gm, (double)t2);
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ tgemm_kk
+// C (M x N) += sum over (batch, k) of fA(A_b)(m,k) * fB(B_b)(n,k); both operands k-contiguous: A_b(m,k) = A[b*sAb + m*lda + k].
+// fA: per-m channel transform (none / bn-bwd, two tensors), fB: per-n channel transform (none / affine+relu).
+// grid (N tiles, M tiles, batch * ksplits); partial tiles are combined with fp32 atomics (C zero-filled by the caller), or stored
+// directly per batch when `per_batch` is set (C_b = C + b*sCb, ksplits must then be 1... or atomics into the per-batch tile).
+struct KKArgs {
+    int M, N, K;
+    const float *A; long sAb; int lda; TOp ta;
+    const float *B; long sBb; int ldb; TOp tb;
+    float *C; long sCb; int ldc;
+    int ksplits, kchunk;
+    int per_batch;
+    int vecA, vecB;
+};
+
+constexpr int KK_BM = 64, KK_BN = 64, KK_BK = 32, KK_S = KK_BK + 2;   // row stride 34: (2m + k) mod 32 distinct for m < 16, k < 2
+
+template <int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void tgemm_kk_kernel(KKArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float As[2][KK_BM * KK_S];
+    __shared__ __attribute__((aligned(16))) float Bs[2][KK_BN * KK_S];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;                 // 2 x 2 waves, 32 x 32 each
+    const int n0 = blockIdx.x * KK_BN, m0 = blockIdx.y * KK_BM;
+    const int b = blockIdx.z / a.ksplits, split = blockIdx.z % a.ksplits;
+    const int kbeg = split * a.kchunk, kend = min(kbeg + a.kchunk, a.K);
+    const float *A = a.A + (size_t)b * a.sAb, *B = a.B + (size_t)b * a.sBb;
+    const float *A2 = AMODE >= TF_BN_BWD_RELU ? a.ta.aux + (size_t)b * a.sAb : nullptr;
+    floatx4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    // staging: 64 rows x 32 k = 512 float4 per operand: thread -> row r = q / 8, k4 = (q % 8) * 4, q = tid, tid + 256
+    float ra[8], rb[8];
+    ChanP ca[2], cb[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int r = (tid + u * 256) >> 3;
+        ca[u] = load_chan<AMODE>(a.ta, m0 + r, m0 + r < a.M);
+        cb[u] = load_chan<BMODE>(a.tb, n0 + r, n0 + r < a.N);
+    }
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int q = tid + u * 256, r = q >> 3, k4 = (q & 7) * 4, gk = k0 + k4;
+            {   // A
+                const int gm = m0 + r;
+                const float *src = A + (size_t)gm * a.lda + gk;
+                float g[4], y[4] = {0.f, 0.f, 0.f, 0.f};
+                if (gm < a.M && gk + 3 < kend && a.vecA) {
+                    const float4 v = *reinterpret_cast<const float4 *>(src);
+                    g[0] = v.x; g[1] = v.y; g[2] = v.z; g[3] = v.w;
+                    if (AMODE >= TF_BN_BWD_RELU) {
+                        const float4 w = *reinterpret_cast<const float4 *>(A2 + (size_t)gm * a.lda + gk);
+                        y[0] = w.x; y[1] = w.y; y[2] = w.z; y[3] = w.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool live = gm < a.M && gk + e < kend;
+                        g[e] = live ? src[e] : 0.f;
+                        if (AMODE >= TF_BN_BWD_RELU) y[e] = live ? A2[(size_t)gm * a.lda + gk + e] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ra[u * 4 + e] = (gm < a.M && gk + e < kend) ? tf_apply<AMODE>(g[e], y[e], ca[u]) : 0.f;
+            }
+            {   // B
+                const int gn = n0 + r;
+                const float *src = B + (size_t)gn * a.ldb + gk;
+                float g[4];
+                if (gn < a.N && gk + 3 < kend && a.vecB) {
+                    const float4 v = *reinterpret_cast<const float4 *>(src);
+                    g[0] = v.x; g[1] = v.y; g[2] = v.z; g[3] = v.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[e] = (gn < a.N && gk + e < kend) ? src[e] : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rb[u * 4 + e] = (gn < a.N && gk + e < kend) ? tf_apply<BMODE>(g[e], 0.f, cb[u]) : 0.f;
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int q = tid + u * 256, r = q >> 3, k4 = (q & 7) * 4;
+            float2 *da = reinterpret_cast<float2 *>(As[buf] + r * KK_S + k4);
+            da[0] = make_float2(ra[u * 4], ra[u * 4 + 1]);
+            da[1] = make_float2(ra[u * 4 + 2], ra[u * 4 + 3]);
+            float2 *db = reinterpret_cast<float2 *>(Bs[buf] + r * KK_S + k4);
+            db[0] = make_float2(rb[u * 4], rb[u * 4 + 1]);
+            db[1] = make_float2(rb[u * 4 + 2], rb[u * 4 + 3]);
+        }
+    };
+    const int nk = (kend - kbeg + KK_BK - 1) / KK_BK;
+    if (nk <= 0) return;
+    fetch(kbeg);
+    stash(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) fetch(kbeg + (kt + 1) * KK_BK);
+        const float *as = As[cur] + (wm * 32 + (lane & 15)) * KK_S + (lane >> 4);
+        const float *bs = Bs[cur] + (wn * 32 + (lane & 15)) * KK_S + (lane >> 4);
+#pragma unroll
+        for (int ks = 0; ks < KK_BK / 4; ++ks) {
+            const float a0 = as[ks * 4], a1 = as[16 * KK_S + ks * 4];
+            const float b0 = bs[ks * 4], b1 = bs[16 * KK_S + ks * 4];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < nk) stash(cur ^ 1);
+        __syncthreads();
+    }
+    float *C = a.C + (a.per_batch ? (size_t)b * a.sCb : (size_t)0);
+    const bool direct = a.per_batch && a.ksplits == 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gm = m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r, gn = n0 + wn * 32 + j * 16 + (lane & 15);
+                if (gm < a.M && gn < a.N) {
+                    if (direct) C[(size_t)gm * a.ldc + gn] = acc[i][j][r];
+                    else atomicAdd(C + (size_t)gm * a.ldc + gn, acc[i][j][r]);
+                }
+            }
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm helpers
+// finalize: stats (fp64 sum, sum of squares per channel over `count` values) -> p[0] scale = gamma*rstd, p[1] shift = beta - mean*scale,
+// p[2] mean, p[3] rstd (biased variance, as torch's training forward); running statistics updated in place with momentum and the
+// unbiased variance (torch.nn.BatchNorm semantics).
+__global__ void bn_finalize_kernel(int nch, double count, const double *__restrict__ stats, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                   float eps, float momentum, float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ p)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nch) return;
+    const double mean = stats[c] / count;
+    double var = stats[nch + c] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+    const float scale = g * rstd;
+    p[c] = scale;
+    p[nch + c] = bt - (float)mean * scale;
+    p[2 * nch + c] = (float)mean;
+    p[3 * nch + c] = rstd;
+    if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// backward reduction over a channel-major (B, C, P) pair (g = gradient w.r.t. the post-activation, y = raw pre-BatchNorm output):
+// sums[c] += sum mask(g), sums[C + c] += sum mask(g) * xhat   (fp64 atomics); grid (chunks of P, C, B)
+template <bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(int C, long P, const float *__restrict__ g, const float *__restrict__ y, const float *__restrict__ p,
+                                                              double *__restrict__ sums, int vec)
+{
+    __shared__ float red[8];
+    const int c = blockIdx.y, b = blockIdx.z;
+    const float scale = p[c], shift = p[C + c], mean = p[2 * C + c], rstd = p[3 * C + c];
+    const size_t base = ((size_t)b * C + c) * P;
+    const long chunk = (P + gridDim.x - 1) / gridDim.x;
+    const long lo = (long)blockIdx.x * chunk, hi = min(lo + chunk, P);
+    float s1 = 0.f, s2 = 0.f;
+    if (vec && (lo & 3) == 0) {
+        long i = lo + (long)threadIdx.x * 4;
+        for (; i + 3 < hi; i += 1024) {
+            const float4 gv = *reinterpret_cast<const float4 *>(g + base + i), yv = *reinterpret_cast<const float4 *>(y + base + i);
+            const float ga[4] = {gv.x, gv.y, gv.z, gv.w}, ya[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gm = (!RELU || fmaf(ya[e], scale, shift) > 0.f) ? ga[e] : 0.f;
+                s1 += gm;
+                s2 += gm * ((ya[e] - mean) * rstd);
+            }
+        }
+        for (; i < hi; ++i) {   // the (at most 3) leftover elements of the thread that reaches the tail
+            if (i >= lo + ((hi - lo) & ~3L)) {
+                const float gm = (!RELU || fmaf(y[base + i], scale, shift) > 0.f) ? g[base + i] : 0.f;
+                s1 += gm;
+                s2 += gm * ((y[base + i] - mean) * rstd);
+            } else break;
+        }
+    } else {
+        for (long i = lo + threadIdx.x; i < hi; i += 256) {
+            const float gm = (!RELU || fmaf(y[base + i], scale, shift) > 0.f) ? g[base + i] : 0.f;
+            s1 += gm;
+            s2 += gm * ((y[base + i] - mean) * rstd);
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s1; red[4 + (threadIdx.x >> 6)] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(sums + c, (double)((red[0] + red[1]) + (red[2] + red[3])));
+        atomicAdd(sums + C + c, (double)((red[4] + red[5]) + (red[6] + red[7])));
+    }
+}
+
+// p[4] = sum mask(g) / count, p[5] = sum(mask(g) * xhat) / count, p[6] = gamma * rstd (= p[0]); dgamma = sum(mask g * xhat), dbeta = sum(mask g)
+__global__ void bn_bwd_finalize_kernel(int nch, double count, const double *__restrict__ sums, float *__restrict__ p, float *__restrict__ dgamma, float *__restrict__ dbeta)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nch) return;
+    p[4 * nch + c] = (float)(sums[c] / count);
+    p[5 * nch + c] = (float)(sums[nch + c] / count);
+    p[6 * nch + c] = p[c];
+    if (dgamma) dgamma[c] = (float)sums[nch + c];
+    if (dbeta) dbeta[c] = (float)sums[c];
+}
+
+// out = relu(y * scale + shift) on (B, C, P); with pool > 0: max over groups of `pool` consecutive points -> out (B, C, P / pool), arg (int8 slot)
+__global__ __launch_bounds__(256) void bn_apply_kernel(int C, long P, int pool, int relu, const float *__restrict__ y, const float *__restrict__ p, float *__restrict__ out,
+                                                        signed char *__restrict__ arg)
+{
+    const long Pout = pool > 0 ? P / pool : P;
+    const long total = (long)gridDim.y * Pout;   // gridDim.y = B * C rows
+    (void)total;
+    const long row = blockIdx.y;
+    const int c = (int)(row % C);
+    const float scale = p[c], shift = p[C + c];
+    const float *src = y + (size_t)row * P;
+    float *dst = out + (size_t)row * Pout;
+    for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < Pout; j += (long)gridDim.x * 256) {
+        if (pool <= 0) {
+            const float v = fmaf(src[j], scale, shift);
+            dst[j] = relu ? fmaxf(v, 0.f) : v;
+        } else {
+            float best = -INFINITY;
+            int bi = 0;
+            for (int s = 0; s < pool; ++s) {
+                float v = fmaf(src[j * pool + s], scale, shift);
+                if (relu) v = fmaxf(v, 0.f);
+                if (v > best) { best = v; bi = s; }     // first maximum, like torch.max
+            }
+            dst[j] = best;
+            arg[(size_t)row * Pout + j] = (signed char)bi;
+        }
+    }
+}
+
+// gradient of the pooled output scattered back to the full (B, C, P) grid: g[j*pool + s] = (s == arg[j]) ? gp[j] : 0
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(long Pout, int pool, const float *__restrict__ gp, const signed char *__restrict__ arg, float *__restrict__ g)
+{
+    const long row = blockIdx.y;
+    for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < Pout; j += (long)gridDim.x * 256) {
+        const float v = gp[(size_t)row * Pout + j];
+        const int a = arg[(size_t)row * Pout + j];
+        float *dst = g + ((size_t)row * Pout + j) * pool;
+        for (int s = 0; s < pool; ++s) dst[s] = s == a ? v : 0.f;
+    }
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+TOp make_top(int mode, const float *aux, const float *p, int nch)
+{
+    TOp t;
+    t.mode = mode; t.aux = aux; t.p = p; t.nch = nch;
+    return t;
+}
+
+}  // namespace
+
+// C_b (M x N) = [beta C_b +] act(A_b . f(B_b) + bias): see tgemm_nn_kernel.  a_kcontig: A(m,k) = A[m*lda + k] (else A[k*lda + m]);
+// sAb = 0 shares A over the batch.  bmode 0 none / 1 affine+relu (bp: 2*K floats) / 2 bn-bwd with ReLU mask / 3 bn-bwd (baux = raw output,
+// bp: 7*K floats).  stats (2*M doubles, accumulated) or NULL.
+PA_API int pa_tgemm_nn(int batch, int M, int N, int K, const float *A, long sAb, int lda, int a_kcontig,
+                       const float *B, long sBb, int ldb, int bmode, const float *baux, const float *bp,
+                       float *C, long sCb, int ldc, int beta, const float *bias, int act, double *stats, pa_stream_t stream)
+{
+    PA_REQUIRE(batch > 0 && M > 0 && N > 0 && K > 0 && A && B && C, "pa_tgemm_nn: bad arguments");
+    PA_REQUIRE(bmode >= 0 && bmode <= 3 && (bmode == 0 || bp) && (bmode < 2 || baux), "pa_tgemm_nn: transform %d needs its parameter / auxiliary tensors", bmode);
+    PA_REQUIRE(batch <= 65535 && (M + 63) / 64 <= 65535, "pa_tgemm_nn: grid limits");
+    NNArgs a;
+    memset(&a, 0, sizeof(a));
+    a.M = M; a.N = N; a.K = K;
+    a.A = A; a.sAb = sAb; a.lda = lda;
+    a.B = B; a.sBb = sBb; a.ldb = ldb;
+    a.tb = make_top(bmode, baux, bp, K);
+    a.C = C; a.sCb = sCb; a.ldc = ldc; a.beta = beta; a.bias = bias; a.act = act; a.stats = stats;
+    a.vecA = aligned16(A) && lda % 4 == 0 && sAb % 4 == 0;
+    a.vecB = aligned16(B) && ldb % 4 == 0 && sBb % 4 == 0 && (bmode < 2 || aligned16(baux));
+    const bool big = M > 64;
+    dim3 grid((N + NN_BN - 1) / NN_BN, (M + (big ? 127 : 63)) / (big ? 128 : 64), batch);
+    hipStream_t st = (hipStream_t)stream;
+#define PA_NN(BMv, KC, MODE) hipLaunchKernelGGL((tgemm_nn_kernel<BMv, KC, MODE>), grid, dim3(256), 0, st, a)
+#define PA_NN_MODE(BMv, KC)                                                                       \
+    switch (bmode) { case 0: PA_NN(BMv, KC, 0); break; case 1: PA_NN(BMv, KC, 1); break;          \
+                     case 2: PA_NN(BMv, KC, 2); break; default: PA_NN(BMv, KC, 3); break; }
+    if (big) { if (a_kcontig) { PA_NN_MODE(128, true) } else { PA_NN_MODE(128, false) } }
+    else { if (a_kcontig) { PA_NN_MODE(64, true) } else { PA_NN_MODE(64, false) } }
+#undef PA_NN_MODE
+#undef PA_NN
+    PA_CHECK_LAUNCH("pa_tgemm_nn");
+    return PA_OK;
+}
+
+// C (M x N) += sum_b sum_k fA(A_b)(m,k) fB(B_b)(n,k)  (per_batch = 0: C must be zero-filled or hold the value to add to), or
+// C_b = ... per batch (per_batch = 1; C_b zero-filled unless K fits one split).  amode 0 / 2 / 3 (aaux, ap: 7*M floats), bmode 0 / 1 (bp: 2*N floats).
+PA_API int pa_tgemm_kk(int batch, int M, int N, long K, const float *A, long sAb, int lda, int amode, const float *aaux, const float *ap,
+                       const float *B, long sBb, int ldb, int bmode, const float *bp,
+                       float *C, long sCb, int ldc, int per_batch, pa_stream_t stream)
+{
+    PA_REQUIRE(batch > 0 && M > 0 && N > 0 && K > 0 && K < 2147483647L && A && B && C, "pa_tgemm_kk: bad arguments");
+    PA_REQUIRE((amode == 0 || ((amode == 2 || amode == 3) && aaux && ap)) && (bmode == 0 || (bmode == 1 && bp)), "pa_tgemm_kk: transform arguments");
+    KKArgs a;
+    memset(&a, 0, sizeof(a));
+    a.M = M; a.N = N; a.K = (int)K;
+    a.A = A; a.sAb = sAb; a.lda = lda; a.ta = make_top(amode, aaux, ap, M);
+    a.B = B; a.sBb = sBb; a.ldb = ldb; a.tb = make_top(bmode, nullptr, bp, N);
+    a.C = C; a.sCb = sCb; a.ldc = ldc; a.per_batch = per_batch;
+    a.vecA = aligned16(A) && lda % 4 == 0 && sAb % 4 == 0 && (amode == 0 || aligned16(aaux));
+    a.vecB = aligned16(B) && ldb % 4 == 0 && sBb % 4 == 0;
+    const long tiles = (long)((M + KK_BM - 1) / KK_BM) * ((N + KK_BN - 1) / KK_BN) * batch;
+    long splits = (2048 + tiles - 1) / tiles;                  // aim at ~2048 workgroups
+    const long maxsplits = (K + 4 * KK_BK - 1) / (4 * KK_BK);  // at least 4 k-tiles per split
+    if (splits > maxsplits) splits = maxsplits;
+    if (splits < 1) splits = 1;
+    long chunk = ((K + splits - 1) / splits + KK_BK - 1) / KK_BK * KK_BK;
+    splits = (K + chunk - 1) / chunk;
+    PA_REQUIRE((long)batch * splits <= 65535, "pa_tgemm_kk: grid limit (batch %d x %ld splits)", batch, splits);
+    a.ksplits = (int)splits; a.kchunk = (int)chunk;
+    dim3 grid((N + KK_BN - 1) / KK_BN, (M + KK_BM - 1) / KK_BM, (unsigned)(batch * splits));
+    hipStream_t st = (hipStream_t)stream;
+#define PA_KK(AM, BMo) hipLaunchKernelGGL((tgemm_kk_kernel<AM, BMo>), grid, dim3(256), 0, st, a)
+    if (amode == 0) { if (bmode == 0) PA_KK(0, 0); else PA_KK(0, 1); }
+    else if (amode == 2) { if (bmode == 0) PA_KK(2, 0); else PA_KK(2, 1); }
+    else { if (bmode == 0) PA_KK(3, 0); else PA_KK(3, 1); }
+#undef PA_KK
+    PA_CHECK_LAUNCH("pa_tgemm_kk");
+    return PA_OK;
+}
+
+
+// BatchNorm (training) statistics -> per-channel parameter block p (7 * nch floats, rows 0..3 written here, 4..6 by pa_bn_bwd_finalize).
+PA_API int pa_bn_finalize(int nch, double count, const double *stats, const float *gamma, const float *beta, float eps, float momentum,
+                          float *running_mean, float *running_var, float *p, pa_stream_t stream)
+{
+    PA_REQUIRE(nch > 0 && count > 0 && stats && p, "pa_bn_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(pa_div_up(nch, 256)), dim3(256), 0, (hipStream_t)stream, nch, count, stats, gamma, beta, eps, momentum,
+                       running_mean, running_var, p);
+    PA_CHECK_LAUNCH("pa_bn_finalize");
+    return PA_OK;
+}
+
+// sums (2*C doubles, zero-filled by the caller) over g, y (B, C, P) channel-major; relu != 0 masks g where BN(y) <= 0.
+PA_API int pa_bn_bwd_reduce(int B, int C, long P, const float *g, const float *y, const float *p, int relu, double *sums, pa_stream_t stream)
+{
+    PA_REQUIRE(B > 0 && C > 0 && P > 0 && g && y && p && sums && B <= 65535 && C <= 65535, "pa_bn_bwd_reduce: bad arguments");
+    long chunks = (2048 + (long)B * C - 1) / ((long)B * C);
+    const long maxc = (P + 4095) / 4096;
+    if (chunks > maxc) chunks = maxc;
+    if (chunks < 1) chunks = 1;
+    const int vec = aligned16(g) && aligned16(y) && P % 4 == 0 && ((P + chunks - 1) / chunks) % 4 == 0;
+    dim3 grid((unsigned)chunks, C, B);
+    if (relu) hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, C, P, g, y, p, sums, vec);
+    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, C, P, g, y, p, sums, vec);
+    PA_CHECK_LAUNCH("pa_bn_bwd_reduce");
+    return PA_OK;
+}
+
+PA_API int pa_bn_bwd_finalize(int nch, double count, const double *sums, float *p, float *dgamma, float *dbeta, pa_stream_t stream)
+{
+    PA_REQUIRE(nch > 0 && count > 0 && sums && p, "pa_bn_bwd_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pa_div_up(nch, 256)), dim3(256), 0, (hipStream_t)stream, nch, count, sums, p, dgamma, dbeta);
+    PA_CHECK_LAUNCH("pa_bn_bwd_finalize");
+    return PA_OK;
+}
+
+// out = [relu](y*scale + shift) over (B, C, P); pool > 0 additionally takes the max over groups of `pool` consecutive points
+// (out (B, C, P/pool), arg (B, C, P/pool) int8 = winning slot; patch_aug_net.py:236).
+PA_API int pa_bn_apply(int B, int C, long P, int pool, int relu, const float *y, const float *p, float *out, signed char *arg, pa_stream_t stream)
+{
+    PA_REQUIRE(B > 0 && C > 0 && P > 0 && y && p && out && (pool <= 0 || (arg && P % pool == 0 && pool < 128)) && (long)B * C <= 65535L * 1, "pa_bn_apply: bad arguments");
+    const long Pout = pool > 0 ? P / pool : P;
+    long gx = (Pout + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)gx, B * C), dim3(256), 0, (hipStream_t)stream, C, P, pool, relu, y, p, out, arg);
+    PA_CHECK_LAUNCH("pa_bn_apply");
+    return PA_OK;
+}
+
+PA_API int pa_maxpool_bwd(int rows, long Pout, int pool, const float *gp, const signed char *arg, float *g, pa_stream_t stream)
+{
+    PA_REQUIRE(rows > 0 && rows <= 65535 && Pout > 0 && pool > 0 && gp && arg && g, "pa_maxpool_bwd: bad arguments");
+    long gx = (Pout + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)gx, rows), dim3(256), 0, (hipStream_t)stream, Pout, pool, gp, arg, g);
+    PA_CHECK_LAUNCH("pa_maxpool_bwd");
+    return PA_OK;
+}

@@ -1,0 +1,340 @@
+"""Training-mode dense path on hand-written MFMA kernels (csrc/train_gemm.hip): forward AND backward.
+
+What the reference runs as cuDNN/cuBLAS convolutions + BatchNorm + ReLU kernels and their autograd twins in ``model.train()``:
+
+  * ``pt_util.SharedMLP``        utils/model_util/pt_util.py:16-41, :98-152   (1x1 conv -> BatchNorm(batch statistics) -> ReLU [-> max over k])
+  * ``PointNetDecoder``          place_recognition/patch_aug_net/models/pointnet_autoencoder.py:85-111
+  * ``NetVLADBase`` and the heads place_recognition/patch_aug_net/models/loupe.py:8-66, :159-222, :332-361
+
+driven by ``train_place_recognition.py:142-169, :386-392``.  Activations stay CHANNEL-MAJOR ``(B, C, P)`` like the reference's, so a
+1x1 convolution is, per cloud, ``Y (O x P) = W (O x C) . X (C x P)``.  BatchNorm needs the batch statistics between layers, so a layer
+is one GEMM launch, but nothing elementwise is ever a pass of its own: the next GEMM's operand loader applies the previous layer's
+BatchNorm + ReLU, the epilogue accumulates the statistics, and in the backward pass the loaders build the BatchNorm/ReLU input
+gradient from (dZ, raw Y) on the fly.  Only the raw (pre-BatchNorm) layer outputs are kept for the backward pass.
+
+Everything here calls libpatchaugnet_hip.so (pa_tgemm_nn / pa_tgemm_kk / pa_bn_*); there is no torch.matmul / rocBLAS / MIOpen in it.
+"""
+import contextlib
+
+import torch
+from torch.autograd import Function
+
+from ._lib import call, check_device, ptr
+
+_hip_dense = True
+
+
+def hip_dense_enabled():
+    return _hip_dense
+
+
+@contextlib.contextmanager
+def torch_dense_path():
+    """TEST HOOK: run the module path's dense layers through torch autograd instead (the comparison side of tests/test_gpu_train_ops.py)."""
+    global _hip_dense
+    old, _hip_dense = _hip_dense, False
+    try:
+        yield
+    finally:
+        _hip_dense = old
+
+
+def _guard(t):
+    return torch.cuda.device(t.device)
+
+
+# ---------------------------------------------------------------------------------------------------- thin wrappers of the C ABI
+def tgemm_nn(batch, M, N, K, A, sAb, lda, a_kcontig, B, sBb, ldb, C, sCb, ldc, *, bmode=0, baux=None, bp=None, beta=0, bias=None, act=0,
+             stats=None):
+    """C_b (M x N) = [beta C_b +] act(A_b (M x K) . f(B_b) (K x N) + bias[m]) -- include/patchaugnet_hip.h: pa_tgemm_nn."""
+    call("pa_tgemm_nn", batch, M, N, K, ptr(A), sAb, lda, int(a_kcontig), ptr(B), sBb, ldb, bmode, ptr(baux), ptr(bp), ptr(C), sCb, ldc,
+         int(beta), ptr(bias), act, ptr(stats))
+
+
+def tgemm_kk(batch, M, N, K, A, sAb, lda, B, sBb, ldb, C, sCb, ldc, *, amode=0, aaux=None, ap=None, bmode=0, bp=None, per_batch=0):
+    """C (M x N) += sum_b sum_k fA(A_b)(m,k) fB(B_b)(n,k) -- include/patchaugnet_hip.h: pa_tgemm_kk."""
+    call("pa_tgemm_kk", batch, M, N, K, ptr(A), sAb, lda, amode, ptr(aaux), ptr(ap), ptr(B), sBb, ldb, bmode, ptr(bp), ptr(C), sCb, ldc,
+         int(per_batch))
+
+
+class BNLayer:
+    """One conv/linear + BatchNorm [+ ReLU] layer of a chain.  weight: (O, C[,1[,1]]) or, with transposed=True, (C, O)."""
+    __slots__ = ("weight", "bias", "bn", "relu", "transposed")
+
+    def __init__(self, weight, bn, bias=None, relu=True, transposed=False):
+        self.weight, self.bias, self.bn, self.relu, self.transposed = weight, bias, bn, relu, transposed
+
+
+def _bn_buffers(bn):
+    if bn.track_running_stats and bn.running_mean is not None:
+        # momentum None = cumulative moving average in torch; the hot path's layers all use the default 0.1
+        assert bn.momentum is not None, "cumulative-average BatchNorm is not built"
+        return bn.running_mean, bn.running_var, float(bn.momentum)
+    return None, None, 0.0
+
+
+class _ChainTrain(Function):
+    """x (B, C0, P) -> L x [W . -> BatchNorm(batch stats) -> ReLU] [-> max over `pool` consecutive points]."""
+
+    @staticmethod
+    def forward(ctx, x, layers, pool, *tensors):
+        check_device(x)
+        B, cin, P = x.shape
+        dev = x.device
+        it = iter(tensors)
+        Ws, biases, gammas, betas = [], [], [], []
+        for L in layers:
+            Ws.append(next(it))
+            biases.append(next(it) if L.bias is not None else None)
+            gammas.append(next(it))
+            betas.append(next(it))
+        ys, ps = [], []
+        prev, prevp = x, None
+        with _guard(x):
+            for i, L in enumerate(layers):
+                W = Ws[i]
+                O = W.shape[1] if L.transposed else W.shape[0]
+                C = W.numel() // O
+                assert C == cin, f"layer {i}: weight has {C} input channels, activation has {cin}"
+                assert L.relu or i == len(layers) - 1, "only the last layer of a chain may come without ReLU"
+                y = torch.empty((B, O, P), dtype=torch.float32, device=dev)
+                stats = torch.zeros((2, O), dtype=torch.float64, device=dev)
+                tgemm_nn(B, O, P, C, W, 0, O if L.transposed else C, not L.transposed, prev, C * P, P, y, O * P, P,
+                         bmode=0 if i == 0 else 1, bp=prevp, bias=biases[i], stats=stats)
+                p = torch.empty((7, O), dtype=torch.float32, device=dev)
+                rm, rv, mom = _bn_buffers(L.bn)
+                call("pa_bn_finalize", O, float(B * P), ptr(stats), ptr(gammas[i]), ptr(betas[i]), float(L.bn.eps), mom, ptr(rm), ptr(rv), ptr(p))
+                if rm is not None and L.bn.num_batches_tracked is not None:
+                    L.bn.num_batches_tracked += 1
+                ys.append(y)
+                ps.append(p)
+                prev, prevp, cin = y, p, O
+            Pout = P // pool if pool else P
+            if pool:
+                assert P % pool == 0
+            out = torch.empty((B, cin, Pout), dtype=torch.float32, device=dev)
+            arg = torch.empty((B, cin, Pout), dtype=torch.int8, device=dev) if pool else None
+            call("pa_bn_apply", B, cin, P, int(pool), int(layers[-1].relu), ptr(prev), ptr(prevp), ptr(out), ptr(arg))
+        ctx.save_for_backward(x, *Ws)
+        ctx.layers, ctx.pool, ctx.ys, ctx.ps, ctx.arg = layers, pool, ys, ps, arg
+        ctx.has_bias = [b is not None for b in biases]
+        ctx.bias_like = [b for b in biases]
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, *Ws = ctx.saved_tensors
+        layers, pool, ys, ps, arg = ctx.layers, ctx.pool, ctx.ys, ctx.ps, ctx.arg
+        B, _, P = x.shape
+        dev = x.device
+        g = gout.contiguous()
+        per_layer = [None] * len(layers)
+        with _guard(x):
+            if pool:
+                O = ys[-1].shape[1]
+                full = torch.empty((B, O, P), dtype=torch.float32, device=dev)
+                call("pa_maxpool_bwd", B * O, P // pool, int(pool), ptr(g), ptr(arg), ptr(full))
+                g = full
+            for i in range(len(layers) - 1, -1, -1):
+                L, W, y, p = layers[i], Ws[i], ys[i], ps[i]
+                O = y.shape[1]
+                prev = x if i == 0 else ys[i - 1]
+                C = prev.shape[1]
+                sums = torch.zeros((2, O), dtype=torch.float64, device=dev)
+                call("pa_bn_bwd_reduce", B, O, P, ptr(g), ptr(y), ptr(p), int(L.relu), ptr(sums))
+                dgamma = torch.empty(O, dtype=torch.float32, device=dev)
+                dbeta = torch.empty(O, dtype=torch.float32, device=dev)
+                call("pa_bn_bwd_finalize", O, float(B * P), ptr(sums), ptr(p), ptr(dgamma), ptr(dbeta))
+                mode = 2 if L.relu else 3
+                dW = torch.zeros((O, C), dtype=torch.float32, device=dev)
+                tgemm_kk(B, O, C, P, g, O * P, P, prev, C * P, P, dW, 0, C, amode=mode, aaux=y, ap=p,
+                         bmode=0 if i == 0 else 1, bp=None if i == 0 else ps[i - 1])
+                if i > 0 or ctx.needs_input_grad[0]:
+                    gp = torch.empty((B, C, P), dtype=torch.float32, device=dev)
+                    # dX (C x P) = W^T (C x O) . dY (O x P): A(m = c, k = o) = W[o*C + c] (or W[c*O + o] for a transposed weight)
+                    tgemm_nn(B, C, P, O, W, 0, O if L.transposed else C, L.transposed, g, O * P, P, gp, C * P, P, bmode=mode, baux=y, bp=p)
+                    g = gp
+                else:
+                    g = None
+                dWr = (dW.t().contiguous() if L.transposed else dW).view_as(W)
+                # a bias in front of a BatchNorm has an identically zero gradient (the mean subtraction removes it)
+                per_layer[i] = [dWr] + ([torch.zeros_like(ctx.bias_like[i])] if ctx.has_bias[i] else []) + [dgamma, dbeta]
+        ctx.ys = ctx.ps = ctx.arg = None
+        flat = [t for pl in per_layer for t in pl]
+        return (g, None, None, *flat)
+
+
+def chain_train(x, layers, pool=0):
+    """x: (B, C0, P) contiguous fp32 on the MI355X; layers: [BNLayer]; returns (B, C_L, P // pool or P)."""
+    tensors = []
+    for L in layers:
+        tensors.append(L.weight)
+        if L.bias is not None:
+            tensors.append(L.bias)
+        tensors += [L.bn.weight, L.bn.bias]
+    return _ChainTrain.apply(x.contiguous(), layers, int(pool), *tensors)
+
+
+class _LinearCM(Function):
+    """Y_b (O x P) = act(W (O x C) . X_b (C x P) + bias); act 0 none / 1 tanh.  W (O, C[,1]) shared by the batch."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias, act):
+        check_device(x, W)
+        B, C, P = x.shape
+        O = W.shape[0]
+        assert W.numel() == O * C
+        y = torch.empty((B, O, P), dtype=torch.float32, device=x.device)
+        with _guard(x):
+            tgemm_nn(B, O, P, C, W, 0, C, True, x, C * P, P, y, O * P, P, bias=bias, act=act)
+        ctx.save_for_backward(x, W, y if act else None)
+        ctx.act, ctx.has_bias = act, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, W, y = ctx.saved_tensors
+        B, C, P = x.shape
+        O = W.shape[0]
+        g = gy.contiguous()
+        if ctx.act == 1:
+            g = g * (1.0 - y * y)
+        dx = dW = db = None
+        with _guard(x):
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                tgemm_nn(B, C, P, O, W, 0, C, False, g, O * P, P, dx, C * P, P)
+            if ctx.needs_input_grad[1]:
+                dW = torch.zeros((O, C), dtype=torch.float32, device=x.device)
+                tgemm_kk(B, O, C, P, g, O * P, P, x, C * P, P, dW, 0, C)
+                dW = dW.view_as(W)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = g.sum(dim=(0, 2))
+        return dx, dW, db, None
+
+
+def linear_cm(x, W, bias=None, act=0):
+    return _LinearCM.apply(x.contiguous(), W, bias, act)
+
+
+class _BmmNT(Function):
+    """C_b (M x N) = A_b (M x K) . B_b (N x K)^T, both operands contiguous along the contraction (NetVLAD: X (C x n) . act (K x n)^T)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        check_device(a, b)
+        batch, M, K = a.shape
+        N = b.shape[1]
+        assert b.shape[0] == batch and b.shape[2] == K
+        c = torch.zeros((batch, M, N), dtype=torch.float32, device=a.device)
+        with _guard(a):
+            tgemm_kk(batch, M, N, K, a, M * K, K, b, N * K, K, c, M * N, N, per_batch=1)
+        ctx.save_for_backward(a, b)
+        return c
+
+    @staticmethod
+    def backward(ctx, gc):
+        a, b = ctx.saved_tensors
+        batch, M, K = a.shape
+        N = b.shape[1]
+        g = gc.contiguous()
+        da = db = None
+        with _guard(a):
+            if ctx.needs_input_grad[0]:      # dA (M x K) = dC (M x N) . B (N x K)
+                da = torch.empty_like(a)
+                tgemm_nn(batch, M, K, N, g, M * N, N, True, b, N * K, K, da, M * K, K)
+            if ctx.needs_input_grad[1]:      # dB (N x K) = dC^T (N x M) . A (M x K)
+                db = torch.empty_like(b)
+                tgemm_nn(batch, N, K, M, g, M * N, N, False, a, M * K, K, db, N * K, K)
+        return da, db
+
+
+def bmm_nt(a, b):
+    return _BmmNT.apply(a.contiguous(), b.contiguous())
+
+
+class _LinearRows(Function):
+    """Y (R x O) = X (R x K) . W (O x K)^T + bias -- nn.Linear on a few rows and a long contraction (APFA's 21504 -> 256 FC): split-K."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias):
+        check_device(x, W)
+        R, K = x.shape
+        O = W.shape[0]
+        y = bias.detach().expand(R, O).contiguous() if bias is not None else torch.zeros((R, O), dtype=torch.float32, device=x.device)
+        with _guard(x):
+            tgemm_kk(1, R, O, K, x, 0, K, W, 0, K, y, 0, O)
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, W = ctx.saved_tensors
+        R, K = x.shape
+        O = W.shape[0]
+        g = gy.contiguous()
+        dx = dW = db = None
+        with _guard(x):
+            if ctx.needs_input_grad[0]:      # dX (R x K) = dY (R x O) . W (O x K)
+                dx = torch.empty_like(x)
+                tgemm_nn(1, R, K, O, g, 0, O, True, W, 0, K, dx, 0, K)
+            if ctx.needs_input_grad[1]:      # dW (O x K) = dY^T (O x R) . X (R x K)
+                dW = torch.empty_like(W)
+                tgemm_nn(1, O, K, R, g, 0, O, False, x, 0, K, dW, 0, K)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = g.sum(0)
+        return dx, dW, db
+
+
+def linear_rows(x, W, bias=None):
+    return _LinearRows.apply(x.contiguous(), W, bias)
+
+
+class _MatmulRows(Function):
+    """Y (R x N) = X (R x K) . W (K x N)  (context gating, the FC heads of aggregation type 0 / PPT-Net)."""
+
+    @staticmethod
+    def forward(ctx, x, W):
+        check_device(x, W)
+        R, K = x.shape
+        N = W.shape[1]
+        y = torch.empty((R, N), dtype=torch.float32, device=x.device)
+        with _guard(x):
+            tgemm_nn(1, R, N, K, x, 0, K, True, W, 0, N, y, 0, N)
+        ctx.save_for_backward(x, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, W = ctx.saved_tensors
+        R, K = x.shape
+        N = W.shape[1]
+        g = gy.contiguous()
+        dx = dW = None
+        with _guard(x):
+            if ctx.needs_input_grad[0]:      # dX (R x K) = dY (R x N) . W (K x N)^T
+                dx = torch.zeros_like(x)
+                tgemm_kk(1, R, K, N, g, 0, N, W, 0, N, dx, 0, K)
+            if ctx.needs_input_grad[1]:      # dW (K x N) = X^T (K x R) . dY (R x N)
+                dW = torch.empty_like(W)
+                tgemm_nn(1, K, N, R, x, 0, K, False, g, 0, N, dW, 0, N)
+        return dx, dW
+
+
+def matmul_rows(x, W):
+    return _MatmulRows.apply(x.contiguous(), W)
+
+
+def bn_rows_train(bn, x):
+    """BatchNorm1d in train mode over the rows of a small (R, F) matrix (the 256-wide heads: R = clouds in the step), as plain
+    elementwise tensor ops under autograd -- a few KB; running statistics updated like torch.nn.BatchNorm1d."""
+    mean = x.mean(0)
+    var = x.var(0, unbiased=False)
+    if bn.track_running_stats and bn.running_mean is not None:
+        with torch.no_grad():
+            n = x.shape[0]
+            bn.running_mean.mul_(1 - bn.momentum).add_(bn.momentum * mean)
+            bn.running_var.mul_(1 - bn.momentum).add_(bn.momentum * var * (n / max(n - 1, 1)))
+            bn.num_batches_tracked += 1
+    return (x - mean) * torch.rsqrt(var + bn.eps) * bn.weight + bn.bias

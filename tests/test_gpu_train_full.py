@@ -62,6 +62,9 @@ def test_full_size_training_step_matches_reference_run():
         samp = f[::step][:8].numpy()
         tol_s = 5e-3 * max(ref_n / np.sqrt(f.numel()), 1e-7) + 5e-3 * np.abs(z["gsamp/" + k])
         # biases in front of a BatchNorm have a mathematically zero gradient: both sides hold rounding noise there (norms ~1e-6)
+        if ref_n < 2e-5:
+            assert n < 1e-4, (k, n, ref_n)
+            continue
         if abs(n - ref_n) > 5e-3 * ref_n + 2e-5 or (np.abs(samp - z["gsamp/" + k]) > tol_s + 2e-5 / np.sqrt(f.numel())).any():
             bad.append((k, n, ref_n, float(np.abs(samp - z["gsamp/" + k]).max())))
     assert not bad, bad[:6]
