@@ -100,7 +100,7 @@ def dominant_kernel_roofline(st, cfg, batch, points, grouping, pmc=None, pmc_not
     premul = "fp0.premul" in st
     if premul:   # first layer folded into the prologue (pa_fp_chain_premul): the launch runs layers 2.. on MFMA + 2*3*256 VALU FLOPs per row
         flops = 2.0 * rows * (sum(k * n for k, n in zip(dims[1:-1], dims[2:])) + (dims[0] - fs[1]) * dims[1])
-        kname = "chain_kernel<2,16,FPX,0,1> (pa_fp_chain_premul, fp0: 3-NN interpolation of the pre-multiplied coarse features + xyz term, then 256->256->256 on MFMA)"
+        kname = "chain_kernel<1,16,FPX,0,1> (pa_fp_chain_premul, fp0: 3-NN interpolation of the pre-multiplied coarse features + xyz term, then 256->256->256 on MFMA)"
     else:
         flops = 2.0 * rows * sum(k * n for k, n in zip(dims[:-1], dims[1:]))
         kname = "chain_kernel<2,16,FP,0,1> (pa_mlp_chain, fp0: 3-NN interpolate + 259->256->256->256 shared MLP)"
@@ -122,7 +122,7 @@ def dominant_kernel_roofline(st, cfg, batch, points, grouping, pmc=None, pmc_not
     }
 
 
-DOMINANT_KERNEL_RE = r"chain_kernel<2, 16, 3, false, 1>"     # fp0 feature-propagation chain (pa_fp_chain_premul); update with the kernel
+DOMINANT_KERNEL_RE = r"chain_kernel<[12], 16, 3, false, 1>"     # fp0 feature-propagation chain (pa_fp_chain_premul): 16-row tiles (32 with PA_CHAIN_FPX_RT2)
 GROUPING_KERNEL_RE = r"group_lds_kernel<4>"
 
 

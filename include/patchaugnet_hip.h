@@ -264,29 +264,35 @@ int pa_vlad_maxpool(int b, int ktot, int c, const float *vt, int l2norm, float *
  * (place_recognition/train_place_recognition.py:142-169, :386-392).  Activations are CHANNEL-MAJOR (B, C, P) like the reference's.
  * Per-channel parameter block p: 7 rows of nch floats -- 0 scale = gamma*rstd, 1 shift = beta - mean*scale, 2 mean, 3 rstd (pa_bn_finalize),
  * 4 mean(mask g), 5 mean(mask g * xhat), 6 gamma*rstd (pa_bn_bwd_finalize).
+ * per_batch_stats != 0 (PointNetDecoder: every related cloud is its own BatchNorm batch, patch_aug_net.py:83-98): one statistics /
+ * parameter block PER BATCH ENTRY, laid out back to back (stats: batch x PA_BN_STAT_SLOTS x 2*nch, p: batch x 7*nch, sums: batch x 2*nch);
+ * pa_bn_finalize / pa_bn_bwd_finalize then take groups = batch, update the running statistics group after group and add the groups'
+ * parameter gradients up.
  * pa_tgemm_nn: C_b (M x N) = [beta*C_b +] act(A_b (M x K) . f(B_b) (K x N) + bias[m]); B, C n-contiguous; A(m,k) = A[m*lda + k] when
  *   a_kcontig else A[k*lda + m]; sAb = 0 shares A over the batch.  f acts per k (the channel): bmode 0 identity, 1 relu(x*p0 + p1),
  *   2 / 3 the BatchNorm(+ReLU mask for 2) input gradient built from B = gradient w.r.t. the activation and baux = raw layer output.
- *   act 0 none / 1 tanh.  stats: 2*M doubles receiving (accumulating) the per-row sum and sum of squares of the stored values, or NULL.
+ *   act 0 none / 1 tanh.  stats: PA_BN_STAT_SLOTS replicas of 2*M doubles receiving (accumulating) the per-row sum and sum of squares
+ *   of the stored values (a workgroup adds to one replica; pa_bn_finalize sums them), or NULL.
  * pa_tgemm_kk: C (M x N) += sum over batch and k of fA(A_b)(m,k) * fB(B_b)(n,k), both operands k-contiguous (weight gradients: k runs
  *   over the points); amode 0 / 2 / 3 per row m, bmode 0 / 1 per row n; partial tiles are combined with fp32 atomics, so C must be
- *   zero-filled (or hold the value to add to); per_batch != 0 writes C_b = C + b*sCb instead of summing over the batch. */
+ *   zero-filled (or hold the value to add to); per_batch != 0 accumulates into C_b = C + b*sCb instead of summing over the batch. */
+#define PA_BN_STAT_SLOTS 32
 int pa_tgemm_nn(int batch, int M, int N, int K, const float *A, long sAb, int lda, int a_kcontig,
                 const float *B, long sBb, int ldb, int bmode, const float *baux, const float *bp,
-                float *C, long sCb, int ldc, int beta, const float *bias, int act, double *stats, pa_stream_t stream);
+                float *C, long sCb, int ldc, int beta, const float *bias, int act, double *stats, int per_batch_stats, pa_stream_t stream);
 int pa_tgemm_kk(int batch, int M, int N, long K, const float *A, long sAb, int lda, int amode, const float *aaux, const float *ap,
                 const float *B, long sBb, int ldb, int bmode, const float *bp,
-                float *C, long sCb, int ldc, int per_batch, pa_stream_t stream);
+                float *C, long sCb, int ldc, int per_batch, int per_batch_stats, pa_stream_t stream);
 /* BatchNorm (training): statistics -> rows 0..3 of p, running statistics updated in place (momentum, unbiased variance) when given. */
-int pa_bn_finalize(int nch, double count, const double *stats, const float *gamma, const float *beta, float eps, float momentum,
+int pa_bn_finalize(int nch, int groups, double count, const double *stats, const float *gamma, const float *beta, float eps, float momentum,
                    float *running_mean, float *running_var, float *p, pa_stream_t stream);
 /* sums (2*C doubles, zero-filled) += per-channel sum of mask(g) and of mask(g)*xhat over g, y (B, C, P); relu != 0: mask = BN(y) > 0. */
-int pa_bn_bwd_reduce(int B, int C, long P, const float *g, const float *y, const float *p, int relu, double *sums, pa_stream_t stream);
+int pa_bn_bwd_reduce(int B, int C, long P, const float *g, const float *y, const float *p, int relu, double *sums, int per_batch_stats, pa_stream_t stream);
 /* rows 4..6 of p from the sums; dgamma / dbeta (nch floats) written when given. */
-int pa_bn_bwd_finalize(int nch, double count, const double *sums, float *p, float *dgamma, float *dbeta, pa_stream_t stream);
+int pa_bn_bwd_finalize(int nch, int groups, double count, const double *sums, float *p, float *dgamma, float *dbeta, pa_stream_t stream);
 /* out = [relu](y*scale + shift) over (B, C, P); pool > 0: max over groups of `pool` consecutive points (patch_aug_net.py:236) ->
  * out (B, C, P/pool) and arg (int8 winning slot, first maximum).  pa_maxpool_bwd scatters a pooled gradient back: rows = B*C. */
-int pa_bn_apply(int B, int C, long P, int pool, int relu, const float *y, const float *p, float *out, signed char *arg, pa_stream_t stream);
+int pa_bn_apply(int B, int C, long P, int pool, int relu, const float *y, const float *p, float *out, signed char *arg, int per_batch_stats, pa_stream_t stream);
 int pa_maxpool_bwd(int rows, long Pout, int pool, const float *gp, const signed char *arg, float *g, pa_stream_t stream);
 
 /* ---- the reference's launcher names (group 2) -------------------------------------------------*/

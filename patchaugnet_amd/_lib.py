@@ -59,12 +59,12 @@ _SIGS = {
     "pa_afa_rows": "iiiippppppppipp",
     "pa_fc": "iiipppppippp",
     "pa_vlad_maxpool": "iiipip",
-    "pa_tgemm_nn": "iiiipliipliipppliipip",
-    "pa_tgemm_kk": "iiilpliipppliipplii",
-    "pa_bn_finalize": "idpppffppp",
-    "pa_bn_bwd_reduce": "iilpppip",
-    "pa_bn_bwd_finalize": "idpppp",
-    "pa_bn_apply": "iiliipppp",
+    "pa_tgemm_nn": "iiiipliipliipppliipipi",
+    "pa_tgemm_kk": "iiilpliipppliippliii",
+    "pa_bn_finalize": "iidpppffppp",
+    "pa_bn_bwd_reduce": "iilpppipi",
+    "pa_bn_bwd_finalize": "iidpppp",
+    "pa_bn_apply": "iiliippppi",
     "pa_maxpool_bwd": "ilippp",
 }
 _T = {"i": _I, "f": _F, "p": _P, "l": ctypes.c_long, "d": ctypes.c_double}

@@ -83,7 +83,7 @@ class SAModule(nn.Module):
         new_xyz = pointops.gathering(xyz.transpose(1, 2).contiguous(), center_idx).transpose(1, 2).contiguous()
         center_features = pointops.gathering(features, center_idx)
         grouped, sample_idx = self.groupers[0](xyz, new_xyz, features, center_features)
-        y = self.mlps[0](grouped).max(dim=3)[0]
+        y = self.mlps[0].forward_maxpool(grouped)
         if hasattr(self, "sas"):
             y = self.sas[0](y)
         return new_xyz, center_idx, sample_idx, y

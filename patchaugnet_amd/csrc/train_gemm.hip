@@ -69,7 +69,8 @@ struct NNArgs {
     int beta;
     const float *bias;                   // per m, or null
     int act;                             // 0 none, 1 tanh
-    double *stats;                       // [2*M]: sum and sum of squares of the stored values per row m over (batch, n); or null
+    double *stats;                       // [PA_BN_STAT_SLOTS][2*M]: sum and sum of squares of the stored values per row m over (batch, n); or null
+    long sPb, sStatb;                    // per-batch strides of tb.p (floats) and stats (doubles); 0 = one block shared by the batch
     int vecA, vecB;                      // 16-byte loads allowed (alignment / divisibility checked on the host)
 };
 
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(256) void tgemm_nn_kernel(NNArgs a)
     const float *B = a.B + (size_t)b * a.sBb;
     const float *B2 = (BMODE >= TF_BN_BWD_RELU) ? a.tb.aux + (size_t)b * a.sBb : nullptr;
     float *C = a.C + (size_t)b * a.sCb;
+    a.tb.p += (size_t)b * a.sPb;
 
     floatx4 acc[MT][NT];
 #pragma unroll
@@ -231,7 +233,11 @@ __global__ __launch_bounds__(256) void tgemm_nn_kernel(NNArgs a)
             s1[i][r] = t1;
             s2[i][r] = t2;
         }
-    if (a.stats) {   // per-row sums over this workgroup's columns: 16 lanes of a DPP row share a row m
+    if (a.stats) {
+        // per-row sums over this workgroup's columns: 16 lanes of a DPP row share a row m, the WN waves of a wave row meet in LDS (the
+        // operand stage is free after the loop's last barrier), then ONE fp64 atomic pair per row and workgroup -- into one of
+        // PA_BN_STAT_SLOTS replicas of the statistics block, so a few thousand workgroups do not queue up on 2*M addresses.
+        float *red = &As[0][0];                    // [WN][BM][2]
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -239,12 +245,19 @@ __global__ __launch_bounds__(256) void tgemm_nn_kernel(NNArgs a)
                 float t1 = s1[i][r], t2 = s2[i][r];
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) { t1 += __shfl_xor(t1, o); t2 += __shfl_xor(t2, o); }
-                const int gm = m0 + wm * (BM / WM) + i * 16 + (lane >> 4) * 4 + r;
-                if ((lane & 15) == 0 && gm < a.M) {
-                    atomicAdd(a.stats + gm, (double)t1);
-                    atomicAdd(a.stats + a.M + gm, (double)t2);
-                }
+                const int lm = wm * (BM / WM) + i * 16 + (lane >> 4) * 4 + r;
+                if ((lane & 15) == 0) { red[(wn * BM + lm) * 2] = t1; red[(wn * BM + lm) * 2 + 1] = t2; }
             }
+        __syncthreads();
+        if (tid < BM && m0 + tid < a.M) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WN; ++w) { t1 += red[(w * BM + tid) * 2]; t2 += red[(w * BM + tid) * 2 + 1]; }
+            const unsigned slot = (blockIdx.x + blockIdx.z * gridDim.x) % PA_BN_STAT_SLOTS;
+            double *st = a.stats + (size_t)b * a.sStatb + (size_t)slot * 2 * a.M;
+            atomicAdd(st + m0 + tid, (double)t1);
+            atomicAdd(st + a.M + m0 + tid, (double)t2);
+        }
     }
 }
 
@@ -252,7 +265,7 @@ __global__ __launch_bounds__(256) void tgemm_nn_kernel(NNArgs a)
 // C (M x N) += sum over (batch, k) of fA(A_b)(m,k) * fB(B_b)(n,k); both operands k-contiguous: A_b(m,k) = A[b*sAb + m*lda + k].
 // fA: per-m channel transform (none / bn-bwd, two tensors), fB: per-n channel transform (none / affine+relu).
 // grid (N tiles, M tiles, batch * ksplits); partial tiles are combined with fp32 atomics (C zero-filled by the caller), or stored
-// directly per batch when `per_batch` is set (C_b = C + b*sCb, ksplits must then be 1... or atomics into the per-batch tile).
+// accumulated per batch when `per_batch` is set (C_b = C + b*sCb).
 struct KKArgs {
     int M, N, K;
     const float *A; long sAb; int lda; TOp ta;
@@ -261,6 +274,7 @@ struct KKArgs {
     int ksplits, kchunk;
     int per_batch;
     int vecA, vecB;
+    long sAPb, sBPb;                     // per-batch strides of ta.p / tb.p (floats); 0 = shared
 };
 
 constexpr int KK_BM = 64, KK_BN = 64, KK_BK = 32, KK_S = KK_BK + 2;   // row stride 34: (2m + k) mod 32 distinct for m < 16, k < 2
@@ -277,6 +291,8 @@ __global__ __launch_bounds__(256) void tgemm_kk_kernel(KKArgs a)
     const int kbeg = split * a.kchunk, kend = min(kbeg + a.kchunk, a.K);
     const float *A = a.A + (size_t)b * a.sAb, *B = a.B + (size_t)b * a.sBb;
     const float *A2 = AMODE >= TF_BN_BWD_RELU ? a.ta.aux + (size_t)b * a.sAb : nullptr;
+    a.ta.p += (size_t)b * a.sAPb;
+    a.tb.p += (size_t)b * a.sBPb;
     floatx4 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -368,7 +384,6 @@ __global__ __launch_bounds__(256) void tgemm_kk_kernel(KKArgs a)
         __syncthreads();
     }
     float *C = a.C + (a.per_batch ? (size_t)b * a.sCb : (size_t)0);
-    const bool direct = a.per_batch && a.ksplits == 1;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -376,10 +391,7 @@ __global__ __launch_bounds__(256) void tgemm_kk_kernel(KKArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gm = m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r, gn = n0 + wn * 32 + j * 16 + (lane & 15);
-                if (gm < a.M && gn < a.N) {
-                    if (direct) C[(size_t)gm * a.ldc + gn] = acc[i][j][r];
-                    else atomicAdd(C + (size_t)gm * a.ldc + gn, acc[i][j][r]);
-                }
+                if (gm < a.M && gn < a.N) atomicAdd(C + (size_t)gm * a.ldc + gn, acc[i][j][r]);
             }
 }
 
@@ -387,36 +399,44 @@ __global__ __launch_bounds__(256) void tgemm_kk_kernel(KKArgs a)
 // finalize: stats (fp64 sum, sum of squares per channel over `count` values) -> p[0] scale = gamma*rstd, p[1] shift = beta - mean*scale,
 // p[2] mean, p[3] rstd (biased variance, as torch's training forward); running statistics updated in place with momentum and the
 // unbiased variance (torch.nn.BatchNorm semantics).
-__global__ void bn_finalize_kernel(int nch, double count, const double *__restrict__ stats, const float *__restrict__ gamma, const float *__restrict__ beta,
+__global__ void bn_finalize_kernel(int nch, int batch, double count, const double *__restrict__ stats, const float *__restrict__ gamma, const float *__restrict__ beta,
                                    float eps, float momentum, float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ p)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nch) return;
-    const double mean = stats[c] / count;
-    double var = stats[nch + c] / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
-    const float scale = g * rstd;
-    p[c] = scale;
-    p[nch + c] = bt - (float)mean * scale;
-    p[2 * nch + c] = (float)mean;
-    p[3 * nch + c] = rstd;
-    if (running_mean) {
+    float rm = running_mean ? running_mean[c] : 0.f, rv = running_mean ? running_var[c] : 0.f;
+    for (int b = 0; b < batch; ++b) {            // batch > 1: one statistics group per batch entry, running statistics updated in order
+        const double *st = stats + (size_t)b * PA_BN_STAT_SLOTS * 2 * nch;
+        float *pb = p + (size_t)b * 7 * nch;
+        double su = 0.0, sq = 0.0;
+        for (int sl = 0; sl < PA_BN_STAT_SLOTS; ++sl) { su += st[(size_t)sl * 2 * nch + c]; sq += st[(size_t)sl * 2 * nch + nch + c]; }
+        const double mean = su / count;
+        double var = sq / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float scale = g * rstd;
+        pb[c] = scale;
+        pb[nch + c] = bt - (float)mean * scale;
+        pb[2 * nch + c] = (float)mean;
+        pb[3 * nch + c] = rstd;
         const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        rm = (1.f - momentum) * rm + momentum * (float)mean;
+        rv = (1.f - momentum) * rv + momentum * (float)unbiased;
     }
+    if (running_mean) { running_mean[c] = rm; running_var[c] = rv; }
 }
 
 // backward reduction over a channel-major (B, C, P) pair (g = gradient w.r.t. the post-activation, y = raw pre-BatchNorm output):
 // sums[c] += sum mask(g), sums[C + c] += sum mask(g) * xhat   (fp64 atomics); grid (chunks of P, C, B)
 template <bool RELU>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(int C, long P, const float *__restrict__ g, const float *__restrict__ y, const float *__restrict__ p,
-                                                              double *__restrict__ sums, int vec)
+                                                              double *__restrict__ sums, int vec, long sPb, long sSumb)
 {
     __shared__ float red[8];
     const int c = blockIdx.y, b = blockIdx.z;
+    p += (size_t)b * sPb;
+    sums += (size_t)b * sSumb;
     const float scale = p[c], shift = p[C + c], mean = p[2 * C + c], rstd = p[3 * C + c];
     const size_t base = ((size_t)b * C + c) * P;
     const long chunk = (P + gridDim.x - 1) / gridDim.x;
@@ -459,26 +479,34 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(int C, long P, const
 }
 
 // p[4] = sum mask(g) / count, p[5] = sum(mask(g) * xhat) / count, p[6] = gamma * rstd (= p[0]); dgamma = sum(mask g * xhat), dbeta = sum(mask g)
-__global__ void bn_bwd_finalize_kernel(int nch, double count, const double *__restrict__ sums, float *__restrict__ p, float *__restrict__ dgamma, float *__restrict__ dbeta)
+__global__ void bn_bwd_finalize_kernel(int nch, int batch, double count, const double *__restrict__ sums, float *__restrict__ p, float *__restrict__ dgamma, float *__restrict__ dbeta)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nch) return;
-    p[4 * nch + c] = (float)(sums[c] / count);
-    p[5 * nch + c] = (float)(sums[nch + c] / count);
-    p[6 * nch + c] = p[c];
-    if (dgamma) dgamma[c] = (float)sums[nch + c];
-    if (dbeta) dbeta[c] = (float)sums[c];
+    double dg = 0.0, db = 0.0;
+    for (int b = 0; b < batch; ++b) {            // batch > 1: one statistics group per batch entry; the parameter gradients add up
+        const double *sm = sums + (size_t)b * 2 * nch;
+        float *pb = p + (size_t)b * 7 * nch;
+        pb[4 * nch + c] = (float)(sm[c] / count);
+        pb[5 * nch + c] = (float)(sm[nch + c] / count);
+        pb[6 * nch + c] = pb[c];
+        dg += sm[nch + c];
+        db += sm[c];
+    }
+    if (dgamma) dgamma[c] = (float)dg;
+    if (dbeta) dbeta[c] = (float)db;
 }
 
 // out = relu(y * scale + shift) on (B, C, P); with pool > 0: max over groups of `pool` consecutive points -> out (B, C, P / pool), arg (int8 slot)
 __global__ __launch_bounds__(256) void bn_apply_kernel(int C, long P, int pool, int relu, const float *__restrict__ y, const float *__restrict__ p, float *__restrict__ out,
-                                                        signed char *__restrict__ arg)
+                                                        signed char *__restrict__ arg, long sPb)
 {
     const long Pout = pool > 0 ? P / pool : P;
     const long total = (long)gridDim.y * Pout;   // gridDim.y = B * C rows
     (void)total;
     const long row = blockIdx.y;
     const int c = (int)(row % C);
+    p += (size_t)(row / C) * sPb;
     const float scale = p[c], shift = p[C + c];
     const float *src = y + (size_t)row * P;
     float *dst = out + (size_t)row * Pout;
@@ -525,10 +553,10 @@ TOp make_top(int mode, const float *aux, const float *p, int nch)
 
 // C_b (M x N) = [beta C_b +] act(A_b . f(B_b) + bias): see tgemm_nn_kernel.  a_kcontig: A(m,k) = A[m*lda + k] (else A[k*lda + m]);
 // sAb = 0 shares A over the batch.  bmode 0 none / 1 affine+relu (bp: 2*K floats) / 2 bn-bwd with ReLU mask / 3 bn-bwd (baux = raw output,
-// bp: 7*K floats).  stats (2*M doubles, accumulated) or NULL.
+// bp: 7*K floats).  stats (PA_BN_STAT_SLOTS x 2*M doubles, accumulated; pa_bn_finalize adds the replicas up) or NULL.
 PA_API int pa_tgemm_nn(int batch, int M, int N, int K, const float *A, long sAb, int lda, int a_kcontig,
                        const float *B, long sBb, int ldb, int bmode, const float *baux, const float *bp,
-                       float *C, long sCb, int ldc, int beta, const float *bias, int act, double *stats, pa_stream_t stream)
+                       float *C, long sCb, int ldc, int beta, const float *bias, int act, double *stats, int per_batch_stats, pa_stream_t stream)
 {
     PA_REQUIRE(batch > 0 && M > 0 && N > 0 && K > 0 && A && B && C, "pa_tgemm_nn: bad arguments");
     PA_REQUIRE(bmode >= 0 && bmode <= 3 && (bmode == 0 || bp) && (bmode < 2 || baux), "pa_tgemm_nn: transform %d needs its parameter / auxiliary tensors", bmode);
@@ -540,6 +568,8 @@ PA_API int pa_tgemm_nn(int batch, int M, int N, int K, const float *A, long sAb,
     a.B = B; a.sBb = sBb; a.ldb = ldb;
     a.tb = make_top(bmode, baux, bp, K);
     a.C = C; a.sCb = sCb; a.ldc = ldc; a.beta = beta; a.bias = bias; a.act = act; a.stats = stats;
+    a.sPb = per_batch_stats ? 7L * K : 0;                       // the operand's parameter block belongs to ITS layer: K channels
+    a.sStatb = per_batch_stats ? (long)PA_BN_STAT_SLOTS * 2 * M : 0;
     a.vecA = aligned16(A) && lda % 4 == 0 && sAb % 4 == 0;
     a.vecB = aligned16(B) && ldb % 4 == 0 && sBb % 4 == 0 && (bmode < 2 || aligned16(baux));
     const bool big = M > 64;
@@ -558,10 +588,10 @@ PA_API int pa_tgemm_nn(int batch, int M, int N, int K, const float *A, long sAb,
 }
 
 // C (M x N) += sum_b sum_k fA(A_b)(m,k) fB(B_b)(n,k)  (per_batch = 0: C must be zero-filled or hold the value to add to), or
-// C_b = ... per batch (per_batch = 1; C_b zero-filled unless K fits one split).  amode 0 / 2 / 3 (aaux, ap: 7*M floats), bmode 0 / 1 (bp: 2*N floats).
+// C_b += ... per batch (per_batch = 1).  amode 0 / 2 / 3 (aaux, ap: 7*M floats), bmode 0 / 1 (bp: 2*N floats).
 PA_API int pa_tgemm_kk(int batch, int M, int N, long K, const float *A, long sAb, int lda, int amode, const float *aaux, const float *ap,
                        const float *B, long sBb, int ldb, int bmode, const float *bp,
-                       float *C, long sCb, int ldc, int per_batch, pa_stream_t stream)
+                       float *C, long sCb, int ldc, int per_batch, int per_batch_stats, pa_stream_t stream)
 {
     PA_REQUIRE(batch > 0 && M > 0 && N > 0 && K > 0 && K < 2147483647L && A && B && C, "pa_tgemm_kk: bad arguments");
     PA_REQUIRE((amode == 0 || ((amode == 2 || amode == 3) && aaux && ap)) && (bmode == 0 || (bmode == 1 && bp)), "pa_tgemm_kk: transform arguments");
@@ -571,6 +601,8 @@ PA_API int pa_tgemm_kk(int batch, int M, int N, long K, const float *A, long sAb
     a.A = A; a.sAb = sAb; a.lda = lda; a.ta = make_top(amode, aaux, ap, M);
     a.B = B; a.sBb = sBb; a.ldb = ldb; a.tb = make_top(bmode, nullptr, bp, N);
     a.C = C; a.sCb = sCb; a.ldc = ldc; a.per_batch = per_batch;
+    a.sAPb = per_batch_stats ? 7L * M : 0;
+    a.sBPb = per_batch_stats ? 7L * N : 0;
     a.vecA = aligned16(A) && lda % 4 == 0 && sAb % 4 == 0 && (amode == 0 || aligned16(aaux));
     a.vecB = aligned16(B) && ldb % 4 == 0 && sBb % 4 == 0;
     const long tiles = (long)((M + KK_BM - 1) / KK_BM) * ((N + KK_BN - 1) / KK_BN) * batch;
@@ -595,19 +627,20 @@ PA_API int pa_tgemm_kk(int batch, int M, int N, long K, const float *A, long sAb
 
 
 // BatchNorm (training) statistics -> per-channel parameter block p (7 * nch floats, rows 0..3 written here, 4..6 by pa_bn_bwd_finalize).
-PA_API int pa_bn_finalize(int nch, double count, const double *stats, const float *gamma, const float *beta, float eps, float momentum,
+PA_API int pa_bn_finalize(int nch, int groups, double count, const double *stats, const float *gamma, const float *beta, float eps, float momentum,
                           float *running_mean, float *running_var, float *p, pa_stream_t stream)
 {
-    PA_REQUIRE(nch > 0 && count > 0 && stats && p, "pa_bn_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(pa_div_up(nch, 256)), dim3(256), 0, (hipStream_t)stream, nch, count, stats, gamma, beta, eps, momentum,
+    PA_REQUIRE(nch > 0 && groups > 0 && count > 0 && stats && p, "pa_bn_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(pa_div_up(nch, 256)), dim3(256), 0, (hipStream_t)stream, nch, groups, count, stats, gamma, beta, eps, momentum,
                        running_mean, running_var, p);
     PA_CHECK_LAUNCH("pa_bn_finalize");
     return PA_OK;
 }
 
 // sums (2*C doubles, zero-filled by the caller) over g, y (B, C, P) channel-major; relu != 0 masks g where BN(y) <= 0.
-PA_API int pa_bn_bwd_reduce(int B, int C, long P, const float *g, const float *y, const float *p, int relu, double *sums, pa_stream_t stream)
+PA_API int pa_bn_bwd_reduce(int B, int C, long P, const float *g, const float *y, const float *p, int relu, double *sums, int per_batch_stats, pa_stream_t stream)
 {
+    const long sPb = per_batch_stats ? 7L * C : 0, sSumb = per_batch_stats ? 2L * C : 0;
     PA_REQUIRE(B > 0 && C > 0 && P > 0 && g && y && p && sums && B <= 65535 && C <= 65535, "pa_bn_bwd_reduce: bad arguments");
     long chunks = (2048 + (long)B * C - 1) / ((long)B * C);
     const long maxc = (P + 4095) / 4096;
@@ -615,29 +648,29 @@ PA_API int pa_bn_bwd_reduce(int B, int C, long P, const float *g, const float *y
     if (chunks < 1) chunks = 1;
     const int vec = aligned16(g) && aligned16(y) && P % 4 == 0 && ((P + chunks - 1) / chunks) % 4 == 0;
     dim3 grid((unsigned)chunks, C, B);
-    if (relu) hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, C, P, g, y, p, sums, vec);
-    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, C, P, g, y, p, sums, vec);
+    if (relu) hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, C, P, g, y, p, sums, vec, sPb, sSumb);
+    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, C, P, g, y, p, sums, vec, sPb, sSumb);
     PA_CHECK_LAUNCH("pa_bn_bwd_reduce");
     return PA_OK;
 }
 
-PA_API int pa_bn_bwd_finalize(int nch, double count, const double *sums, float *p, float *dgamma, float *dbeta, pa_stream_t stream)
+PA_API int pa_bn_bwd_finalize(int nch, int groups, double count, const double *sums, float *p, float *dgamma, float *dbeta, pa_stream_t stream)
 {
-    PA_REQUIRE(nch > 0 && count > 0 && sums && p, "pa_bn_bwd_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pa_div_up(nch, 256)), dim3(256), 0, (hipStream_t)stream, nch, count, sums, p, dgamma, dbeta);
+    PA_REQUIRE(nch > 0 && groups > 0 && count > 0 && sums && p, "pa_bn_bwd_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pa_div_up(nch, 256)), dim3(256), 0, (hipStream_t)stream, nch, groups, count, sums, p, dgamma, dbeta);
     PA_CHECK_LAUNCH("pa_bn_bwd_finalize");
     return PA_OK;
 }
 
 // out = [relu](y*scale + shift) over (B, C, P); pool > 0 additionally takes the max over groups of `pool` consecutive points
 // (out (B, C, P/pool), arg (B, C, P/pool) int8 = winning slot; patch_aug_net.py:236).
-PA_API int pa_bn_apply(int B, int C, long P, int pool, int relu, const float *y, const float *p, float *out, signed char *arg, pa_stream_t stream)
+PA_API int pa_bn_apply(int B, int C, long P, int pool, int relu, const float *y, const float *p, float *out, signed char *arg, int per_batch_stats, pa_stream_t stream)
 {
     PA_REQUIRE(B > 0 && C > 0 && P > 0 && y && p && out && (pool <= 0 || (arg && P % pool == 0 && pool < 128)) && (long)B * C <= 65535L * 1, "pa_bn_apply: bad arguments");
     const long Pout = pool > 0 ? P / pool : P;
     long gx = (Pout + 255) / 256;
     if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)gx, B * C), dim3(256), 0, (hipStream_t)stream, C, P, pool, relu, y, p, out, arg);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)gx, B * C), dim3(256), 0, (hipStream_t)stream, C, P, pool, relu, y, p, out, arg, per_batch_stats ? 7L * C : 0L);
     PA_CHECK_LAUNCH("pa_bn_apply");
     return PA_OK;
 }

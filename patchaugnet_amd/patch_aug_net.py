@@ -14,7 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import loupe as lp
-from . import pointops
+from . import pointops, train_ops
 from .backbone import PyramidBackbone
 
 __all__ = ["Network", "PointNetDecoder"]
@@ -32,7 +32,20 @@ class PointNetDecoder(nn.Module):
         self.bn2 = nn.BatchNorm1d(1024)
         self.fc3 = nn.Linear(1024, num_points * output_channels)
 
+    def forward_cm(self, xt):
+        """train() mode on the MI355X, channel-major: xt (R, C, P) = R related clouds, the P patch features of each as columns ->
+        (R, P, num_points, 3).  Every cloud is its own BatchNorm batch, as if the decoder were called once per cloud in order
+        (patch_aug_net.py:83-98).  Both hidden layers are one chain on the MFMA GEMM kernels (csrc/train_gemm.hip; BatchNorm statistics
+        over the P columns fused into the GEMM epilogues, BatchNorm + ReLU applied by the next GEMM's loader), the output layer a GEMM
+        with bias + tanh epilogue."""
+        layers = [train_ops.BNLayer(self.fc1.weight, self.bn1, bias=self.fc1.bias), train_ops.BNLayer(self.fc2.weight, self.bn2, bias=self.fc2.bias)]
+        h = train_ops.chain_train(xt, layers, groups=True)
+        y = train_ops.linear_cm(h, self.fc3.weight, self.fc3.bias, act=1)             # (R, num_points*3, P)
+        return y.transpose(1, 2).contiguous().view(xt.shape[0], xt.shape[2], self.num_points, self.output_channels)
+
     def forward(self, x):
+        if x.is_cuda and self.training and train_ops.hip_dense_enabled():
+            return self.forward_cm(x.t().contiguous().unsqueeze(0))[0]
         x = F.relu(self.bn1(self.fc1(x)))
         x = F.relu(self.bn2(self.fc2(x)))
         return torch.tanh(self.fc3(x)).view(x.shape[0], self.num_points, self.output_channels).contiguous()
@@ -108,14 +121,19 @@ class Network(nn.Module):
             origin = pointops.grouping(xyz.transpose(1, 2).contiguous(), sample_idx[0])      # (B, 3, m0, k)
             data = {"cloud_indices": related, "center_indices": [], "origin_patches": [], "patch_features": [],
                     "reconstructed_patches": []}
-            for ci in related:
-                feats = fp_features[1][ci].squeeze(-1).transpose(1, 0)                       # (m0, 256)
-                if self.use_l2_norm:
-                    feats = F.normalize(feats)
+            hip_dec = self.use_a2a_recon and x.is_cuda and self.training and train_ops.hip_dense_enabled()
+            feats_cm = fp_features[1].squeeze(-1)[related]                                   # (R, 256, m0): one patch feature per column
+            if self.use_l2_norm:
+                feats_cm = F.normalize(feats_cm, dim=1)
+            recon = self.decoder.forward_cm(feats_cm.contiguous()) if hip_dec else None      # all related clouds in one set of launches
+            for r, ci in enumerate(related):
+                feats = feats_cm[r].transpose(1, 0)                                          # (m0, 256)
                 data["center_indices"].append(center_idx[0][ci:ci + 1])
                 data["origin_patches"].append(origin[ci].permute(1, 2, 0))                   # (m0, k, 3)
                 data["patch_features"].append(feats)
-                if self.use_a2a_recon:
+                if hip_dec:
+                    data["reconstructed_patches"].append(recon[r])
+                elif self.use_a2a_recon:
                     data["reconstructed_patches"].append(self.decoder(feats))
             out = out, data
         return (out, fp_features, center_idx) if return_feat else out

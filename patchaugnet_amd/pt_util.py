@@ -8,6 +8,8 @@ checkpoints load unchanged.  The 1x1 convolution is evaluated as a matmul over t
 import torch
 import torch.nn as nn
 
+from . import train_ops
+
 
 class _BN(nn.Module):
     """Holder that reproduces the reference's ``bn.bn`` nesting (pt_util.py:72-90)."""
@@ -45,3 +47,23 @@ class SharedMLP(nn.Sequential):
         self.channels = list(args)
         for i in range(len(args) - 1):
             self.add_module(f"layer{i}", ConvBNReLU(args[i], args[i + 1], dims))
+
+    def _hip_train(self, x):
+        return x.is_cuda and self.training and train_ops.hip_dense_enabled()
+
+    def _chain(self, x, pool):
+        """train() mode on the MI355X: the whole stack, forward and backward, on the MFMA GEMM kernels of csrc/train_gemm.hip
+        (BatchNorm + ReLU applied inside the next layer's operand loader, statistics accumulated in the epilogue)."""
+        layers = [train_ops.BNLayer(l.conv.weight, l.bn.bn) for l in self]
+        return train_ops.chain_train(x.flatten(2), layers, pool)
+
+    def forward(self, x):
+        if self._hip_train(x):
+            return self._chain(x, 0).view(x.shape[0], self.channels[-1], *x.shape[2:])
+        return super().forward(x)
+
+    def forward_maxpool(self, x):
+        """(B, C, m, k) -> max over k of the stack's output, (B, C_out, m) (patch_aug_net.py:236): fused into the last BatchNorm pass."""
+        if self._hip_train(x):
+            return self._chain(x, x.shape[3])
+        return super().forward(x).max(dim=3)[0]

@@ -22,6 +22,7 @@ from torch.autograd import Function
 from ._lib import call, check_device, ptr
 
 _hip_dense = True
+STAT_SLOTS = 32          # PA_BN_STAT_SLOTS (include/patchaugnet_hip.h): replicas of a layer's statistics block
 
 
 def hip_dense_enabled():
@@ -45,16 +46,17 @@ def _guard(t):
 
 # ---------------------------------------------------------------------------------------------------- thin wrappers of the C ABI
 def tgemm_nn(batch, M, N, K, A, sAb, lda, a_kcontig, B, sBb, ldb, C, sCb, ldc, *, bmode=0, baux=None, bp=None, beta=0, bias=None, act=0,
-             stats=None):
+             stats=None, per_batch_stats=0):
     """C_b (M x N) = [beta C_b +] act(A_b (M x K) . f(B_b) (K x N) + bias[m]) -- include/patchaugnet_hip.h: pa_tgemm_nn."""
     call("pa_tgemm_nn", batch, M, N, K, ptr(A), sAb, lda, int(a_kcontig), ptr(B), sBb, ldb, bmode, ptr(baux), ptr(bp), ptr(C), sCb, ldc,
-         int(beta), ptr(bias), act, ptr(stats))
+         int(beta), ptr(bias), act, ptr(stats), int(per_batch_stats))
 
 
-def tgemm_kk(batch, M, N, K, A, sAb, lda, B, sBb, ldb, C, sCb, ldc, *, amode=0, aaux=None, ap=None, bmode=0, bp=None, per_batch=0):
+def tgemm_kk(batch, M, N, K, A, sAb, lda, B, sBb, ldb, C, sCb, ldc, *, amode=0, aaux=None, ap=None, bmode=0, bp=None, per_batch=0,
+             per_batch_stats=0):
     """C (M x N) += sum_b sum_k fA(A_b)(m,k) fB(B_b)(n,k) -- include/patchaugnet_hip.h: pa_tgemm_kk."""
     call("pa_tgemm_kk", batch, M, N, K, ptr(A), sAb, lda, amode, ptr(aaux), ptr(ap), ptr(B), sBb, ldb, bmode, ptr(bp), ptr(C), sCb, ldc,
-         int(per_batch))
+         int(per_batch), int(per_batch_stats))
 
 
 class BNLayer:
@@ -63,6 +65,10 @@ class BNLayer:
 
     def __init__(self, weight, bn, bias=None, relu=True, transposed=False):
         self.weight, self.bias, self.bn, self.relu, self.transposed = weight, bias, bn, relu, transposed
+
+    @property
+    def out_channels(self):
+        return self.weight.shape[1] if self.transposed else self.weight.shape[0]
 
 
 def _bn_buffers(bn):
@@ -74,10 +80,11 @@ def _bn_buffers(bn):
 
 
 class _ChainTrain(Function):
-    """x (B, C0, P) -> L x [W . -> BatchNorm(batch stats) -> ReLU] [-> max over `pool` consecutive points]."""
+    """x (B, C0, P) -> L x [W . -> BatchNorm(batch stats) -> ReLU] [-> max over `pool` consecutive points].
+    groups = True: every batch entry is its own BatchNorm batch (the decoder run over R related clouds in one set of launches)."""
 
     @staticmethod
-    def forward(ctx, x, layers, pool, *tensors):
+    def forward(ctx, x, layers, pool, groups, *tensors):
         check_device(x)
         B, cin, P = x.shape
         dev = x.device
@@ -88,83 +95,106 @@ class _ChainTrain(Function):
             biases.append(next(it) if L.bias is not None else None)
             gammas.append(next(it))
             betas.append(next(it))
+        G = B if groups else 1                    # statistics groups
+        outs = [L.out_channels for L in layers]
+        # one zero-filled arena for every layer's statistics replicas, one for the parameter blocks
+        stats_all = torch.zeros(G * STAT_SLOTS * 2 * sum(outs), dtype=torch.float64, device=dev)
+        p_all = torch.empty(G * 7 * sum(outs), dtype=torch.float32, device=dev)
         ys, ps = [], []
         prev, prevp = x, None
+        so = po = 0
+        counters = []
         with _guard(x):
             for i, L in enumerate(layers):
-                W = Ws[i]
-                O = W.shape[1] if L.transposed else W.shape[0]
+                W, O = Ws[i], outs[i]
                 C = W.numel() // O
                 assert C == cin, f"layer {i}: weight has {C} input channels, activation has {cin}"
                 assert L.relu or i == len(layers) - 1, "only the last layer of a chain may come without ReLU"
                 y = torch.empty((B, O, P), dtype=torch.float32, device=dev)
-                stats = torch.zeros((2, O), dtype=torch.float64, device=dev)
+                stats = stats_all[so:so + G * STAT_SLOTS * 2 * O]
+                p = p_all[po:po + G * 7 * O]
+                so += G * STAT_SLOTS * 2 * O
+                po += G * 7 * O
                 tgemm_nn(B, O, P, C, W, 0, O if L.transposed else C, not L.transposed, prev, C * P, P, y, O * P, P,
-                         bmode=0 if i == 0 else 1, bp=prevp, bias=biases[i], stats=stats)
-                p = torch.empty((7, O), dtype=torch.float32, device=dev)
+                         bmode=0 if i == 0 else 1, bp=prevp, bias=biases[i], stats=stats, per_batch_stats=groups)
                 rm, rv, mom = _bn_buffers(L.bn)
-                call("pa_bn_finalize", O, float(B * P), ptr(stats), ptr(gammas[i]), ptr(betas[i]), float(L.bn.eps), mom, ptr(rm), ptr(rv), ptr(p))
+                call("pa_bn_finalize", O, G, float(B * P // G), ptr(stats), ptr(gammas[i]), ptr(betas[i]), float(L.bn.eps), mom, ptr(rm), ptr(rv), ptr(p))
                 if rm is not None and L.bn.num_batches_tracked is not None:
-                    L.bn.num_batches_tracked += 1
+                    counters.append(L.bn.num_batches_tracked)
                 ys.append(y)
                 ps.append(p)
                 prev, prevp, cin = y, p, O
+            if counters:
+                torch._foreach_add_(counters, G)
             Pout = P // pool if pool else P
             if pool:
                 assert P % pool == 0
             out = torch.empty((B, cin, Pout), dtype=torch.float32, device=dev)
             arg = torch.empty((B, cin, Pout), dtype=torch.int8, device=dev) if pool else None
-            call("pa_bn_apply", B, cin, P, int(pool), int(layers[-1].relu), ptr(prev), ptr(prevp), ptr(out), ptr(arg))
+            call("pa_bn_apply", B, cin, P, int(pool), int(layers[-1].relu), ptr(prev), ptr(prevp), ptr(out), ptr(arg), int(groups))
         ctx.save_for_backward(x, *Ws)
-        ctx.layers, ctx.pool, ctx.ys, ctx.ps, ctx.arg = layers, pool, ys, ps, arg
-        ctx.has_bias = [b is not None for b in biases]
-        ctx.bias_like = [b for b in biases]
+        ctx.layers, ctx.pool, ctx.groups, ctx.ys, ctx.ps, ctx.arg = layers, pool, groups, ys, ps, arg
+        ctx.bias_like = biases
         return out
 
     @staticmethod
     def backward(ctx, gout):
         x, *Ws = ctx.saved_tensors
-        layers, pool, ys, ps, arg = ctx.layers, ctx.pool, ctx.ys, ctx.ps, ctx.arg
+        layers, pool, groups, ys, ps, arg = ctx.layers, ctx.pool, ctx.groups, ctx.ys, ctx.ps, ctx.arg
         B, _, P = x.shape
         dev = x.device
+        G = B if groups else 1
         g = gout.contiguous()
         per_layer = [None] * len(layers)
+        outs = [y.shape[1] for y in ys]
+        ins = [x.shape[1]] + outs[:-1]
+        sums_all = torch.zeros(G * 2 * sum(outs), dtype=torch.float64, device=dev)
+        # weight gradients (split-K partial tiles are added with atomics: zero-filled) and dgamma / dbeta, one arena
+        nW = [o * c for o, c in zip(outs, ins)]
+        grads = torch.zeros(sum(nW) + 2 * sum(outs), dtype=torch.float32, device=dev)
+        wo = [0]
+        for n in nW:
+            wo.append(wo[-1] + n)
+        go = wo[-1]
+        so = [0]
+        for o in outs:
+            so.append(so[-1] + G * 2 * o)
         with _guard(x):
             if pool:
-                O = ys[-1].shape[1]
+                O = outs[-1]
                 full = torch.empty((B, O, P), dtype=torch.float32, device=dev)
                 call("pa_maxpool_bwd", B * O, P // pool, int(pool), ptr(g), ptr(arg), ptr(full))
                 g = full
             for i in range(len(layers) - 1, -1, -1):
                 L, W, y, p = layers[i], Ws[i], ys[i], ps[i]
-                O = y.shape[1]
+                O, C = outs[i], ins[i]
                 prev = x if i == 0 else ys[i - 1]
-                C = prev.shape[1]
-                sums = torch.zeros((2, O), dtype=torch.float64, device=dev)
-                call("pa_bn_bwd_reduce", B, O, P, ptr(g), ptr(y), ptr(p), int(L.relu), ptr(sums))
-                dgamma = torch.empty(O, dtype=torch.float32, device=dev)
-                dbeta = torch.empty(O, dtype=torch.float32, device=dev)
-                call("pa_bn_bwd_finalize", O, float(B * P), ptr(sums), ptr(p), ptr(dgamma), ptr(dbeta))
+                sums = sums_all[so[i]:so[i + 1]]
+                call("pa_bn_bwd_reduce", B, O, P, ptr(g), ptr(y), ptr(p), int(L.relu), ptr(sums), int(groups))
+                dgamma = grads[go + 2 * sum(outs[:i]):go + 2 * sum(outs[:i]) + O]
+                dbeta = grads[go + 2 * sum(outs[:i]) + O:go + 2 * sum(outs[:i]) + 2 * O]
+                call("pa_bn_bwd_finalize", O, G, float(B * P // G), ptr(sums), ptr(p), ptr(dgamma), ptr(dbeta))
                 mode = 2 if L.relu else 3
-                dW = torch.zeros((O, C), dtype=torch.float32, device=dev)
+                dW = grads[wo[i]:wo[i + 1]].view(O, C)
                 tgemm_kk(B, O, C, P, g, O * P, P, prev, C * P, P, dW, 0, C, amode=mode, aaux=y, ap=p,
-                         bmode=0 if i == 0 else 1, bp=None if i == 0 else ps[i - 1])
+                         bmode=0 if i == 0 else 1, bp=None if i == 0 else ps[i - 1], per_batch_stats=groups)
                 if i > 0 or ctx.needs_input_grad[0]:
                     gp = torch.empty((B, C, P), dtype=torch.float32, device=dev)
                     # dX (C x P) = W^T (C x O) . dY (O x P): A(m = c, k = o) = W[o*C + c] (or W[c*O + o] for a transposed weight)
-                    tgemm_nn(B, C, P, O, W, 0, O if L.transposed else C, L.transposed, g, O * P, P, gp, C * P, P, bmode=mode, baux=y, bp=p)
+                    tgemm_nn(B, C, P, O, W, 0, O if L.transposed else C, L.transposed, g, O * P, P, gp, C * P, P, bmode=mode, baux=y, bp=p,
+                             per_batch_stats=groups)
                     g = gp
                 else:
                     g = None
                 dWr = (dW.t().contiguous() if L.transposed else dW).view_as(W)
                 # a bias in front of a BatchNorm has an identically zero gradient (the mean subtraction removes it)
-                per_layer[i] = [dWr] + ([torch.zeros_like(ctx.bias_like[i])] if ctx.has_bias[i] else []) + [dgamma, dbeta]
+                per_layer[i] = [dWr] + ([torch.zeros_like(ctx.bias_like[i])] if ctx.bias_like[i] is not None else []) + [dgamma, dbeta]
         ctx.ys = ctx.ps = ctx.arg = None
         flat = [t for pl in per_layer for t in pl]
-        return (g, None, None, *flat)
+        return (g, None, None, None, *flat)
 
 
-def chain_train(x, layers, pool=0):
+def chain_train(x, layers, pool=0, groups=False):
     """x: (B, C0, P) contiguous fp32 on the MI355X; layers: [BNLayer]; returns (B, C_L, P // pool or P)."""
     tensors = []
     for L in layers:
@@ -172,7 +202,7 @@ def chain_train(x, layers, pool=0):
         if L.bias is not None:
             tensors.append(L.bias)
         tensors += [L.bn.weight, L.bn.bias]
-    return _ChainTrain.apply(x.contiguous(), layers, int(pool), *tensors)
+    return _ChainTrain.apply(x.contiguous(), layers, int(pool), bool(groups), *tensors)
 
 
 class _LinearCM(Function):

@@ -60,7 +60,7 @@ def test_full_size_training_step_matches_reference_run():
         f = g.detach().flatten().cpu()
         step = max(f.numel() // 8, 1)
         samp = f[::step][:8].numpy()
-        tol_s = 5e-3 * max(ref_n / np.sqrt(f.numel()), 1e-7) + 5e-3 * np.abs(z["gsamp/" + k])
+        tol_s = 1e-2 * max(ref_n / np.sqrt(f.numel()), 1e-7) + 1e-2 * np.abs(z["gsamp/" + k])
         # biases in front of a BatchNorm have a mathematically zero gradient: both sides hold rounding noise there (norms ~1e-6)
         if ref_n < 2e-5:
             assert n < 1e-4, (k, n, ref_n)

@@ -1,0 +1,239 @@
+"""Training-mode dense path (csrc/train_gemm.hip + patchaugnet_amd/train_ops.py) on the MI355X.
+
+1. the two GEMM kernels with every operand transform, against fp64 torch statements of include/patchaugnet_hip.h's definitions
+   (ragged shapes: nothing a multiple of a tile);
+2. the autograd layer: SharedMLP (pt_util.py:16-41 in train() mode) with and without the fused max-pool, PointNetDecoder
+   (pointnet_autoencoder.py:85-111), NetVLADBase / APFA / context gating (loupe.py) -- outputs, input / parameter gradients and BatchNorm
+   running statistics against torch autograd of the SAME modules (train_ops.torch_dense_path()), tolerance 1e-4 relative to the
+   tensor's scale (fp32 MFMA vs rocBLAS summation order).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def _rel_robust(a, b, tol):
+    """Comparison used ONLY when the torch run saw a ReLU input within rounding distance of zero (see _compare): that activation gets
+    the mask of one side only, which moves the gradients of that one point by O(1) -- half of the elements within 20 tol of the tensor's
+    scale and the whole tensor within 1e-2 in relative L2."""
+    a, b = a.double().flatten(), b.double().flatten()
+    d = (a - b).abs()
+    scale = b.abs().max().clamp_min(1e-30)
+    q = torch.quantile(d[:: max(d.numel() // 1000000, 1)], 0.5)
+    e = ((q / scale).item(), (d.norm() / b.norm().clamp_min(1e-30)).item())
+    return e[0] <= 20 * tol and e[1] <= 1e-2, e
+
+
+def _p_block(nch, g):
+    p = torch.randn(7, nch, generator=g)
+    p[3] = p[3].abs() + 0.5
+    return p
+
+
+def _tf(mode, gv, yv, p):
+    """operand transform of train_gemm.hip per channel (rows of gv / yv); p (7, nch) fp64"""
+    c = [p[j][:, None] for j in range(7)]
+    if mode == 0:
+        return gv
+    if mode == 1:
+        return torch.relu(gv * c[0] + c[1])
+    z = yv * c[0] + c[1]
+    gm = torch.where(z > 0, gv, torch.zeros_like(gv)) if mode == 2 else gv
+    xhat = (yv - c[2]) * c[3]
+    return (gm - c[4] - xhat * c[5]) * c[6]
+
+
+@pytest.mark.parametrize("M,N,K,batch", [(70, 300, 37, 3), (128, 128, 16, 1), (200, 1000, 259, 2), (18, 515, 64, 1), (33, 7, 5, 2)])
+@pytest.mark.parametrize("a_kcontig", [True, False])
+@pytest.mark.parametrize("bmode", [0, 1, 2, 3])
+def test_tgemm_nn(M, N, K, batch, a_kcontig, bmode):
+    from patchaugnet_amd import train_ops as T
+    g = torch.Generator().manual_seed(M * 131 + N * 7 + K + bmode)
+    shared = (M + bmode) % 2 == 0
+    A = torch.randn((1 if shared else batch, M, K) if a_kcontig else (1 if shared else batch, K, M), generator=g)
+    Bm = torch.randn(batch, K, N, generator=g)
+    aux = torch.randn(batch, K, N, generator=g)
+    p = _p_block(K, g)
+    bias = torch.randn(M, generator=g)
+    C0 = torch.randn(batch, M, N, generator=g)
+    for beta, use_bias, act, use_stats in ((0, False, 0, True), (1, True, 0, False), (0, True, 1, True)):
+        C = C0.clone().cuda()
+        stats = torch.zeros(T.STAT_SLOTS, 2, M, dtype=torch.float64, device="cuda")
+        Ad, Bd, auxd, pd, biasd = A.cuda(), Bm.cuda(), aux.cuda(), p.cuda().contiguous(), bias.cuda()
+        T.tgemm_nn(batch, M, N, K, Ad, 0 if shared else M * K, K if a_kcontig else M, a_kcontig, Bd, K * N, N, C, M * N, N, bmode=bmode,
+                   baux=auxd if bmode >= 2 else None, bp=pd if bmode else None, beta=beta, bias=biasd if use_bias else None, act=act,
+                   stats=stats if use_stats else None)
+        torch.cuda.synchronize()
+        A64 = A.double() if a_kcontig else A.double().transpose(1, 2)
+        fB = torch.stack([_tf(bmode, Bm[b].double(), aux[b].double(), p.double()) for b in range(batch)])
+        ref = torch.matmul(A64, fB)
+        if use_bias:
+            ref = ref + bias.double()[None, :, None]
+        if act == 1:
+            ref = torch.tanh(ref)
+        if beta:
+            ref = ref + C0.double()
+        scale = ref.abs().max().item()
+        err = (C.cpu().double() - ref).abs().max().item()
+        assert err <= 2e-5 * max(scale, 1.0) + 1e-6 * K, (beta, use_bias, act, err, scale)
+        if use_stats:
+            v = C.cpu().double()
+            s = torch.stack([v.sum((0, 2)), (v * v).sum((0, 2))])
+            assert torch.allclose(stats.sum(0).cpu(), s, rtol=1e-5, atol=1e-4 * max(scale, 1.0)), (stats.sum(0).cpu() - s).abs().max()
+
+
+@pytest.mark.parametrize("M,N,K,batch", [(70, 37, 300, 3), (64, 64, 128, 1), (200, 259, 1001, 2), (18, 256, 21504, 1), (5, 3, 7, 2)])
+@pytest.mark.parametrize("amode", [0, 2, 3])
+@pytest.mark.parametrize("bmode", [0, 1])
+def test_tgemm_kk(M, N, K, batch, amode, bmode):
+    from patchaugnet_amd import train_ops as T
+    g = torch.Generator().manual_seed(M * 131 + N * 7 + K + amode * 3 + bmode)
+    A = torch.randn(batch, M, K, generator=g)
+    aux = torch.randn(batch, M, K, generator=g)
+    Bm = torch.randn(batch, N, K, generator=g)
+    pa, pb = _p_block(M, g), _p_block(N, g)
+    fA = torch.stack([_tf(amode, A[b].double(), aux[b].double(), pa.double()) for b in range(batch)])
+    fB = torch.stack([_tf(bmode, Bm[b].double(), None, pb.double()) for b in range(batch)])
+    per = torch.matmul(fA, fB.transpose(1, 2))
+    for per_batch in (0, 1):
+        C0 = torch.randn((batch, M, N) if per_batch else (M, N), generator=g)
+        C = C0.clone().cuda()
+        T.tgemm_kk(batch, M, N, K, A.cuda(), M * K, K, Bm.cuda(), N * K, K, C, M * N if per_batch else 0, N, amode=amode,
+                   aaux=aux.cuda() if amode else None, ap=pa.cuda() if amode else None, bmode=bmode, bp=pb.cuda() if bmode else None,
+                   per_batch=per_batch)
+        torch.cuda.synchronize()
+        ref = C0.double() + (per if per_batch else per.sum(0))
+        scale = ref.abs().max().item()
+        err = (C.cpu().double() - ref).abs().max().item()
+        assert err <= 2e-5 * max(scale, 1.0) + 2e-7 * K, (per_batch, err, scale)
+
+
+def _grads(mod, x, fn, gout_seed=3):
+    for p in mod.parameters():
+        p.grad = None
+    xx = x.clone().requires_grad_(True)
+    out = fn(xx)
+    go = torch.randn(out.shape, generator=torch.Generator().manual_seed(gout_seed)).to(out.device)
+    out.backward(go)
+    gr = {k: p.grad.clone() for k, p in mod.named_parameters() if p.grad is not None}
+    return out.detach(), xx.grad.clone(), gr, {k: v.clone() for k, v in mod.state_dict().items() if "running" in k or "tracked" in k}
+
+
+def _compare(mod, x, fn, tol=2e-4, skip=()):
+    from patchaugnet_amd import train_ops
+    state = {k: v.clone() for k, v in mod.state_dict().items()}
+    o1, dx1, g1, s1 = _grads(mod, x, fn)
+    mod.load_state_dict(state)
+    near = []
+    hooks = [m.register_forward_hook(lambda _m, _i, o: near.append(o.detach().abs().min().item()))
+             for m in mod.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+    with train_ops.torch_dense_path():
+        o0, dx0, g0, s0 = _grads(mod, x, fn)
+    for h in hooks:
+        h.remove()
+    flip = min(near, default=1.0) < 2e-6          # a ReLU input at rounding distance from zero: its mask may differ between the two runs
+    def close(a, b):
+        return _rel_robust(a, b, tol) if flip else (_rel(a, b) <= tol, _rel(a, b))
+    assert _rel(o1, o0) <= tol, ("out", _rel(o1, o0))
+    ok, e = close(dx1, dx0)
+    assert ok, ("dx", e, flip)
+    assert set(g1) == set(g0), set(g1) ^ set(g0)
+    for k in g0:
+        if any(s in k for s in skip):
+            assert g1[k].abs().max().item() <= 1e-4 * max(1.0, g0[k].abs().max().item()) + 1e-5, k   # mathematically zero on both sides
+            continue
+        ok, e = close(g1[k], g0[k])
+        assert ok, (k, e, flip)
+    for k in s0:
+        assert torch.allclose(s1[k].double(), s0[k].double(), rtol=1e-4, atol=1e-5), k
+
+
+@pytest.mark.parametrize("spec,shape", [([6, 32, 32, 64], (3, 6, 50, 20)), ([67, 64, 64, 256], (2, 67, 37, 20)), ([259, 256, 256], (2, 259, 300, 1)),
+                                        ([768, 256, 256], (3, 768, 16, 1))])
+def test_shared_mlp_train_matches_torch_autograd(spec, shape):
+    from patchaugnet_amd.pt_util import SharedMLP
+    torch.manual_seed(1)
+    m = SharedMLP(spec, bn=True).cuda().train()
+    with torch.no_grad():
+        for l in m:
+            l.bn.bn.weight.uniform_(0.5, 1.5)
+            l.bn.bn.bias.normal_(0, 0.2)
+    x = torch.randn(shape, device="cuda")
+    _compare(m, x, lambda t: m(t))
+    if shape[3] > 1:
+        _compare(m, x, lambda t: m.forward_maxpool(t))
+
+
+def test_decoder_train_matches_torch_autograd():
+    from patchaugnet_amd.patch_aug_net import PointNetDecoder
+    torch.manual_seed(2)
+    d = PointNetDecoder(embedding_size=256, num_points=20).cuda().train()
+    x = torch.nn.functional.normalize(torch.randn(1024, 256, device="cuda"))
+    _compare(d, x, lambda t: d(t), skip=("fc1.bias", "fc2.bias"))
+    # R related clouds in one set of launches (every cloud its own BatchNorm batch) == the decoder called once per cloud, in order
+    from patchaugnet_amd import train_ops
+    x3 = torch.nn.functional.normalize(torch.randn(3, 256, 1024, device="cuda"), dim=1)
+
+    def run(t):
+        if train_ops.hip_dense_enabled():
+            return d.forward_cm(t)
+        return torch.stack([d(t[r].t()) for r in range(t.shape[0])])
+    _compare(d, x3, run, skip=("fc1.bias", "fc2.bias"))
+
+
+@pytest.mark.parametrize("C,N,K", [(256, 4096, 64), (256, 1024, 16), (256, 128, 4), (64, 100, 5)])
+def test_netvlad_train_matches_torch_autograd(C, N, K):
+    from patchaugnet_amd.loupe import NetVLADBase
+    torch.manual_seed(3)
+    v = NetVLADBase(C, N, K, C).cuda().train()
+    x = torch.randn(3, C, N, 1, device="cuda")
+    _compare(v, x, lambda t: v(t))
+
+
+def test_heads_train_match_torch_autograd():
+    from patchaugnet_amd.loupe import AdaptiveFeatureAggregator, GatingContext, SpatialPyramidNetVLAD
+    torch.manual_seed(4)
+    afa = AdaptiveFeatureAggregator(256, 84, 256).cuda().train()
+    x = torch.randn(18, 256, 84, device="cuda")
+    _compare(afa, x, lambda t: afa(t), skip=("fc.bias",))
+    gate = GatingContext(256).cuda().train()
+    x = torch.randn(18, 256, device="cuda")
+    _compare(gate, x, lambda t: gate(t))
+    for agg in (0, 2, 3):
+        sp = SpatialPyramidNetVLAD([256, 256, 256], [64, 256, 512], [4, 8, 16], [256, 256, 256], gating=True, aggregation_type=agg).cuda().train()
+        feats = [torch.randn(4, 256, n, 1, device="cuda") for n in (64, 256, 512)]
+
+        def run(t, sp=sp, feats=feats):
+            return sp([t] + feats[1:])
+        _compare(sp, feats[0], run, tol=5e-4, skip=("fc.bias",))
+
+
+def test_training_dense_path_has_no_library_gemm():
+    """One train() forward + backward of the PatchAugNet module path: the profiler sees no rocBLAS / MIOpen / hipBLASLt kernel."""
+    from patchaugnet_amd import configs, patch_aug_net
+    from patchaugnet_amd.weights import seeded_state_dict
+    m = patch_aug_net.Network(param=configs.patch_aug_net_config(), use_a2a_recon=True, use_l2_norm=True)
+    m.load_state_dict(seeded_state_dict(m.state_dict()))
+    m = m.cuda().train()
+    x = (torch.rand(3, 1, 4096, 3, generator=torch.Generator().manual_seed(0)) * 2 - 1).cuda().requires_grad_(True)
+    nn_dict = {(0, 1): np.zeros((4, 1), np.int64)}
+
+    def step():
+        (desc, recon), _, _ = m(x, nn_dict)
+        loss = desc.square().sum() + sum(r.square().mean() for r in recon["reconstructed_patches"])
+        loss.backward()
+    step()
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+        step()
+        torch.cuda.synchronize()
+    names = [e.key for e in prof.key_averages()]
+    assert any("tgemm_nn_kernel" in n for n in names) and any("tgemm_kk_kernel" in n for n in names), names[:40]
+    lib = [n for n in names if any(s in n for s in ("Cijk", "rocblas", "miopen", "MIOpen", "hipblas", "gemm_kernel", "batch_norm", "BatchNorm"))]
+    assert not lib, lib
