@@ -43,6 +43,8 @@ def parse():
                    help="f16: shared-MLP chains on fp16 MFMA (fp32 accumulate; cosine >= 0.999 contract) -- not the headline configuration")
     p.add_argument("--no-graphs", action="store_true", help="issue every step's launches from Python instead of replaying one captured hipGraph per stream")
     p.add_argument("--streams", type=int, default=4, help="HIP streams the consecutive steps are issued on (1 = strictly sequential)")
+    p.add_argument("--config", choices=["extract", "train"], default="extract",
+                   help="extract = BASELINE.json configs[1] (the headline metric); train = configs[3], one quadruplet training step per step")
     return p.parse_args()
 
 
@@ -235,6 +237,60 @@ def pcie_inclusive(model, a, pipe):
                     "the K steps after one warm-up repetition (never the headline value)"}
 
 
+def train_bench(a):
+    """BASELINE.json configs[3]: one training step per bench step -- the reference's native tuple of 18 clouds (1 query + 2 positives +
+    14 negatives + 1 other negative, configs/patch_aug_net.yaml:60-62; BASELINE.json says batch=16, the reference's loader only makes
+    18), nn_dict with 2 (query, positive) pairs => 3 related clouds through the decoder and the patch Chamfer loss, quadruplet loss,
+    backward, Adam step (train_place_recognition.py:142-169, :255-392).  The dense path runs on csrc/train_gemm.hip."""
+    from patchaugnet_amd import configs, patch_aug_net, train_ops
+    from patchaugnet_amd.train import training_step
+    from patchaugnet_amd.weights import seeded_state_dict
+    cfg = configs.patch_aug_net_config()
+    model = patch_aug_net.Network(param=cfg, use_a2a_recon=True, use_l2_norm=True)
+    model.load_state_dict(seeded_state_dict(model.state_dict()))
+    model = model.cuda()
+    g = torch.Generator().manual_seed(5)
+    n = a.points
+    q, pos, neg, oth = (torch.rand(1, k, n, 3, generator=g) * 2 - 1 for k in (1, 2, 14, 1))
+    nn_dict = {(0, 1): torch.randint(0, n, (1024, 1), generator=g).numpy(), (0, 2): torch.randint(0, n, (1024, 1), generator=g).numpy()}
+    opt = torch.optim.Adam(model.parameters(), lr=1e-5)
+    q, pos, neg, oth = (t.cuda() for t in (q, pos, neg, oth))           # inputs resident in HBM before the clock starts
+    for _ in range(max(a.warmup, 2)):
+        losses = training_step(model, opt, q, pos, neg, oth, nn_dict=nn_dict, num_points=n)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        losses = training_step(model, opt, q, pos, neg, oth, nn_dict=nn_dict, num_points=n)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    clouds = 18
+    # dominant dense kernel: the 256 -> 256 layers of the finest feature-propagation level, forward form (BatchNorm + ReLU of the previous
+    # layer in the operand loader, statistics in the epilogue), in isolation on the launch stream
+    B, M, N, K = clouds, 256, n, 256
+    W = torch.randn(M, K, device="cuda")
+    X = torch.randn(B, K, N, device="cuda")
+    Y = torch.empty(B, M, N, device="cuda")
+    pblk = torch.rand(7, K, device="cuda")
+    stats = torch.zeros(train_ops.STAT_SLOTS, 2, M, dtype=torch.float64, device="cuda")
+    ms = ev_time_ms(lambda: train_ops.tgemm_nn(B, M, N, K, W, 0, K, True, X, K * N, N, Y, M * N, N, bmode=1, bp=pblk, stats=stats), iters=20)
+    flops = 2.0 * B * M * N * K
+    tf = flops / (ms * 1e-3) / 1e12
+    line = {
+        "metric": "training steps/sec (PatchAugNet quadruplet step, patch Chamfer reconstruction loss)", "value": a.steps / dt, "unit": "steps/s",
+        "clouds_per_s": clouds * a.steps / dt, "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"PatchAugNet training step, quadruplet tuple of {clouds} x {n}-pt synthetic submaps (1+2+14+1), 3 related clouds "
+                               "through the decoder, patch Chamfer + quadruplet loss, backward, Adam (BASELINE.json configs[3]), 1xMI355X",
+                   "clouds_per_step": clouds, "points": n, "path": "HIP point ops + HIP training GEMMs (csrc/train_gemm.hip), autograd graph in torch",
+                   "weights": "key-seeded random init", "parallelism": "dp1"},
+        "losses_last_step": losses,
+        "roofline": {"kernel": "tgemm_nn_kernel<128,true,1> (pa_tgemm_nn: 256 -> 256 layer of the finest FP level, forward: BatchNorm + ReLU of the "
+                               "previous layer in the loader, statistics in the epilogue)", "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None, "algorithmic_flops_per_launch": flops, "ms_per_launch": ms},
+    }
+    print(json.dumps(line))
+
+
 def self_launch(a):
     """`python bench.py --gpus N` with no launcher around it: start one child per GPU (rank i on GPU i) with the torchrun environment
     contract and wait for them.  Rank 0's stdout (the JSON line) is this process's stdout."""
@@ -279,6 +335,10 @@ def main():
     from patchaugnet_amd.hostcpu import cpu_budget
     limit_host_threads(max(1, cpu_budget() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))))
     torch.cuda.set_device(local)
+    if a.config == "train":
+        if world != 1:
+            raise SystemExit("bench.py --config train is a single-GPU configuration (BASELINE.json configs[3])")
+        return train_bench(a)
     dist = None
     if world > 1:
         import torch.distributed as dist

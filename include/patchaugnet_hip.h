@@ -295,6 +295,17 @@ int pa_bn_bwd_finalize(int nch, int groups, double count, const double *sums, fl
 int pa_bn_apply(int B, int C, long P, int pool, int relu, const float *y, const float *p, float *out, signed char *arg, int per_batch_stats, pa_stream_t stream);
 int pa_maxpool_bwd(int rows, long Pout, int pool, const float *gp, const signed char *arg, float *g, pa_stream_t stream);
 
+/* ---- Patch overlap-pair selection of the training step's contrastive patch-feature term (the Python loops of train_one_epoch,
+ * place_recognition/train_place_recognition.py:308-372), csrc/patch_pairs.hip.  Records in CSR form: idx1 (nrec), near_off / far_off
+ * (nrec + 1), near / far = original point indices; center_m / center_n = the m0 FPS centre indices (original indices < npoints) of the
+ * query / positive cloud.  Pass 1 fills scratch_inv (2*npoints ints) and counts (nrec: triplets per record, 0 = record dropped); pass 2
+ * takes offsets = exclusive prefix sum of counts and writes the triplets (positions in the centre lists: query in m, positive / negative
+ * in n; positives ascending per record like np.where(np.isin(...)), negatives uniform with replacement from a counter hash of seed). */
+int pa_patch_pairs_count(int nrec, const int *idx1, const int *near_off, const int *near_v, const int *far_off, const int *far_v, int npoints, int m0,
+                         const int *center_m, const int *center_n, int *scratch_inv, int *counts, pa_stream_t stream);
+int pa_patch_pairs_fill(int nrec, const int *idx1, const int *near_off, const int *near_v, const int *far_off, const int *far_v, int npoints, int m0,
+                        const int *scratch_inv, unsigned long long seed, const int *offsets, int *out_idx1, int *out_pos2, int *out_neg2, pa_stream_t stream);
+
 /* ---- the reference's launcher names (group 2) -------------------------------------------------*/
 void furthestsampling_cuda_launcher(int b, int n, int m, const float *dataset, float *temp, int *idxs);
 void gathering_forward_cuda_launcher(int b, int c, int n, int m, const float *points, const int *idx, float *out);

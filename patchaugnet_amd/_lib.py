@@ -66,8 +66,10 @@ _SIGS = {
     "pa_bn_bwd_finalize": "iidpppp",
     "pa_bn_apply": "iiliippppi",
     "pa_maxpool_bwd": "ilippp",
+    "pa_patch_pairs_count": "ipppppiipppp",
+    "pa_patch_pairs_fill": "ipppppiipqpppp",
 }
-_T = {"i": _I, "f": _F, "p": _P, "l": ctypes.c_long, "d": ctypes.c_double}
+_T = {"i": _I, "f": _F, "p": _P, "l": ctypes.c_long, "d": ctypes.c_double, "q": ctypes.c_ulonglong}
 
 
 def build(force=False, verbose=False):

@@ -78,3 +78,65 @@ class BatchStager:
         ev.record(torch.cuda.current_stream(self.device))
         self.events[slot] = ev
         return d
+
+
+# ---- on-disk descriptor cache ------------------------------------------------------------------------------------------------------
+# SceneDataSet.make_descs(save=True) writes, per submap index, `<g_desc_dir>/<idx>.pickle` = the (1, C) float32 global descriptor and
+# `<l_desc_dir>/<idx>.pickle` = (l_pos (K, 3), l_desc (K, C), norm_meta) -- the K = 1024 FPS centres of the second-finest level and
+# their features (datasets/scene_dataset.py:689-707); get_g_desc / get_l_kpt_desc read them back (:784-798, :807-831).  Same file names,
+# same pickle protocol, same array shapes and dtypes, so caches are interchangeable with the reference's in both directions.
+import pickle
+
+
+def save_descriptor_cache(g_desc_dir, l_desc_dir, beg_idx, global_descs, feed=None, fp_features=None, center_idx=None, norm_metas=None):
+    """scene_dataset.py:689-707.  global_descs (B, C); feed (B, 1, N, 3) or (B, N, 3) = the batch that went into the model;
+    fp_features / center_idx = the model's other two outputs (local descriptors = fp_features[-2], centres = center_idx[0]).  The local
+    files are written only when center_idx is given, like the reference.  Device tensors are brought to the host in ONE copy each."""
+    g = global_descs.detach().cpu().numpy() if torch.is_tensor(global_descs) else np.asarray(global_descs)
+    g = np.squeeze(g).reshape([-1, g.shape[-1]])
+    os.makedirs(g_desc_dir, exist_ok=True)
+    l_pos = l_desc = None
+    if center_idx is not None:
+        os.makedirs(l_desc_dir, exist_ok=True)
+        pts = feed.squeeze(1) if feed.dim() == 4 else feed                                     # (B, N, 3)
+        ci = center_idx[0].long()                                                              # (B, K)
+        l_pos = torch.gather(pts, 1, ci.unsqueeze(-1).expand(-1, -1, 3)).detach().cpu().numpy()          # index_select per cloud, batched
+        l_desc = fp_features[-2].squeeze(-1).permute(0, 2, 1).detach().cpu().numpy()           # (B, K, C)
+    for b_i in range(g.shape[0]):
+        with open(os.path.join(g_desc_dir, f"{beg_idx + b_i}.pickle"), "wb") as handle:
+            pickle.dump(g[b_i].reshape(1, -1), handle, protocol=pickle.HIGHEST_PROTOCOL)
+        if l_pos is not None:
+            meta = norm_metas[b_i] if norm_metas is not None else None
+            with open(os.path.join(l_desc_dir, f"{beg_idx + b_i}.pickle"), "wb") as handle:
+                pickle.dump((l_pos[b_i], l_desc[b_i], meta), handle, protocol=pickle.HIGHEST_PROTOCOL)
+
+
+def load_global_descriptor(g_desc_dir, idx):
+    """scene_dataset.py:784-798 (get_g_desc without the LRU bookkeeping): (1, d) array, or None when the file does not exist."""
+    path = os.path.join(g_desc_dir, f"{idx}.pickle")
+    if not os.path.exists(path):
+        return None
+    with open(path, "rb") as handle:
+        return pickle.load(handle).reshape(1, -1)
+
+
+def load_global_descriptors(g_desc_dir, idxs):
+    """scene_dataset.py:800-804 (get_g_descs): (len(idxs), d)."""
+    return np.concatenate([load_global_descriptor(g_desc_dir, i) for i in idxs], axis=0)
+
+
+def load_local_descriptor(l_desc_dir, idx, unify_coord=False, global_offset=0.0):
+    """scene_dataset.py:807-831 (get_l_kpt_desc without the LRU bookkeeping): (l_kpt (K, 3) float64, l_desc (K, d), norm_meta), or None
+    when the file does not exist.  unify_coord maps the key points back to world coordinates: kpt * scale + (trans - global_offset)."""
+    path = os.path.join(l_desc_dir, f"{idx}.pickle")
+    if not os.path.exists(path):
+        return None
+    with open(path, "rb") as handle:
+        l_kpt, l_desc, norm_meta = pickle.load(handle)
+    l_kpt = np.array(l_kpt, dtype=np.float64)
+    K = l_kpt.shape[0]
+    l_kpt, l_desc = l_kpt.reshape(K, -1), l_desc.reshape(K, -1)
+    if unify_coord:
+        trans = norm_meta["trans"].reshape(1, norm_meta["trans"].shape[0]) - global_offset
+        l_kpt = l_kpt * norm_meta["scale"] + trans
+    return l_kpt, l_desc, norm_meta

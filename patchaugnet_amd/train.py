@@ -3,13 +3,14 @@
 Mirrors ``run_model`` (place_recognition/train_place_recognition.py:142-164) and the loss assembly of ``train_one_epoch``
 (:255-392): the tuple (query, positives, negatives, other negative) is concatenated to one (T, 1, N, 3) batch, pushed through
 the model (module path: autograd over the HIP point ops' backward kernels), descriptors are split back into the four
-groups for the quadruplet loss, and the patch-reconstruction branch feeds the HIP Chamfer loss.  The contrastive
-patch-feature term (:308-385) needs the reference's precomputed overlap protobufs and is out of scope here.
+groups for the quadruplet loss, and the patch-reconstruction branch feeds the HIP Chamfer loss.  The contrastive patch-feature term
+(:308-385) takes the overlap tables that ride in nn_dict's values (the reference's Uint32Pair records, or any objects / dicts with the
+same four fields) and runs on the device (patchaugnet_amd/patch_pairs.py).
 """
 import numpy as np
 import torch
 
-from . import losses
+from . import losses, patch_pairs
 
 DEFAULTS = {  # configs/patch_aug_net.yaml:55-75 (training section)
     "TRAIN_POSITIVES_PER_QUERY": 2, "TRAIN_NEGATIVES_PER_QUERY": 14, "MARGIN_1": 0.5, "MARGIN_2": 0.2,
@@ -38,9 +39,12 @@ def run_model(model, queries, positives, negatives, other_neg, nn_dict=None, num
 
 
 def training_step(model, optimizer, queries, positives, negatives, other_neg, nn_dict=None, num_points=4096, args=DEFAULTS,
-                  loss_alpha=None, place_loss="quadruplet", recon_loss="patch_chamfer"):
-    """train_one_epoch's body for one batch (:255-392 without the overlap-pair term): returns the dict of weighted losses."""
-    loss_alpha = loss_alpha or {"place_recognition": 1.0, "patch_recon_a2a": 1.0}
+                  loss_alpha=None, place_loss="quadruplet", recon_loss="patch_chamfer", use_patch_feature_contrast=False, epoch=0,
+                  use_hard_negative_patch_mining=False, hard_neg_epoch_for_patch_align=10, step_seed=0):
+    """train_one_epoch's body for one batch (:255-392): returns the dict of weighted losses.  use_patch_feature_contrast adds the
+    contrastive patch-feature term over nn_dict's overlap tables (:308-385; hard-negative patches only once
+    epoch > hard_neg_epoch_for_patch_align with use_hard_negative_patch_mining, :345)."""
+    loss_alpha = loss_alpha or {"place_recognition": 1.0, "patch_recon_a2a": 1.0, "patch_recon_a2b": 1.0}
     model.train()
     optimizer.zero_grad(set_to_none=True)
     out = run_model(model, queries, positives, negatives, other_neg, nn_dict, num_points, True, args=args)
@@ -51,6 +55,12 @@ def training_step(model, optimizer, queries, positives, negatives, other_neg, nn
     recon = out["patch_recon"]
     if recon is not None and getattr(model, "use_a2a_recon", False):
         cur["patch_recon_a2a"] = losses.get_loss_func(recon_loss)(recon["origin_patches"], recon["reconstructed_patches"])
+    if recon is not None and use_patch_feature_contrast:
+        a2b = patch_pairs.patch_feature_contrast_loss(nn_dict, recon, args["MARGIN_1"], num_points,
+                                                      hard_only=epoch > hard_neg_epoch_for_patch_align and use_hard_negative_patch_mining,
+                                                      seed=step_seed)
+        if a2b is not None:
+            cur["patch_recon_a2b"] = a2b
     total = 0.0
     for k in cur:
         cur[k] = cur[k] * loss_alpha.get(k, 1.0)
@@ -60,3 +70,33 @@ def training_step(model, optimizer, queries, positives, negatives, other_neg, nn
         optimizer.step()
     cur["total"] = total
     return {k: float(v.detach()) for k, v in cur.items()}
+
+
+def hard_negative_refresh_due(count, batch_size, epoch, hard_neg_epoch, use_hard_neg=True):
+    """train_place_recognition.py:401-406 -- after `count` batches of this epoch: re-extract every training submap's descriptor once the
+    model is robust enough (epoch > hard_neg_epoch), every 1400 // batch_size batches, at phase 29."""
+    return bool(epoch > hard_neg_epoch and use_hard_neg and count % (1400 // batch_size) == 29)
+
+
+@torch.no_grad()
+def update_global_descs(model, load_batch, n_total, batch_size=36, save_dirs=None, n_streams=4):
+    """``PlaceRecognitionDataSet.update_global_descs`` -> ``SceneDataSet.make_descs`` (place_recognition_dataset.py:37-39,
+    scene_dataset.py:494-711) as the training loop uses it (:403-406, batch_size 36): descriptors of all n_total submaps through the fused
+    HIP engine (sharded over the ranks when a process group is up: patchaugnet_amd/distributed.py), the model left in the mode it was in.
+    save_dirs = (g_desc_dir, l_desc_dir) also writes the reference's per-submap pickle cache (patchaugnet_amd/io.py).  Returns the
+    (n_total, 256) matrix on the device: the input of retrieval.get_hard_negatives_batch."""
+    from .distributed import extract_dataset
+    from .io import save_descriptor_cache
+    was_training = model.training
+    model.eval()
+    try:
+        descs = extract_dataset(model, load_batch, n_total, batch_size=batch_size, n_streams=n_streams)
+        if save_dirs is not None:
+            for b0 in range(0, n_total, batch_size):
+                b1 = min(b0 + batch_size, n_total)
+                x = load_batch(b0, b1)
+                d, fp, ci = model(x)
+                save_descriptor_cache(save_dirs[0], save_dirs[1], b0, d, x, fp, ci)
+    finally:
+        model.train(was_training)
+    return descs

@@ -162,3 +162,30 @@ def test_bench_refuses_more_gpus_than_the_box_has():
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1"],
                          capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode != 0 and "refusing" in out.stderr and '"n_gpus"' not in out.stdout
+
+
+def test_update_global_descs_refresh_and_pickle_cache(tmp_path):
+    """The hard-negative refresh of the training loop (train_place_recognition.py:403-406 -> make_descs(save=True)): every submap's
+    descriptor through the fused engine, the reference's per-submap pickle cache written and read back, model left in train() mode."""
+    import numpy as np
+    from patchaugnet_amd import configs, patch_aug_net, io as pio
+    from patchaugnet_amd.train import update_global_descs
+    from patchaugnet_amd.weights import seeded_state_dict, synthetic_submaps
+    n = 1024
+    cfg = configs.scaled_config(configs.patch_aug_net_config(), n)
+    m = patch_aug_net.Network(param=cfg, use_a2a_recon=True, use_l2_norm=True)
+    m.load_state_dict(seeded_state_dict(m.state_dict()))
+    m = m.cuda().train()
+    x = synthetic_submaps(22, n, seed=9).cuda()
+    gd, ld = str(tmp_path / "g"), str(tmp_path / "l")
+    descs = update_global_descs(m, lambda lo, hi: x[lo:hi], 22, batch_size=8, save_dirs=(gd, ld))
+    assert m.training and descs.shape == (22, 256)
+    m.eval()
+    with torch.no_grad():
+        want, fp, ci = m(x)
+    assert torch.equal(descs, want)
+    got = pio.load_global_descriptors(gd, list(range(22)))
+    assert np.array_equal(got, want.cpu().numpy())
+    kpt, desc, meta = pio.load_local_descriptor(ld, 13)
+    assert np.array_equal(kpt, x[13, 0][ci[0][13].long()].cpu().numpy().astype(np.float64))
+    assert np.array_equal(desc, fp[-2][13, :, :, 0].t().cpu().numpy()) and meta is None

@@ -79,3 +79,39 @@ def test_batch_stager_and_point_set_losses_on_gpu():
     e = losses.emd_loss(p1, p2)
     st_, dist, _ = o.emd_forward(p1[0].cpu().numpy(), p2[0].cpu().numpy(), 0.02, 1024)
     assert st_ == 1 and abs(float(e) - np.sqrt(dist).mean()) < 1e-6
+
+
+def test_descriptor_cache_files_are_the_references(tmp_path):
+    """make_descs(save=True) (scene_dataset.py:689-707) and get_g_desc / get_l_kpt_desc (:784-798, :807-831): file names, pickle
+    protocol, shapes and dtypes -- the global file is byte-identical to what the reference's three lines write."""
+    import pickle
+    from patchaugnet_amd import io as pio
+    rs = np.random.RandomState(0)
+    B, N, K, C = 3, 64, 16, 8
+    feed = torch.from_numpy(rs.standard_normal((B, 1, N, 3)).astype(np.float32))
+    g = torch.from_numpy(rs.standard_normal((B, C)).astype(np.float32))
+    fp = [torch.zeros(B, C, 4, 1), torch.from_numpy(rs.standard_normal((B, C, K, 1)).astype(np.float32)), torch.zeros(B, C, N, 1)]
+    ci = [torch.from_numpy(np.stack([rs.permutation(N)[:K] for _ in range(B)]).astype(np.int32))]
+    metas = [{"scale": 2.0 + i, "trans": np.array([1.0, 2.0, 3.0]) * i} for i in range(B)]
+    gd, ld = str(tmp_path / "g"), str(tmp_path / "l")
+    pio.save_descriptor_cache(gd, ld, 40, g, feed, fp, ci, metas)
+    for b in range(B):
+        want = pickle.dumps(g.numpy()[b].reshape(1, -1), protocol=pickle.HIGHEST_PROTOCOL)
+        assert open(f"{gd}/{40 + b}.pickle", "rb").read() == want
+        got = pio.load_global_descriptor(gd, 40 + b)
+        assert got.shape == (1, C) and got.dtype == np.float32 and np.array_equal(got[0], g.numpy()[b])
+        kpt, desc, meta = pio.load_local_descriptor(ld, 40 + b)
+        assert kpt.dtype == np.float64 and np.array_equal(kpt, feed.numpy()[b, 0][ci[0].numpy()[b]].astype(np.float64))
+        assert np.array_equal(desc, fp[1].numpy()[b, :, :, 0].T) and meta["scale"] == 2.0 + b
+        world, _, _ = pio.load_local_descriptor(ld, 40 + b, unify_coord=True, global_offset=np.array([0.5, 0.5, 0.5]))
+        assert np.allclose(world, kpt * (2.0 + b) + (metas[b]["trans"].reshape(1, 3) - 0.5))
+    assert pio.load_global_descriptor(gd, 7) is None and pio.load_local_descriptor(ld, 7) is None
+    assert pio.load_global_descriptors(gd, [41, 40]).shape == (2, C)
+
+
+def test_hard_negative_refresh_schedule():
+    """train_place_recognition.py:401-406: every 1400 // batch_size batches at phase 29, only past hard_neg_epoch."""
+    from patchaugnet_amd.train import hard_negative_refresh_due as due
+    assert [c for c in range(1, 800) if due(c, 4, 6, 5)] == [29, 379, 729]
+    assert not any(due(c, 4, 5, 5) for c in range(1, 800))
+    assert not any(due(c, 4, 9, 5, use_hard_neg=False) for c in range(1, 800))
