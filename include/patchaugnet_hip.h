@@ -271,7 +271,7 @@ int pa_vlad_maxpool(int b, int ktot, int c, const float *vt, int l2norm, float *
  * pa_tgemm_nn: C_b (M x N) = [beta*C_b +] act(A_b (M x K) . f(B_b) (K x N) + bias[m]); B, C n-contiguous; A(m,k) = A[m*lda + k] when
  *   a_kcontig else A[k*lda + m]; sAb = 0 shares A over the batch.  f acts per k (the channel): bmode 0 identity, 1 relu(x*p0 + p1),
  *   2 / 3 the BatchNorm(+ReLU mask for 2) input gradient built from B = gradient w.r.t. the activation and baux = raw layer output.
- *   act 0 none / 1 tanh.  stats: PA_BN_STAT_SLOTS replicas of 2*M doubles receiving (accumulating) the per-row sum and sum of squares
+ *   act 0 none / 1 tanh / 2 squared distance C = max(bias[m] + colv[n] - 2 A.B, 0) (retrieval, pa_knn_mfma_select).  stats: PA_BN_STAT_SLOTS replicas of 2*M doubles receiving (accumulating) the per-row sum and sum of squares
  *   of the stored values (a workgroup adds to one replica; pa_bn_finalize sums them), or NULL.
  * pa_tgemm_kk: C (M x N) += sum over batch and k of fA(A_b)(m,k) * fB(B_b)(n,k), both operands k-contiguous (weight gradients: k runs
  *   over the points); amode 0 / 2 / 3 per row m, bmode 0 / 1 per row n; partial tiles are combined with fp32 atomics, so C must be
@@ -279,7 +279,7 @@ int pa_vlad_maxpool(int b, int ktot, int c, const float *vt, int l2norm, float *
 #define PA_BN_STAT_SLOTS 32
 int pa_tgemm_nn(int batch, int M, int N, int K, const float *A, long sAb, int lda, int a_kcontig,
                 const float *B, long sBb, int ldb, int bmode, const float *baux, const float *bp,
-                float *C, long sCb, int ldc, int beta, const float *bias, int act, double *stats, int per_batch_stats, pa_stream_t stream);
+                float *C, long sCb, int ldc, int beta, const float *bias, const float *colv, int act, double *stats, int per_batch_stats, pa_stream_t stream);
 int pa_tgemm_kk(int batch, int M, int N, long K, const float *A, long sAb, int lda, int amode, const float *aaux, const float *ap,
                 const float *B, long sBb, int ldb, int bmode, const float *bp,
                 float *C, long sCb, int ldc, int per_batch, int per_batch_stats, pa_stream_t stream);
@@ -305,6 +305,14 @@ int pa_patch_pairs_count(int nrec, const int *idx1, const int *near_off, const i
                          const int *center_m, const int *center_n, int *scratch_inv, int *counts, pa_stream_t stream);
 int pa_patch_pairs_fill(int nrec, const int *idx1, const int *near_off, const int *near_v, const int *far_off, const int *far_v, int npoints, int m0,
                         const int *scratch_inv, unsigned long long seed, const int *offsets, int *out_idx1, int *out_pos2, int *out_neg2, pa_stream_t stream);
+
+/* ---- Retrieval kNN at database scale (csrc/knn_mfma.hip): the recall harness' brute-force search (datasets/scene_dataset.py:1016-1099,
+ * KNN_CUDA knn.cu:232-269) with the distance matrix on MFMA and an exact re-rank: columns equal pa_knn_generic's bit for bit.
+ * a (nq_blk x lda) = pa_tgemm_nn(act = 2) output for a block of queries: a[q][r] = max(|q|^2 + |r|^2 - 2 q.r, 0); ref_rows (nr, dim),
+ * query_rows (nq_blk, dim) row-major; qnorm (nq_blk); rnorm_max: device scalar max |r|^2.  dist / ind: (k, nq_total) KNN_CUDA layout,
+ * 1-based int64 indices, columns q0.. written; flags[q0 + q] = 1: candidate overflow, column NOT written -- rerun through pa_knn_generic. */
+int pa_knn_mfma_select(const float *a, long lda, int nq_blk, int nr, int dim, int k, const float *ref_rows, const float *query_rows,
+                       const float *qnorm, const float *rnorm_max, int q0, int nq_total, float *dist, int64_t *ind, int *flags, pa_stream_t stream);
 
 /* ---- the reference's launcher names (group 2) -------------------------------------------------*/
 void furthestsampling_cuda_launcher(int b, int n, int m, const float *dataset, float *temp, int *idxs);

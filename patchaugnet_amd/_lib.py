@@ -59,13 +59,14 @@ _SIGS = {
     "pa_afa_rows": "iiiippppppppipp",
     "pa_fc": "iiipppppippp",
     "pa_vlad_maxpool": "iiipip",
-    "pa_tgemm_nn": "iiiipliipliipppliipipi",
+    "pa_tgemm_nn": "iiiipliipliipppliippipi",
     "pa_tgemm_kk": "iiilpliipppliippliii",
     "pa_bn_finalize": "iidpppffppp",
     "pa_bn_bwd_reduce": "iilpppipi",
     "pa_bn_bwd_finalize": "iidpppp",
     "pa_bn_apply": "iiliippppi",
     "pa_maxpool_bwd": "ilippp",
+    "pa_knn_mfma_select": "pliiiippppiippp",
     "pa_patch_pairs_count": "ipppppiipppp",
     "pa_patch_pairs_fill": "ipppppiipqpppp",
 }

@@ -316,12 +316,19 @@ template <int RT, int NC, int MODE, bool POOLED, int WPT>
 __device__ __forceinline__ void run_layer_chunks(float *act, const PaChain &a, const PaLayer &L, float *out, const float *residual, int l, long tile,
                                                  int lane, int c_begin, int c_end)
 {
-    constexpr bool SWAP = POOLED || WPT > 1;   // see the note above store_hidden_nat
+#ifndef PA_RT1_SWAP
+#define PA_RT1_SWAP 0
+#endif
+#ifndef PA_RT1_PD
+#define PA_RT1_PD 2
+#endif
+    constexpr bool RT1 = RT == 1 && WPT == 1 && !POOLED;                        // the eight-wave 16-row variant (finest FP level)
+    constexpr bool SWAP = POOLED || WPT > 1 || (RT1 && PA_RT1_SWAP);   // see the note above store_hidden_nat
     const bool last = (l == a.nlayers - 1);
     for (int c0 = c_begin; c0 < c_end; c0 += NC) {
         floatx4 acc[RT][NC];
         const bool fold = MODE == MODE_FP && l == 0 && a.fold0;     // layer 0 contracts the skip columns only and adds the interpolated term
-        gemm_chunk<RT, NC, (WPT == 1 ? 2 : (RT * NC >= 16 ? 4 : 8)), SWAP>(fold ? act + a.c2 : act, a.lds_stride, L, c0, lane, acc);
+        gemm_chunk<RT, NC, (RT1 ? PA_RT1_PD : WPT == 1 ? 2 : (RT * NC >= 16 ? 4 : 8)), SWAP>(fold ? act + a.c2 : act, a.lds_stride, L, c0, lane, acc);
         if (!last) {
             tile_sync<WPT>();  // every A read of this layer has landed before its rows are overwritten (single chunk per wave: host-checked)
             if (fold) {

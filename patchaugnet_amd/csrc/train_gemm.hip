@@ -68,7 +68,8 @@ struct NNArgs {
     float *C; long sCb; int ldc;
     int beta;
     const float *bias;                   // per m, or null
-    int act;                             // 0 none, 1 tanh
+    const float *colv;                   // act 2: per n
+    int act;                             // 0 none, 1 tanh, 2 squared distance: max(bias[m] + colv[n] - 2 acc, 0)
     double *stats;                       // [PA_BN_STAT_SLOTS][2*M]: sum and sum of squares of the stored values per row m over (batch, n); or null
     long sPb, sStatb;                    // per-batch strides of tb.p (floats) and stats (doubles); 0 = one block shared by the batch
     int vecA, vecB;                      // 16-byte loads allowed (alignment / divisibility checked on the host)
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(256) void tgemm_nn_kernel(NNArgs a)
                 if (gm < a.M && gn < a.N) {
                     float v = acc[i][j][r] + bias;
                     if (a.act == 1) v = tanhf(v);
+                    else if (a.act == 2) { v = (bias + a.colv[gn]) - 2.f * acc[i][j][r]; v = v > 0.f ? v : 0.f; }
                     float *dst = C + (size_t)gm * a.ldc + gn;
                     if (a.beta) v += *dst;
                     *dst = v;
@@ -556,9 +558,10 @@ TOp make_top(int mode, const float *aux, const float *p, int nch)
 // bp: 7*K floats).  stats (PA_BN_STAT_SLOTS x 2*M doubles, accumulated; pa_bn_finalize adds the replicas up) or NULL.
 PA_API int pa_tgemm_nn(int batch, int M, int N, int K, const float *A, long sAb, int lda, int a_kcontig,
                        const float *B, long sBb, int ldb, int bmode, const float *baux, const float *bp,
-                       float *C, long sCb, int ldc, int beta, const float *bias, int act, double *stats, int per_batch_stats, pa_stream_t stream)
+                       float *C, long sCb, int ldc, int beta, const float *bias, const float *colv, int act, double *stats, int per_batch_stats, pa_stream_t stream)
 {
     PA_REQUIRE(batch > 0 && M > 0 && N > 0 && K > 0 && A && B && C, "pa_tgemm_nn: bad arguments");
+    PA_REQUIRE(act != 2 || (bias && colv), "pa_tgemm_nn: the squared-distance epilogue needs the row and column norms");
     PA_REQUIRE(bmode >= 0 && bmode <= 3 && (bmode == 0 || bp) && (bmode < 2 || baux), "pa_tgemm_nn: transform %d needs its parameter / auxiliary tensors", bmode);
     PA_REQUIRE(batch <= 65535 && (M + 63) / 64 <= 65535, "pa_tgemm_nn: grid limits");
     NNArgs a;
@@ -567,7 +570,7 @@ PA_API int pa_tgemm_nn(int batch, int M, int N, int K, const float *A, long sAb,
     a.A = A; a.sAb = sAb; a.lda = lda;
     a.B = B; a.sBb = sBb; a.ldb = ldb;
     a.tb = make_top(bmode, baux, bp, K);
-    a.C = C; a.sCb = sCb; a.ldc = ldc; a.beta = beta; a.bias = bias; a.act = act; a.stats = stats;
+    a.C = C; a.sCb = sCb; a.ldc = ldc; a.beta = beta; a.bias = bias; a.colv = colv; a.act = act; a.stats = stats;
     a.sPb = per_batch_stats ? 7L * K : 0;                       // the operand's parameter block belongs to ITS layer: K channels
     a.sStatb = per_batch_stats ? (long)PA_BN_STAT_SLOTS * 2 * M : 0;
     a.vecA = aligned16(A) && lda % 4 == 0 && sAb % 4 == 0;

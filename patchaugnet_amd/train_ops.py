@@ -45,11 +45,11 @@ def _guard(t):
 
 
 # ---------------------------------------------------------------------------------------------------- thin wrappers of the C ABI
-def tgemm_nn(batch, M, N, K, A, sAb, lda, a_kcontig, B, sBb, ldb, C, sCb, ldc, *, bmode=0, baux=None, bp=None, beta=0, bias=None, act=0,
-             stats=None, per_batch_stats=0):
+def tgemm_nn(batch, M, N, K, A, sAb, lda, a_kcontig, B, sBb, ldb, C, sCb, ldc, *, bmode=0, baux=None, bp=None, beta=0, bias=None, colv=None,
+             act=0, stats=None, per_batch_stats=0):
     """C_b (M x N) = [beta C_b +] act(A_b (M x K) . f(B_b) (K x N) + bias[m]) -- include/patchaugnet_hip.h: pa_tgemm_nn."""
     call("pa_tgemm_nn", batch, M, N, K, ptr(A), sAb, lda, int(a_kcontig), ptr(B), sBb, ldb, bmode, ptr(baux), ptr(bp), ptr(C), sCb, ldc,
-         int(beta), ptr(bias), act, ptr(stats), int(per_batch_stats))
+         int(beta), ptr(bias), ptr(colv), act, ptr(stats), int(per_batch_stats))
 
 
 def tgemm_kk(batch, M, N, K, A, sAb, lda, B, sBb, ldb, C, sCb, ldc, *, amode=0, aaux=None, ap=None, bmode=0, bp=None, per_batch=0,
