@@ -442,7 +442,7 @@ template <int MODE>
 void launch_rows(const PaChain &a, int rt, bool split, int wpw, long ntiles, hipStream_t st)
 {
     if (!split && rt == 1) {
-        if (MODE == MODE_FPX) launch_chain<1, 16, MODE_FPX, false, 1>(a, wpw, ntiles, st);     // only instantiated where it is used
+        if (MODE == MODE_FPX || MODE == MODE_FP || MODE == MODE_PLAIN) launch_chain<1, 16, MODE, false, 1>(a, wpw, ntiles, st);
         else launch_chain<2, 16, MODE, false, 1>(a, wpw, ntiles, st);
     } else if (!split) launch_chain<2, 16, MODE, false, 1>(a, wpw, ntiles, st);
     else if (rt == 2) launch_chain<2, 8, MODE, false, 4>(a, 4, ntiles, st);
@@ -534,7 +534,15 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
     // buffer-load k-loop the partner wave's MFMAs fill the slots one wave leaves while it gathers / stores (0.332 -> 0.307 ms at B = 32).
     static const bool fpx_rt2 = getenv("PA_CHAIN_FPX_RT2") != nullptr;   // A/B knob: the former 32-row, one-wave-per-SIMD tiling
     static const int stagger_env = getenv("PA_CHAIN_STAGGER") ? atoi(getenv("PA_CHAIN_STAGGER")) : 0;
-    const bool rt1 = !fpx_rt2 && mode == MODE_FPX && !split && !is_pooled && !wp16;
+    // The same tiling for the mid-sized plain / FP launches (32 768 rows at B = 32: fp1 and the pre-multiplies): 2048 wave tiles = one
+    // eight-wave workgroup per CU in a single round, instead of 1024 four-wave shared-tile workgroups of which three fit a CU at a time.
+    static const long rt1_min_rows = getenv("PA_CHAIN_RT1_MIN_ROWS") ? atol(getenv("PA_CHAIN_RT1_MIN_ROWS")) : 0;
+    bool rt1 = !fpx_rt2 && mode == MODE_FPX && !split && !is_pooled && !wp16;
+    if (!rt1 && rt1_min_rows > 0 && !is_pooled && !wp16 && col_slices <= 1 && (mode == MODE_FP || mode == MODE_PLAIN) && total_rows >= rt1_min_rows) {
+        bool ok = true;
+        for (int l = 0; l + 1 < nlayers; ++l) ok = ok && nout[l] / 16 <= 16 && ((nout[l] / 16) & (nout[l] / 16 - 1)) == 0;
+        if (ok) { rt1 = true; split = false; }
+    }
     if (rt1) { RTv = 1; a.stagger = stagger_env; }
     PA_REQUIRE(col_slices <= 1 || split, "pa_linear: column slices are built for the shared-tile (few rows) variant");
     const int R = RTv * 16;
@@ -593,7 +601,7 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
     // (kNN: 70 KB, 3-NN, FPS) can become resident next to a chain workgroup when several streams are in flight.
     static const int wpw_env = getenv("PA_CHAIN_WPW") ? atoi(getenv("PA_CHAIN_WPW")) : 0;
     int wpw = wpw_env > 0 ? wpw_env : (rt1 ? 8 : 4);
-    while (wpw > 1 && wpw * per_wave > 156 * 1024) wpw >>= 1;
+    while (wpw > 1 && wpw * per_wave > 156 * 1024) wpw = rt1 ? wpw - 1 : wpw >> 1;
     const long ntiles = is_pooled ? (rows + 3) / 4 : (total_rows + R - 1) / R;
 
     if (is_pooled) {

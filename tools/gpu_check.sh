@@ -14,6 +14,11 @@ timeout 300 python bench.py --model pptnet --no-cpu-baseline > gpurun_out/${TAG}
 timeout 300 python bench.py --model pptnet --mlp-dtype f16 --no-cpu-baseline > gpurun_out/${TAG}_bench_pptnet_f16.json 2>> gpurun_out/${TAG}_bench.err
 timeout 300 python bench.py --mlp-dtype f16 --no-cpu-baseline > gpurun_out/${TAG}_bench_patchaugnet_f16.json 2>> gpurun_out/${TAG}_bench.err
 timeout 600 python tools/config_sweep.py > gpurun_out/${TAG}_config_sweep.json 2>> gpurun_out/${TAG}_bench.err
+# BASELINE configs[3]: the training step (bench line + kernel stats of the same command)
+timeout 300 python bench.py --config train --steps 30 --warmup 5 > gpurun_out/${TAG}_bench_train.json 2>> gpurun_out/${TAG}_bench.err
+rm -rf gpurun_out/${TAG}_prof
+timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_prof -o ${TAG} -- python bench.py --config train --steps 10 --warmup 3 > gpurun_out/${TAG}_prof_train.log 2>&1; echo "rocprof(train) rc=$?"
+python tools/rocprof_summary.py $(ls gpurun_out/${TAG}_prof/*results.db | head -1) gpurun_out/${TAG}_train_step_kernel_stats.csv
 python - <<'PY'
 import json, glob
 for f in sorted(glob.glob("gpurun_out/*_bench_*.json")):
@@ -64,5 +69,5 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $C -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$C -o pmc -- python $GRAFT_REPO_ROOT/tools/pmc_target.py > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_$C.log 2>&1
   python $GRAFT_REPO_ROOT/tools/pmc_summary.py $(ls $GRAFT_REPO_ROOT/gpurun_out/pmc_$C/*results.db | head -1) > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_$C.txt 2>&1
   rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmc_$C
-  grep -E "chain_kernel<2, 16, 3|group_lds_kernel<4>|knn_grid|vlad_accum_kernel<4>" $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_$C.txt | cut -c1-60,90-200
+  grep -E "chain_kernel<1, 16, 3|group_lds_kernel<4>|knn_grid|vlad_accum_kernel<4>" $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_$C.txt | cut -c1-60,90-200
 done
