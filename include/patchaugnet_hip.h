@@ -306,6 +306,10 @@ int pa_patch_pairs_count(int nrec, const int *idx1, const int *near_off, const i
 int pa_patch_pairs_fill(int nrec, const int *idx1, const int *near_off, const int *near_v, const int *far_off, const int *far_v, int npoints, int m0,
                         const int *scratch_inv, unsigned long long seed, const int *offsets, int *out_idx1, int *out_pos2, int *out_neg2, pa_stream_t stream);
 
+/* Opt-in alternative for pa_knnquery at 2048..4096 source points, >= 256 queries, nsample 16 / 20 / 32: one lane per query over an
+ * 8 x 8 x 8 cell grid (csrc/knn_lane.hip; same results bit for bit; slower than the default at the model's problem size, see the file). */
+void pa_knn_lane_enable(int on);
+
 /* ---- Retrieval kNN at database scale (csrc/knn_mfma.hip): the recall harness' brute-force search (datasets/scene_dataset.py:1016-1099,
  * KNN_CUDA knn.cu:232-269) with the distance matrix on MFMA and an exact re-rank: columns equal pa_knn_generic's bit for bit.
  * a (nq_blk x lda) = pa_tgemm_nn(act = 2) output for a block of queries: a[q][r] = max(|q|^2 + |r|^2 - 2 q.r, 0); ref_rows (nr, dim),

@@ -536,9 +536,13 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
     static const int stagger_env = getenv("PA_CHAIN_STAGGER") ? atoi(getenv("PA_CHAIN_STAGGER")) : 0;
     // The same tiling for the mid-sized plain / FP launches (32 768 rows at B = 32: fp1 and the pre-multiplies): 2048 wave tiles = one
     // eight-wave workgroup per CU in a single round, instead of 1024 four-wave shared-tile workgroups of which three fit a CU at a time.
-    static const long rt1_min_rows = getenv("PA_CHAIN_RT1_MIN_ROWS") ? atol(getenv("PA_CHAIN_RT1_MIN_ROWS")) : 0;
+    // Measured at B = 32: the plain 32 768-row pre-multiply 0.056 -> 0.050 ms; the FP-mode launches get SLOWER (fp1 0.072 -> 0.120 ms: their
+    // 3-NN interpolation prologue weighs more against only K = 64 + 256 of MFMA work, and K = 320 leaves room for seven waves), so FP mode
+    // keeps the shared-tile variant unless PA_CHAIN_RT1_FP is set.
+    static const long rt1_min_rows = getenv("PA_CHAIN_RT1_MIN_ROWS") ? atol(getenv("PA_CHAIN_RT1_MIN_ROWS")) : 30000;
+    static const bool rt1_fp = getenv("PA_CHAIN_RT1_FP") != nullptr;
     bool rt1 = !fpx_rt2 && mode == MODE_FPX && !split && !is_pooled && !wp16;
-    if (!rt1 && rt1_min_rows > 0 && !is_pooled && !wp16 && col_slices <= 1 && (mode == MODE_FP || mode == MODE_PLAIN) && total_rows >= rt1_min_rows) {
+    if (!rt1 && rt1_min_rows > 0 && !is_pooled && !wp16 && col_slices <= 1 && (mode == MODE_PLAIN || (mode == MODE_FP && rt1_fp)) && total_rows >= rt1_min_rows) {
         bool ok = true;
         for (int l = 0; l + 1 < nlayers; ++l) ok = ok && nout[l] / 16 <= 16 && ((nout[l] / 16) & (nout[l] / 16 - 1)) == 0;
         if (ok) { rt1 = true; split = false; }

@@ -39,9 +39,12 @@ constexpr int KG_AUX_FLOATS = 64 * 8 + (KG_CELLS + 1) + 16 * 6;
 // sorted[0 .. n_valid) = finite points in Morton-cell order as (x, y, z, original index bits); [n_valid, n) = the non-finite ones.
 // box[c*8 + 0..5] = lo.xyz, hi.xyz of chunk c.  Returns n_valid; *nchunks_out = ceil(n_valid / 64) (<= 64: n <= 4096).
 // All NT threads of the workgroup must call; ends with a barrier.
-template <int PTS, int NT>
+// ROWMAJOR: cells are numbered (cz * 8 + cy) * 8 + cx instead of in Morton order, so the cells cx-1 .. cx+1 of one (cy, cz) row are ONE
+// contiguous range of the sorted array (the per-lane query kernel, knn_lane.hip); grid_out (6 floats, LDS): lo.xyz and scale.xyz of the
+// cell function cell_a(p) = clamp((int)((p_a - lo_a) * scale_a), 0, 7).  After the call cnt[c] = END of cell c in `sorted` (c < 512).
+template <int PTS, int NT, bool ROWMAJOR = false>
 __device__ __forceinline__ int cell_sort_cloud(int n, const float *__restrict__ xyz, float4 *sorted, float *box, int *cnt, float *red,
-                                               int *nchunks_out)
+                                               int *nchunks_out, float *grid_out = nullptr)
 {
     constexpr int NW = NT / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -78,6 +81,10 @@ __device__ __forceinline__ int cell_sort_cloud(int n, const float *__restrict__ 
         const float ext = hi[t] - lo[t];
         scale[t] = (ext > 0.f && isfinite(ext)) ? 8.0f / ext : 0.f;
     }
+    if (grid_out && tid == 0) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { grid_out[t] = lo[t]; grid_out[3 + t] = scale[t]; }
+    }
     // ---- 2. Morton cell of every point, histogram
     int cell[PTS];
 #pragma unroll
@@ -90,7 +97,7 @@ __device__ __forceinline__ int cell_sort_cloud(int n, const float *__restrict__ 
                 const u32 cx = (u32)min(max((int)((px[u] - lo[0]) * scale[0]), 0), 7);
                 const u32 cy = (u32)min(max((int)((py[u] - lo[1]) * scale[1]), 0), 7);
                 const u32 cz = (u32)min(max((int)((pz[u] - lo[2]) * scale[2]), 0), 7);
-                cell[u] = (int)(kg_spread3(cx) | (kg_spread3(cy) << 1) | (kg_spread3(cz) << 2));
+                cell[u] = ROWMAJOR ? (int)((cz * 8u + cy) * 8u + cx) : (int)(kg_spread3(cx) | (kg_spread3(cy) << 1) | (kg_spread3(cz) << 2));
             }
             atomicAdd(&cnt[cell[u]], 1);
         }

@@ -76,6 +76,59 @@ def test_knn_bit_exact(P, b, n, m, k, kind):
     assert np.array_equal(P.knnquery(k, dev(x), dev(q)).cpu().numpy(), ri)
 
 
+LANE_CASES = ["uniform", "lattice", "dup", "planar", "clustered", "outside", "nonfinite", "line", "ragged"]
+
+
+@pytest.mark.parametrize("kind", LANE_CASES)
+@pytest.mark.parametrize("k", [16, 20, 32])
+def test_knn_lane_kernel_bit_exact(P, kind, k):
+    """The one-lane-per-query kernel (csrc/knn_lane.hip: 2048..4096 source points, >= 256 queries, k in 16 / 20 / 32) on the shapes that
+    stress its grid walk: exact ties beyond the queue (lattice, duplicates -> direct-insertion path), a degenerate axis (planar, line),
+    dense clusters with far outliers (many shells), queries outside the cloud's box (no early stop), non-finite points, ragged n."""
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(f"{kind}-{k}".encode()))
+    b, n, m = 2, 4096, 1024
+    x = (rng.random((b, n, 3), dtype=np.float32) * 2 - 1).astype(np.float32)
+    q = None
+    if kind == "lattice":
+        x = (np.round(x * 4) / 4).astype(np.float32)
+    elif kind == "dup":
+        x[:, rng.choice(n, 400, replace=False)] = x[:, rng.choice(n, 400, replace=False)]
+    elif kind == "planar":
+        x[..., 2] = 0.25
+    elif kind == "line":
+        x[..., 1] = -0.5
+        x[..., 2] = 0.125
+    elif kind == "clustered":
+        x[:, : n - 40] = (x[:, : n - 40] * 0.02 + 0.7).astype(np.float32)       # 4056 points inside one cell, 40 spread over the box
+    elif kind == "outside":
+        q = (rng.random((b, m, 3), dtype=np.float32) * 6 - 3).astype(np.float32)
+    elif kind == "nonfinite":
+        x[0, 7] = np.inf
+        x[1, 100, 1] = np.nan
+        x[1, 2000] = -np.inf
+    elif kind == "ragged":
+        n, m = 3001, 301
+        x = x[:, :n].copy()
+    if q is None:
+        q = x[:, rng.choice(n, m, replace=False)].copy()
+        q[:, ::5] += (rng.random((b, len(range(0, m, 5)), 3), dtype=np.float32) * 0.01).astype(np.float32)   # queries that are not cloud points
+    ri, rd = o.knnquery(k, x, q)
+    from patchaugnet_amd import _lib
+    lib = _lib.lib()
+    lib.pa_knn_lane_enable.argtypes, lib.pa_knn_lane_enable.restype = [__import__("ctypes").c_int], None
+    lib.pa_knn_lane_enable(1)
+    try:
+        gi, gd = P.knnquery_with_dist(k, dev(x), dev(q))
+        torch.cuda.synchronize()
+    finally:
+        lib.pa_knn_lane_enable(0)
+    assert np.array_equal(gi.cpu().numpy(), ri)
+    assert np.array_equal(gd.cpu().numpy().view(np.uint32), rd.view(np.uint32))
+    gi2, gd2 = P.knnquery_with_dist(k, dev(x), dev(q))                      # the default kernel on the same stress shapes
+    assert np.array_equal(gi2.cpu().numpy(), ri) and np.array_equal(gd2.cpu().numpy().view(np.uint32), rd.view(np.uint32))
+
+
 def test_knn_non_finite_points(P):
     x = cloud(1, 200)
     x[0, 5] = np.inf
