@@ -75,9 +75,11 @@ struct NNArgs {
     int vecA, vecB;                      // 16-byte loads allowed (alignment / divisibility checked on the host)
 };
 
-constexpr int NN_BN = 128, NN_BK = 16;
+constexpr int NN_BN = 128;
 
-template <int BM, bool A_KCONTIG, int BMODE>
+// NN_BK = 32 halves the number of (barrier, fetch) rounds of a long contraction: with few workgroups per CU a round is bound by the
+// latency of its global loads, not by its MFMAs; 16 stays for the short contractions (K <= 16: first layers, cluster counts).
+template <int BM, int NN_BK, bool A_KCONTIG, int BMODE>
 __global__ __launch_bounds__(256) void tgemm_nn_kernel(NNArgs a)
 {
     constexpr int SA = BM + 16, SB = NN_BN + 16;          // row strides = 16 mod 32 floats: conflict-free fragment reads (rows k, k+1 per 32-lane half)
@@ -102,15 +104,16 @@ __global__ __launch_bounds__(256) void tgemm_nn_kernel(NNArgs a)
         for (int j = 0; j < NT; ++j) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
 
     float ra[AE];
-    float rb[8];
+    constexpr int BP = NN_BK / 8;                           // B staging passes of 8 rows
+    float rb[BP * 4];
     // B staging: thread -> rows kb, kb + 8; 4 consecutive columns nb4
     const int kb = tid >> 5, nb4 = (tid & 31) * 4;
     auto fetch = [&](int k0) {
         // ---- A tile
-        if (A_KCONTIG) {                                   // 4 consecutive k per load: m = q / 4, k4 = (q % 4) * 4
+        if (A_KCONTIG) {                                   // 4 consecutive k per load: m = q / (BK/4), k4 = (q % (BK/4)) * 4
 #pragma unroll
             for (int u = 0; u < AE / 4; ++u) {
-                const int q = tid + u * 256, m = q >> 2, k4 = (q & 3) * 4;
+                const int q = tid + u * 256, m = q / (NN_BK / 4), k4 = (q % (NN_BK / 4)) * 4;
                 const int gm = m0 + m, gk = k0 + k4;
                 const float *src = A + (size_t)gm * a.lda + gk;
                 if (gm < a.M && gk + 3 < a.K && a.vecA) {
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(256) void tgemm_nn_kernel(NNArgs a)
         }
         // ---- B tile (transform applied here, in registers)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < BP; ++h) {
             const int gk = k0 + kb + h * 8, gn = n0 + nb4;
             const bool klive = gk < a.K;
             const ChanP cp = load_chan<BMODE>(a.tb, gk, klive);
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(256) void tgemm_nn_kernel(NNArgs a)
         if (A_KCONTIG) {
 #pragma unroll
             for (int u = 0; u < AE / 4; ++u) {
-                const int q = tid + u * 256, m = q >> 2, k4 = (q & 3) * 4;
+                const int q = tid + u * 256, m = q / (NN_BK / 4), k4 = (q % (NN_BK / 4)) * 4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) as[(k4 + e) * SA + m] = ra[u * 4 + e];
             }
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(256) void tgemm_nn_kernel(NNArgs a)
             }
         }
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < BP; ++h)
             *reinterpret_cast<float4 *>(bs + (kb + h * 8) * SB + nb4) = make_float4(rb[h * 4], rb[h * 4 + 1], rb[h * 4 + 2], rb[h * 4 + 3]);
     };
 
@@ -575,15 +578,22 @@ PA_API int pa_tgemm_nn(int batch, int M, int N, int K, const float *A, long sAb,
     a.sStatb = per_batch_stats ? (long)PA_BN_STAT_SLOTS * 2 * M : 0;
     a.vecA = aligned16(A) && lda % 4 == 0 && sAb % 4 == 0;
     a.vecB = aligned16(B) && ldb % 4 == 0 && sBb % 4 == 0 && (bmode < 2 || aligned16(baux));
-    const bool big = M > 64;
+    // 128-row tiles when there are enough of them to fill the chip twice over; 64-row tiles otherwise (the decoder's 1024 x 1024 layers
+    // over three clouds, the coarse levels): twice the workgroups, each with half the accumulators
+    const long t128 = (long)((M + 127) / 128) * ((N + NN_BN - 1) / NN_BN) * batch;
+    const bool big = M > 64 && t128 >= 512;
+    const long t64 = (long)((M + 63) / 64) * ((N + NN_BN - 1) / NN_BN) * batch;
+    const bool deep = K > 16 && !big && t64 < 1024;     // few workgroups: latency-bound rounds, halve their number (measured: hurts the chip-filling launches)
     dim3 grid((N + NN_BN - 1) / NN_BN, (M + (big ? 127 : 63)) / (big ? 128 : 64), batch);
     hipStream_t st = (hipStream_t)stream;
-#define PA_NN(BMv, KC, MODE) hipLaunchKernelGGL((tgemm_nn_kernel<BMv, KC, MODE>), grid, dim3(256), 0, st, a)
-#define PA_NN_MODE(BMv, KC)                                                                       \
-    switch (bmode) { case 0: PA_NN(BMv, KC, 0); break; case 1: PA_NN(BMv, KC, 1); break;          \
-                     case 2: PA_NN(BMv, KC, 2); break; default: PA_NN(BMv, KC, 3); break; }
-    if (big) { if (a_kcontig) { PA_NN_MODE(128, true) } else { PA_NN_MODE(128, false) } }
-    else { if (a_kcontig) { PA_NN_MODE(64, true) } else { PA_NN_MODE(64, false) } }
+#define PA_NN(BMv, BKv, KC, MODE) hipLaunchKernelGGL((tgemm_nn_kernel<BMv, BKv, KC, MODE>), grid, dim3(256), 0, st, a)
+#define PA_NN_MODE(BMv, BKv, KC)                                                                            \
+    switch (bmode) { case 0: PA_NN(BMv, BKv, KC, 0); break; case 1: PA_NN(BMv, BKv, KC, 1); break;          \
+                     case 2: PA_NN(BMv, BKv, KC, 2); break; default: PA_NN(BMv, BKv, KC, 3); break; }
+#define PA_NN_KC(BMv, BKv) if (a_kcontig) { PA_NN_MODE(BMv, BKv, true) } else { PA_NN_MODE(BMv, BKv, false) }
+    if (big) { if (deep) { PA_NN_KC(128, 32) } else { PA_NN_KC(128, 16) } }
+    else { if (deep) { PA_NN_KC(64, 32) } else { PA_NN_KC(64, 16) } }
+#undef PA_NN_KC
 #undef PA_NN_MODE
 #undef PA_NN
     PA_CHECK_LAUNCH("pa_tgemm_nn");
