@@ -87,7 +87,7 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, FpsOrder ord,
             t[p] = fminf(d, t[p]);                        // :94
             best = pa_max_u64(best, pa_make_key(t[p], low[p]));
         }
-        u64 g = pa_wave_max_u64(best);
+        u64 g = pa_wave_max_key2(best);   // two 32-bit DPP reductions: -1 % per round against the 64-bit form (the round is bound by the LDS / barrier round trips)
         if (NW > 1) {
             u64 *s = slots + (j & 1) * NW;
             if ((tid & 63) == 0) s[tid >> 6] = g;
