@@ -310,6 +310,10 @@ int pa_patch_pairs_fill(int nrec, const int *idx1, const int *near_off, const in
  * 8 x 8 x 8 cell grid (csrc/knn_lane.hip; same results bit for bit; slower than the default at the model's problem size, see the file). */
 void pa_knn_lane_enable(int on);
 
+/* pa_nearestneighbor / pa_three_nn_weights use a cell-grid kernel (csrc/three_nn_grid.hip, same results bit for bit) for 512..4096 known
+ * points and >= 1024 queries; 0 forces the brute-force scan (A/B, tests). */
+void pa_three_nn_grid_enable(int on);
+
 /* ---- Retrieval kNN at database scale (csrc/knn_mfma.hip): the recall harness' brute-force search (datasets/scene_dataset.py:1016-1099,
  * KNN_CUDA knn.cu:232-269) with the distance matrix on MFMA and an exact re-rank: columns equal pa_knn_generic's bit for bit.
  * a (nq_blk x lda) = pa_tgemm_nn(act = 2) output for a block of queries: a[q][r] = max(|q|^2 + |r|^2 - 2 q.r, 0); ref_rows (nr, dim),

@@ -190,11 +190,14 @@ __global__ __launch_bounds__(256) void labelstat_idx_kernel(int n, int m, int ns
 
 #define PA_GRID_B(b, name) PA_REQUIRE((b) <= 65535, name ": b=%d exceeds the grid limit 65535", (b))
 
+int pa_three_nn_grid_try(int b, int n, int m, const float *unknown, const float *known, float *out, int *idx, int weights, hipStream_t st);   // three_nn_grid.hip
+
 PA_API int pa_nearestneighbor(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx, pa_stream_t stream)
 {
     PA_REQUIRE(b > 0 && n > 0 && m > 0, "pa_nearestneighbor: b=%d n=%d m=%d must be positive", b, n, m);
     PA_REQUIRE(unknown && known && dist2 && idx, "pa_nearestneighbor: null pointer");
     PA_GRID_B(b, "pa_nearestneighbor");
+    if (pa_three_nn_grid_try(b, n, m, unknown, known, dist2, idx, 0, (hipStream_t)stream)) { PA_CHECK_LAUNCH("pa_nearestneighbor(grid)"); return PA_OK; }
     hipLaunchKernelGGL(three_nn_kernel<false>, dim3(pa_div_up(n, 256), b), dim3(256), 0, (hipStream_t)stream, n, m, unknown, known, dist2, idx);
     PA_CHECK_LAUNCH("pa_nearestneighbor");
     return PA_OK;
@@ -207,6 +210,7 @@ PA_API int pa_three_nn_weights(int b, int n, int m, const float *unknown, const 
     PA_REQUIRE(b > 0 && n > 0 && m > 0, "pa_three_nn_weights: b=%d n=%d m=%d must be positive", b, n, m);
     PA_REQUIRE(unknown && known && weight && idx, "pa_three_nn_weights: null pointer");
     PA_GRID_B(b, "pa_three_nn_weights");
+    if (pa_three_nn_grid_try(b, n, m, unknown, known, weight, idx, 1, (hipStream_t)stream)) { PA_CHECK_LAUNCH("pa_three_nn_weights(grid)"); return PA_OK; }
     hipLaunchKernelGGL(three_nn_kernel<true>, dim3(pa_div_up(n, 256), b), dim3(256), 0, (hipStream_t)stream, n, m, unknown, known, weight, idx);
     PA_CHECK_LAUNCH("pa_three_nn_weights");
     return PA_OK;

@@ -139,6 +139,63 @@ def test_knn_non_finite_points(P):
     assert np.array_equal(gi.cpu().numpy(), ri) and np.array_equal(gd.cpu().numpy().view(np.uint32), rd.view(np.uint32))
 
 
+@pytest.mark.parametrize("kind", ["uniform", "lattice", "dup", "planar", "clustered", "outside", "faraway", "nonfinite", "line", "ragged", "bigknown"])
+def test_three_nn_grid_kernel_bit_exact(P, kind):
+    """The cell-grid 3-NN (csrc/three_nn_grid.hip: 512..4096 known points, >= 1024 queries) against the oracle on the shapes that stress
+    its walk: ties (lattice, duplicates), a degenerate axis, one dense cluster + outliers (many shells), queries outside the known cloud's
+    box (near and 1e4 away), non-finite points on both sides, ragged sizes; and the fused-weights form against the brute-force kernel."""
+    import zlib
+    from patchaugnet_amd import _lib
+    rng = np.random.default_rng(zlib.crc32(kind.encode()))
+    b, n, m = 2, 4096, 1024
+    kn = (rng.random((b, m, 3), dtype=np.float32) * 2 - 1).astype(np.float32)
+    u = (rng.random((b, n, 3), dtype=np.float32) * 2 - 1).astype(np.float32)
+    if kind == "lattice":
+        kn, u = (np.round(kn * 4) / 4).astype(np.float32), (np.round(u * 4) / 4).astype(np.float32)
+    elif kind == "dup":
+        kn[:, rng.choice(m, 200, replace=False)] = kn[:, rng.choice(m, 200, replace=False)]
+        u[:, :m] = kn
+    elif kind == "planar":
+        kn[..., 2] = 0.25
+    elif kind == "line":
+        kn[..., 1] = -0.5
+        kn[..., 2] = 0.125
+    elif kind == "clustered":
+        kn[:, : m - 20] = (kn[:, : m - 20] * 0.02 + 0.7).astype(np.float32)
+    elif kind == "outside":
+        u = (u * 3).astype(np.float32)
+    elif kind == "faraway":
+        u[:, ::3] = (u[:, ::3] * 1e4).astype(np.float32)
+    elif kind == "nonfinite":
+        kn[0, 7] = np.inf
+        kn[1, 100, 1] = np.nan
+        u[0, 5] = np.nan
+        u[1, 9, 2] = -np.inf
+    elif kind == "ragged":
+        n, m = 3001, 777
+        kn, u = kn[:, :m].copy(), u[:, :n].copy()
+    elif kind == "bigknown":
+        m = 4000
+        kn = (rng.random((b, m, 3), dtype=np.float32) * 2 - 1).astype(np.float32)
+    rd, ri = o.nearestneighbor(u, kn)
+    gd, gi = P.nearestneighbor(dev(u), dev(kn))
+    assert np.array_equal(gi.cpu().numpy(), ri)
+    assert np.array_equal(gd.cpu().numpy(), np.sqrt(rd))
+    lib = _lib.lib()
+    lib.pa_three_nn_grid_enable.argtypes, lib.pa_three_nn_grid_enable.restype = [__import__("ctypes").c_int], None
+    ud, kd = dev(u), dev(kn)
+    w1, i1, w0, i0 = (torch.empty((b, n, 3), device="cuda"), torch.empty((b, n, 3), dtype=torch.int32, device="cuda"),
+                      torch.empty((b, n, 3), device="cuda"), torch.empty((b, n, 3), dtype=torch.int32, device="cuda"))
+    _lib.call("pa_three_nn_weights", b, n, m, _lib.ptr(ud), _lib.ptr(kd), _lib.ptr(w1), _lib.ptr(i1))
+    lib.pa_three_nn_grid_enable(0)
+    try:
+        _lib.call("pa_three_nn_weights", b, n, m, _lib.ptr(ud), _lib.ptr(kd), _lib.ptr(w0), _lib.ptr(i0))
+        torch.cuda.synchronize()
+    finally:
+        lib.pa_three_nn_grid_enable(1)
+    assert torch.equal(i1, i0) and torch.equal(w1.view(torch.int32), w0.view(torch.int32))
+
+
 NN_CASES = [(2, 4096, 1024, "uniform"), (2, 1024, 128, "uniform"), (2, 128, 16, "lattice"), (1, 50, 2, "uniform"),
             (1, 40, 1, "uniform"), (1, 300, 2500, "uniform"), (2, 257, 100, "dup")]
 
