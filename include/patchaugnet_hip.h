@@ -309,6 +309,9 @@ int pa_patch_pairs_fill(int nrec, const int *idx1, const int *near_off, const in
 /* Opt-in alternative for pa_knnquery at 2048..4096 source points, >= 256 queries, nsample 16 / 20 / 32: one lane per query over an
  * 8 x 8 x 8 cell grid (csrc/knn_lane.hip; same results bit for bit; slower than the default at the model's problem size, see the file). */
 void pa_knn_lane_enable(int on);
+/* pa_knnquery at 2048..4096 source points, >= 256 queries, nsample 16 / 20 / 32 runs four lanes per query over the cell grid
+ * (csrc/knn_quad.hip, same results bit for bit); 0 forces the wave-per-query kernels (A/B, tests). */
+void pa_knn_quad_enable(int on);
 
 /* pa_nearestneighbor / pa_three_nn_weights use a cell-grid kernel (csrc/three_nn_grid.hip, same results bit for bit) for 512..4096 known
  * points and >= 1024 queries; 0 forces the brute-force scan (A/B, tests). */

@@ -1,0 +1,305 @@
+// K4, fourth form: FOUR lanes per query over an 8 x 8 x 8 cell grid (the set-abstraction kNN at 2048-4096 source points).
+//
+// Reference semantics (knnquery_cuda_kernel.cu:6-50): per query the first nsample entries of the stable ascending
+// sort of (d2, index), d2 = (qx-x)*(qx-x) + (qy-y)*(qy-y) + (qz-z)*(qz-z) in fp32 without contraction; unfilled slots (0, +inf).
+//
+// What round 2 measured: the wave-per-query grid kernel (knn.hip) costs ~2000 wave instructions per query (0.149 ms per batch); one LANE per
+// query (knn_lane.hip) costs ~200 but leaves 512 waves with 600 k-cycle chains for 1024 SIMDs (0.287 ms); the same lane-per-query walk for
+// the 3-NN (three_nn_grid.hip: 2048 waves, short chains) took 0.030 ms instead of 0.085.  This kernel gives the kNN that shape: a QUAD of
+// adjacent lanes shares a query, lane j takes every fourth candidate of every cell row, so a batch is 2048 waves again and a lane's chain
+// is a quarter as long.
+//   pass 1  each lane keeps the K smallest DISTANCES of its quarter (sorted register array, one v_med3_f32 per slot and candidate);
+//           the quad's K-th smallest comes from two min / max merge steps over quad shuffles (no indices involved); shells are added
+//           until that K-th distance is provably smaller than anything unvisited (stop rule of three_nn_grid.hip / knn_lane.hip);
+//   pass 2  each lane walks its quarter again and queues the positions of the candidates with d <= K-th distance (~K / 4 per lane);
+//   pass 3  the quad's queued candidates become 64-bit (d2 bits, index) keys in LDS; a candidate's output slot is its rank among them
+//           (exact (d2, index) order whatever the ties), slots beyond the candidates are (0, +inf).
+// More than KQ_QCAP queued candidates in a lane or KQ_TCAP in a quad (a dozen exact ties with the K-th distance: lattice clouds) sends the
+// query down a slow exact path: lane 0 of the quad inserts every candidate of the visited cells into a sorted key list.
+//
+// Measured (MI355X, b = 32, n = 4096, m = 1024, k = 20; tools/knn_time.py), uniform / plane-like clouds, wave-per-query kernel 148 / 150 us:
+//   256 threads, 128 queries per workgroup (one wave per SIMD, every LDS access at full latency)   158 / 219 us
+//   512 threads, 128 queries per workgroup (two waves per SIMD; shipped)                             97 / 172 us
+//   1024 threads (64-register budget: spills)                                                      242 / 482 us
+// i.e. -35 % on uniform clouds (the benchmark distribution), +15 % on plane-like ones (dense cells: more candidates per neighbourhood and
+// more imbalance inside a wave); the cell-grid 3-NN gains on both (85 -> 30 / 45 us).
+#include <stdlib.h>
+
+#include "pa_common.h"
+#include "pa_cellsort.h"
+
+namespace {
+
+constexpr u64 KQ_INF0 = ((u64)0x7F800000u) << 32;
+#ifndef KQ_QCAP_V
+#define KQ_QCAP_V 12
+#endif
+#ifndef KQ_TCAP_V
+#define KQ_TCAP_V 32
+#endif
+#ifndef KQ_NT
+#define KQ_NT 512
+#endif
+constexpr int KQ_QCAP = KQ_QCAP_V;      // queued positions per lane
+constexpr int KQ_TCAP = KQ_TCAP_V;      // keys per query
+constexpr int KQ_AUX_FLOATS = KG_AUX_FLOATS + 8;
+
+// K smallest (ascending) of two ascending K-lists held by this lane (a) and the lane `mask` away (quad shuffle): bitonic merge on 32 slots
+template <int K>
+__device__ __forceinline__ void merge_pair(float (&a)[K], int mask)
+{
+    static_assert(K <= 32, "padded to 32 slots");
+    float c[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int jb = 31 - j;                                   // partner element paired with slot j
+        float pb = INFINITY;
+        if (jb < K) pb = __shfl_xor(a[jb], mask);
+        c[j] = j < K ? (jb < K ? fminf(a[j], pb) : a[j]) : pb;    // min(A[j] or inf, B[31 - j] or inf)
+    }
+#pragma unroll
+    for (int s = 16; s >= 1; s >>= 1)
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+            if ((i & s) == 0) {
+                const float lo = fminf(c[i], c[i + s]), hi = fmaxf(c[i], c[i + s]);
+                c[i] = lo;
+                c[i + s] = hi;
+            }
+#pragma unroll
+    for (int j = 0; j < K; ++j) a[j] = c[j];
+}
+
+template <int K, int PTS, int NT>
+__global__ __launch_bounds__(NT) void knn_quad_kernel(int n, int m, int q_per_block, const float *__restrict__ xyz_all, const float *__restrict__ new_xyz_all,
+                                                       int *__restrict__ idx_all, float *__restrict__ dist2_all)
+{
+    constexpr int NQ = NT / 4;        // queries per pass
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float4 *sorted = reinterpret_cast<float4 *>(smem);
+    float *box = smem + 4 * (size_t)n;
+    int *cnt = reinterpret_cast<int *>(box + 64 * 8);
+    float *red = reinterpret_cast<float *>(cnt + KG_CELLS + 1);
+    float *grid = red + 16 * 6;
+    int *qcnt = reinterpret_cast<int *>(grid + 8);
+    u64 *keys = reinterpret_cast<u64 *>((reinterpret_cast<uintptr_t>(qcnt + KG_CELLS + 1) + 7) & ~(uintptr_t)7);   // [NQ][KQ_TCAP], 8-byte aligned
+    unsigned short *queue = reinterpret_cast<unsigned short *>(keys + NQ * KQ_TCAP);    // [KQ_QCAP][NT]
+    unsigned short *qorder = queue + KQ_QCAP * NT;                                      // [q_per_block]
+    const int b = blockIdx.y, tid = threadIdx.x, part = tid & 3, ql = tid >> 2;
+    const float *xyz = xyz_all + (size_t)b * n * 3;
+    int nchunks;
+    cell_sort_cloud<PTS, NT, true>(n, xyz, sorted, box, cnt, red, &nchunks, grid);
+    const float lo0 = grid[0], lo1 = grid[1], lo2 = grid[2], sc0 = grid[3], sc1 = grid[4], sc2 = grid[5];
+
+    // this workgroup's queries in cell order
+    const int q_begin = blockIdx.x * q_per_block, q_end = min(q_begin + q_per_block, m);
+    {
+        for (int c = tid; c <= KG_CELLS; c += NT) qcnt[c] = 0;
+        __syncthreads();
+        auto qcell = [&](int qi) {
+            const float *qp = new_xyz_all + ((size_t)b * m + qi) * 3;
+            const int cx = min(max((int)((qp[0] - lo0) * sc0), 0), 7), cy = min(max((int)((qp[1] - lo1) * sc1), 0), 7), cz = min(max((int)((qp[2] - lo2) * sc2), 0), 7);
+            return (cz * 8 + cy) * 8 + cx;
+        };
+        for (int qi = q_begin + tid; qi < q_end; qi += NT) atomicAdd(&qcnt[qcell(qi)], 1);
+        __syncthreads();
+        if (tid < 64) {
+            int v[9], sum = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) { const int c = tid * 9 + t; v[t] = c <= KG_CELLS ? qcnt[c] : 0; sum += v[t]; }
+            int incl = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (tid >= o) incl += u; }
+            int run = incl - sum;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) { const int c = tid * 9 + t; if (c <= KG_CELLS) qcnt[c] = run; run += v[t]; }
+        }
+        __syncthreads();
+        for (int qi = q_begin + tid; qi < q_end; qi += NT) qorder[atomicAdd(&qcnt[qcell(qi)], 1)] = (unsigned short)(qi - q_begin);
+        __syncthreads();
+    }
+
+    for (int qs = ql; qs < q_end - q_begin; qs += NQ) {          // the four lanes of a quad run this loop together
+        const int q = q_begin + qorder[qs];
+        const float *qp = new_xyz_all + ((size_t)b * m + q) * 3;
+        const float qx = qp[0], qy = qp[1], qz = qp[2];
+        const float f0 = (qx - lo0) * sc0, f1 = (qy - lo1) * sc1, f2 = (qz - lo2) * sc2;
+        const bool tame = fabsf(f0) < 1000.f && fabsf(f1) < 1000.f && fabsf(f2) < 1000.f;   // false for NaN / inf
+        const int cx = min(max((int)f0, 0), 7), cy = min(max((int)f1, 0), 7), cz = min(max((int)f2, 0), 7);
+
+        // every `step`-th point (from `first`) of the cells at Chebyshev distance r_from .. r_to from the query's cell
+        auto scan = [&](int r_from, int r_to, int first, int step, auto &&fn) {
+            for (int dz = -r_to; dz <= r_to; ++dz) {
+                const int z = cz + dz;
+                if (z < 0 || z > 7) continue;
+                for (int dy = -r_to; dy <= r_to; ++dy) {
+                    const int y = cy + dy;
+                    if (y < 0 || y > 7) continue;
+                    const int rowbase = (z * 8 + y) * 8;
+                    const int xl = max(cx - r_to, 0), xh = min(cx + r_to, 7);
+                    const bool interior = r_from > 0 && abs(dz) < r_from && abs(dy) < r_from;   // the middle of the row was scanned before
+                    {
+                        const int c0 = rowbase + xl, c1 = rowbase + (interior ? min(cx - r_from, xh) : xh);
+                        if (c1 >= c0) {
+                            const int beg = c0 ? cnt[c0 - 1] : 0, end = cnt[c1];
+                            for (int pos = beg + first; pos < end; pos += step) fn(pos, sorted[pos]);
+                        }
+                    }
+                    if (interior) {
+                        const int c0 = rowbase + max(cx + r_from, xl), c1 = rowbase + xh;
+                        if (c1 >= c0) {
+                            const int beg = c0 ? cnt[c0 - 1] : 0, end = cnt[c1];
+                            for (int pos = beg + first; pos < end; pos += step) fn(pos, sorted[pos]);
+                        }
+                    }
+                }
+            }
+        };
+        auto dist = [&](const float4 &p) { return (qx - p.x) * (qx - p.x) + (qy - p.y) * (qy - p.y) + (qz - p.z) * (qz - p.z); };   // :31
+        auto outside_bound = [&](int R) {
+            float best = INFINITY;
+            auto face = [&](float f, int c, float sc) {
+                if (!(sc > 0.f)) return;
+                const float inv = 0.999f / sc;
+                if (c + R + 1 <= 7) { const float g = fmaxf((float)(c + R + 1) - f - 1e-3f, 0.f) * inv; best = fminf(best, g * g); }
+                if (c - R - 1 >= 0) { const float g = fmaxf(f - (float)(c - R) - 1e-3f, 0.f) * inv; best = fminf(best, g * g); }
+            };
+            face(f0, cx, sc0); face(f1, cy, sc1); face(f2, cz, sc2);
+            return best;
+        };
+
+        // ---- pass 1: this lane's K smallest distances; the quad's K-th smallest
+        float L[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) L[j] = INFINITY;
+        int nfin = 0;
+        auto pass1 = [&](int, const float4 &p) {
+            float d = dist(p);
+            d = d < INFINITY ? d : INFINITY;          // NaN / inf: never admitted
+            nfin += d < INFINITY ? 1 : 0;
+#pragma unroll
+            for (int j = K - 1; j >= 1; --j) L[j] = __builtin_amdgcn_fmed3f(L[j - 1], d, L[j]);
+            L[0] = fminf(L[0], d);
+        };
+        auto quad_kth = [&]() {                        // K-th smallest of the four lanes' lists (same value in all four lanes)
+            float M[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) M[j] = L[j];
+            merge_pair<K>(M, 1);                        // lanes {0,1} and {2,3}: K smallest of each pair, ascending
+            float kth = 0.f;
+#pragma unroll
+            for (int j = 0; j < K; ++j) kth = fmaxf(kth, fminf(M[j], __shfl_xor(M[K - 1 - j], 2)));   // the K smallest of the union are min(M[j], P[K-1-j])
+            return kth;
+        };
+        int R = 1;
+        scan(0, 1, part, 4, pass1);
+        float kth;
+        int nfin4;
+        while (true) {
+            kth = quad_kth();
+            nfin4 = nfin + __shfl_xor(nfin, 1);
+            nfin4 += __shfl_xor(nfin4, 2);
+            if (R >= 7 || (tame && nfin4 >= K && kth < outside_bound(R))) break;
+            ++R;
+            scan(R, R, part, 4, pass1);
+        }
+
+        // ---- pass 2: positions of this lane's candidates with d <= kth
+        int qn = 0;
+        auto pass2 = [&](int pos, const float4 &p) {
+            const float d = dist(p);
+            if (d <= kth && d < INFINITY) {
+                if (qn < KQ_QCAP) queue[qn * NT + tid] = (unsigned short)pos;
+                ++qn;
+            }
+        };
+        scan(0, R, part, 4, pass2);
+        const int base = (tid & 63) & ~3;
+        const int c0 = __shfl(qn, base), c1 = __shfl(qn, base + 1), c2 = __shfl(qn, base + 2), c3 = __shfl(qn, base + 3);
+        const int total = c0 + c1 + c2 + c3;
+        const bool overflow = c0 > KQ_QCAP || c1 > KQ_QCAP || c2 > KQ_QCAP || c3 > KQ_QCAP || total > KQ_TCAP;
+        const size_t o = ((size_t)b * m + q) * K;
+        if (!overflow) {
+            // ---- pass 3: keys to LDS, output slot = rank among the quad's keys
+            const int off = (part > 0 ? c0 : 0) + (part > 1 ? c1 : 0) + (part > 2 ? c2 : 0);
+            u64 *kq = keys + ql * KQ_TCAP;
+            for (int e = 0; e < qn; ++e) {
+                const float4 p = sorted[queue[e * NT + tid]];
+                kq[off + e] = pa_make_key(dist(p), (u32)__float_as_int(p.w));
+            }
+            // (same wavefront: the LDS writes above are complete before the reads below are issued)
+            for (int e = 0; e < qn; ++e) {
+                const u64 mine = kq[off + e];
+                int rank = 0;
+                for (int t = 0; t < total; ++t) rank += kq[t] < mine ? 1 : 0;
+                if (rank < K) {
+                    idx_all[o + rank] = (int)(u32)mine;
+                    dist2_all[o + rank] = __uint_as_float((u32)(mine >> 32));
+                }
+            }
+            for (int j = total + part; j < K; j += 4) {          // fewer than K admissible points: (0, +inf) like the reference
+                idx_all[o + j] = 0;
+                dist2_all[o + j] = __uint_as_float(0x7F800000u);
+            }
+        } else if (part == 0) {
+            // ---- slow exact path: every candidate of the visited cells into a sorted key list
+            u64 Lk[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) Lk[j] = KQ_INF0;
+            auto slow = [&](int, const float4 &p) {
+                u64 key = pa_make_key(dist(p), (u32)__float_as_int(p.w));
+                if (key < Lk[K - 1]) {                 // key >= KQ_INF0 (inf / NaN distance) never passes
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        const bool lt = key < Lk[j];
+                        const u64 lo = lt ? key : Lk[j], hi = lt ? Lk[j] : key;
+                        Lk[j] = lo;
+                        key = hi;
+                    }
+                }
+            };
+            scan(0, R, 0, 1, slow);
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                idx_all[o + j] = (int)(u32)Lk[j];
+                dist2_all[o + j] = __uint_as_float((u32)(Lk[j] >> 32));
+            }
+        }
+    }
+}
+
+#ifndef KQ_QPB
+#define KQ_QPB 128
+#endif
+
+template <int K>
+int launch_quad(int b, int n, int m, const float *xyz, const float *new_xyz, int *idx, float *dist2, hipStream_t st)
+{
+    constexpr int NT = KQ_NT, PTS = 4096 / KQ_NT;
+    const int qpb = KQ_QPB;
+    const size_t lds = (size_t)n * 16 + (size_t)KQ_AUX_FLOATS * 4 + (size_t)(KG_CELLS + 3) * 4 + (size_t)(NT / 4) * KQ_TCAP * 8 + (size_t)KQ_QCAP * NT * 2 +
+                       (size_t)qpb * 2;
+    auto kern = knn_quad_kernel<K, PTS, NT>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(pa_div_up(m, qpb), b), dim3(NT), lds, st, n, m, qpb, xyz, new_xyz, idx, dist2);
+    return 0;
+}
+
+}  // namespace
+
+static int g_quad_on = -1;
+// A/B and test switch: 1 = the quad kernel where it applies (default; PA_KNN_NO_QUAD=1 turns it off), 0 = the wave-per-query kernels
+PA_API void pa_knn_quad_enable(int on) { g_quad_on = on ? 1 : 0; }
+
+// 1 when the quad kernel took the call, 0 when it is off or the shape is not one it is built for.
+int pa_knn_quad_try(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx, float *dist2, hipStream_t st)
+{
+    if (g_quad_on < 0) g_quad_on = getenv("PA_KNN_NO_QUAD") != nullptr ? 0 : 1;
+    if (!g_quad_on || n < 2048 || n > 4096 || m < 256) return 0;
+    switch (nsample) {
+        case 16: launch_quad<16>(b, n, m, xyz, new_xyz, idx, dist2, st); return 1;
+        case 20: launch_quad<20>(b, n, m, xyz, new_xyz, idx, dist2, st); return 1;
+        case 32: launch_quad<32>(b, n, m, xyz, new_xyz, idx, dist2, st); return 1;
+        default: return 0;
+    }
+}

@@ -125,8 +125,16 @@ def test_knn_lane_kernel_bit_exact(P, kind, k):
         lib.pa_knn_lane_enable(0)
     assert np.array_equal(gi.cpu().numpy(), ri)
     assert np.array_equal(gd.cpu().numpy().view(np.uint32), rd.view(np.uint32))
-    gi2, gd2 = P.knnquery_with_dist(k, dev(x), dev(q))                      # the default kernel on the same stress shapes
+    gi2, gd2 = P.knnquery_with_dist(k, dev(x), dev(q))                      # the default: four lanes per query (knn_quad.hip)
     assert np.array_equal(gi2.cpu().numpy(), ri) and np.array_equal(gd2.cpu().numpy().view(np.uint32), rd.view(np.uint32))
+    lib.pa_knn_quad_enable.argtypes, lib.pa_knn_quad_enable.restype = [__import__("ctypes").c_int], None
+    lib.pa_knn_quad_enable(0)
+    try:
+        gi3, gd3 = P.knnquery_with_dist(k, dev(x), dev(q))                  # the wave-per-query grid kernel on the same stress shapes
+        torch.cuda.synchronize()
+    finally:
+        lib.pa_knn_quad_enable(1)
+    assert np.array_equal(gi3.cpu().numpy(), ri) and np.array_equal(gd3.cpu().numpy().view(np.uint32), rd.view(np.uint32))
 
 
 def test_knn_non_finite_points(P):

@@ -17,7 +17,7 @@ for kind in ("uniform", "street"):
     s.record()
     for _ in range(20): fn()
     e.record(); e.synchronize()
-    print(f"{kind}: pa_knnquery(32, 4096, 1024, 20) {s.elapsed_time(e) / 20 * 1000:.1f} us  (lane kernel {'on' if os.environ.get('PA_KNN_LANE') else 'off'})")
+    print(f"{kind}: pa_knnquery(32, 4096, 1024, 20) {s.elapsed_time(e) / 20 * 1000:.1f} us  (lane {'on' if os.environ.get('PA_KNN_LANE') else 'off'}, quad {'off' if os.environ.get('PA_KNN_NO_QUAD') else 'on'})")
     import ctypes
     lib = _lib.lib(); lib.pa_knn_debug_buffer.argtypes = [ctypes.c_void_p]; lib.pa_knn_debug_buffer.restype = None
     buf = torch.zeros(16, dtype=torch.int64, device="cuda")
