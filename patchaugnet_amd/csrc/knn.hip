@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void knn_select_kernel(int n, int m, int k, co
 
 int pa_knn_lane_try(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx, float *dist2, hipStream_t st, long long *dbg);   // knn_lane.hip
 
-int pa_knn_quad_try(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx, float *dist2, hipStream_t st);   // knn_quad.hip
+int pa_knn_quad_try(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx, float *dist2, hipStream_t st, long long *dbg);   // knn_quad.hip
 
 static long long *g_knn_dbg = nullptr;
 PA_API void pa_knn_debug_buffer(long long *buf) { g_knn_dbg = buf; }   // profiling hook (6 int64), NULL = off
@@ -257,7 +257,7 @@ PA_API int pa_knnquery(int b, int n, int m, int nsample, const float *xyz, const
         return PA_OK;
     }
     // 2048-4096 source points, 16 / 20 / 32 neighbours: four lanes per query over an 8 x 8 x 8 grid (knn_quad.hip)
-    if (!g_knn_dbg && pa_knn_quad_try(b, n, m, nsample, xyz, new_xyz, idx, dist2, st)) {
+    if (pa_knn_quad_try(b, n, m, nsample, xyz, new_xyz, idx, dist2, st, g_knn_dbg)) {
         PA_CHECK_LAUNCH("pa_knnquery(quad)");
         return PA_OK;
     }

@@ -72,8 +72,9 @@ __device__ __forceinline__ void merge_pair(float (&a)[K], int mask)
 
 template <int K, int PTS, int NT>
 __global__ __launch_bounds__(NT) void knn_quad_kernel(int n, int m, int q_per_block, const float *__restrict__ xyz_all, const float *__restrict__ new_xyz_all,
-                                                       int *__restrict__ idx_all, float *__restrict__ dist2_all)
+                                                       int *__restrict__ idx_all, float *__restrict__ dist2_all, long long *dbg)
 {
+#define KQ_STAMP(i) do { if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
     constexpr int NQ = NT / 4;        // queries per pass
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float4 *sorted = reinterpret_cast<float4 *>(smem);
@@ -82,13 +83,15 @@ __global__ __launch_bounds__(NT) void knn_quad_kernel(int n, int m, int q_per_bl
     float *red = reinterpret_cast<float *>(cnt + KG_CELLS + 1);
     float *grid = red + 16 * 6;
     int *qcnt = reinterpret_cast<int *>(grid + 8);
-    u64 *keys = reinterpret_cast<u64 *>((reinterpret_cast<uintptr_t>(qcnt + KG_CELLS + 1) + 7) & ~(uintptr_t)7);   // [NQ][KQ_TCAP], 8-byte aligned
-    unsigned short *queue = reinterpret_cast<unsigned short *>(keys + NQ * KQ_TCAP);    // [KQ_QCAP][NT]
+    u64 *keys = reinterpret_cast<u64 *>((reinterpret_cast<uintptr_t>(qcnt + KG_CELLS + 1) + 7) & ~(uintptr_t)7);   // [NQ][KQ_TCAP + 4], 8-byte aligned
+    unsigned short *queue = reinterpret_cast<unsigned short *>(keys + NQ * (KQ_TCAP + 4));    // [KQ_QCAP][NT]
     unsigned short *qorder = queue + KQ_QCAP * NT;                                      // [q_per_block]
     const int b = blockIdx.y, tid = threadIdx.x, part = tid & 3, ql = tid >> 2;
     const float *xyz = xyz_all + (size_t)b * n * 3;
     int nchunks;
+    KQ_STAMP(0);
     cell_sort_cloud<PTS, NT, true>(n, xyz, sorted, box, cnt, red, &nchunks, grid);
+    KQ_STAMP(1);
     const float lo0 = grid[0], lo1 = grid[1], lo2 = grid[2], sc0 = grid[3], sc1 = grid[4], sc2 = grid[5];
 
     // this workgroup's queries in cell order
@@ -119,6 +122,7 @@ __global__ __launch_bounds__(NT) void knn_quad_kernel(int n, int m, int q_per_bl
         __syncthreads();
     }
 
+    KQ_STAMP(2);
     for (int qs = ql; qs < q_end - q_begin; qs += NQ) {          // the four lanes of a quad run this loop together
         const int q = q_begin + qorder[qs];
         const float *qp = new_xyz_all + ((size_t)b * m + q) * 3;
@@ -142,14 +146,26 @@ __global__ __launch_bounds__(NT) void knn_quad_kernel(int n, int m, int q_per_bl
                         const int c0 = rowbase + xl, c1 = rowbase + (interior ? min(cx - r_from, xh) : xh);
                         if (c1 >= c0) {
                             const int beg = c0 ? cnt[c0 - 1] : 0, end = cnt[c1];
-                            for (int pos = beg + first; pos < end; pos += step) fn(pos, sorted[pos]);
+                            int pos = beg + first;
+                            for (; pos + step < end; pos += 2 * step) {      // two candidates per trip: both LDS reads in flight together
+                                const float4 pa = sorted[pos], pb = sorted[pos + step];
+                                fn(pos, pa);
+                                fn(pos + step, pb);
+                            }
+                            if (pos < end) fn(pos, sorted[pos]);
                         }
                     }
                     if (interior) {
                         const int c0 = rowbase + max(cx + r_from, xl), c1 = rowbase + xh;
                         if (c1 >= c0) {
                             const int beg = c0 ? cnt[c0 - 1] : 0, end = cnt[c1];
-                            for (int pos = beg + first; pos < end; pos += step) fn(pos, sorted[pos]);
+                            int pos = beg + first;
+                            for (; pos + step < end; pos += 2 * step) {      // two candidates per trip: both LDS reads in flight together
+                                const float4 pa = sorted[pos], pb = sorted[pos + step];
+                                fn(pos, pa);
+                                fn(pos + step, pb);
+                            }
+                            if (pos < end) fn(pos, sorted[pos]);
                         }
                     }
                 }
@@ -172,11 +188,8 @@ __global__ __launch_bounds__(NT) void knn_quad_kernel(int n, int m, int q_per_bl
         float L[K];
 #pragma unroll
         for (int j = 0; j < K; ++j) L[j] = INFINITY;
-        int nfin = 0;
         auto pass1 = [&](int, const float4 &p) {
-            float d = dist(p);
-            d = d < INFINITY ? d : INFINITY;          // NaN / inf: never admitted
-            nfin += d < INFINITY ? 1 : 0;
+            const float d = fminf(dist(p), INFINITY);   // NaN -> +inf: never admitted
 #pragma unroll
             for (int j = K - 1; j >= 1; --j) L[j] = __builtin_amdgcn_fmed3f(L[j - 1], d, L[j]);
             L[0] = fminf(L[0], d);
@@ -194,16 +207,15 @@ __global__ __launch_bounds__(NT) void knn_quad_kernel(int n, int m, int q_per_bl
         int R = 1;
         scan(0, 1, part, 4, pass1);
         float kth;
-        int nfin4;
         while (true) {
-            kth = quad_kth();
-            nfin4 = nfin + __shfl_xor(nfin, 1);
-            nfin4 += __shfl_xor(nfin4, 2);
-            if (R >= 7 || (tame && nfin4 >= K && kth < outside_bound(R))) break;
+            kth = quad_kth();                          // finite <=> the quad has seen K admissible candidates
+            if (R >= 7 || (tame && kth < INFINITY && kth < outside_bound(R))) break;
             ++R;
             scan(R, R, part, 4, pass1);
         }
 
+        KQ_STAMP(3);
+        if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) dbg[8] = R;
         // ---- pass 2: positions of this lane's candidates with d <= kth
         int qn = 0;
         auto pass2 = [&](int pos, const float4 &p) {
@@ -214,6 +226,7 @@ __global__ __launch_bounds__(NT) void knn_quad_kernel(int n, int m, int q_per_bl
             }
         };
         scan(0, R, part, 4, pass2);
+        KQ_STAMP(4);
         const int base = (tid & 63) & ~3;
         const int c0 = __shfl(qn, base), c1 = __shfl(qn, base + 1), c2 = __shfl(qn, base + 2), c3 = __shfl(qn, base + 3);
         const int total = c0 + c1 + c2 + c3;
@@ -222,16 +235,20 @@ __global__ __launch_bounds__(NT) void knn_quad_kernel(int n, int m, int q_per_bl
         if (!overflow) {
             // ---- pass 3: keys to LDS, output slot = rank among the quad's keys
             const int off = (part > 0 ? c0 : 0) + (part > 1 ? c1 : 0) + (part > 2 ? c2 : 0);
-            u64 *kq = keys + ql * KQ_TCAP;
+            u64 *kq = keys + ql * (KQ_TCAP + 4);
             for (int e = 0; e < qn; ++e) {
                 const float4 p = sorted[queue[e * NT + tid]];
                 kq[off + e] = pa_make_key(dist(p), (u32)__float_as_int(p.w));
             }
             // (same wavefront: the LDS writes above are complete before the reads below are issued)
+            if (part == 0) { kq[total] = ~0ull; kq[total + 1] = ~0ull; kq[total + 2] = ~0ull; }      // the rank loop reads four keys per trip
             for (int e = 0; e < qn; ++e) {
                 const u64 mine = kq[off + e];
                 int rank = 0;
-                for (int t = 0; t < total; ++t) rank += kq[t] < mine ? 1 : 0;
+                for (int t = 0; t < total; t += 4) {
+                    const u64 a0 = kq[t], a1 = kq[t + 1], a2 = kq[t + 2], a3 = kq[t + 3];
+                    rank += (a0 < mine ? 1 : 0) + (a1 < mine ? 1 : 0) + (a2 < mine ? 1 : 0) + (a3 < mine ? 1 : 0);
+                }
                 if (rank < K) {
                     idx_all[o + rank] = (int)(u32)mine;
                     dist2_all[o + rank] = __uint_as_float((u32)(mine >> 32));
@@ -265,7 +282,10 @@ __global__ __launch_bounds__(NT) void knn_quad_kernel(int n, int m, int q_per_bl
                 dist2_all[o + j] = __uint_as_float((u32)(Lk[j] >> 32));
             }
         }
+        KQ_STAMP(5);
+        if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { dbg[9] = total; dbg[10] = overflow; }
     }
+#undef KQ_STAMP
 }
 
 #ifndef KQ_QPB
@@ -273,15 +293,15 @@ __global__ __launch_bounds__(NT) void knn_quad_kernel(int n, int m, int q_per_bl
 #endif
 
 template <int K>
-int launch_quad(int b, int n, int m, const float *xyz, const float *new_xyz, int *idx, float *dist2, hipStream_t st)
+int launch_quad(int b, int n, int m, const float *xyz, const float *new_xyz, int *idx, float *dist2, hipStream_t st, long long *dbg)
 {
     constexpr int NT = KQ_NT, PTS = 4096 / KQ_NT;
     const int qpb = KQ_QPB;
-    const size_t lds = (size_t)n * 16 + (size_t)KQ_AUX_FLOATS * 4 + (size_t)(KG_CELLS + 3) * 4 + (size_t)(NT / 4) * KQ_TCAP * 8 + (size_t)KQ_QCAP * NT * 2 +
+    const size_t lds = (size_t)n * 16 + (size_t)KQ_AUX_FLOATS * 4 + (size_t)(KG_CELLS + 3) * 4 + (size_t)(NT / 4) * (KQ_TCAP + 4) * 8 + (size_t)KQ_QCAP * NT * 2 +
                        (size_t)qpb * 2;
     auto kern = knn_quad_kernel<K, PTS, NT>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(pa_div_up(m, qpb), b), dim3(NT), lds, st, n, m, qpb, xyz, new_xyz, idx, dist2);
+    hipLaunchKernelGGL(kern, dim3(pa_div_up(m, qpb), b), dim3(NT), lds, st, n, m, qpb, xyz, new_xyz, idx, dist2, dbg);
     return 0;
 }
 
@@ -292,14 +312,14 @@ static int g_quad_on = -1;
 PA_API void pa_knn_quad_enable(int on) { g_quad_on = on ? 1 : 0; }
 
 // 1 when the quad kernel took the call, 0 when it is off or the shape is not one it is built for.
-int pa_knn_quad_try(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx, float *dist2, hipStream_t st)
+int pa_knn_quad_try(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx, float *dist2, hipStream_t st, long long *dbg)
 {
     if (g_quad_on < 0) g_quad_on = getenv("PA_KNN_NO_QUAD") != nullptr ? 0 : 1;
     if (!g_quad_on || n < 2048 || n > 4096 || m < 256) return 0;
     switch (nsample) {
-        case 16: launch_quad<16>(b, n, m, xyz, new_xyz, idx, dist2, st); return 1;
-        case 20: launch_quad<20>(b, n, m, xyz, new_xyz, idx, dist2, st); return 1;
-        case 32: launch_quad<32>(b, n, m, xyz, new_xyz, idx, dist2, st); return 1;
+        case 16: launch_quad<16>(b, n, m, xyz, new_xyz, idx, dist2, st, dbg); return 1;
+        case 20: launch_quad<20>(b, n, m, xyz, new_xyz, idx, dist2, st, dbg); return 1;
+        case 32: launch_quad<32>(b, n, m, xyz, new_xyz, idx, dist2, st, dbg); return 1;
         default: return 0;
     }
 }

@@ -23,5 +23,7 @@ for kind in ("uniform", "street"):
     buf = torch.zeros(16, dtype=torch.int64, device="cuda")
     lib.pa_knn_debug_buffer(ctypes.c_void_p(buf.data_ptr())); fn(); torch.cuda.synchronize(); lib.pa_knn_debug_buffer(None)
     t = buf.cpu().tolist()
+    if not os.environ.get("PA_KNN_LANE") and not os.environ.get("PA_KNN_NO_QUAD"):
+        print(f"   quad kernel, block 0 thread 0: cloud sort {t[1]-t[0]} cyc, query sort {t[2]-t[1]}, pass1 {t[3]-t[2]}, pass2 {t[4]-t[3]}, pass3 {t[5]-t[4]}; R = {t[8]}, keys {t[9]}, overflow {t[10]}")
     if os.environ.get("PA_KNN_LANE"):
         print(f"   block 0, thread 0: sort {t[1]-t[0]} cyc, pass1 {t[2]-t[1]}, pass2 {t[3]-t[2]}, pass3 {t[4]-t[3]}, store {t[5]-t[4]}; R = {t[6]}, queued {t[7]}; pass-1 candidates per lane: max {t[8]}, mean {t[9] / 64:.0f}")
