@@ -84,7 +84,7 @@ def main():
         losses = step()
         t = timed(step, 5, warm=2)
         res["config4_training_step"] = {"clouds": 18, "related_clouds": 3, "ms_fwd_bwd_opt": round(t * 1e3, 2), "losses": losses,
-                                        "note": "module path: autograd over the HIP point-op backward kernels + torch dense layers; quadruplet + patch Chamfer loss, Adam step"}
+                                        "note": "module path: autograd over the HIP point-op backward kernels + the HIP training GEMMs (csrc/train_gemm.hip); quadruplet + patch Chamfer loss, Adam step"}
     except Exception as ex:   # keep the other numbers
         res["config4_training_step"] = {"error": repr(ex)}
     model.eval()
