@@ -8,18 +8,23 @@
 // the 3-NN (three_nn_grid.hip: 2048 waves, short chains) took 0.030 ms instead of 0.085.  This kernel gives the kNN that shape: a QUAD of
 // adjacent lanes shares a query, lane j takes every fourth candidate of every cell row, so a batch is 2048 waves again and a lane's chain
 // is a quarter as long.
-//   pass 1  each lane keeps the K smallest DISTANCES of its quarter (sorted register array, one v_med3_f32 per slot and candidate);
-//           the quad's K-th smallest comes from two min / max merge steps over quad shuffles (no indices involved); shells are added
-//           until that K-th distance is provably smaller than anything unvisited (stop rule of three_nn_grid.hip / knn_lane.hip);
-//   pass 2  each lane walks its quarter again and queues the positions of the candidates with d <= K-th distance (~K / 4 per lane);
-//   pass 3  the quad's queued candidates become 64-bit (d2 bits, index) keys in LDS; a candidate's output slot is its rank among them
+//   pass 1  each lane keeps the K smallest TAGGED distances of its quarter in a sorted register list: the distance's bit pattern with the low
+//           12 mantissa bits replaced by the candidate's position, two integer min / max per slot and candidate; the quad's K-th smallest
+//           comes from min / max merges over quad shuffles; shells are added until the top of the K-th's truncation bucket is provably
+//           smaller than anything unvisited (stop rule of three_nn_grid.hip);
+//   pass 2  (none: the survivors' positions are in the lists) every list entry whose truncated distance is <= the K-th's is a candidate --
+//           the exact K best are among them;
+//   pass 3  the quad's candidates become exact 64-bit (d2 bits, index) keys in LDS; a candidate's output slot is its rank among them
 //           (exact (d2, index) order whatever the ties), slots beyond the candidates are (0, +inf).
-// More than KQ_QCAP queued candidates in a lane or KQ_TCAP in a quad (a dozen exact ties with the K-th distance: lattice clouds) sends the
-// query down a slow exact path: lane 0 of the quad inserts every candidate of the visited cells into a sorted key list.
+// A lane whose whole list qualifies (it may have dropped candidates) or more than KQ_TCAP candidates in a quad (a dozen ties inside one
+// 2^-12 bucket: lattice clouds) send the query down a slow exact path: lane 0 of the quad inserts every candidate of the visited cells into
+// a sorted key list.
 //
 // Measured (MI355X, b = 32, n = 4096, m = 1024, k = 20; tools/knn_time.py), uniform / plane-like clouds, wave-per-query kernel 148 / 150 us:
 //   256 threads, 128 queries per workgroup (one wave per SIMD, every LDS access at full latency)   158 / 219 us
-//   512 threads, 128 queries per workgroup (two waves per SIMD; shipped)                             97 / 172 us
+//   512 threads, 128 queries per workgroup (two waves per SIMD)                                      97 / 172 us
+//   + two candidates per trip, four keys per rank trip                                              88 / 151 us
+//   + tagged distances instead of a second walk (shipped)                                           see DESIGN.md
 //   1024 threads (64-register budget: spills)                                                      242 / 482 us
 // i.e. -35 % on uniform clouds (the benchmark distribution), +15 % on plane-like ones (dense cells: more candidates per neighbourhood and
 // more imbalance inside a wave); the cell-grid 3-NN gains on both (85 -> 30 / 45 us).
@@ -31,38 +36,43 @@
 namespace {
 
 constexpr u64 KQ_INF0 = ((u64)0x7F800000u) << 32;
-#ifndef KQ_QCAP_V
-#define KQ_QCAP_V 12
-#endif
+constexpr u32 KQ_NONE = 0x7F800000u;     // list entry "nothing": the bit pattern of +inf (every admissible tagged distance is below it)
+constexpr int KQ_TAG = 12;               // low mantissa bits of a list entry that hold the candidate's position in the sorted cloud (n <= 4096)
 #ifndef KQ_TCAP_V
 #define KQ_TCAP_V 32
 #endif
 #ifndef KQ_NT
 #define KQ_NT 512
 #endif
-constexpr int KQ_QCAP = KQ_QCAP_V;      // queued positions per lane
 constexpr int KQ_TCAP = KQ_TCAP_V;      // keys per query
 constexpr int KQ_AUX_FLOATS = KG_AUX_FLOATS + 8;
 
+__device__ __forceinline__ u32 med3_u32(u32 a, u32 b, u32 c)
+{
+    u32 r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // K smallest (ascending) of two ascending K-lists held by this lane (a) and the lane `mask` away (quad shuffle): bitonic merge on 32 slots
 template <int K>
-__device__ __forceinline__ void merge_pair(float (&a)[K], int mask)
+__device__ __forceinline__ void merge_pair(u32 (&a)[K], int mask)
 {
     static_assert(K <= 32, "padded to 32 slots");
-    float c[32];
+    u32 c[32];
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
         const int jb = 31 - j;                                   // partner element paired with slot j
-        float pb = INFINITY;
-        if (jb < K) pb = __shfl_xor(a[jb], mask);
-        c[j] = j < K ? (jb < K ? fminf(a[j], pb) : a[j]) : pb;    // min(A[j] or inf, B[31 - j] or inf)
+        u32 pb = KQ_NONE;
+        if (jb < K) pb = (u32)__shfl_xor((int)a[jb], mask);
+        c[j] = j < K ? (jb < K ? min(a[j], pb) : a[j]) : pb;      // min(A[j] or none, B[31 - j] or none)
     }
 #pragma unroll
     for (int s = 16; s >= 1; s >>= 1)
 #pragma unroll
         for (int i = 0; i < 32; ++i)
             if ((i & s) == 0) {
-                const float lo = fminf(c[i], c[i + s]), hi = fmaxf(c[i], c[i + s]);
+                const u32 lo = min(c[i], c[i + s]), hi = max(c[i], c[i + s]);
                 c[i] = lo;
                 c[i + s] = hi;
             }
@@ -84,8 +94,7 @@ __global__ __launch_bounds__(NT) void knn_quad_kernel(int n, int m, int q_per_bl
     float *grid = red + 16 * 6;
     int *qcnt = reinterpret_cast<int *>(grid + 8);
     u64 *keys = reinterpret_cast<u64 *>((reinterpret_cast<uintptr_t>(qcnt + KG_CELLS + 1) + 7) & ~(uintptr_t)7);   // [NQ][KQ_TCAP + 4], 8-byte aligned
-    unsigned short *queue = reinterpret_cast<unsigned short *>(keys + NQ * (KQ_TCAP + 4));    // [KQ_QCAP][NT]
-    unsigned short *qorder = queue + KQ_QCAP * NT;                                      // [q_per_block]
+    unsigned short *qorder = reinterpret_cast<unsigned short *>(keys + NQ * (KQ_TCAP + 4));   // [q_per_block]
     const int b = blockIdx.y, tid = threadIdx.x, part = tid & 3, ql = tid >> 2;
     const float *xyz = xyz_all + (size_t)b * n * 3;
     int nchunks;
@@ -184,61 +193,67 @@ __global__ __launch_bounds__(NT) void knn_quad_kernel(int n, int m, int q_per_bl
             return best;
         };
 
-        // ---- pass 1: this lane's K smallest distances; the quad's K-th smallest
-        float L[K];
+        // ---- pass 1: this lane's K smallest TAGGED distances.  A list entry is the distance's bit pattern with its low KQ_TAG bits replaced
+        // by the candidate's position in the sorted cloud: d >= 0, so unsigned order on the patterns is the order of the truncated distances
+        // (ties broken by position), the lists stay plain 32-bit integers (v_med3_u32 / v_min_u32 / v_max_u32: no float modes involved), and the
+        // positions of the survivors come back out of the list -- no second walk over the cells.
+        u32 L[K];
 #pragma unroll
-        for (int j = 0; j < K; ++j) L[j] = INFINITY;
-        auto pass1 = [&](int, const float4 &p) {
-            const float d = fminf(dist(p), INFINITY);   // NaN -> +inf: never admitted
+        for (int j = 0; j < K; ++j) L[j] = KQ_NONE;
+        auto pass1 = [&](int pos, const float4 &p) {
+            const u32 bits = __float_as_uint(dist(p));
+            const u32 d = bits < KQ_NONE ? ((bits & ~((1u << KQ_TAG) - 1u)) | (u32)pos) : KQ_NONE;     // +inf / NaN (either sign): never admitted
 #pragma unroll
-            for (int j = K - 1; j >= 1; --j) L[j] = __builtin_amdgcn_fmed3f(L[j - 1], d, L[j]);
-            L[0] = fminf(L[0], d);
+            for (int j = K - 1; j >= 1; --j) L[j] = med3_u32(L[j - 1], d, L[j]);
+            L[0] = min(L[0], d);
         };
-        auto quad_kth = [&]() {                        // K-th smallest of the four lanes' lists (same value in all four lanes)
-            float M[K];
+        auto quad_kth = [&]() {                        // K-th smallest entry of the four lanes' lists (same value in all four lanes)
+            u32 M[K];
 #pragma unroll
             for (int j = 0; j < K; ++j) M[j] = L[j];
             merge_pair<K>(M, 1);                        // lanes {0,1} and {2,3}: K smallest of each pair, ascending
-            float kth = 0.f;
+            u32 kth = 0u;
 #pragma unroll
-            for (int j = 0; j < K; ++j) kth = fmaxf(kth, fminf(M[j], __shfl_xor(M[K - 1 - j], 2)));   // the K smallest of the union are min(M[j], P[K-1-j])
+            for (int j = 0; j < K; ++j) kth = max(kth, min(M[j], (u32)__shfl_xor((int)M[K - 1 - j], 2)));   // the K smallest of the union are min(M[j], P[K-1-j])
             return kth;
         };
         int R = 1;
         scan(0, 1, part, 4, pass1);
-        float kth;
+        u32 kth;
         while (true) {
-            kth = quad_kth();                          // finite <=> the quad has seen K admissible candidates
-            if (R >= 7 || (tame && kth < INFINITY && kth < outside_bound(R))) break;
+            kth = quad_kth();                          // < KQ_NONE <=> the quad has seen K admissible candidates
+            // every distance whose truncation equals the K-th's is still a candidate: compare the stop bound with the top of that bucket
+            const float kth_hi = __uint_as_float(kth | ((1u << KQ_TAG) - 1u));
+            if (R >= 7 || (tame && kth < KQ_NONE && kth_hi < outside_bound(R))) break;
             ++R;
             scan(R, R, part, 4, pass1);
         }
-
         KQ_STAMP(3);
         if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) dbg[8] = R;
-        // ---- pass 2: positions of this lane's candidates with d <= kth
+        // ---- candidates: the exact K best all have a truncated distance <= the K-th's (at least K entries are <= the K-th entry, and anything
+        // with a larger truncated distance is farther than all of them).  A lane's candidates are a prefix of its sorted list; a lane whose
+        // whole list qualifies may have dropped some -> slow path.
+        const u32 tmax = kth >> KQ_TAG;
         int qn = 0;
-        auto pass2 = [&](int pos, const float4 &p) {
-            const float d = dist(p);
-            if (d <= kth && d < INFINITY) {
-                if (qn < KQ_QCAP) queue[qn * NT + tid] = (unsigned short)pos;
-                ++qn;
-            }
-        };
-        scan(0, R, part, 4, pass2);
+#pragma unroll
+        for (int j = 0; j < K; ++j) qn += (L[j] < KQ_NONE && (L[j] >> KQ_TAG) <= tmax) ? 1 : 0;
         KQ_STAMP(4);
         const int base = (tid & 63) & ~3;
         const int c0 = __shfl(qn, base), c1 = __shfl(qn, base + 1), c2 = __shfl(qn, base + 2), c3 = __shfl(qn, base + 3);
         const int total = c0 + c1 + c2 + c3;
-        const bool overflow = c0 > KQ_QCAP || c1 > KQ_QCAP || c2 > KQ_QCAP || c3 > KQ_QCAP || total > KQ_TCAP;
+        const bool overflow = c0 >= K || c1 >= K || c2 >= K || c3 >= K || total > KQ_TCAP;
         const size_t o = ((size_t)b * m + q) * K;
         if (!overflow) {
-            // ---- pass 3: keys to LDS, output slot = rank among the quad's keys
+            // ---- pass 3: exact keys to LDS, output slot = rank among the quad's keys
             const int off = (part > 0 ? c0 : 0) + (part > 1 ? c1 : 0) + (part > 2 ? c2 : 0);
             u64 *kq = keys + ql * (KQ_TCAP + 4);
-            for (int e = 0; e < qn; ++e) {
-                const float4 p = sorted[queue[e * NT + tid]];
-                kq[off + e] = pa_make_key(dist(p), (u32)__float_as_int(p.w));
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                if (!__any(j < qn)) break;
+                if (j < qn) {
+                    const float4 p = sorted[L[j] & ((1u << KQ_TAG) - 1u)];
+                    kq[off + j] = pa_make_key(dist(p), (u32)__float_as_int(p.w));
+                }
             }
             // (same wavefront: the LDS writes above are complete before the reads below are issued)
             if (part == 0) { kq[total] = ~0ull; kq[total + 1] = ~0ull; kq[total + 2] = ~0ull; }      // the rank loop reads four keys per trip
@@ -297,8 +312,7 @@ int launch_quad(int b, int n, int m, const float *xyz, const float *new_xyz, int
 {
     constexpr int NT = KQ_NT, PTS = 4096 / KQ_NT;
     const int qpb = KQ_QPB;
-    const size_t lds = (size_t)n * 16 + (size_t)KQ_AUX_FLOATS * 4 + (size_t)(KG_CELLS + 3) * 4 + (size_t)(NT / 4) * (KQ_TCAP + 4) * 8 + (size_t)KQ_QCAP * NT * 2 +
-                       (size_t)qpb * 2;
+    const size_t lds = (size_t)n * 16 + (size_t)KQ_AUX_FLOATS * 4 + (size_t)(KG_CELLS + 3) * 4 + (size_t)(NT / 4) * (KQ_TCAP + 4) * 8 + (size_t)qpb * 2;
     auto kern = knn_quad_kernel<K, PTS, NT>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(pa_div_up(m, qpb), b), dim3(NT), lds, st, n, m, qpb, xyz, new_xyz, idx, dist2, dbg);
