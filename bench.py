@@ -253,16 +253,29 @@ def train_bench(a):
     n = a.points
     q, pos, neg, oth = (torch.rand(1, k, n, 3, generator=g) * 2 - 1 for k in (1, 2, 14, 1))
     nn_dict = {(0, 1): torch.randint(0, n, (1024, 1), generator=g).numpy(), (0, 2): torch.randint(0, n, (1024, 1), generator=g).numpy()}
-    opt = torch.optim.Adam(model.parameters(), lr=1e-5)
+    graphed = not a.no_graphs
+    opt = torch.optim.Adam(model.parameters(), lr=1e-5, capturable=graphed)
     q, pos, neg, oth = (t.cuda() for t in (q, pos, neg, oth))           # inputs resident in HBM before the clock starts
+    if graphed:     # forward + losses + backward + Adam captured once (train.GraphedTrainer), one replay per step
+        from patchaugnet_amd.train import GraphedTrainer
+        try:
+            trainer = GraphedTrainer(model, opt, q, pos, neg, oth, nn_dict, num_points=n)
+            step = lambda: trainer.step(q, pos, neg, oth)
+        except Exception as ex:
+            print(f"bench.py: hipGraph capture of the training step failed ({ex!r}); eager launches instead", file=sys.stderr)
+            graphed = False
+            opt = torch.optim.Adam(model.parameters(), lr=1e-5)
+    if not graphed:
+        step = lambda: training_step(model, opt, q, pos, neg, oth, nn_dict=nn_dict, num_points=n)
     for _ in range(max(a.warmup, 2)):
-        losses = training_step(model, opt, q, pos, neg, oth, nn_dict=nn_dict, num_points=n)
+        losses = step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        losses = training_step(model, opt, q, pos, neg, oth, nn_dict=nn_dict, num_points=n)
+        losses = step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    losses = {k: float(v) for k, v in losses.items()}
     clouds = 18
     # dominant dense kernel: the 256 -> 256 layers of the finest feature-propagation level, forward form (BatchNorm + ReLU of the previous
     # layer in the operand loader, statistics in the epilogue), in isolation on the launch stream
@@ -282,7 +295,8 @@ def train_bench(a):
         "config": {"workload": f"PatchAugNet training step, quadruplet tuple of {clouds} x {n}-pt synthetic submaps (1+2+14+1), 3 related clouds "
                                "through the decoder, patch Chamfer + quadruplet loss, backward, Adam (BASELINE.json configs[3]), 1xMI355X",
                    "clouds_per_step": clouds, "points": n, "path": "HIP point ops + HIP training GEMMs (csrc/train_gemm.hip), autograd graph in torch",
-                   "weights": "key-seeded random init", "parallelism": "dp1"},
+                   "weights": "key-seeded random init", "parallelism": "dp1",
+                   "launch": "one hipGraph replay per step (forward + losses + backward + Adam)" if graphed else "python launches"},
         "losses_last_step": losses,
         "roofline": {"kernel": "tgemm_nn_kernel<128,true,1> (pa_tgemm_nn: 256 -> 256 layer of the finest FP level, forward: BatchNorm + ReLU of the "
                                "previous layer in the loader, statistics in the epilogue)", "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS,

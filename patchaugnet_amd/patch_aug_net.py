@@ -102,6 +102,8 @@ class Network(nn.Module):
         """The engine holds ctypes pointer arrays into device buffers: never copied or pickled (copy.deepcopy / torch.save of the module)."""
         st = self.__dict__.copy()
         st["_engine"] = None
+        st.pop("_related_key", None)
+        st.pop("_related_idx", None)
         return st
 
     def forward(self, x, nn_dict=None, return_feat=True, use_engine=None):
@@ -122,7 +124,10 @@ class Network(nn.Module):
             data = {"cloud_indices": related, "center_indices": [], "origin_patches": [], "patch_features": [],
                     "reconstructed_patches": []}
             hip_dec = self.use_a2a_recon and x.is_cuda and self.training and train_ops.hip_dense_enabled()
-            feats_cm = fp_features[1].squeeze(-1)[related]                                   # (R, 256, m0): one patch feature per column
+            key = (x.device, tuple(related))
+            if getattr(self, "_related_key", None) != key:      # device index tensor made once per key set (no host -> device copy per step)
+                self._related_key, self._related_idx = key, torch.tensor(related, dtype=torch.long, device=x.device)
+            feats_cm = fp_features[1].squeeze(-1).index_select(0, self._related_idx)         # (R, 256, m0): one patch feature per column
             if self.use_l2_norm:
                 feats_cm = F.normalize(feats_cm, dim=1)
             recon = self.decoder.forward_cm(feats_cm.contiguous()) if hip_dec else None      # all related clouds in one set of launches

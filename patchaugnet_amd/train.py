@@ -100,3 +100,80 @@ def update_global_descs(model, load_batch, n_total, batch_size=36, save_dirs=Non
     finally:
         model.train(was_training)
     return descs
+
+
+class GraphedTrainer:
+    """The whole training step -- forward (module path), quadruplet + patch-Chamfer losses, backward, optimizer step -- captured ONCE into
+    a hipGraph and replayed per batch (train_one_epoch's body, train_place_recognition.py:255-392, for a fixed tuple shape and a fixed
+    set of nn_dict keys).  An eager step issues ~700 launches from Python; on a slow or shared host that, not the GPU, sets the step
+    time.  Every launch of the step is capturable: the HIP ops run on the capture stream through the C ABI, nothing synchronises.
+
+    What changes against ``training_step``: the kNN permutation of ``QueryAndGroup_Edge`` (``torch.randperm`` on the host, pointops.py:553)
+    is drawn on the host per step and copied into a device buffer the graph reads; the zero-loss branch of :390-392 (skip backward when
+    the summed loss is <= 1e-10) is dropped -- with the reconstruction term in the sum the loss is never zero; the optimizer must be
+    built with ``capturable=True``; the contrastive patch-feature term (host-side table packing per step) is not part of the graph.
+    Losses come back as device scalars (no synchronisation unless the caller reads them)."""
+
+    def __init__(self, model, optimizer, queries, positives, negatives, other_neg, nn_dict, num_points=4096, args=DEFAULTS, loss_alpha=None,
+                 place_loss="quadruplet", recon_loss="patch_chamfer", warmup=3):
+        from . import pointops
+        self.model, self.optimizer, self.args, self.num_points = model, optimizer, dict(args), num_points
+        self.nn_dict = nn_dict
+        self.loss_alpha = loss_alpha or {"place_recognition": 1.0, "patch_recon_a2a": 1.0}
+        self.place_loss, self.recon_loss = place_loss, recon_loss
+        dev = next(model.parameters()).device
+        assert dev.type == "cuda", "GraphedTrainer runs on the MI355X"
+        assert all(g.get("capturable", True) for g in optimizer.param_groups), "build the optimizer with capturable=True (Adam / AdamW ...)"
+        self.device = dev
+        self.static = [_as_tensor(t).to(dev).clone() for t in (queries, positives, negatives, other_neg)]
+        self.groupers = [m for m in model.modules() if isinstance(m, pointops.QueryAndGroup_Edge) and m.radius is None and m.knn_dilation > 1]
+        for g in self.groupers:
+            g.perm_buffer = torch.randperm(g.nsample).to(dev)
+        model.train()
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(warmup):                    # allocator pools, lazy buffers and the optimizer state exist before capture
+                optimizer.zero_grad(set_to_none=True)
+                self._body()
+        cur.wait_stream(side)
+        torch.cuda.synchronize(dev)
+        optimizer.zero_grad(set_to_none=True)          # the captured backward then CREATES the gradients inside the graph's pool
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self.losses = self._body()
+        torch.cuda.synchronize(dev)
+
+    def _body(self):
+        q, p, n, o = self.static
+        out = run_model(self.model, q, p, n, o, self.nn_dict, self.num_points, True, device=self.device, args=self.args)
+        oq, op, on, oo = out["global_desc"]
+        a = self.args
+        cur = {"place_recognition": losses.get_loss_func(self.place_loss)(oq, op, on, oo, a["MARGIN_1"], a["MARGIN_2"], use_min=a["TRIPLET_USE_BEST_POSITIVES"],
+                                                                          lazy=a["LOSS_LAZY"], ignore_zero_loss=a["LOSS_IGNORE_ZERO_BATCH"])}
+        recon = out["patch_recon"]
+        if recon is not None and getattr(self.model, "use_a2a_recon", False):
+            cur["patch_recon_a2a"] = losses.get_loss_func(self.recon_loss)(recon["origin_patches"], recon["reconstructed_patches"])
+        total = 0.0
+        for k in cur:
+            cur[k] = cur[k] * self.loss_alpha.get(k, 1.0)
+            total = total + cur[k]
+        total.backward()
+        self.optimizer.step()
+        cur["total"] = total
+        return {k: v.detach() for k, v in cur.items()}
+
+    def step(self, queries, positives, negatives, other_neg):
+        """Copy the batch into the graph's input buffers, draw the step's kNN permutations, replay.  Returns the dict of weighted losses
+        (device scalars owned by the graph: valid until the next step)."""
+        for dst, src in zip(self.static, (queries, positives, negatives, other_neg)):
+            dst.copy_(_as_tensor(src), non_blocking=True)
+        for g in self.groupers:
+            g.perm_buffer.copy_(torch.randperm(g.nsample), non_blocking=True)
+        self.graph.replay()
+        return self.losses
+
+    def close(self):
+        for g in self.groupers:
+            g.perm_buffer = None

@@ -237,3 +237,46 @@ def test_training_dense_path_has_no_library_gemm():
     assert any("tgemm_nn_kernel" in n for n in names) and any("tgemm_kk_kernel" in n for n in names), names[:40]
     lib = [n for n in names if any(s in n for s in ("Cijk", "rocblas", "miopen", "MIOpen", "hipblas", "gemm_kernel", "batch_norm", "BatchNorm"))]
     assert not lib, lib
+
+
+def test_graphed_training_step_equals_the_eager_step():
+    """train.GraphedTrainer (forward + losses + backward + optimizer step in ONE hipGraph) against train.training_step on the same
+    weights, inputs and kNN permutations.  SGD for the three-step trajectory (an update proportional to the gradient keeps the atomics'
+    last-bit noise small; Adam's g / sqrt(v) turns it into sign flips on near-zero gradients), Adam(capturable) for one step."""
+    import copy
+    from patchaugnet_amd import configs, patch_aug_net
+    from patchaugnet_amd.train import DEFAULTS, GraphedTrainer, training_step
+    from patchaugnet_amd.weights import seeded_state_dict
+    n = 1024
+    cfg = configs.scaled_config(configs.patch_aug_net_config(), n)
+    base = patch_aug_net.Network(param=cfg, use_a2a_recon=True, use_l2_norm=True)
+    base.load_state_dict(seeded_state_dict(base.state_dict()))
+    base = base.cuda()
+    g = torch.Generator().manual_seed(3)
+    batches = [tuple((torch.rand(1, k, n, 3, generator=g) * 2 - 1).cuda() for k in (1, 2, 4, 1)) for _ in range(3)]
+    nn_dict = {(0, 1): None, (0, 2): None}
+    args = dict(DEFAULTS, TRAIN_NEGATIVES_PER_QUERY=4)
+    for make, steps in ((lambda ps, cap: torch.optim.SGD(ps, lr=2e-3), 3), (lambda ps, cap: torch.optim.Adam(ps, lr=1e-4, capturable=cap), 1)):
+        m0, m1 = copy.deepcopy(base), copy.deepcopy(base)
+        o0, o1 = make(m0.parameters(), False), make(m1.parameters(), True)
+        tr = GraphedTrainer(m1, o1, *batches[0], nn_dict, num_points=n, args=args, warmup=2)
+        m1.load_state_dict(base.state_dict())               # the warm-up steps moved m1: start both from the same point again ...
+        for st in o1.state.values():                        # ... and the optimizer state IN PLACE (the graph holds these tensors' addresses)
+            for v in st.values():
+                if torch.is_tensor(v):
+                    v.zero_()
+        for i, b in enumerate(batches[:steps]):
+            torch.manual_seed(11 + i)
+            e = training_step(m0, o0, *b, nn_dict=nn_dict, num_points=n, args=args)
+            torch.manual_seed(11 + i)
+            gl = {k: float(v) for k, v in tr.step(*b).items()}
+            for k in e:
+                assert abs(e[k] - gl[k]) <= (2e-5 if i == 0 else 1e-2) * max(1.0, abs(e[k])), (i, k, e[k], gl[k])
+        sd0, sd1 = m0.state_dict(), m1.state_dict()
+        # the two trajectories share every kernel but not the order of their fp32 atomics: per tensor within 1e-3 in relative L2
+        # (tensors of norm < 1: absolute), worst single element within 3e-2 of the tensor's largest
+        for k in sd0:
+            a, c = sd0[k].double(), sd1[k].double()
+            assert ((a - c).norm() / a.norm().clamp_min(1.0)).item() <= 5e-3, k
+            assert ((a - c).abs().max() / a.abs().max().clamp_min(1e-2)).item() <= 3e-2, k
+        tr.close()
