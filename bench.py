@@ -254,7 +254,7 @@ def train_bench(a):
     q, pos, neg, oth = (torch.rand(1, k, n, 3, generator=g) * 2 - 1 for k in (1, 2, 14, 1))
     nn_dict = {(0, 1): torch.randint(0, n, (1024, 1), generator=g).numpy(), (0, 2): torch.randint(0, n, (1024, 1), generator=g).numpy()}
     graphed = not a.no_graphs
-    opt = torch.optim.Adam(model.parameters(), lr=1e-5, capturable=graphed)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-5, capturable=graphed, fused=graphed)   # fused: one multi-tensor kernel instead of ~300 small ones
     q, pos, neg, oth = (t.cuda() for t in (q, pos, neg, oth))           # inputs resident in HBM before the clock starts
     if graphed:     # forward + losses + backward + Adam captured once (train.GraphedTrainer), one replay per step
         from patchaugnet_amd.train import GraphedTrainer
