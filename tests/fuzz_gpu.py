@@ -81,6 +81,62 @@ def f_knn():
         return f"b={b} n={n} m={m} k={k}"
 
 
+def hard_cloud(b, n):
+    """clouds that stress the cell-grid kernels: everything cloud() draws, plus dense clusters with far outliers, anisotropic boxes,
+    tiny scales, large offsets (coarse fp32 grid of coordinates), a line"""
+    kind = rng.integers(0, 9)
+    if kind < 4:
+        return cloud(b, n)
+    x = (rng.random((b, n, 3), dtype=np.float32) * 2 - 1).astype(np.float32)
+    if kind == 4 and n > 50:
+        x[:, : n - n // 50] = (x[:, : n - n // 50] * rng.choice([0.01, 0.05, 0.2]) + rng.uniform(-0.8, 0.8, 3)).astype(np.float32)
+    elif kind == 5:
+        x = (x * np.array([1.0, rng.choice([0.01, 0.1]), rng.choice([1e-3, 0.5])], dtype=np.float32)).astype(np.float32)
+    elif kind == 6:
+        x = (x * np.float32(rng.choice([1e-3, 1e-2, 30.0]))).astype(np.float32)
+    elif kind == 7:
+        x = (x + np.float32(rng.choice([100.0, 1000.0, -5000.0]))).astype(np.float32)
+    elif kind == 8:
+        x[..., 1] = x[..., 0] * 0.5
+        x[..., 2] = -0.25
+    return x
+
+
+def f_knn_grid():
+    """the four-lanes-per-query kernel's domain (knn_quad.hip): 2048..4096 source points, >= 256 queries, 16 / 20 / 32 neighbours"""
+    b, n, m = int(rng.integers(1, 3)), int(rng.integers(2048, 4097)), int(rng.integers(256, 1300))
+    k = int(rng.choice([16, 20, 32]))
+    x = hard_cloud(b, n)
+    mode = rng.integers(0, 3)
+    if mode == 0:
+        q = x[:, rng.choice(n, min(m, n), replace=False)].copy()
+    elif mode == 1:
+        q = hard_cloud(b, m)
+    else:                                   # queries around the cloud, some far outside its box
+        q = (x[:, rng.choice(n, m)] + rng.standard_normal((b, m, 3)).astype(np.float32) * np.float32(rng.choice([1e-4, 0.05, 3.0]))).astype(np.float32)
+    ri, rd = o.knnquery(k, x, q)
+    gi, gd = P.knnquery_with_dist(k, dev(x), dev(q))
+    if not (np.array_equal(gi.cpu().numpy(), ri) and np.array_equal(gd.cpu().numpy().view(np.uint32), rd.view(np.uint32))):
+        return f"b={b} n={n} m={q.shape[1]} k={k} mode={mode}"
+
+
+def f_3nn_grid():
+    """the cell-grid 3-NN's domain (three_nn_grid.hip): 512..4096 known points, >= 1024 queries"""
+    b, m, n = int(rng.integers(1, 3)), int(rng.integers(512, 4097)), int(rng.integers(1024, 5000))
+    kn = hard_cloud(b, m)
+    mode = rng.integers(0, 3)
+    if mode == 0:
+        u = hard_cloud(b, n)
+    elif mode == 1:
+        u = (kn[:, rng.choice(m, n)] + rng.standard_normal((b, n, 3)).astype(np.float32) * np.float32(rng.choice([0.0, 1e-4, 0.05, 3.0]))).astype(np.float32)
+    else:
+        u = np.concatenate([kn, hard_cloud(b, n)], 1)[:, :n].copy()
+    rd, ri = o.nearestneighbor(u, kn)
+    gd, gi = P.nearestneighbor(dev(u), dev(kn))
+    if not (np.array_equal(gi.cpu().numpy(), ri) and np.array_equal(gd.cpu().numpy(), np.sqrt(rd))):
+        return f"b={b} n={n} m={m} mode={mode}"
+
+
 def f_3nn():
     b, n, m = int(rng.integers(1, 4)), logint(1, 5000), logint(1, 3000)
     u, kn = cloud(b, n), cloud(b, m)
@@ -271,7 +327,7 @@ def f_afa():
         return f"b={b} ktot={ktot} err={e1} err_rows={e2}"
 
 
-FAMILIES = (("fps", f_fps), ("knn", f_knn), ("3nn", f_3nn), ("gather", f_gather), ("backward", f_backward), ("linear", f_linear),
+FAMILIES = (("fps", f_fps), ("knn", f_knn), ("3nn", f_3nn), ("knn_grid", f_knn_grid), ("3nn_grid", f_3nn_grid), ("gather", f_gather), ("backward", f_backward), ("linear", f_linear),
             ("attention", f_attention), ("chain_sa", f_chain_sa), ("chain_fp", f_chain_fp), ("netvlad", f_netvlad), ("afa", f_afa))
 
 if __name__ == "__main__":
