@@ -255,8 +255,12 @@ __global__ __launch_bounds__(NT) void knn_quad_kernel(int n, int m, int q_per_bl
                     kq[off + j] = pa_make_key(dist(p), (u32)__float_as_int(p.w));
                 }
             }
-            // (same wavefront: the LDS writes above are complete before the reads below are issued)
             if (part == 0) { kq[total] = ~0ull; kq[total + 1] = ~0ull; kq[total + 2] = ~0ull; }      // the rank loop reads four keys per trip
+            // the four lanes of a quad read each other's keys: same wavefront, LDS operations retire in order; the fence keeps the compiler
+            // from moving the reads above the writes
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             for (int e = 0; e < qn; ++e) {
                 const u64 mine = kq[off + e];
                 int rank = 0;
