@@ -149,6 +149,12 @@ int pa_mlp_chain(int mode, int pooled, int nlayers, const float *const *wt, cons
 int pa_fp_chain_premul(int nlayers, const float *const *wt, const float *const *wpk, const float *const *bias, const int *kpad, const int *nout,
                        long rows, const float *g, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2,
                        int c1, const float *wskip, const float *wskip_p, const float *bias0, float *out, int ldo, pa_stream_t stream);
+/* Same with a fused tail: the last layer (wt[nlayers - 1], zero bias, relu_last = 0) is the next finer level's pre-multiply applied to this
+ * level's output; that output (the result of layer nlayers - 2) leaves through tap (ldtap), the pre-multiplied rows through out. */
+int pa_fp_chain_premul_tap(int nlayers, const float *const *wt, const float *const *wpk, const float *const *bias, const int *kpad, const int *nout,
+                           long rows, const float *g, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2,
+                           int c1, const float *wskip, const float *wskip_p, const float *bias0, float *out, int ldo, float *tap, int ldtap,
+                           int relu_last, pa_stream_t stream);
 /*   c1 > 4 (coarser levels, skip = encoder features, c1 % 4 == 0, nlayers <= 2): the first layer stays in the chain as a c1-wide
  *   contraction over the skip channels (wskip, optional packed copy wskip_p) whose output gets the interpolated term added. */
 

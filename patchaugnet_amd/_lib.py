@@ -48,6 +48,7 @@ _SIGS = {
     "pa_linear_f16": "liipipppipipi",
     "pa_fp_chain_premul_f16": "ippppplppppiiiippppi",
     "pa_fp_chain_premul": "ippppplppppiiiippppi",
+    "pa_fp_chain_premul_tap": "ippppplppppiiiippppipii",
     "pa_fpx256": "lppppiiipppppppi",
     "pa_mlp_chain_packed": "iiippppplipippppiiiippppiiiipi",
     "pa_sa_attention": "iiipppp",

@@ -312,6 +312,19 @@ __device__ __forceinline__ void copy_rows_out(const float *act, int ostride, int
     }
 }
 
+// hidden tile (rows x n, LDS row stride even) -> global rows, 8-byte pieces (the activation stride is even, not a multiple of 4)
+template <int R>
+__device__ __forceinline__ void copy_rows_tap(const float *act, int stride, int n, float *__restrict__ out, int ldo, long row0, long rows, int tid, int nth)
+{
+    const int hpr = n >> 1;
+    for (int q = tid; q < R * hpr; q += nth) {
+        const int r = q / hpr, part = q - r * hpr;
+        const long row = row0 + r;
+        if (row >= rows) continue;
+        *reinterpret_cast<float2 *>(out + row * ldo + part * 2) = *reinterpret_cast<const float2 *>(act + r * stride + part * 2);
+    }
+}
+
 template <int RT, int NC, int MODE, bool POOLED, int WPT>
 __device__ __forceinline__ void run_layer_chunks(float *act, const PaChain &a, const PaLayer &L, float *out, const float *residual, int l, long tile,
                                                  int lane, int c_begin, int c_end)
@@ -350,8 +363,13 @@ __device__ __forceinline__ void run_layer_chunks(float *act, const PaChain &a, c
             else store_rows<RT, NC, false>(out, a.ldo, tile * (RT * 16), total_rows, L, c0, lane, acc, a.relu_last, residual, a.ldr);
         }
     }
-    if (!last) tile_sync<WPT>();
-    else if (!POOLED && a.ep_stride > 0) {
+    if (!last) {
+        tile_sync<WPT>();
+        if (!POOLED && a.tap && l == a.nlayers - 2) {       // second output: this layer's result, straight from the tile the next layer reads
+            const long total_rows = (MODE == MODE_SA) ? a.rows * a.ns : a.rows;
+            copy_rows_tap<RT * 16>(act, a.lds_stride, L.n, a.tap, a.ldtap, tile * (RT * 16), total_rows, WPT == 1 ? lane : (int)threadIdx.x, WPT * 64);
+        }
+    } else if (!POOLED && a.ep_stride > 0) {
         tile_sync<WPT>();
         const long total_rows = (MODE == MODE_SA) ? a.rows * a.ns : a.rows;
         copy_rows_out<RT * 16>(act, a.ep_stride, L.n, out, a.ldo, tile * (RT * 16), total_rows, residual, a.ldr,
@@ -465,7 +483,8 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
                           const float *xyz, const float *feat, const int *center_idx, const int *nbr_idx, int n_src, int m_ctr, int ns, int c_feat,
                           const float *known, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2, int c1,
                           float *out, int ldo, int relu_last, const float *residual, int ldr, pa_stream_t stream,
-                          const float *wskip = nullptr, const float *bias0 = nullptr, const void *const *wp16 = nullptr, int fold0 = 0, int col_slices = 1)
+                          const float *wskip = nullptr, const float *bias0 = nullptr, const void *const *wp16 = nullptr, int fold0 = 0, int col_slices = 1,
+                          float *tap = nullptr, int ldtap = 0)
 {
     PA_REQUIRE(nlayers >= 1 && nlayers <= 3, "pa_mlp_chain: nlayers=%d must be 1..3", nlayers);
     PA_REQUIRE(rows > 0 && k0 > 0 && out, "pa_mlp_chain: rows/k0 must be positive and out non-null");
@@ -495,6 +514,9 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
     a.known = known; a.idx3 = idx3; a.w3 = w3; a.skip = skip; a.n_unknown = n_unknown; a.m_known = m_known; a.c2 = c2; a.c1 = c1;
     a.wskip = wskip; a.bias0 = bias0;
     a.out = out; a.ldo = ldo;
+    a.tap = tap; a.ldtap = ldtap;
+    PA_REQUIRE(tap == nullptr || (nlayers >= 2 && pooled == 0 && !wp16 && ldtap % 2 == 0 && ldtap >= nout[nlayers - 2] && nout[nlayers - 2] % 2 == 0 &&
+                                  ((uintptr_t)tap & 7) == 0), "pa_mlp_chain: the tap output needs >= 2 fp32 layers, an unpooled chain and 8-byte aligned rows");
     a.relu_last = relu_last; a.residual = residual; a.ldr = ldr;
     a.dbg = g_chain_dbg;
     if (col_slices > 1) {   // pa_linear over few rows: nout[0] is the slice width
@@ -687,11 +709,11 @@ PA_API int pa_linear(long rows, int k, int n, const float *x, int ldx, const flo
 static int fp_premul_dispatch(int nlayers, const float *const *wt, const float *const *wpk, const void *const *wp16, const float *const *bias,
                               const int *kpad, const int *nout, long rows, const float *g, const int *idx3, const float *w3, const float *skip,
                               int n_unknown, int m_known, int c2, int c1, const float *wskip, const float *wskip_p, const void *wskip16,
-                              const float *bias0, float *out, int ldo, pa_stream_t stream)
+                              const float *bias0, float *out, int ldo, pa_stream_t stream, float *tap = nullptr, int ldtap = 0, int relu_last = 1)
 {
     if (c1 <= 4)
         return chain_dispatch(MODE_FPX, 0, nlayers, wt, wpk, bias, kpad, nout, rows, c2, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0,
-                              g, idx3, w3, skip, n_unknown, m_known, c2, c1, out, ldo, 1, nullptr, 0, stream, wskip, bias0, wp16);
+                              g, idx3, w3, skip, n_unknown, m_known, c2, c1, out, ldo, relu_last, nullptr, 0, stream, wskip, bias0, wp16, 0, 1, tap, ldtap);
     PA_REQUIRE(nlayers >= 1 && nlayers <= 2 && c1 % 4 == 0 && wskip && bias0, "pa_fp_chain_premul: c1=%d > 4 needs c1 %% 4 == 0 and at most 2 remaining layers", c1);
     const float *wt2[3] = {wskip, wt[0], nlayers > 1 ? wt[1] : nullptr};
     const float *wp2[3] = {wskip_p, wpk ? wpk[0] : nullptr, (wpk && nlayers > 1) ? wpk[1] : nullptr};
@@ -699,7 +721,8 @@ static int fp_premul_dispatch(int nlayers, const float *const *wt, const float *
     const float *b2[3] = {bias0, bias[0], nlayers > 1 ? bias[1] : nullptr};
     const int k2[3] = {c1, kpad[0], nlayers > 1 ? kpad[1] : 0}, n2[3] = {c2, nout[0], nlayers > 1 ? nout[1] : 0};
     return chain_dispatch(MODE_FP, 0, nlayers + 1, wt2, wp2, b2, k2, n2, rows, c1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0,
-                          g, idx3, w3, skip, n_unknown, m_known, c2, c1, out, ldo, 1, nullptr, 0, stream, nullptr, nullptr, wp16 ? w162 : nullptr, 1);
+                          g, idx3, w3, skip, n_unknown, m_known, c2, c1, out, ldo, relu_last, nullptr, 0, stream, nullptr, nullptr, wp16 ? w162 : nullptr, 1, 1,
+                          tap, ldtap);
 }
 
 PA_API int pa_fp_chain_premul(int nlayers, const float *const *wt, const float *const *wpk, const float *const *bias, const int *kpad, const int *nout,
@@ -708,6 +731,19 @@ PA_API int pa_fp_chain_premul(int nlayers, const float *const *wt, const float *
 {
     return fp_premul_dispatch(nlayers, wt, wpk, nullptr, bias, kpad, nout, rows, g, idx3, w3, skip, n_unknown, m_known, c2, c1, wskip, wskip_p, nullptr,
                               bias0, out, ldo, stream);
+}
+
+// pa_fp_chain_premul with a fused tail: the chain's LAST layer (wt[nlayers - 1], relu_last = 0, zero bias) is the NEXT finer level's pre-multiply
+// applied to this level's output, which is the result of layer nlayers - 2 and leaves through `tap` (ldtap) -- one launch instead of the
+// chain + a pa_linear over the same rows, and the tile is contracted while it is still in LDS.
+PA_API int pa_fp_chain_premul_tap(int nlayers, const float *const *wt, const float *const *wpk, const float *const *bias, const int *kpad, const int *nout,
+                                  long rows, const float *g, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2,
+                                  int c1, const float *wskip, const float *wskip_p, const float *bias0, float *out, int ldo, float *tap, int ldtap,
+                                  int relu_last, pa_stream_t stream)
+{
+    PA_REQUIRE(tap, "pa_fp_chain_premul_tap: null tap");
+    return fp_premul_dispatch(nlayers, wt, wpk, nullptr, bias, kpad, nout, rows, g, idx3, w3, skip, n_unknown, m_known, c2, c1, wskip, wskip_p, nullptr,
+                              bias0, out, ldo, stream, tap, ldtap, relu_last);
 }
 
 // ---- fp16-operand variants (BASELINE configs[4], opt-in): same arguments, wp16[l] = pa_pack_weights_f16 of layer l -----------

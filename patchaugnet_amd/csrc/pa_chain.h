@@ -44,6 +44,8 @@ struct PaChain {
     const float *bias0;  // (c2)
     float *out;
     int ldo;
+    float *tap;                  // optional second output: the result of layer nlayers - 2 (row-major, ldtap), written when that layer finishes --
+    int ldtap;                   // the chain then continues with one more layer on the tile that is still in LDS (fused pre-multiply)
     // last-layer epilogue (plain rows only): out = residual + act(acc + bias), act = ReLU when relu_last != 0 else identity
     int relu_last;
     const float *residual;   // (rows, ldr) or null

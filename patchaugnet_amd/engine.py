@@ -156,21 +156,50 @@ class _Chain:
         if kperm and not self.f16 and m == 2 and all(l[2] == 256 and l[4] == 256 for l in rest):
             self._premul["kperm"] = [pack_weights_kperm(l[0]) for l in rest]
 
-    def fp_premul(self, known_feat, idx3, w3, skip, B, n_unknown, m_known, c2, c1, mark=None):
+    def attach_tail(self, finer):
+        """Fuse the NEXT finer level's pre-multiply into this level's chain (pa_fp_chain_premul_tap): its first-layer slice w1a becomes one
+        more layer (no bias, no ReLU) on this level's output tile while that is still in LDS.  Packed once, at engine construction."""
+        pm, fm = self._premul, finer._premul
+        assert pm["m"] + 1 <= 2 and fm["w1a"].shape[0] == self.n_last and not self.f16
+        m = pm["m"] + 1
+        rest = self.layers[1:]
+        zero = torch.zeros(fm["n0"], dtype=torch.float32, device=fm["w1a"].device)
+        packed = list(self.packed[1:]) + [fm["w1a_p"]]
+        self._tail = {
+            "m": m, "zero": zero, "n_tail": fm["n0"],
+            "wt": (ctypes.c_void_p * m)(*([l[0].data_ptr() for l in rest] + [fm["w1a"].data_ptr()])),
+            "wpk": (ctypes.c_void_p * m)(*[(p.data_ptr() if p is not None else None) for p in packed]),
+            "bias": (ctypes.c_void_p * m)(*([l[1].data_ptr() for l in rest] + [zero.data_ptr()])),
+            "kpad": (ctypes.c_int * m)(*([l[3] for l in rest] + [fm["w1a"].shape[0]])),
+            "nout": (ctypes.c_int * m)(*([l[4] for l in rest] + [fm["n0"]])),
+        }
+
+    def fp_premul(self, known_feat, idx3, w3, skip, B, n_unknown, m_known, c2, c1, mark=None, g_pre=None, tail=False):
         """Finest feature-propagation level: the first layer is applied to the m_known coarse points BEFORE interpolation
         (pa_fp_chain_premul; interpolation is linear), the skip (xyz) term is added in the kernel's prologue."""
         dev = known_feat.device
         if getattr(self, "_premul", None) is None or (self._premul["c2"], self._premul["c1"]) != (c2, c1):
             raise RuntimeError("fp_premul: build_premul(c2, c1) was not run for this level at engine construction")
         pm = self._premul
-        g = torch.empty((B * m_known, pm["n0"]), dtype=torch.float32, device=dev)
-        call("pa_linear_f16" if self.f16 else "pa_linear", B * m_known, c2, pm["n0"], ptr(known_feat), c2, ptr(pm["w1a"]), ptr(pm["w1a_p"]),
-             ptr(pm["zero"]), 0, None, 0, ptr(g), pm["n0"])
+        if g_pre is not None:       # the coarser level's chain already produced known_feat . w1a (attach_tail)
+            g = g_pre
+        else:
+            g = torch.empty((B * m_known, pm["n0"]), dtype=torch.float32, device=dev)
+            call("pa_linear_f16" if self.f16 else "pa_linear", B * m_known, c2, pm["n0"], ptr(known_feat), c2, ptr(pm["w1a"]), ptr(pm["w1a_p"]),
+                 ptr(pm["zero"]), 0, None, 0, ptr(g), pm["n0"])
         if mark is not None:
             mark()
         rows = B * n_unknown
         out = torch.empty((rows, self.n_last), dtype=torch.float32, device=dev)
         rest = self.layers[1:]
+        if tail:                    # this level's output leaves through the tap, the finer level's pre-multiplied rows through `out`
+            tl = self._tail
+            g_next = torch.empty((rows, tl["n_tail"]), dtype=torch.float32, device=dev)
+            cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
+            call("pa_fp_chain_premul_tap", tl["m"], cast(tl["wt"]), cast(tl["wpk"]), cast(tl["bias"]), cast(tl["kpad"]), cast(tl["nout"]), rows,
+                 ptr(g), ptr(idx3), ptr(w3), ptr(skip), n_unknown, m_known, pm["n0"], c1, ptr(pm["wskip"]), ptr(pm["wskip_p"]), ptr(pm["bias0"]),
+                 ptr(g_next), tl["n_tail"], ptr(out), self.n_last, 0)
+            return out, g_next
         if (not self.f16 and c1 <= 4 and pm["n0"] == 256 and len(rest) == 2 and all(l[2] == 256 and l[4] == 256 for l in rest)
                 and "kperm" in pm):
             # experimental register-resident variant (fpx_reg.hip, opt-in: slower than the LDS-tiled kernel so far); a function of the
@@ -428,6 +457,18 @@ class PatchAugNetEngine:
                 self._fold_static.append(ok)
                 if ok:
                     chain.build_premul(c2, c1, kperm=os.environ.get("PA_ENGINE_FPX_REG", "0") == "1")
+            # a level whose chain runs as [skip layer | one 256-wide layer] can carry the next finer level's pre-multiply as a third layer
+            # (pa_fp_chain_premul_tap).  Measured at B = 32 and NOT the default: the pre-multiply launch goes 0.050 -> 0.005 ms but the
+            # shared-tile chain that now carries it 0.072 -> 0.112 ms (the stand-alone launch runs the faster eight-wave tiling) -- net zero.
+            self._tail_static = [False] * nfp
+            if os.environ.get("PA_ENGINE_TAIL") is not None:
+                for j in range(1, nfp):
+                    c1 = self.sa[j - 1].n_last
+                    fine, here = self.fp[j - 1], self.fp[j]
+                    if (self._fold_static[j] and self._fold_static[j - 1] and c1 > 4 and not here.f16 and here._premul["m"] == 1 and here._premul["wskip_p"] is not None
+                            and fine._premul["w1a_p"] is not None and here.n_last % 64 == 0 and fine._premul["n0"] % 64 == 0):
+                        here.attach_tail(fine)
+                        self._tail_static[j] = True
         self._tensors = list(model.parameters()) + list(model.buffers())
         self._key = self._params_key(model)
         self.timer = None     # optional profiling.StageTimer: per-stage HIP-event marks (bench.py kernel attribution)
@@ -487,6 +528,7 @@ class PatchAugNetEngine:
             l_c.append(cidx)
             c_feat = chain.n_last
         nfp = len(self.fp)
+        g_pre = None
         for i in range(-1, -(nfp + 1), -1):
             chain = self.fp[nfp + i]
             unknown, known = l_xyz[i - 1], l_xyz[i]
@@ -504,9 +546,18 @@ class PatchAugNetEngine:
             # c1 <= 4 (xyz skip): always; wider skips only at levels with enough points per cloud to amortise the extra pre-multiply
             # launch (a per-level rule, NOT a function of the batch size: results must not depend on how clouds are batched)
             if self._fold_static[nfp + i] and (c1 <= 4 or n_u >= 512) and n_u >= 2 * m_k:
-                y = chain.fp_premul(known_feat.contiguous(), idx3, w3, skip.contiguous(), B, n_u, m_k, c2, c1,
-                                    mark=lambda k=nfp + i: self._mark(f"fp{k}.premul"))
+                # the finer level's pre-multiply rides on this level's chain when that level will take the pre-multiplied path too
+                # (a per-level rule on the architecture's point counts, like the condition above: never a function of the batch size)
+                fuse = False
+                if self._tail_static[nfp + i] and nfp + i >= 1:
+                    nn_u, nm_k = l_xyz[i - 2].shape[1], n_u
+                    nc1 = (3 if self.use_origin else 0) if nfp + i - 1 == 0 else self.sa[nfp + i - 2].n_last
+                    fuse = (nc1 <= 4 or nn_u >= 512) and nn_u >= 2 * nm_k
+                res = chain.fp_premul(known_feat.contiguous(), idx3, w3, skip.contiguous(), B, n_u, m_k, c2, c1,
+                                      mark=lambda k=nfp + i: self._mark(f"fp{k}.premul"), g_pre=g_pre, tail=fuse)
+                y, g_pre = res if fuse else (res, None)
             else:
+                g_pre = None
                 y = chain.fp(known_feat.contiguous(), idx3, w3, skip.contiguous() if skip is not None else None, B, n_u, m_k, c2, c1)
             self._mark(f"fp{nfp + i}.chain")
             l_feat[i - 1] = y.view(B, n_u, chain.n_last)
