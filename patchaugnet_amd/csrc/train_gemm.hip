@@ -16,6 +16,7 @@
 //   * two thin HBM-bound passes remain per layer: the statistics finalize (a few hundred channels) and the dZ reduction that BatchNorm's
 //     backward needs before any dY can be formed.
 // Kernels are LDS-tiled (BM x 128 x 16, register-staged double buffer, one barrier per k-tile), v_mfma_f32_16x16x4_f32.
+#include <stdlib.h>
 #include <string.h>
 
 #include "pa_common.h"
@@ -622,6 +623,20 @@ PA_API int pa_tgemm_kk(int batch, int M, int N, long K, const float *A, long sAb
     long splits = (2048 + tiles - 1) / tiles;                  // aim at ~2048 workgroups
     const long maxsplits = (K + 4 * KK_BK - 1) / (4 * KK_BK);  // at least 4 k-tiles per split
     if (splits > maxsplits) splits = maxsplits;
+    // every split adds its partial tile with fp32 atomics: (batch x splits) workgroups per output address.  With few output tiles (the
+    // 32 x 6 weight gradient of the first set-abstraction layer over 18 x 20 480 points) 2000 workgroups queue up on 192 addresses (186 us
+    // for 56 MB of operands); the sum of the k-loop (~ K / 32 / splits tile rounds) and of the queue (~ contributors x one atomic) is smallest
+    // at splits = sqrt(c (K / 32) / contributors per split); c = 30 from a sweep of the three first-level shapes (tools/kk_splits.py:
+    // 32 splits: 186 / 85 / 92 us -> 100 / 69 / 72 us)
+    {
+        const double per_split = per_batch ? 1.0 : (double)batch;
+        const long cap = (long)(sqrt(30.0 * ((double)K / KK_BK) / per_split) + 0.999);
+        if (splits > cap) splits = cap < 1 ? 1 : cap;
+    }
+    {
+        static const long force = getenv("PA_KK_SPLITS") ? atol(getenv("PA_KK_SPLITS")) : 0;   // tuning knob
+        if (force > 0) splits = force > maxsplits ? maxsplits : force;
+    }
     if (splits < 1) splits = 1;
     long chunk = ((K + splits - 1) / splits + KK_BK - 1) / KK_BK * KK_BK;
     splits = (K + chunk - 1) / chunk;
