@@ -472,6 +472,12 @@ class PatchAugNetEngine:
         self._tensors = list(model.parameters()) + list(model.buffers())
         self._key = self._params_key(model)
         self.timer = None     # optional profiling.StageTimer: per-stage HIP-event marks (bench.py kernel attribution)
+        # latency mode (model.geo_overlap = True or PA_ENGINE_GEO_OVERLAP=1): coordinate-only kernels of the coarser levels on a side stream.
+        # Single-stream step at B = 32: 1.78 -> 1.68 ms, at B = 1: 1.25 -> 1.16 ms.  NOT for the throughput pipeline: a captured graph with
+        # a forked branch serialises against the other streams' graphs at replay (34.5 k -> 18.7 k submaps/s measured), so it is never
+        # applied while a stream is capturing.
+        self.geo_overlap = os.environ.get("PA_ENGINE_GEO_OVERLAP") is not None
+        self._geo_streams = {}
 
     def _mark(self, name):
         if self.timer is not None:
@@ -498,44 +504,95 @@ class PatchAugNetEngine:
         return self._key != self._params_key(model)
 
     def backbone(self, xyz):
-        """xyz (B, N, 3) -> point-major features per level + level-0 centre indices."""
+        """xyz (B, N, 3) -> point-major features per level + level-0 centre indices.
+
+        Everything that depends on coordinates only -- sampling, kNN and 3-NN of every level -- is independent of the feature chains.
+        Level 0 (the long one: 1024 serial FPS rounds) has to come first; the coarser levels' sampling / kNN and all three 3-NN launches
+        (0.17 ms of small, latency-bound kernels at B = 32) can then run on a side stream under the first set-abstraction chain instead
+        of between the chains (fork / join with events).  Latency mode only (self.geo_overlap, see __init__); off while a stage timer is
+        attached (profiling wants one stream) and while the stream is being captured into a hipGraph."""
         B = xyz.shape[0]
-        l_xyz, l_feat, l_c, c_feat = [xyz], [xyz], [], 3
+        dev = self.device
+        L, nfp = len(self.sa), len(self.fp)
+        npts = [xyz.shape[1]] + list(self.sampling[:L])
+        # outputs of the geometry kernels, allocated on the main stream before any fork
+        cidx = [torch.empty((B, npts[i + 1]), dtype=torch.int32, device=dev) for i in range(L)]
+        nxyz = [torch.empty((B, npts[i + 1], 3), dtype=torch.float32, device=dev) for i in range(L)]
+        nbr = [torch.empty((B, npts[i + 1], self.knn[i]), dtype=torch.int32, device=dev) for i in range(L)]
+        d2 = [torch.empty((B, npts[i + 1], self.knn[i]), dtype=torch.float32, device=dev) for i in range(L)]
+        off = L - nfp                              # FP level j interpolates level j + off + 1's features onto level j + off's points
+        w3 = [torch.empty((B, npts[j + off], 3), dtype=torch.float32, device=dev) for j in range(nfp)]
+        idx3 = [torch.empty((B, npts[j + off], 3), dtype=torch.int32, device=dev) for j in range(nfp)]
+        l_xyz = [xyz] + nxyz
+
+        def fps(i):
+            call("pa_furthestsampling_gather", B, npts[i], npts[i + 1], ptr(l_xyz[i]), ptr(cidx[i]), ptr(nxyz[i]))
+
+        def knn(i):
+            call("pa_knnquery", B, npts[i], npts[i + 1], self.knn[i], ptr(l_xyz[i]), ptr(nxyz[i]), ptr(nbr[i]), ptr(d2[i]))
+
+        def tnn(j):      # patch_aug_net.py:350-353
+            call("pa_three_nn_weights", B, npts[j + off], npts[j + off + 1], ptr(l_xyz[j + off]), ptr(l_xyz[j + off + 1]), ptr(w3[j]), ptr(idx3[j]))
+
+        overlap = self.geo_overlap and self.timer is None and L > 1 and not torch.cuda.is_current_stream_capturing()
+        ev_sa, ev_fp = [None] * L, [None] * nfp
+        main = torch.cuda.current_stream(dev)
+        fps(0)
+        self._mark("sa0.fps")
+        if overlap:
+            geo = self._geo_streams.get(main.cuda_stream)
+            if geo is None:
+                geo = self._geo_streams[main.cuda_stream] = torch.cuda.Stream(device=dev)
+            ev0 = torch.cuda.Event()
+            ev0.record(main)
+            geo.wait_event(ev0)
+            with torch.cuda.stream(geo):
+                for i in range(1, L):
+                    fps(i)
+                    knn(i)
+                    ev_sa[i] = torch.cuda.Event()
+                    ev_sa[i].record(geo)
+                for j in range(nfp - 1, -1, -1):           # coarsest first: the order the FP chains consume them
+                    tnn(j)
+                    ev_fp[j] = torch.cuda.Event()
+                    ev_fp[j].record(geo)
+        l_feat, l_c, c_feat = [xyz], [], 3
         for i, chain in enumerate(self.sa):
             src = l_xyz[i]
-            n, m, ns = src.shape[1], self.sampling[i], self.knn[i]
-            cidx = torch.empty((B, m), dtype=torch.int32, device=self.device)
-            new_xyz = torch.empty((B, m, 3), dtype=torch.float32, device=self.device)
-            call("pa_furthestsampling_gather", B, n, m, ptr(src), ptr(cidx), ptr(new_xyz))
-            self._mark(f"sa{i}.fps")
-            nbr = torch.empty((B, m, ns), dtype=torch.int32, device=self.device)
-            d2 = torch.empty((B, m, ns), dtype=torch.float32, device=self.device)
-            call("pa_knnquery", B, n, m, ns, ptr(src), ptr(new_xyz), ptr(nbr), ptr(d2))
+            m, ns = npts[i + 1], self.knn[i]
+            if i == 0:
+                knn(0)
+            elif overlap:
+                main.wait_event(ev_sa[i])
+            else:
+                fps(i)
+                self._mark(f"sa{i}.fps")
+                knn(i)
             self._mark(f"sa{i}.knn")
             feat = l_feat[i]
             if chain.pooled_ok(B * m, ns):
-                y = chain.sa(src, feat, cidx, nbr, c_feat, pooled=True)                      # (B*m, C')
+                y = chain.sa(src, feat, cidx[i], nbr[i], c_feat, pooled=True)                      # (B*m, C')
             else:  # wide hidden layers: rows in group order, then the max over each group's ns rows
-                full = chain.sa(src, feat, cidx, nbr, c_feat, pooled=False)                  # (B*m*ns, C')
+                full = chain.sa(src, feat, cidx[i], nbr[i], c_feat, pooled=False)                  # (B*m*ns, C')
                 y = torch.empty((B * m, chain.n_last), dtype=torch.float32, device=self.device)
                 call("pa_rowgroup_max", B * m, ns, chain.n_last, ptr(full), ptr(y))
             self._mark(f"sa{i}.chain")
             if self.attn[i] is not None:
                 y = self.attn[i].run(y, B, m)
                 self._mark(f"sa{i}.attn")
-            l_xyz.append(new_xyz)
             l_feat.append(y.view(B, m, chain.n_last))
-            l_c.append(cidx)
+            l_c.append(cidx[i])
             c_feat = chain.n_last
-        nfp = len(self.fp)
         g_pre = None
         for i in range(-1, -(nfp + 1), -1):
             chain = self.fp[nfp + i]
             unknown, known = l_xyz[i - 1], l_xyz[i]
             n_u, m_k = unknown.shape[1], known.shape[1]
-            w3 = torch.empty((B, n_u, 3), dtype=torch.float32, device=self.device)
-            idx3 = torch.empty((B, n_u, 3), dtype=torch.int32, device=self.device)
-            call("pa_three_nn_weights", B, n_u, m_k, ptr(unknown), ptr(known), ptr(w3), ptr(idx3))   # patch_aug_net.py:350-353
+            if overlap:
+                main.wait_event(ev_fp[nfp + i])
+            else:
+                tnn(nfp + i)
+            w3_l, idx3_l = w3[nfp + i], idx3[nfp + i]
             self._mark(f"fp{nfp + i}.3nn")
             skip = l_feat[i - 1]
             if i == -nfp and not self.use_origin:
@@ -553,12 +610,12 @@ class PatchAugNetEngine:
                     nn_u, nm_k = l_xyz[i - 2].shape[1], n_u
                     nc1 = (3 if self.use_origin else 0) if nfp + i - 1 == 0 else self.sa[nfp + i - 2].n_last
                     fuse = (nc1 <= 4 or nn_u >= 512) and nn_u >= 2 * nm_k
-                res = chain.fp_premul(known_feat.contiguous(), idx3, w3, skip.contiguous(), B, n_u, m_k, c2, c1,
+                res = chain.fp_premul(known_feat.contiguous(), idx3_l, w3_l, skip.contiguous(), B, n_u, m_k, c2, c1,
                                       mark=lambda k=nfp + i: self._mark(f"fp{k}.premul"), g_pre=g_pre, tail=fuse)
                 y, g_pre = res if fuse else (res, None)
             else:
                 g_pre = None
-                y = chain.fp(known_feat.contiguous(), idx3, w3, skip.contiguous() if skip is not None else None, B, n_u, m_k, c2, c1)
+                y = chain.fp(known_feat.contiguous(), idx3_l, w3_l, skip.contiguous() if skip is not None else None, B, n_u, m_k, c2, c1)
             self._mark(f"fp{nfp + i}.chain")
             l_feat[i - 1] = y.view(B, n_u, chain.n_last)
         return l_feat, l_c

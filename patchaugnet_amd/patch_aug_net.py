@@ -76,7 +76,10 @@ class Network(nn.Module):
     # ---- fused inference engine (eval + no_grad) ----------------------------------------------------------------
     def _fused(self, x, views=True):
         from .engine import engine_for
-        return engine_for(self, x.device).forward(x, views=views)
+        eng = engine_for(self, x.device)
+        if getattr(self, "geo_overlap", None) is not None:       # latency mode: see PatchAugNetEngine.geo_overlap
+            eng.geo_overlap = bool(self.geo_overlap)
+        return eng.forward(x, views=views)
 
     def prepare(self, device=None):
         """Build the fused engine (BatchNorm folding, weight packing) NOW, on the caller's current stream of `device`.  Callers that

@@ -62,7 +62,10 @@ class Network(nn.Module):
             use_engine = self.fused_eval and not self.training and not torch.is_grad_enabled()
         if use_engine:
             from .engine import engine_for
-            d, (fp, cidx) = engine_for(self, x.device).forward(x, views=return_feat)
+            eng = engine_for(self, x.device)
+            if getattr(self, "geo_overlap", None) is not None:       # latency mode: see PatchAugNetEngine.geo_overlap
+                eng.geo_overlap = bool(self.geo_overlap)
+            d, (fp, cidx) = eng.forward(x, views=return_feat)
             return (d, fp, cidx) if return_feat else d
         res = self.backbone(x.squeeze(1))
         fp = res["fp_features"]

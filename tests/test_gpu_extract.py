@@ -189,3 +189,23 @@ def test_update_global_descs_refresh_and_pickle_cache(tmp_path):
     kpt, desc, meta = pio.load_local_descriptor(ld, 13)
     assert np.array_equal(kpt, x[13, 0][ci[0][13].long()].cpu().numpy().astype(np.float64))
     assert np.array_equal(desc, fp[-2][13, :, :, 0].t().cpu().numpy()) and meta is None
+
+
+def test_latency_mode_is_bit_identical():
+    """model.geo_overlap = True (coordinate-only kernels of the coarser levels on a side stream, engine.py) changes the schedule, not one bit
+    of the output -- PatchAugNet and PPT-Net."""
+    from patchaugnet_amd import configs, patch_aug_net, pptnet
+    from patchaugnet_amd.weights import seeded_state_dict, synthetic_submaps
+    x = synthetic_submaps(5, 4096, seed=21).cuda()
+    for make in (lambda: patch_aug_net.Network(param=configs.patch_aug_net_config(), use_a2a_recon=True, use_l2_norm=True),
+                 lambda: pptnet.Network(param=configs.pptnet_config(), use_normalize=True)):
+        m = make()
+        m.load_state_dict(seeded_state_dict(m.state_dict()))
+        m = m.cuda().eval()
+        with torch.no_grad():
+            d0, fp0, c0 = m(x)
+            m.geo_overlap = True
+            for _ in range(3):
+                d1, fp1, c1 = m(x)
+            torch.cuda.synchronize()
+        assert torch.equal(d0, d1) and all(torch.equal(a, b) for a, b in zip(fp0, fp1)) and all(torch.equal(a, b) for a, b in zip(c0, c1))

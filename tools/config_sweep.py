@@ -69,6 +69,9 @@ def main():
     res["config2_batch_sweep"] = [extraction_rate(model, b, "uniform") for b in (1, 8, 32, 100, 256)]
     res["config2_street_like"] = [extraction_rate(model, b, "street") for b in (32, 100)]
     res["config2_single_stream_latency"] = [extraction_rate(model, b, "uniform", streams=1) for b in (1, 32)]
+    model.geo_overlap = True      # latency mode: coordinate-only kernels of the coarser levels on a side stream (engine.py)
+    res["config2_single_stream_latency_mode"] = [extraction_rate(model, b, "uniform", streams=1) for b in (1, 32)]
+    model.geo_overlap = False
 
     # config 4: the reference's native tuple = 1 query + 2 positives + 14 negatives + 1 other negative = 18 clouds
     # (configs/patch_aug_net.yaml:60-62); nn_dict with 2 (query, positive) pairs => 3 related clouds => Chamfer on (3072,20,3)
