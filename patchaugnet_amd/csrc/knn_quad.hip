@@ -333,7 +333,8 @@ PA_API void pa_knn_quad_enable(int on) { g_quad_on = on ? 1 : 0; }
 int pa_knn_quad_try(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx, float *dist2, hipStream_t st, long long *dbg)
 {
     if (g_quad_on < 0) g_quad_on = getenv("PA_KNN_NO_QUAD") != nullptr ? 0 : 1;
-    if (!g_quad_on || n < 2048 || n > 4096 || m < 256) return 0;
+    static const int nmin = getenv("PA_KNN_QUAD_NMIN") ? atoi(getenv("PA_KNN_QUAD_NMIN")) : 2048, mmin = getenv("PA_KNN_QUAD_MMIN") ? atoi(getenv("PA_KNN_QUAD_MMIN")) : 256;   // tuning knobs
+    if (!g_quad_on || n < nmin || n > 4096 || m < mmin) return 0;
     switch (nsample) {
         case 16: launch_quad<16>(b, n, m, xyz, new_xyz, idx, dist2, st, dbg); return 1;
         case 20: launch_quad<20>(b, n, m, xyz, new_xyz, idx, dist2, st, dbg); return 1;
