@@ -127,8 +127,9 @@ class GraphedTrainer:
         self.device = dev
         self.static = [_as_tensor(t).to(dev).clone() for t in (queries, positives, negatives, other_neg)]
         self.groupers = [m for m in model.modules() if isinstance(m, pointops.QueryAndGroup_Edge) and m.radius is None and m.knn_dilation > 1]
-        for g in self.groupers:
-            g.perm_buffer = torch.randperm(g.nsample).to(dev)
+        self._perms = [torch.randperm(g.nsample).to(dev) for g in self.groupers]
+        for g, buf in zip(self.groupers, self._perms):
+            g.perm_buffer = buf                        # read by the forward during warm-up and capture only (reset below)
         model.train()
         cur = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(device=dev)
@@ -141,8 +142,12 @@ class GraphedTrainer:
         torch.cuda.synchronize(dev)
         optimizer.zero_grad(set_to_none=True)          # the captured backward then CREATES the gradients inside the graph's pool
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.losses = self._body()
+        try:
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.losses = self._body()
+        finally:
+            for g in self.groupers:                    # the graph has the buffers' addresses; eager forwards of the model draw their own again
+                g.perm_buffer = None
         torch.cuda.synchronize(dev)
 
     def _body(self):
@@ -169,11 +174,11 @@ class GraphedTrainer:
         (device scalars owned by the graph: valid until the next step)."""
         for dst, src in zip(self.static, (queries, positives, negatives, other_neg)):
             dst.copy_(_as_tensor(src), non_blocking=True)
-        for g in self.groupers:
-            g.perm_buffer.copy_(torch.randperm(g.nsample), non_blocking=True)
+        for g, buf in zip(self.groupers, self._perms):
+            buf.copy_(torch.randperm(g.nsample), non_blocking=True)
         self.graph.replay()
         return self.losses
 
     def close(self):
-        for g in self.groupers:
-            g.perm_buffer = None
+        """Nothing to undo on the model (the permutation buffers are the trainer's own); kept for symmetry with GraphedExtractor."""
+        self.graph = None
