@@ -1,7 +1,10 @@
 """Graph capture next to an initialised RCCL process group (watchdog thread polling events): world size 1 on one GPU."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+import socket
+with socket.socket() as _s:                       # a free port: a fixed one can still be in TIME_WAIT from the previous run
+    _s.bind(("127.0.0.1", 0)); _port = _s.getsockname()[1]
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(_port))
 import torch, torch.distributed as dist
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1)
