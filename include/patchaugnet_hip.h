@@ -240,6 +240,9 @@ int pa_netvlad(int b, int n, int c, int k, const float *x, const float *wc_t, co
  * (watt_t = the attention conv as a K-major (in, out) matrix, watt_p its packed copy or NULL, zero_bias = 256 zeros), and the FC
  * weight must have its ROWS ORDERED k*256 + c (the reference's nn.Linear weight is c*ktot + k: permute once on the host).
  * scratch: pa_afa_rows_scratch_floats(b, 256, ktot, nout) floats. */
+/* wc_p of pa_netvlad_rows: NULL, or (k > 48 only) the fragment-ordered copy of wc_t (256, 64) that pa_netvlad_pack_weights writes
+ * (256 * 64 floats; the assignment GEMM contracts channels in a permuted order that lets it read its LDS tile 16 bytes at a time). */
+int pa_netvlad_pack_weights(int c, int kp, const float *wc_t, float *wc_p, pa_stream_t stream);
 int pa_netvlad_rows(int b, int n, int c, int k, const float *x, const float *wc_t, const float *wc_p, const float *bias, const float *w2,
                     float *scratch, float *out, int ktot, int koff, pa_stream_t stream);   /* wc_p: pa_pack_weights(256, 64, wc_t) when k > 48, else NULL */
 long pa_afa_rows_scratch_floats(int b, int c, int ktot, int nout);

@@ -57,6 +57,7 @@ _SIGS = {
     "pa_three_nn_weights": "iiipppp",
     "pa_afa": "iiiippppppipp",
     "pa_netvlad_rows": "iiiipppppppii",
+    "pa_netvlad_pack_weights": "iipp",
     "pa_afa_rows": "iiiippppppppipp",
     "pa_fc": "iiipppppippp",
     "pa_vlad_maxpool": "iiipip",

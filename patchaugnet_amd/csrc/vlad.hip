@@ -18,6 +18,7 @@
 #include "pa_common.h"
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -41,31 +42,62 @@ __device__ __forceinline__ float row16_sum(float v)
 
 constexpr int VC = 256;         // feature channels (every shipped config; checked on the host)
 constexpr int VROWS = 64;       // rows of X per LDS tile
-constexpr int XS = VC + 2;      // LDS row stride of the X tile (conflict-free A-fragment reads, see mlp_chain.hip)
+
+// LDS layout of the NetVLAD kernel.  The X tile (64 rows x 256 channels) is stored UNPADDED with whole float4 groups XOR-swizzled per row,
+//     X[row][c] at Xs[row * 256 + (c ^ 4 (row % 16))],
+// so that the tile (64 KB) plus the assignment tile (16 KB at K = 64) is exactly half of the CU's 160 KB: two workgroups co-reside and one's
+// soft-max / barriers / refill run under the other's MFMAs.  Every MFMA fragment is fetched with 16-byte LDS reads (ds_read_b32 reaches a
+// fifth of its rate from one or two waves per SIMD, MI355X_MICROARCH.md section LDS); the contraction / tile indices are permuted to fit:
+//   assignment GEMM  (A operand = X rows): lane (i, q) reads X[16 w + i][16 j + 4 q .. + 3]; its four values feed k-steps 4 j .. 4 j + 3, so
+//       k-step s = 4 j + e contracts channels {16 j + 4 q + e}: the packed weights are permuted accordingly (pa_netvlad_pack_weights);
+//   aggregation GEMM (A operand = X columns, B operand = assignments): lane (i, q) reads X[4 ks + q][64 w + 4 i .. + 3] and, at K = 64,
+//       A[4 ks + q][4 i .. + 3]: MFMA tile e has row i <-> channel 64 w + 4 i + e and column i <-> cluster 4 i + e.
+// A ds_read_b128 is served in groups of 16 lanes, {i 0-3, 12-15 of q} + {i 4-11 of q + 1}; (4 j + q) ^ i (resp. i ^ (4 ks + q) % 16) takes 16
+// distinct values over such a group: conflict-free.  The assignment tile uses the same swizzle, A[row][k] at As[row * 64 + (k ^ 4 (row % 16))];
+// its 4-byte writes (rows 16 w + 4 q + r, clusters 16 ct + i) land on (16 ct + i) ^ (16 q + 4 r): 32 distinct banks per 32 lanes.
+__device__ __forceinline__ int vlad_swz(int row) { return (row & 15) << 2; }
 
 // ------------------------------------------------------------------------------------------------ NetVLAD accumulate
 // grid (chunks, B); each workgroup walks rows [chunk*rows_per_wg, +rows_per_wg) of cloud b in 64-row tiles.
 // part[b][chunk][kp][VC] = sum over its rows of A[row][k] * X[row][c];   asum_part[b][chunk][kp] = sum of A[row][k]
+#ifdef PA_VLAD_DEBUG
+__device__ long long vlad_stamps[16];
+#define VSTAMP(i) do { if (KT == 4 && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && r0 == row_begin + VROWS) vlad_stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define VSTAMPK(i) do { if (KT == 4 && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) vlad_stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define VSTAMP(i) do { } while (0)
+#define VSTAMPK(i) do { } while (0)
+#endif
+
+#ifndef PA_VLAD_WGS
+#define PA_VLAD_WGS 2           // workgroups per CU at the finest scale
+#endif
+
+// channel contracted by k-step s (0..63) in k-group q (0..3) of the assignment GEMM
+__host__ __device__ __forceinline__ int vlad_chan(int s, int q) { return 16 * (s >> 2) + 4 * q + (s & 3); }
+
 template <int KT>
-__global__ __launch_bounds__(256) void vlad_accum_kernel(int n, int k_true, int rows_per_wg, const float *__restrict__ x_all,
+__global__ __launch_bounds__(256, KT == 4 ? PA_VLAD_WGS : 1) void vlad_accum_kernel(int n, int k_true, int rows_per_wg, const float *__restrict__ x_all,
                                                            const float *__restrict__ wc_t,   // [VC][16*KT] K-major, BN folded
-                                                           const float *__restrict__ wc_p,   // optional fragment-major packing of wc_t (KT == 4), or null
+                                                           const float *__restrict__ wc_p,   // optional pa_netvlad_pack_weights(wc_t) (KT == 4), or null
                                                            const float *__restrict__ bias,   // [16*KT]
                                                            float *__restrict__ part, float *__restrict__ asum_part)
 {
     constexpr int KP = 16 * KT;
-    constexpr int AS = KP + 2;
+    constexpr bool SWZ_A = KT == 4;        // unpadded, swizzled assignment tile read 16 bytes at a time (needs all 64 columns)
+    constexpr int AS = SWZ_A ? KP : KP + 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *Xs = smem;                      // [VROWS][XS]
-    float *As = smem + VROWS * XS;         // [VROWS][AS]
-    float *red = As + VROWS * AS;          // [4][KP] cross-wave a_sum
+    float *Xs = smem;                      // [VROWS][VC], float4 groups swizzled (vlad_swz)
+    float *As = smem + VROWS * VC;         // [VROWS][AS]
+    float *red = As;                       // [4][KP] cross-wave a_sum, after the last tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
     const int b = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
     const int row_begin = chunk * rows_per_wg;
     const int row_end = min(row_begin + rows_per_wg, n);
     const float *x = x_all + (size_t)b * n * VC;
 
-    floatx4 acc2[KT][4];                   // A^T X: KT cluster tiles x this wave's 4 channel tiles
+    floatx4 acc2[KT][4];                   // (A^T X)^T: [cluster tile rt][channel tile e]; rows of an MFMA tile = channels, columns = clusters
 #pragma unroll
     for (int rt = 0; rt < KT; ++rt)
 #pragma unroll
@@ -75,84 +107,96 @@ __global__ __launch_bounds__(256) void vlad_accum_kernel(int n, int k_true, int 
     for (int ct = 0; ct < KT; ++ct) asum[ct] = 0.f;
     float bia[KT];
 #pragma unroll
-    for (int ct = 0; ct < KT; ++ct) bia[ct] = bias[ct * 16 + (lane & 15)];
+    for (int ct = 0; ct < KT; ++ct) bia[ct] = bias[ct * 16 + li];
 
     // X tiles are prefetched one tile ahead into registers (16 float4 per thread): the global loads of tile t+1 are in flight
     // during the two GEMM phases of tile t, and LDS is refilled right after the barrier that ends phase 4.
     constexpr int PF = VROWS * (VC / 4) / 256;
     float4 pre[PF];
+    // Through a buffer descriptor over this workgroup's rows: one loop-invariant 32-bit lane offset and no 64-bit address math (flat
+    // addressing kept 16 address pairs alive across the tile, which spilled at two waves per SIMD); rows past row_end read as zero.
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + (size_t)row_begin * VC), 0,
+                                                                         (row_end - row_begin) * VC * 4, 0x00020000);
     auto fetch = [&](int r0) {
-        const int cnt = min(VROWS, row_end - r0);
-        const float4 *x4 = reinterpret_cast<const float4 *>(x + (size_t)r0 * VC);
+        const unsigned base = (unsigned)(r0 - row_begin) * (VC * 4) + (unsigned)tid * 16u;       // the range check covers voffset + imm
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
-            const int q = tid + u * 256, r = q / (VC / 4);
-            pre[u] = (r0 < row_end && r < cnt) ? x4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrs, base + (unsigned)u * 4096u, 0, 0);
+            pre[u] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
         }
     };
+    VSTAMPK(9);
     fetch(row_begin);
+    // A fragments of the assignment GEMM: byte address of X[16 w + i][16 j + 4 q] = arow * 1024 + ((64 j + 16 q) ^ 16 i) = abase ^ (64 j)
+    const char *xs_bytes = reinterpret_cast<const char *>(Xs);
+    const unsigned abase = (unsigned)(wave * 16 + li) * (VC * 4) + (unsigned)((16 * lq) ^ (16 * li));
+    auto lda = [&](int j) { return *reinterpret_cast<const float4 *>(xs_bytes + (abase ^ ((unsigned)j << 6))); };
     for (int r0 = row_begin; r0 < row_end; r0 += VROWS) {
         const int cnt = min(VROWS, row_end - r0);
-        // 1. registers -> LDS (XS is even: 8-byte aligned stores), then start fetching the next tile
+        if (r0 == row_begin) VSTAMPK(10);
+        VSTAMP(0);
+        // 1. registers -> LDS (the swizzle moves whole float4 groups: 16-byte stores), then start fetching the next tile
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             const int q = tid + u * 256, r = q / (VC / 4), part4 = q - r * (VC / 4);
-            float2 *d = reinterpret_cast<float2 *>(Xs + r * XS + part4 * 4);
-            d[0] = make_float2(pre[u].x, pre[u].y);
-            d[1] = make_float2(pre[u].z, pre[u].w);
+            *reinterpret_cast<float4 *>(Xs + r * VC + ((part4 * 4) ^ vlad_swz(r))) = pre[u];
         }
+        VSTAMP(1);
         __syncthreads();
+        VSTAMP(2);
         fetch(r0 + VROWS);
+        VSTAMP(3);
         // 2. assignment logits for this wave's 16 rows: X[16 x 256] * Wc[256 x KP]
         floatx4 acc[KT];
 #pragma unroll
         for (int ct = 0; ct < KT; ++ct) acc[ct] = (floatx4){0.f, 0.f, 0.f, 0.f};
         if (KT == 4 && wc_p != nullptr) {
-            // packed weights: one 16-byte load per k-step brings the lane's four cluster-tile fragments; two k-steps of lookahead
-            const float *ap = Xs + (wave * 16 + (lane & 15)) * XS + (lane >> 4);
-            const float4 *wq = reinterpret_cast<const float4 *>(wc_p) + lane;
-            float4 b0 = wq[0], b1 = wq[64];
-            float a0 = ap[0], a1 = ap[4];
-            for (int ks = 0; ks < VC / 4; ks += 2) {
-                const int n0 = min(ks + 2, VC / 4 - 1), n1 = min(ks + 3, VC / 4 - 1);
-                const float an0 = ap[n0 * 4], an1 = ap[n1 * 4];
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0.x, acc[0], 0, 0, 0);
-                acc[1 % KT] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0.y, acc[1 % KT], 0, 0, 0);
-                acc[2 % KT] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0.z, acc[2 % KT], 0, 0, 0);
-                acc[3 % KT] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0.w, acc[3 % KT], 0, 0, 0);
-                b0 = wq[(size_t)n0 * 64];
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1.x, acc[0], 0, 0, 0);
-                acc[1 % KT] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1.y, acc[1 % KT], 0, 0, 0);
-                acc[2 % KT] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1.z, acc[2 % KT], 0, 0, 0);
-                acc[3 % KT] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1.w, acc[3 % KT], 0, 0, 0);
-                b1 = wq[(size_t)n1 * 64];
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                a0 = an0;
-                a1 = an1;
+            // packed weights: one 16-byte load per k-step brings the lane's four cluster-tile fragments, refilled four k-steps (16 MFMAs)
+            // ahead through a buffer descriptor with the k-step as a scalar offset; one 16-byte LDS read per four k-steps for X.
+            const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wc_p), 0, 0x7fffffff, 0x00020000);
+            const unsigned wvo = (unsigned)lane * 16u;
+            auto ldw = [&](int s) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo, s * 1024, 0);
+                return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+            };
+            float4 bw[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bw[e] = ldw(e);
+            float4 a4 = lda(0);
+#pragma unroll 4
+            for (int j = 0; j < VC / 16; ++j) {
+                const int jn = min(j + 1, VC / 16 - 1);
+                const float4 an = lda(jn);
+                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bw[e].x, acc[0], 0, 0, 0);
+                    acc[1 % KT] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bw[e].y, acc[1 % KT], 0, 0, 0);
+                    acc[2 % KT] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bw[e].z, acc[2 % KT], 0, 0, 0);
+                    acc[3 % KT] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bw[e].w, acc[3 % KT], 0, 0, 0);
+                    bw[e] = ldw(jn * 4 + e);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    if (e == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+                a4 = an;
             }
         } else {
-            const float *ap = Xs + (wave * 16 + (lane & 15)) * XS + (lane >> 4);
-            const float *wp = wc_t + (size_t)(lane >> 4) * KP + (lane & 15);
-            float bn[KT], an = ap[0];
+            const float *wp = wc_t + li;
+            for (int j = 0; j < VC / 16; ++j) {
+                const float4 a4 = lda(j);
+                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
-            for (int ct = 0; ct < KT; ++ct) bn[ct] = wp[ct * 16];
-            for (int ks = 0; ks < VC / 4; ++ks) {
-                float bc[KT];
-                const float ac = an;
+                for (int e = 0; e < 4; ++e) {
+                    float bc[KT];
 #pragma unroll
-                for (int ct = 0; ct < KT; ++ct) bc[ct] = bn[ct];
-                if (ks + 1 < VC / 4) {
-                    an = ap[(ks + 1) * 4];
+                    for (int ct = 0; ct < KT; ++ct) bc[ct] = wp[(size_t)vlad_chan(4 * j + e, lq) * KP + ct * 16];
 #pragma unroll
-                    for (int ct = 0; ct < KT; ++ct) bn[ct] = wp[(size_t)(ks + 1) * 4 * KP + ct * 16];
+                    for (int ct = 0; ct < KT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bc[ct], acc[ct], 0, 0, 0);
                 }
-#pragma unroll
-                for (int ct = 0; ct < KT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac, bc[ct], acc[ct], 0, 0, 0);
             }
         }
+        VSTAMP(4);
         // 3. soft-max over the k_true clusters of each row.  C/D layout: column (cluster) = 16*ct + lane%16,
         //    row = 4*(lane/16) + r: a row's clusters live in the 16 lanes of a DPP row and the KT tiles.
 #pragma unroll
@@ -160,7 +204,7 @@ __global__ __launch_bounds__(256) void vlad_accum_kernel(int n, int k_true, int 
             float v[KT], mx = -3.0e38f;
 #pragma unroll
             for (int ct = 0; ct < KT; ++ct) {
-                const bool live = ct * 16 + (lane & 15) < k_true;
+                const bool live = ct * 16 + li < k_true;
                 v[ct] = live ? acc[ct][r] + bia[ct] : -3.0e38f;
                 mx = fmaxf(mx, v[ct]);
             }
@@ -168,48 +212,87 @@ __global__ __launch_bounds__(256) void vlad_accum_kernel(int n, int k_true, int 
             float s = 0.f;
 #pragma unroll
             for (int ct = 0; ct < KT; ++ct) {
-                v[ct] = (ct * 16 + (lane & 15) < k_true) ? __expf(v[ct] - mx) : 0.f;
+                v[ct] = (ct * 16 + li < k_true) ? __expf(v[ct] - mx) : 0.f;
                 s += v[ct];
             }
             s = row16_sum(s);
             const float inv = 1.0f / s;
-            const int row = wave * 16 + (lane >> 4) * 4 + r;
+            const int row = wave * 16 + lq * 4 + r;
             const bool row_live = row < cnt;
 #pragma unroll
             for (int ct = 0; ct < KT; ++ct) {
                 const float a = row_live ? v[ct] * inv : 0.f;
-                As[row * AS + ct * 16 + (lane & 15)] = a;
+                As[row * AS + (SWZ_A ? ((ct * 16 + li) ^ vlad_swz(row)) : ct * 16 + li)] = a;
                 asum[ct] += a;
             }
         }
+        VSTAMP(5);
         __syncthreads();
-        // 4. aggregation: acc2[cluster tile][channel tile] += A^T[KP x 64 rows] * X[64 rows x 64 channels of this wave]
+        VSTAMP(6);
+        // 4. aggregation: acc2[rt][e] += X^T[this wave's channels 64 w + 4 i + e][64 rows] * A[64 rows][clusters of tile rt].
+        //    Fragments of k-step ks + 1 are read before the 16 MFMAs of k-step ks (register double buffer).
         {
-            const float *ap = As + (lane >> 4) * AS + (lane & 15);            // A^T[i = cluster][k = row] = As[row][cluster]
-            const float *bp = Xs + (lane >> 4) * XS + wave * 64 + (lane & 15);
+            auto ldx = [&](int ks) {                                          // contraction index of k-group lq in k-step ks: row 4 ks + lq
+                const int row = ks * 4 + lq, sw = ((ks & 3) << 4) | (lq << 2);   // sw = vlad_swz(row)
+                return *reinterpret_cast<const float4 *>(Xs + row * VC + wave * 64 + ((4 * li) ^ sw));
+            };
+            auto ldas = [&](int ks) {
+                const int row = ks * 4 + lq, sw = ((ks & 3) << 4) | (lq << 2);
+                return *reinterpret_cast<const float4 *>(As + row * AS + ((4 * li) ^ sw));
+            };
+            float4 x4 = ldx(0), a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (SWZ_A) a4 = ldas(0);
+#pragma unroll
             for (int ks = 0; ks < VROWS / 4; ++ks) {
-                float af[KT], bf[4];
+#ifdef PA_VLAD_NO_PIPE
+                x4 = ldx(ks);
+                if (SWZ_A) a4 = ldas(ks);
+                const float4 xn = x4, an = a4;
+#else
+                const int kn = ks + 1 < VROWS / 4 ? ks + 1 : ks;
+                const float4 xn = ldx(kn);
+                float4 an = a4;
+                if (SWZ_A) an = ldas(kn);
+#endif
+                const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+                float af[KT];
+                if (SWZ_A) {
+                    af[0] = a4.x; af[1 % KT] = a4.y; af[2 % KT] = a4.z; af[3 % KT] = a4.w;
+                } else {
 #pragma unroll
-                for (int rt = 0; rt < KT; ++rt) af[rt] = ap[ks * 4 * AS + rt * 16];
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) bf[ct] = bp[ks * 4 * XS + ct * 16];
+                    for (int rt = 0; rt < KT; ++rt) af[rt] = As[(ks * 4 + lq) * AS + rt * 16 + li];
+                }
 #pragma unroll
                 for (int rt = 0; rt < KT; ++rt)
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) acc2[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[rt], bf[ct], acc2[rt][ct], 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) acc2[rt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[e], af[rt], acc2[rt][e], 0, 0, 0);
+#ifndef PA_VLAD_NO_PIPE
+                if (SWZ_A) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+                }
+#endif
+                x4 = xn;
+                a4 = an;
             }
         }
+        VSTAMP(7);
         __syncthreads();
+        VSTAMP(8);
     }
-    // partial A^T X
+    VSTAMPK(11);
+    // partial A^T X.  MFMA tile (rt, e): row m = 4 q + r <-> channel 64 w + 4 m + e, column i <-> cluster (K = 64: 4 i + rt, else 16 rt + i),
+    // so (acc2[rt][0..3][r]) are four CONSECUTIVE CHANNELS of one cluster: 16-byte stores (the A^T X orientation with cluster-major tiles
+    // needed 4 x as many 4-byte stores, ~16 k cycles per workgroup).
     float *po = part + ((size_t)b * nchunks + chunk) * KP * VC;
 #pragma unroll
     for (int rt = 0; rt < KT; ++rt)
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                po[(size_t)(rt * 16 + (lane >> 4) * 4 + r) * VC + wave * 64 + ct * 16 + (lane & 15)] = acc2[rt][ct][r];
+        for (int r = 0; r < 4; ++r) {
+            const int cl = SWZ_A ? 4 * li + rt : rt * 16 + li;
+            *reinterpret_cast<float4 *>(po + (size_t)cl * VC + wave * 64 + 16 * lq + 4 * r) =
+                make_float4(acc2[rt][0][r], acc2[rt][1][r], acc2[rt][2][r], acc2[rt][3][r]);
+        }
     // partial a_sum: lanes sharing lane%16 hold different rows of the same cluster
 #pragma unroll
     for (int ct = 0; ct < KT; ++ct) {
@@ -220,6 +303,16 @@ __global__ __launch_bounds__(256) void vlad_accum_kernel(int n, int k_true, int 
     }
     __syncthreads();
     if (tid < KP) asum_part[((size_t)b * nchunks + chunk) * KP + tid] = (red[tid] + red[KP + tid]) + (red[2 * KP + tid] + red[3 * KP + tid]);
+    VSTAMPK(12);
+}
+
+// wc_t [256][64] K-major -> the fragment order of the assignment GEMM above: wc_p[(s * 64 + lane) * 4 + ct] = wc_t[vlad_chan(s, lane / 16)][16 ct + lane % 16]
+__global__ __launch_bounds__(256) void vlad_pack_kernel(const float *__restrict__ wc_t, float *__restrict__ wc_p)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;                  // (s, lane)
+    const int s = t >> 6, lane = t & 63;
+    const float *src = wc_t + (size_t)vlad_chan(s, lane >> 4) * 64 + (lane & 15);
+    reinterpret_cast<float4 *>(wc_p)[t] = make_float4(src[0], src[16], src[32], src[48]);
 }
 
 // grid (k_true, B), 256 threads = channels: reduce partials, subtract a_sum*W2, intra-normalise, write (B, VC, ldo) at column koff+k
@@ -448,8 +541,9 @@ __global__ __launch_bounds__(256) void afa_rows_reweight_kernel(int ktot, const 
     }
 }
 
-int vlad_chunks(int n) { int rows = n >= 2048 ? 512 : 64; return (n + rows - 1) / rows; }
-int vlad_rows_per_wg(int n) { return n >= 2048 ? 512 : 64; }
+// two workgroups per CU: 4096 points x 32 clouds = 512 workgroups of four 64-row tiles
+int vlad_rows_per_wg(int n) { return n >= 2048 ? 512 / PA_VLAD_WGS : 64; }
+int vlad_chunks(int n) { const int rows = vlad_rows_per_wg(n); return (n + rows - 1) / rows; }
 
 // split-K FC + finalize for any batch size: rows are processed 64 at a time (the split-K kernel holds <= 4 row tiles)
 int fc_launch(int b, int kdim, int nout, const float *y, const float *fc_wt, const float *fc_bias, const float *scale, const float *shift, int l2norm,
@@ -474,6 +568,16 @@ int fc_launch(int b, int kdim, int nout, const float *y, const float *fc_wt, con
 
 }  // namespace
 
+// Fragment-ordered copy of the K = 64 assignment weights for pa_netvlad_rows: wc_t (256, 64) K-major (BatchNorm folded) -> wc_p (256 * 64 floats).
+PA_API int pa_netvlad_pack_weights(int c, int kp, const float *wc_t, float *wc_p, pa_stream_t stream)
+{
+    PA_REQUIRE(wc_t && wc_p, "pa_netvlad_pack_weights: null pointer");
+    if (c != VC || kp != 64) { pa_set_error("pa_netvlad_pack_weights: built for 256 channels x 64 padded clusters (got c=%d kp=%d)", c, kp); return PA_EUNSUPPORTED; }
+    hipLaunchKernelGGL(vlad_pack_kernel, dim3(VC / 4 * 64 / 256), dim3(256), 0, (hipStream_t)stream, wc_t, wc_p);
+    PA_CHECK_LAUNCH("pa_netvlad_pack_weights");
+    return PA_OK;
+}
+
 PA_API long pa_netvlad_scratch_floats(int b, int n, int k)
 {
     const int kp = (k + 15) & ~15;
@@ -492,7 +596,7 @@ static int netvlad_impl(int b, int n, int c, int k, const float *x, const float 
     const int chunks = vlad_chunks(n), rows = vlad_rows_per_wg(n);
     float *part = scratch;
     float *asum = scratch + (size_t)b * chunks * kp * VC;
-    const size_t lds = (size_t)(VROWS * XS + VROWS * (kp + 2) + 4 * kp) * 4;
+    const size_t lds = (size_t)(VROWS * VC + VROWS * (kt == 4 ? kp : kp + 2)) * 4;      // K = 64: 80 KB, half a CU
 #define PA_VLAD_LAUNCH(KT)                                                                                                              \
     do {                                                                                                                                \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vlad_accum_kernel<KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -640,3 +744,10 @@ PA_API int pa_vlad_maxpool(int b, int ktot, int c, const float *vt, int l2norm, 
     PA_CHECK_LAUNCH("pa_vlad_maxpool");
     return PA_OK;
 }
+
+#ifdef PA_VLAD_DEBUG
+PA_API int pa_vlad_debug_read(long long *host16)
+{
+    return hipMemcpyFromSymbol(host16, HIP_SYMBOL(vlad_stamps), sizeof(long long) * 16) == hipSuccess ? PA_OK : PA_EINVAL;
+}
+#endif

@@ -243,7 +243,10 @@ class _Vlad:
         self.wc_t = wc.float().contiguous().to(device)
         self.bias = bias.float().contiguous().to(device)
         self.w2 = v.cluster_weights2.detach()[0].float().contiguous().to(device)      # (C, K)
-        self.wc_p = pack_weights(self.wc_t) if kp == 64 else None
+        self.wc_p = None
+        if kp == 64:                                   # fragment order of the K = 64 assignment GEMM (vlad.hip)
+            self.wc_p = torch.empty(c * kp, dtype=torch.float32, device=device)
+            call("pa_netvlad_pack_weights", c, kp, ptr(self.wc_t), ptr(self.wc_p))
 
     def run(self, x, out, ldo, koff, rows=False):
         """rows=False: out (B, C, ldo) as the reference lays it out; rows=True: out (B, ldo, C), one contiguous row per cluster."""
