@@ -322,6 +322,10 @@ void pa_knn_lane_enable(int on);
  * (csrc/knn_quad.hip, same results bit for bit); 0 forces the wave-per-query kernels (A/B, tests). */
 void pa_knn_quad_enable(int on);
 
+/* Opt-in variant of the register-resident furthest point sampling kernels (n <= 8192) that keeps no copy of the cloud in LDS (256 bytes
+ * instead of 12 n: the winner's coordinates come from the owning lane's registers).  Same samples bit for bit; slower per round (fps.hip). */
+void pa_fps_reg_xyz_enable(int on);
+
 /* pa_nearestneighbor / pa_three_nn_weights use a cell-grid kernel (csrc/three_nn_grid.hip, same results bit for bit) for 512..4096 known
  * points and >= 1024 queries; 0 forces the brute-force scan (A/B, tests). */
 void pa_three_nn_grid_enable(int on);

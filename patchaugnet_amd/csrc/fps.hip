@@ -37,15 +37,25 @@ __device__ __forceinline__ int fps_decode(u32 lowkey, FpsOrder o)
     return (int)((q << o.log2bs) | r);
 }
 
-// Register-resident path: NT threads, PPT points per lane, n <= NT*PPT, cloud copy in LDS (SoA, 12 B/point).
-template <int NT, int PPT>
+// Register-resident path: NT threads, PPT points per lane, n <= NT*PPT.
+// LDSXYZ = true: cloud copy in LDS (SoA, 12 B/point: 48 KB at n = 4096), the winner's coordinates are read from it after the barrier.
+// LDSXYZ = false (opt-in, see fps_lds_xyz below): no cloud copy.  Each wave fetches ITS winner's coordinates from the owning lane's registers (uniform register index
+//   + v_readlane) and publishes (key, x, y, z) in its slot before the round's single barrier; after it every thread takes the slot
+//   with the largest key.  LDS: 256 bytes, so the 0.7 ms launch no longer keeps LDS-heavy kernels of other streams (the 132 KB
+//   chain workgroups, the 80 KB NetVLAD ones) off the CUs it runs on; the post-barrier critical path loses one LDS round trip.
+struct FpsSlot { u64 key; float x, y, z; float pad[3]; };   // 32 bytes
+
+template <int NT, int PPT, bool LDSXYZ>
 __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, FpsOrder ord, const float *__restrict__ xyz_all,
                                                        float *__restrict__ temp_all, int *__restrict__ idx_all, float *__restrict__ new_xyz_all)
 {
     constexpr int NW = NT / 64;
+    constexpr int LOG_NT = NT == 64 ? 6 : NT == 128 ? 7 : NT == 256 ? 8 : NT == 512 ? 9 : 10;
+    static_assert((1 << LOG_NT) == NT, "NT must be a power of two");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sx = smem, *sy = smem + n, *sz = smem + 2 * n;
     u64 *slots = reinterpret_cast<u64 *>(smem + 3 * n + ((3 * n) & 1));  // 8-byte aligned, [2][NW]
+    FpsSlot *rslots = reinterpret_cast<FpsSlot *>(smem);                  // LDSXYZ = false: [2][NW]
 
     const int b = blockIdx.x, tid = threadIdx.x;
     const float *xyz = xyz_all + (size_t)b * n * 3;
@@ -53,7 +63,10 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, FpsOrder ord,
     int *idxs = idx_all + (size_t)b * m;
     float *nxyz = new_xyz_all ? new_xyz_all + (size_t)b * m * 3 : nullptr;   // optional fused gather of the sampled coordinates
 
-    float px[PPT], py[PPT], pz[PPT], t[PPT];
+    // coordinates as vector values: a register set indexed by a wave-uniform p is then one s_set_gpr_idx_on + v_mov (LDSXYZ = false)
+    typedef float vecp __attribute__((ext_vector_type(PPT)));
+    vecp px, py, pz;
+    float t[PPT];
     u32 low[PPT];
 #pragma unroll
     for (int p = 0; p < PPT; ++p) {
@@ -64,9 +77,11 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, FpsOrder ord,
             pz[p] = xyz[k * 3 + 2];
             t[p] = temp ? temp[k] : 1e10f;
             low[p] = fps_lowkey(k, ord);
-            sx[k] = px[p];
-            sy[k] = py[p];
-            sz[k] = pz[p];
+            if (LDSXYZ) {
+                sx[k] = px[p];
+                sy[k] = py[p];
+                sz[k] = pz[p];
+            }
         } else {  // padding: key 0 never beats a real point (real low keys are >= 1)
             px[p] = py[p] = pz[p] = 0.f;
             t[p] = 0.f;
@@ -74,8 +89,13 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, FpsOrder ord,
         }
     }
     if (tid == 0) idxs[0] = 0;
-    __syncthreads();
-    float ox = sx[0], oy = sy[0], oz = sz[0];
+    float ox, oy, oz;
+    if (LDSXYZ) {
+        __syncthreads();
+        ox = sx[0]; oy = sy[0]; oz = sz[0];
+    } else {
+        ox = xyz[0]; oy = xyz[1]; oz = xyz[2];
+    }
     if (tid == 0 && nxyz) { nxyz[0] = ox; nxyz[1] = oy; nxyz[2] = oz; }
 
     for (int j = 1; j < m; ++j) {
@@ -88,17 +108,46 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, FpsOrder ord,
             best = pa_max_u64(best, pa_make_key(t[p], low[p]));
         }
         u64 g = pa_wave_max_key2(best);   // two 32-bit DPP reductions: -1 % per round against the 64-bit form (the round is bound by the LDS / barrier round trips)
-        if (NW > 1) {
-            u64 *s = slots + (j & 1) * NW;
-            if ((tid & 63) == 0) s[tid >> 6] = g;
-            __syncthreads();
+        int old;
+        if (LDSXYZ) {
+            if (NW > 1) {
+                u64 *s = slots + (j & 1) * NW;
+                if ((tid & 63) == 0) s[tid >> 6] = g;
+                __syncthreads();
 #pragma unroll
-            for (int w = 0; w < NW; ++w) g = pa_max_u64(g, s[w]);
+                for (int w = 0; w < NW; ++w) g = pa_max_u64(g, s[w]);
+            }
+            old = fps_decode((u32)g, ord);
+            ox = sx[old];
+            oy = sy[old];
+            oz = sz[old];
+        } else {
+            // this wave's winner: point kw = owner thread + p * NT lives in register set p of lane kw % 64 of THIS wave (g is wave-uniform)
+            const int kw = fps_decode((u32)g, ord);
+            const int pw = __builtin_amdgcn_readfirstlane(kw >> LOG_NT), lw = __builtin_amdgcn_readfirstlane(kw & 63);
+            const int pi = pw < PPT ? pw : 0;                             // a wave of padding lanes only decodes garbage (its key never wins)
+            float cx = px[pi], cy = py[pi], cz = pz[pi];
+            cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cx), lw));
+            cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cy), lw));
+            cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cz), lw));
+            if (NW > 1) {
+                FpsSlot *s = rslots + (j & 1) * NW;
+                if ((tid & 63) == 0) { s[tid >> 6].key = g; s[tid >> 6].x = cx; s[tid >> 6].y = cy; s[tid >> 6].z = cz; }
+                __syncthreads();
+                u64 gk[NW];
+                float gx[NW], gy[NW], gz[NW];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) { gk[w] = s[w].key; gx[w] = s[w].x; gy[w] = s[w].y; gz[w] = s[w].z; }
+                g = gk[0]; cx = gx[0]; cy = gy[0]; cz = gz[0];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) {
+                    const bool up = gk[w] > g;
+                    g = up ? gk[w] : g; cx = up ? gx[w] : cx; cy = up ? gy[w] : cy; cz = up ? gz[w] : cz;
+                }
+            }
+            old = fps_decode((u32)g, ord);
+            ox = cx; oy = cy; oz = cz;
         }
-        const int old = fps_decode((u32)g, ord);
-        ox = sx[old];
-        oy = sy[old];
-        oz = sz[old];
         if (tid == 0) {
             idxs[j] = old;
             if (nxyz) { nxyz[j * 3 + 0] = ox; nxyz[j * 3 + 1] = oy; nxyz[j * 3 + 2] = oz; }
@@ -146,14 +195,29 @@ __global__ __launch_bounds__(1024) void fps_stream_kernel(int n, int m, FpsOrder
     }
 }
 
+// Default: cloud copy in LDS.  PA_FPS_REG_XYZ=1 selects the 256-byte-LDS variant (winner coordinates from the owner's registers).  Measured
+// on MI355X at b = 32: bit-identical samples, but the round is longer (n = 4096: 0.70 -> 0.86 us, 719 -> 876 us per launch: the register-set
+// select + three v_readlane + the wider slot exchange sit on the serial chain) and the four-stream extraction rate drops 33.3 k -> 30.8 k
+// submaps/s even though the chain workgroups can now share a CU with it -- the launch's own length matters more than the LDS it pins.
+int g_fps_reg_xyz = -1;
+bool fps_lds_xyz()
+{
+    if (g_fps_reg_xyz < 0) { const char *e = getenv("PA_FPS_REG_XYZ"); g_fps_reg_xyz = (e && e[0] == '1') ? 1 : 0; }
+    return g_fps_reg_xyz == 0;
+}
+
 template <int NT, int PPT>
 int launch_reg(int b, int n, int m, FpsOrder ord, const float *xyz, float *temp, int *idx, float *new_xyz, hipStream_t st)
 {
+    if (!fps_lds_xyz()) {
+        hipLaunchKernelGGL((fps_reg_kernel<NT, PPT, false>), dim3(b), dim3(NT), 2 * (NT / 64) * sizeof(FpsSlot), st, n, m, ord, xyz, temp, idx, new_xyz);
+        return 0;
+    }
     const size_t lds = (size_t)(3 * n + ((3 * n) & 1)) * 4 + 2 * (NT / 64) * 8;
     if (lds > 48 * 1024)  // opt in to the large-LDS carve-out (gfx950: 160 KiB per CU)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_reg_kernel<NT, PPT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_reg_kernel<NT, PPT, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((fps_reg_kernel<NT, PPT>), dim3(b), dim3(NT), lds, st, n, m, ord, xyz, temp, idx, new_xyz);
+    hipLaunchKernelGGL((fps_reg_kernel<NT, PPT, true>), dim3(b), dim3(NT), lds, st, n, m, ord, xyz, temp, idx, new_xyz);
     return 0;
 }
 
@@ -188,6 +252,8 @@ static int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int 
     PA_CHECK_LAUNCH("pa_furthestsampling");
     return PA_OK;
 }
+
+PA_API void pa_fps_reg_xyz_enable(int on) { g_fps_reg_xyz = on ? 1 : 0; }
 
 PA_API int pa_furthestsampling(int b, int n, int m, const float *xyz, float *temp, int *idx, pa_stream_t stream)
 {

@@ -44,6 +44,35 @@ def test_fps_bit_exact(P, b, n, m, kind):
     assert got.dtype == np.int32 and np.array_equal(got, ref), f"first mismatch col {np.argmax((got != ref).any(0))}"
 
 
+@pytest.mark.parametrize("b,n,m,kind", FPS_CASES)
+def test_fps_register_coordinate_variant_bit_exact(b, n, m, kind):
+    """pa_fps_reg_xyz_enable(1): no LDS copy of the cloud, winner coordinates from the owning lane's registers (fps.hip).  Same samples,
+    same gathered coordinates, same running minima as the oracle."""
+    import ctypes
+    from patchaugnet_amd import _lib
+    lib = _lib.lib()
+    lib.pa_fps_reg_xyz_enable.argtypes, lib.pa_fps_reg_xyz_enable.restype = [ctypes.c_int], None
+    x = cloud(b, n, kind)
+    xd = dev(x)
+    ref = o.furthestsampling(x, m)
+    idx = torch.empty((b, m), dtype=torch.int32, device="cuda")
+    idx2 = torch.empty((b, m), dtype=torch.int32, device="cuda")
+    nx = torch.empty((b, m, 3), device="cuda")
+    temp = torch.full((b, n), 1e10, device="cuda")
+    lib.pa_fps_reg_xyz_enable(1)
+    try:
+        _lib.call("pa_furthestsampling", b, n, m, _lib.ptr(xd), _lib.ptr(temp), _lib.ptr(idx))
+        if n <= 8192:
+            _lib.call("pa_furthestsampling_gather", b, n, m, _lib.ptr(xd), _lib.ptr(idx2), _lib.ptr(nx))
+        torch.cuda.synchronize()
+    finally:
+        lib.pa_fps_reg_xyz_enable(0)
+    assert np.array_equal(idx.cpu().numpy(), ref)
+    if n <= 8192:
+        assert np.array_equal(idx2.cpu().numpy(), ref)
+        assert np.array_equal(nx.cpu().numpy(), np.take_along_axis(x, ref[..., None].astype(np.int64), 1))
+
+
 def test_fps_leaves_temp_like_reference():
     """temp holds the final running minima after the call (sampling_cuda_kernel.cu:94-95 writes it back every round)."""
     from patchaugnet_amd import _lib
