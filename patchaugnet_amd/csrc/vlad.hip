@@ -414,11 +414,16 @@ __global__ __launch_bounds__(256) void afa_reweight_kernel(int ktot, const float
 
 // ------------------------------------------------------------------------------------------------ split-K FC
 // out_part[s][b][n] = sum_{k in slice s} y[b][k] * Wt[k][n];  Wt K-major (kdim x nout), slices of KS rows, grid = nslices.
+// The 22 MB weight stream comes from HBM once: every operand is fetched 16 bytes per lane.  A lane's float4 of Wt is four CONSECUTIVE
+// COLUMNS of one k row (MFMA tile j of the wave's 64-column group holds columns 4 i + j in its column i), its float4 of y four consecutive
+// k of one batch row (k-step (u, e) contracts k0 + 16 u + 4 q + e in k-group q) -- 256-byte segments instead of 64-byte ones, a quarter of
+// the load instructions (17 -> ~10 us at b = 32, 21 504 x 256); needs nout % 64 == 0, 16-byte aligned rows, else the 4-byte path.
 template <int RT>
 __global__ __launch_bounds__(256) void fc_splitk_kernel(int bsz, int kdim, int nout, int ks_rows, const float *__restrict__ y,
-                                                          const float *__restrict__ wt, float *__restrict__ out_part)
+                                                          const float *__restrict__ wt, float *__restrict__ out_part, int vec)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lq = lane >> 4;
     const int s = blockIdx.x;
     const int k_begin = s * ks_rows, k_end = min(k_begin + ks_rows, kdim);
     const int nct = nout >> 4;
@@ -428,6 +433,48 @@ __global__ __launch_bounds__(256) void fc_splitk_kernel(int bsz, int kdim, int n
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = (floatx4){0.f, 0.f, 0.f, 0.f};
+        if (vec) {
+            for (int k0 = k_begin; k0 < k_end; k0 += 32) {   // 8 k-steps of operands in flight
+                float4 a4[2][RT], b4[8];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int kk = k0 + 16 * u + 4 * lq;     // k_end - k_begin and kdim are multiples of 4 here: a float4 is all in or all out
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const int row = rt * 16 + li;
+                        a4[u][rt] = (row < bsz && kk < k_end) ? *reinterpret_cast<const float4 *>(y + (size_t)row * kdim + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int kr = kk + e;
+                        b4[u * 4 + e] = kr < k_end ? *reinterpret_cast<const float4 *>(wt + (size_t)kr * nout + c0 * 16 + 4 * li) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float4 bw = b4[u * 4 + e];
+                        const float bv[4] = {bw.x, bw.y, bw.z, bw.w};
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) {
+                            const float av = e == 0 ? a4[u][rt].x : e == 1 ? a4[u][rt].y : e == 2 ? a4[u][rt].z : a4[u][rt].w;
+#pragma unroll
+                            for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[ct], acc[rt][ct], 0, 0, 0);
+                        }
+                    }
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rt * 16 + lq * 4 + r;
+                    if (row < bsz)
+                        *reinterpret_cast<float4 *>(out_part + ((size_t)s * bsz + row) * nout + c0 * 16 + 4 * li) =
+                            make_float4(acc[rt][0][r], acc[rt][1][r], acc[rt][2][r], acc[rt][3][r]);
+                }
+            continue;
+        }
         for (int k0 = k_begin; k0 < k_end; k0 += 32) {   // 8 k-steps of operands in flight: the weight stream comes from HBM
             float af[8][RT], bf[8][4];
 #pragma unroll
@@ -551,14 +598,16 @@ int fc_launch(int b, int kdim, int nout, const float *y, const float *fc_wt, con
 {
     const int ks_rows = 128;
     const int nslices = (kdim + ks_rows - 1) / ks_rows;
+    // 16-byte operand path: whole 64-column groups, k in whole float4s, aligned rows
+    const int vec = (nout % 64 == 0 && kdim % 4 == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)fc_wt & 15) == 0 && ((uintptr_t)opart & 15) == 0) ? 1 : 0;
     for (int b0 = 0; b0 < b; b0 += 64) {
         const int bc = b - b0 < 64 ? b - b0 : 64;
         const float *yc = y + (size_t)b0 * kdim;
         switch ((bc + 15) / 16) {
-            case 1: hipLaunchKernelGGL(fc_splitk_kernel<1>, dim3(nslices), dim3(256), 0, st, bc, kdim, nout, ks_rows, yc, fc_wt, opart); break;
-            case 2: hipLaunchKernelGGL(fc_splitk_kernel<2>, dim3(nslices), dim3(256), 0, st, bc, kdim, nout, ks_rows, yc, fc_wt, opart); break;
-            case 3: hipLaunchKernelGGL(fc_splitk_kernel<3>, dim3(nslices), dim3(256), 0, st, bc, kdim, nout, ks_rows, yc, fc_wt, opart); break;
-            default: hipLaunchKernelGGL(fc_splitk_kernel<4>, dim3(nslices), dim3(256), 0, st, bc, kdim, nout, ks_rows, yc, fc_wt, opart); break;
+            case 1: hipLaunchKernelGGL(fc_splitk_kernel<1>, dim3(nslices), dim3(256), 0, st, bc, kdim, nout, ks_rows, yc, fc_wt, opart, vec); break;
+            case 2: hipLaunchKernelGGL(fc_splitk_kernel<2>, dim3(nslices), dim3(256), 0, st, bc, kdim, nout, ks_rows, yc, fc_wt, opart, vec); break;
+            case 3: hipLaunchKernelGGL(fc_splitk_kernel<3>, dim3(nslices), dim3(256), 0, st, bc, kdim, nout, ks_rows, yc, fc_wt, opart, vec); break;
+            default: hipLaunchKernelGGL(fc_splitk_kernel<4>, dim3(nslices), dim3(256), 0, st, bc, kdim, nout, ks_rows, yc, fc_wt, opart, vec); break;
         }
         hipLaunchKernelGGL(fc_finalize_kernel, dim3(bc), dim3(nout <= 256 ? 4 * nout : nout), 0, st, bc, nout, nslices, opart, fc_bias, scale, shift, l2norm,
                            gate_x ? gate_x + (size_t)b0 * nout : nullptr, out + (size_t)b0 * nout);
