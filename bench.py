@@ -85,6 +85,14 @@ def stage_pass(model, x, iters=5):
         return profiling.stage_times(model, x, iters)
 
 
+def profiling_fp0_launch_ms(model, x):
+    from patchaugnet_amd import profiling
+    try:
+        return profiling.fp0_launch_time_ms(model, x)
+    except Exception:
+        return None
+
+
 def dominant_kernel_roofline(st, cfg, batch, points, grouping, pmc=None, pmc_note=None):
     """Roofline of the kernel that owns the most CU-time in a step.
 
@@ -472,6 +480,11 @@ def main():
             try:
                 st = stage_pass(model, x)
                 line["kernels"]["stages_ms"] = st
+                with torch.no_grad():
+                    b2b = profiling_fp0_launch_ms(model, x)
+                if b2b:       # for reference beside the roofline figure (which stays the conservative one: ONE launch bracketed by two events, ~15 us of
+                    #           event / dispatch overhead included): the same launch back to back, warm caches -- rocprofv3's duration lies between the two
+                    line["kernels"]["fp0_chain_back_to_back_ms"] = b2b
                 pmc, note = (None, "--no-pmc") if a.no_pmc else measure_traffic(a.batch, a.points)
                 line.update(dominant_kernel_roofline(st, cfg, a.batch, a.points, g, pmc, note))
             except Exception as ex:  # attribution is diagnostics; never lose the bench line over it

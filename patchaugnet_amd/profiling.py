@@ -34,6 +34,34 @@ def engine_stage_times(model, x, iters=5):
     return acc
 
 
+def fp0_launch_time_ms(model, x, repeat=9, iters=3):
+    """Average duration of ONE launch of the finest feature-propagation chain (the dominant kernel), HIP events on the launch stream:
+    the stage is timed with the launch issued once and `repeat` times back to back; the difference / (repeat - 1) is the launch's own
+    duration, free of the two event records and the dispatch gap that a single bracketed launch includes (~15 us on a 0.3 ms kernel).
+    None when the level does not run the pre-multiplied chain."""
+    model(x, return_feat=False)
+    eng = model._engine
+    chain = eng.fp[0]
+    if getattr(chain, "_premul", None) is None:
+        return None
+
+    def stage(rep):
+        chain.bench_repeat = rep
+        try:
+            tot = 0.0
+            for _ in range(iters):
+                eng.timer = StageTimer()
+                model(x, return_feat=False)
+                t, eng.timer = eng.timer, None
+                tot += t.result().get("fp0.chain", 0.0) / iters
+            return tot
+        finally:
+            chain.bench_repeat = 1
+    stage(1)
+    one, many = stage(1), stage(repeat)
+    return (many - one) / (repeat - 1)
+
+
 def stage_times(model, x, iters=5):
     """Average ms per stage over `iters` steps of the module path (stages: fps, knn, group+mlp, 3nn+interp+mlp, vlad, afa)."""
     if getattr(model, "fused_eval", False):

@@ -50,16 +50,16 @@ root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 tag = [f for f in os.listdir(root + "/gpurun_out") if f.endswith("_pmc_mfma.txt")][-1]
 vals = collections.defaultdict(dict)
 for line in open(root + "/gpurun_out/" + tag):
-    m = re.match(r"(.*?)\s+(SQ_\w+|GRBM_\w+)\s+n=\s*\d+ avg=([0-9.]+)", line)
-    if m:
-        vals[m.group(1).strip()][m.group(2)] = float(m.group(3))
+    m = re.match(r"(.*?)\s+(SQ_\w+|GRBM_\w+)\s+n=\s*\d+ avg=([0-9.]+) min=([0-9.]+)", line)
+    if m:      # kernel cycles: the MINIMUM over the launches (the first launch of a kernel can be several times longer: cold caches, clock ramp)
+        vals[m.group(1).strip()][m.group(2)] = float(m.group(4) if m.group(2) == "GRBM_GUI_ACTIVE" else m.group(3))
 out = []
 for k, v in vals.items():
     if v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) > 0 and v.get("GRBM_GUI_ACTIVE", 0) > 0:
         util = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] / 8 * 1024)
         out.append((util, k))
 with open(root + "/gpurun_out/" + tag.replace("_pmc_mfma.txt", "_mfma_util.txt"), "w") as f:
-    f.write("MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), averages per kernel over tools/pmc_target.py\n")
+    f.write("MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); busy cycles averaged, kernel cycles the minimum over the launches of tools/pmc_target.py\n")
     for util, k in sorted(out, reverse=True):
         f.write(f"{util:6.1%}  {k[:150]}\n")
         print(f"{util:6.1%}  {k[:110]}")
