@@ -306,7 +306,7 @@ def train_bench(a):
                    "weights": "key-seeded random init", "parallelism": "dp1",
                    "launch": "one hipGraph replay per step (forward + losses + backward + Adam)" if graphed else "python launches"},
         "losses_last_step": losses,
-        "roofline": {"kernel": "tgemm_nn_kernel<128,true,1> (pa_tgemm_nn: 256 -> 256 layer of the finest FP level, forward: BatchNorm + ReLU of the "
+        "roofline": {"kernel": "tgemm_nn_kernel<64,16,true,1> (pa_tgemm_nn: 256 -> 256 layer of the finest FP level, forward: BatchNorm + ReLU of the "
                                "previous layer in the loader, statistics in the epilogue)", "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None, "algorithmic_flops_per_launch": flops, "ms_per_launch": ms},
     }

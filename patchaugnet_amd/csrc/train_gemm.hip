@@ -579,10 +579,13 @@ PA_API int pa_tgemm_nn(int batch, int M, int N, int K, const float *A, long sAb,
     a.sStatb = per_batch_stats ? (long)PA_BN_STAT_SLOTS * 2 * M : 0;
     a.vecA = aligned16(A) && lda % 4 == 0 && sAb % 4 == 0;
     a.vecB = aligned16(B) && ldb % 4 == 0 && sBb % 4 == 0 && (bmode < 2 || aligned16(baux));
-    // 128-row tiles when there are enough of them to fill the chip twice over; 64-row tiles otherwise (the decoder's 1024 x 1024 layers
-    // over three clouds, the coarse levels): twice the workgroups, each with half the accumulators
+    // 64-row tiles (half the accumulators: 4-5 workgroups per CU instead of 3) for every shape.  128-row tiles remain behind
+    // PA_TGEMM_BIG_MIN (minimum number of 128 x 128 tiles to use them): measured on MI355X they lose even where they fill the chip -- the
+    // finest level's 256 x 4096 x 256 per cloud x 18 is 1152 such tiles on 768 resident slots = two rounds (153 us; 64-row tiles 145 us), the
+    // whole step's GEMMs 5.35 -> 5.18 ms, the 20 k x 20 k retrieval distance GEMM + select 7.64 -> 7.50 ms.
     const long t128 = (long)((M + 127) / 128) * ((N + NN_BN - 1) / NN_BN) * batch;
-    const bool big = M > 64 && t128 >= 512;
+    static const long big_min = getenv("PA_TGEMM_BIG_MIN") ? atol(getenv("PA_TGEMM_BIG_MIN")) : (1L << 40);   // tuning knob
+    const bool big = M > 64 && t128 >= big_min;
     const long t64 = (long)((M + 63) / 64) * ((N + NN_BN - 1) / NN_BN) * batch;
     const bool deep = K > 16 && !big && t64 < 1024;     // few workgroups: latency-bound rounds, halve their number (measured: hurts the chip-filling launches)
     dim3 grid((N + NN_BN - 1) / NN_BN, (M + (big ? 127 : 63)) / (big ? 128 : 64), batch);

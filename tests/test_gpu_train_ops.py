@@ -89,6 +89,19 @@ def test_tgemm_nn(M, N, K, batch, a_kcontig, bmode):
             assert torch.allclose(stats.sum(0).cpu(), s, rtol=1e-5, atol=1e-4 * max(scale, 1.0)), (stats.sum(0).cpu() - s).abs().max()
 
 
+def test_tgemm_nn_128_row_tile_variant_in_a_subprocess():
+    """The 128-row tiles of pa_tgemm_nn are an A/B knob now (PA_TGEMM_BIG_MIN, read once per process): run the GEMM cases with it forced on."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if os.environ.get("PA_TGEMM_BIG_MIN"):
+        pytest.skip("already inside the forced-variant run")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_train_ops.py"), "-q", "-m", "gpu", "-k", "test_tgemm_nn and not subprocess",
+                          "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, PA_TGEMM_BIG_MIN="1"))
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
+
+
 @pytest.mark.parametrize("M,N,K,batch", [(70, 37, 300, 3), (64, 64, 128, 1), (200, 259, 1001, 2), (18, 256, 21504, 1), (5, 3, 7, 2)])
 @pytest.mark.parametrize("amode", [0, 2, 3])
 @pytest.mark.parametrize("bmode", [0, 1])
