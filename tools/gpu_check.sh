@@ -9,6 +9,13 @@ timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_tests.log 2>
 tail -5 gpurun_out/${TAG}_tests.log
 timeout 600 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"
 cat gpurun_out/${TAG}_bench.json
+# the driver's round-end command line (20 timed steps: pipeline fill / drain weigh ~5 %), three times
+for i in 1 2 3; do timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-pmc 2>> gpurun_out/${TAG}_bench.err; done > gpurun_out/${TAG}_bench_driver_protocol.json
+python - <<'PY'
+import json, glob
+f = sorted(glob.glob("gpurun_out/*_bench_driver_protocol.json"))[-1]
+print("driver protocol (--steps 20 --warmup 5):", [round(json.loads(l)["value"]) for l in open(f).read().strip().splitlines() if l.startswith("{")])
+PY
 # the other BASELINE configurations: PPT-Net (fp32 and the fp16 MLP path = configs[4]), PatchAugNet fp16 MLP path, section-8(d) sweep
 timeout 300 python bench.py --model pptnet --no-cpu-baseline > gpurun_out/${TAG}_bench_pptnet_f32.json 2>> gpurun_out/${TAG}_bench.err
 timeout 300 python bench.py --model pptnet --mlp-dtype f16 --no-cpu-baseline > gpurun_out/${TAG}_bench_pptnet_f16.json 2>> gpurun_out/${TAG}_bench.err
