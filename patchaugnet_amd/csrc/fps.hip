@@ -162,6 +162,14 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, FpsOrder ord,
     }
 }
 
+// Measured and not kept (round 2): block pruning.  With the cloud counting-sorted into Morton cells a register set of a wave is a compact
+// block of 64 points with a bounding sphere (c, r); every running minimum is <= M (the minimum of the point just selected), so a block with
+// |o - c| >= (r + sqrt(M)) * 1.0005 cannot change and its nine instructions per point can be skipped -- exact (bit-identical samples on every
+// test cloud), and only 20-25 % of the blocks are touched per round on uniform and plane-like clouds.  But a block is ONE point per lane:
+// the skip is a wave-uniform branch around nine VALU instructions, sixteen of them per round, and a taken s_cbranch costs about as much as
+// the instructions it jumps over; the per-lane key maximum over all sixteen sets (48 instructions) cannot be skipped.  Result at n = 4096,
+// m = 1024: 0.95 us per round against 0.70 (973 vs 721 us per launch).  Skipping in groups of four sets would recover ~10 % at best.
+
 // Any-n path: temp stays in global memory (as in the reference), same key order, 1024 threads.
 __global__ __launch_bounds__(1024) void fps_stream_kernel(int n, int m, FpsOrder ord, const float *__restrict__ xyz_all,
                                                             float *__restrict__ temp_all, int *__restrict__ idx_all)
