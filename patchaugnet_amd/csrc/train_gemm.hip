@@ -48,6 +48,18 @@ __device__ __forceinline__ ChanP load_chan(const TOp &t, int ch, bool live)
     return c;
 }
 
+// the same parameters fetched UNCONDITIONALLY from a clamped channel (no branch around the loads; the caller masks the result)
+template <int MODE>
+__device__ __forceinline__ ChanP load_chan_clamped(const TOp &t, int ch)
+{
+    ChanP c;
+    constexpr int NP = MODE == TF_NONE ? 0 : (MODE == TF_AFFINE_RELU ? 2 : 7);
+    const int cc = min(ch, t.nch - 1);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) c.v[j] = j < NP ? t.p[(size_t)j * t.nch + cc] : 0.f;
+    return c;
+}
+
 template <int MODE>
 __device__ __forceinline__ float tf_apply(float g, float y, const ChanP &c)
 {
@@ -80,7 +92,9 @@ constexpr int NN_BN = 128;
 
 // NN_BK = 32 halves the number of (barrier, fetch) rounds of a long contraction: with few workgroups per CU a round is bound by the
 // latency of its global loads, not by its MFMAs; 16 stays for the short contractions (K <= 16: first layers, cluster counts).
-template <int BM, int NN_BK, bool A_KCONTIG, int BMODE>
+// VA / VB: 16-byte global loads of the A / B operand (host-checked alignment and divisibility) -- compile-time, so that the k-loop has no
+// branch between its loads (a run-time flag made the compiler wait for all outstanding loads at every block boundary).
+template <int BM, int NN_BK, bool A_KCONTIG, int BMODE, bool VA, bool VB>
 __global__ __launch_bounds__(256) void tgemm_nn_kernel(NNArgs a)
 {
     constexpr int SA = BM + 16, SB = NN_BN + 16;          // row strides = 16 mod 32 floats: conflict-free fragment reads (rows k, k+1 per 32-lane half)
@@ -104,25 +118,39 @@ __global__ __launch_bounds__(256) void tgemm_nn_kernel(NNArgs a)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
 
+    // Operand staging, global -> registers -> (transform) -> LDS.  fetch() only ISSUES loads: every load is unconditional from a clamped
+    // address (out-of-range elements are zeroed by a select in stash()), and the BatchNorm / ReLU transform of the B operand is applied in
+    // stash(), after the MFMAs of the current tile -- so the loads of tile kt + 1 are in flight during the whole MFMA block of tile kt.
+    // (Before: predicated loads compiled to a branch per load and the transform right behind them put s_waitcnt vmcnt(0) BEFORE the
+    // MFMAs: the global latency of every k-tile was exposed in every wave.)
     float ra[AE];
+    unsigned fa = 0;                                       // validity bits of ra
     constexpr int BP = NN_BK / 8;                           // B staging passes of 8 rows
-    float rb[BP * 4];
+    float rb[BP * 4], ry[BP * 4];
+    ChanP rcp[BP];
+    unsigned fb = 0;                                       // validity bits of rb
     // B staging: thread -> rows kb, kb + 8; 4 consecutive columns nb4
     const int kb = tid >> 5, nb4 = (tid & 31) * 4;
+    const int Km1 = a.K - 1, Mm1 = a.M - 1, Nm1 = a.N - 1;
     auto fetch = [&](int k0) {
+        fa = 0; fb = 0;
         // ---- A tile
         if (A_KCONTIG) {                                   // 4 consecutive k per load: m = q / (BK/4), k4 = (q % (BK/4)) * 4
 #pragma unroll
             for (int u = 0; u < AE / 4; ++u) {
                 const int q = tid + u * 256, m = q / (NN_BK / 4), k4 = (q % (NN_BK / 4)) * 4;
                 const int gm = m0 + m, gk = k0 + k4;
-                const float *src = A + (size_t)gm * a.lda + gk;
-                if (gm < a.M && gk + 3 < a.K && a.vecA) {
-                    const float4 v = *reinterpret_cast<const float4 *>(src);
+                const float *row = A + (size_t)min(gm, Mm1) * a.lda;
+                if (VA) {                                  // K % 4 == 0 here (host): a group is all in or all out
+                    const float4 v = *reinterpret_cast<const float4 *>(row + min(gk, a.K - 4));
                     ra[u * 4] = v.x; ra[u * 4 + 1] = v.y; ra[u * 4 + 2] = v.z; ra[u * 4 + 3] = v.w;
+                    if (gm < a.M && gk < a.K) fa |= 0xfu << (u * 4);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) ra[u * 4 + e] = (gm < a.M && gk + e < a.K) ? src[e] : 0.f;
+                    for (int e = 0; e < 4; ++e) {
+                        ra[u * 4 + e] = row[min(gk + e, Km1)];
+                        if (gm < a.M && gk + e < a.K) fa |= 1u << (u * 4 + e);
+                    }
                 }
             }
         } else {                                           // 4 consecutive m per load: k = q / (BM/4), m4 = (q % (BM/4)) * 4
@@ -130,45 +158,51 @@ __global__ __launch_bounds__(256) void tgemm_nn_kernel(NNArgs a)
             for (int u = 0; u < AE / 4; ++u) {
                 const int q = tid + u * 256, k = q / (BM / 4), m4 = (q % (BM / 4)) * 4;
                 const int gm = m0 + m4, gk = k0 + k;
-                const float *src = A + (size_t)gk * a.lda + gm;
-                if (gk < a.K && gm + 3 < a.M && a.vecA) {
-                    const float4 v = *reinterpret_cast<const float4 *>(src);
+                const float *row = A + (size_t)min(gk, Km1) * a.lda;
+                if (VA) {                                  // M % 4 == 0 here (host)
+                    const float4 v = *reinterpret_cast<const float4 *>(row + min(gm, a.M - 4));
                     ra[u * 4] = v.x; ra[u * 4 + 1] = v.y; ra[u * 4 + 2] = v.z; ra[u * 4 + 3] = v.w;
+                    if (gk < a.K && gm < a.M) fa |= 0xfu << (u * 4);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) ra[u * 4 + e] = (gk < a.K && gm + e < a.M) ? src[e] : 0.f;
+                    for (int e = 0; e < 4; ++e) {
+                        ra[u * 4 + e] = row[min(gm + e, Mm1)];
+                        if (gk < a.K && gm + e < a.M) fa |= 1u << (u * 4 + e);
+                    }
                 }
             }
         }
-        // ---- B tile (transform applied here, in registers)
+        // ---- B tile (raw; transformed in stash)
 #pragma unroll
         for (int h = 0; h < BP; ++h) {
             const int gk = k0 + kb + h * 8, gn = n0 + nb4;
             const bool klive = gk < a.K;
-            const ChanP cp = load_chan<BMODE>(a.tb, gk, klive);
-            float g[4], y[4] = {0.f, 0.f, 0.f, 0.f};
-            const float *src = B + (size_t)gk * a.ldb + gn;
-            if (klive && gn + 3 < a.N && a.vecB) {
-                const float4 v = *reinterpret_cast<const float4 *>(src);
-                g[0] = v.x; g[1] = v.y; g[2] = v.z; g[3] = v.w;
+            rcp[h] = load_chan_clamped<BMODE>(a.tb, gk);
+            const size_t roff = (size_t)min(gk, Km1) * a.ldb;
+            if (VB) {                                      // N % 4 == 0 here (host)
+                const int cn = min(gn, a.N - 4);
+                const float4 v = *reinterpret_cast<const float4 *>(B + roff + cn);
+                rb[h * 4] = v.x; rb[h * 4 + 1] = v.y; rb[h * 4 + 2] = v.z; rb[h * 4 + 3] = v.w;
                 if (BMODE >= TF_BN_BWD_RELU) {
-                    const float4 w = *reinterpret_cast<const float4 *>(B2 + (size_t)gk * a.ldb + gn);
-                    y[0] = w.x; y[1] = w.y; y[2] = w.z; y[3] = w.w;
+                    const float4 w = *reinterpret_cast<const float4 *>(B2 + roff + cn);
+                    ry[h * 4] = w.x; ry[h * 4 + 1] = w.y; ry[h * 4 + 2] = w.z; ry[h * 4 + 3] = w.w;
                 }
+                if (klive && gn < a.N) fb |= 0xfu << (h * 4);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const bool live = klive && gn + e < a.N;
-                    g[e] = live ? src[e] : 0.f;
-                    if (BMODE >= TF_BN_BWD_RELU) y[e] = live ? B2[(size_t)gk * a.ldb + gn + e] : 0.f;
+                    const int cn = min(gn + e, Nm1);
+                    rb[h * 4 + e] = B[roff + cn];
+                    if (BMODE >= TF_BN_BWD_RELU) ry[h * 4 + e] = B2[roff + cn];
+                    if (klive && gn + e < a.N) fb |= 1u << (h * 4 + e);
                 }
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) rb[h * 4 + e] = (klive && gn + e < a.N) ? tf_apply<BMODE>(g[e], y[e], cp) : 0.f;
         }
     };
     auto stash = [&](int buf) {
         float *as = As[buf], *bs = Bs[buf];
+#pragma unroll
+        for (int e = 0; e < AE; ++e) ra[e] = (fa >> e) & 1u ? ra[e] : 0.f;
         if (A_KCONTIG) {
 #pragma unroll
             for (int u = 0; u < AE / 4; ++u) {
@@ -184,8 +218,15 @@ __global__ __launch_bounds__(256) void tgemm_nn_kernel(NNArgs a)
             }
         }
 #pragma unroll
-        for (int h = 0; h < BP; ++h)
-            *reinterpret_cast<float4 *>(bs + (kb + h * 8) * SB + nb4) = make_float4(rb[h * 4], rb[h * 4 + 1], rb[h * 4 + 2], rb[h * 4 + 3]);
+        for (int h = 0; h < BP; ++h) {
+            float t[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = tf_apply<BMODE>(rb[h * 4 + e], BMODE >= TF_BN_BWD_RELU ? ry[h * 4 + e] : 0.f, rcp[h]);
+                t[e] = (fb >> (h * 4 + e)) & 1u ? v : 0.f;
+            }
+            *reinterpret_cast<float4 *>(bs + (kb + h * 8) * SB + nb4) = make_float4(t[0], t[1], t[2], t[3]);
+        }
     };
 
     const int nk = (a.K + NN_BK - 1) / NN_BK;
@@ -577,8 +618,8 @@ PA_API int pa_tgemm_nn(int batch, int M, int N, int K, const float *A, long sAb,
     a.C = C; a.sCb = sCb; a.ldc = ldc; a.beta = beta; a.bias = bias; a.colv = colv; a.act = act; a.stats = stats;
     a.sPb = per_batch_stats ? 7L * K : 0;                       // the operand's parameter block belongs to ITS layer: K channels
     a.sStatb = per_batch_stats ? (long)PA_BN_STAT_SLOTS * 2 * M : 0;
-    a.vecA = aligned16(A) && lda % 4 == 0 && sAb % 4 == 0;
-    a.vecB = aligned16(B) && ldb % 4 == 0 && sBb % 4 == 0 && (bmode < 2 || aligned16(baux));
+    a.vecA = aligned16(A) && lda % 4 == 0 && sAb % 4 == 0 && (a_kcontig ? (K % 4 == 0 && K >= 4) : (M % 4 == 0 && M >= 4));
+    a.vecB = aligned16(B) && ldb % 4 == 0 && sBb % 4 == 0 && (bmode < 2 || aligned16(baux)) && N % 4 == 0 && N >= 4;
     // 64-row tiles (half the accumulators: 4-5 workgroups per CU instead of 3) for every shape.  128-row tiles remain behind
     // PA_TGEMM_BIG_MIN (minimum number of 128 x 128 tiles to use them): measured on MI355X they lose even where they fill the chip -- the
     // finest level's 256 x 4096 x 256 per cloud x 18 is 1152 such tiles on 768 resident slots = two rounds (153 us; 64-row tiles 145 us), the
@@ -590,15 +631,19 @@ PA_API int pa_tgemm_nn(int batch, int M, int N, int K, const float *A, long sAb,
     const bool deep = K > 16 && !big && t64 < 1024;     // few workgroups: latency-bound rounds, halve their number (measured: hurts the chip-filling launches)
     dim3 grid((N + NN_BN - 1) / NN_BN, (M + (big ? 127 : 63)) / (big ? 128 : 64), batch);
     hipStream_t st = (hipStream_t)stream;
-#define PA_NN(BMv, BKv, KC, MODE) hipLaunchKernelGGL((tgemm_nn_kernel<BMv, BKv, KC, MODE>), grid, dim3(256), 0, st, a)
+#define PA_NN(BMv, BKv, KC, MODE, VAv, VBv) hipLaunchKernelGGL((tgemm_nn_kernel<BMv, BKv, KC, MODE, VAv, VBv>), grid, dim3(256), 0, st, a)
+#define PA_NN_VEC(BMv, BKv, KC, MODE)                                                                       \
+    if (a.vecA) { if (a.vecB) PA_NN(BMv, BKv, KC, MODE, true, true); else PA_NN(BMv, BKv, KC, MODE, true, false); } \
+    else { if (a.vecB) PA_NN(BMv, BKv, KC, MODE, false, true); else PA_NN(BMv, BKv, KC, MODE, false, false); }
 #define PA_NN_MODE(BMv, BKv, KC)                                                                            \
-    switch (bmode) { case 0: PA_NN(BMv, BKv, KC, 0); break; case 1: PA_NN(BMv, BKv, KC, 1); break;          \
-                     case 2: PA_NN(BMv, BKv, KC, 2); break; default: PA_NN(BMv, BKv, KC, 3); break; }
+    switch (bmode) { case 0: PA_NN_VEC(BMv, BKv, KC, 0) break; case 1: PA_NN_VEC(BMv, BKv, KC, 1) break;    \
+                     case 2: PA_NN_VEC(BMv, BKv, KC, 2) break; default: PA_NN_VEC(BMv, BKv, KC, 3) break; }
 #define PA_NN_KC(BMv, BKv) if (a_kcontig) { PA_NN_MODE(BMv, BKv, true) } else { PA_NN_MODE(BMv, BKv, false) }
     if (big) { if (deep) { PA_NN_KC(128, 32) } else { PA_NN_KC(128, 16) } }
     else { if (deep) { PA_NN_KC(64, 32) } else { PA_NN_KC(64, 16) } }
 #undef PA_NN_KC
 #undef PA_NN_MODE
+#undef PA_NN_VEC
 #undef PA_NN
     PA_CHECK_LAUNCH("pa_tgemm_nn");
     return PA_OK;
