@@ -326,7 +326,8 @@ struct KKArgs {
 
 constexpr int KK_BM = 64, KK_BN = 64, KK_BK = 32, KK_S = KK_BK + 2;   // row stride 34: (2m + k) mod 32 distinct for m < 16, k < 2
 
-template <int AMODE, int BMODE>
+// VEC: 16-byte global loads of both operands (host: alignment, K and the split size multiples of 4); compile-time for a branch-free k-loop
+template <int AMODE, int BMODE, bool VEC>
 __global__ __launch_bounds__(256) void tgemm_kk_kernel(KKArgs a)
 {
     __shared__ __attribute__((aligned(16))) float As[2][KK_BM * KK_S];
@@ -346,7 +347,10 @@ __global__ __launch_bounds__(256) void tgemm_kk_kernel(KKArgs a)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
     // staging: 64 rows x 32 k = 512 float4 per operand: thread -> row r = q / 8, k4 = (q % 8) * 4, q = tid, tid + 256
-    float ra[8], rb[8];
+    // fetch() only issues loads (unconditional, clamped addresses); masks and the BatchNorm transforms are applied in stash(), after the
+    // MFMAs of the current tile (see tgemm_nn_kernel)
+    float ra[8], ry[8], rb[8];
+    unsigned fa = 0, fb = 0;
     ChanP ca[2], cb[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -354,45 +358,36 @@ __global__ __launch_bounds__(256) void tgemm_kk_kernel(KKArgs a)
         ca[u] = load_chan<AMODE>(a.ta, m0 + r, m0 + r < a.M);
         cb[u] = load_chan<BMODE>(a.tb, n0 + r, n0 + r < a.N);
     }
+    const int Mm1 = a.M - 1, Nm1 = a.N - 1, kl1 = kend - 1;
     auto fetch = [&](int k0) {
+        fa = 0; fb = 0;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int q = tid + u * 256, r = q >> 3, k4 = (q & 7) * 4, gk = k0 + k4;
-            {   // A
-                const int gm = m0 + r;
-                const float *src = A + (size_t)gm * a.lda + gk;
-                float g[4], y[4] = {0.f, 0.f, 0.f, 0.f};
-                if (gm < a.M && gk + 3 < kend && a.vecA) {
-                    const float4 v = *reinterpret_cast<const float4 *>(src);
-                    g[0] = v.x; g[1] = v.y; g[2] = v.z; g[3] = v.w;
-                    if (AMODE >= TF_BN_BWD_RELU) {
-                        const float4 w = *reinterpret_cast<const float4 *>(A2 + (size_t)gm * a.lda + gk);
-                        y[0] = w.x; y[1] = w.y; y[2] = w.z; y[3] = w.w;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const bool live = gm < a.M && gk + e < kend;
-                        g[e] = live ? src[e] : 0.f;
-                        if (AMODE >= TF_BN_BWD_RELU) y[e] = live ? A2[(size_t)gm * a.lda + gk + e] : 0.f;
-                    }
+            const int gm = m0 + r, gn = n0 + r;
+            const size_t aoff = (size_t)min(gm, Mm1) * a.lda, boff = (size_t)min(gn, Nm1) * a.ldb;
+            if (VEC) {                                     // kend % 4 == 0: a group of four k is all in or all out
+                const int ck = min(gk, kend - 4);
+                const float4 v = *reinterpret_cast<const float4 *>(A + aoff + ck);
+                ra[u * 4] = v.x; ra[u * 4 + 1] = v.y; ra[u * 4 + 2] = v.z; ra[u * 4 + 3] = v.w;
+                if (AMODE >= TF_BN_BWD_RELU) {
+                    const float4 w = *reinterpret_cast<const float4 *>(A2 + aoff + ck);
+                    ry[u * 4] = w.x; ry[u * 4 + 1] = w.y; ry[u * 4 + 2] = w.z; ry[u * 4 + 3] = w.w;
                 }
+                const float4 x = *reinterpret_cast<const float4 *>(B + boff + ck);
+                rb[u * 4] = x.x; rb[u * 4 + 1] = x.y; rb[u * 4 + 2] = x.z; rb[u * 4 + 3] = x.w;
+                if (gm < a.M && gk < kend) fa |= 0xfu << (u * 4);
+                if (gn < a.N && gk < kend) fb |= 0xfu << (u * 4);
+            } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ra[u * 4 + e] = (gm < a.M && gk + e < kend) ? tf_apply<AMODE>(g[e], y[e], ca[u]) : 0.f;
-            }
-            {   // B
-                const int gn = n0 + r;
-                const float *src = B + (size_t)gn * a.ldb + gk;
-                float g[4];
-                if (gn < a.N && gk + 3 < kend && a.vecB) {
-                    const float4 v = *reinterpret_cast<const float4 *>(src);
-                    g[0] = v.x; g[1] = v.y; g[2] = v.z; g[3] = v.w;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) g[e] = (gn < a.N && gk + e < kend) ? src[e] : 0.f;
+                for (int e = 0; e < 4; ++e) {
+                    const int ck = min(gk + e, kl1);
+                    ra[u * 4 + e] = A[aoff + ck];
+                    if (AMODE >= TF_BN_BWD_RELU) ry[u * 4 + e] = A2[aoff + ck];
+                    rb[u * 4 + e] = B[boff + ck];
+                    if (gm < a.M && gk + e < kend) fa |= 1u << (u * 4 + e);
+                    if (gn < a.N && gk + e < kend) fb |= 1u << (u * 4 + e);
                 }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) rb[u * 4 + e] = (gn < a.N && gk + e < kend) ? tf_apply<BMODE>(g[e], 0.f, cb[u]) : 0.f;
             }
         }
     };
@@ -400,12 +395,20 @@ __global__ __launch_bounds__(256) void tgemm_kk_kernel(KKArgs a)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int q = tid + u * 256, r = q >> 3, k4 = (q & 7) * 4;
+            float ta[4], tb[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float va = tf_apply<AMODE>(ra[u * 4 + e], AMODE >= TF_BN_BWD_RELU ? ry[u * 4 + e] : 0.f, ca[u]);
+                const float vb = tf_apply<BMODE>(rb[u * 4 + e], 0.f, cb[u]);
+                ta[e] = (fa >> (u * 4 + e)) & 1u ? va : 0.f;
+                tb[e] = (fb >> (u * 4 + e)) & 1u ? vb : 0.f;
+            }
             float2 *da = reinterpret_cast<float2 *>(As[buf] + r * KK_S + k4);
-            da[0] = make_float2(ra[u * 4], ra[u * 4 + 1]);
-            da[1] = make_float2(ra[u * 4 + 2], ra[u * 4 + 3]);
+            da[0] = make_float2(ta[0], ta[1]);
+            da[1] = make_float2(ta[2], ta[3]);
             float2 *db = reinterpret_cast<float2 *>(Bs[buf] + r * KK_S + k4);
-            db[0] = make_float2(rb[u * 4], rb[u * 4 + 1]);
-            db[1] = make_float2(rb[u * 4 + 2], rb[u * 4 + 3]);
+            db[0] = make_float2(tb[0], tb[1]);
+            db[1] = make_float2(tb[2], tb[3]);
         }
     };
     const int nk = (kend - kbeg + KK_BK - 1) / KK_BK;
@@ -665,7 +668,7 @@ PA_API int pa_tgemm_kk(int batch, int M, int N, long K, const float *A, long sAb
     a.C = C; a.sCb = sCb; a.ldc = ldc; a.per_batch = per_batch;
     a.sAPb = per_batch_stats ? 7L * M : 0;
     a.sBPb = per_batch_stats ? 7L * N : 0;
-    a.vecA = aligned16(A) && lda % 4 == 0 && sAb % 4 == 0 && (amode == 0 || aligned16(aaux));
+    a.vecA = aligned16(A) && lda % 4 == 0 && sAb % 4 == 0 && (amode == 0 || aligned16(aaux)) && K % 4 == 0 && K >= 4;
     a.vecB = aligned16(B) && ldb % 4 == 0 && sBb % 4 == 0;
     const long tiles = (long)((M + KK_BM - 1) / KK_BM) * ((N + KK_BN - 1) / KK_BN) * batch;
     long splits = (2048 + tiles - 1) / tiles;                  // aim at ~2048 workgroups
@@ -692,7 +695,9 @@ PA_API int pa_tgemm_kk(int batch, int M, int N, long K, const float *A, long sAb
     a.ksplits = (int)splits; a.kchunk = (int)chunk;
     dim3 grid((N + KK_BN - 1) / KK_BN, (M + KK_BM - 1) / KK_BM, (unsigned)(batch * splits));
     hipStream_t st = (hipStream_t)stream;
-#define PA_KK(AM, BMo) hipLaunchKernelGGL((tgemm_kk_kernel<AM, BMo>), grid, dim3(256), 0, st, a)
+    const bool vec = a.vecA && a.vecB;       // the split size is a multiple of 32, K of 4: every split ends on a multiple of 4
+#define PA_KK(AM, BMo) do { if (vec) hipLaunchKernelGGL((tgemm_kk_kernel<AM, BMo, true>), grid, dim3(256), 0, st, a); \
+                            else hipLaunchKernelGGL((tgemm_kk_kernel<AM, BMo, false>), grid, dim3(256), 0, st, a); } while (0)
     if (amode == 0) { if (bmode == 0) PA_KK(0, 0); else PA_KK(0, 1); }
     else if (amode == 2) { if (bmode == 0) PA_KK(2, 0); else PA_KK(2, 1); }
     else { if (bmode == 0) PA_KK(3, 0); else PA_KK(3, 1); }
