@@ -78,6 +78,12 @@ int pa_grouping_int_forward(int b, int c, int n, int m, int nsample, const int64
 int pa_nearestneighbor(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx, pa_stream_t stream);
 int pa_interpolation_forward(int b, int c, int m, int n, const float *points, const int *idx, const float *weight, float *out, pa_stream_t stream);
 int pa_interpolation_backward(int b, int c, int n, int m, const float *grad_out, const int *idx, const float *weight, float *grad_points, pa_stream_t stream);
+/* The same gradient without atomics (csrc/gather.hip): the (point, neighbour) references are counting-sorted by target once per launch, then
+ * every output element is a plain sum over its list.  Equal to pa_interpolation_backward up to the order of the float sums; n <= 4096,
+ * m <= 8192; scratch: pa_interpolation_backward_scratch_ints(b, n, m) ints, 8-byte aligned. */
+long pa_interpolation_backward_scratch_ints(int b, int n, int m);
+int pa_interpolation_backward_gather(int b, int c, int n, int m, const float *grad_out, const int *idx, const float *weight, float *grad_points,
+                                     int *scratch, pa_stream_t stream);
 
 /* K9 with the FP module's inverse-distance weights fused in (patch_aug_net.py:350-353): weight (b,n,3), idx (b,n,3). */
 int pa_three_nn_weights(int b, int n, int m, const float *unknown, const float *known, float *weight, int *idx, pa_stream_t stream);

@@ -27,6 +27,7 @@ _SIGS = {
     "pa_nearestneighbor": "iiipppp",
     "pa_interpolation_forward": "iiiipppp",
     "pa_interpolation_backward": "iiiipppp",
+    "pa_interpolation_backward_gather": "iiiippppp",
     "pa_ballquery": "iiifippp",
     "pa_featuredistribute": "iiippp",
     "pa_featuregather_forward": "iiiippp",
@@ -110,7 +111,7 @@ def lib():
         l = ctypes.CDLL(LIB_PATH)
         l.pa_last_error.restype = ctypes.c_char_p
         l.pa_abi_version.restype = _I
-        for name, nargs in (("pa_netvlad_scratch_floats", 3), ("pa_afa_scratch_floats", 4), ("pa_fc_scratch_floats", 3), ("pa_afa_rows_scratch_floats", 4), ("pa_pack_weights_f16_halfs", 2)):
+        for name, nargs in (("pa_interpolation_backward_scratch_ints", 3), ("pa_netvlad_scratch_floats", 3), ("pa_afa_scratch_floats", 4), ("pa_fc_scratch_floats", 3), ("pa_afa_rows_scratch_floats", 4), ("pa_pack_weights_f16_halfs", 2)):
             getattr(l, name).argtypes = [_I] * nargs
             getattr(l, name).restype = ctypes.c_long
         _declare(l, _SIGS)

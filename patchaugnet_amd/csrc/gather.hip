@@ -359,6 +359,120 @@ PA_API int pa_interpolation_forward(int b, int c, int m, int n, const float *poi
     return PA_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ interpolation backward without atomics
+// grad_points[b][c][j] += sum over the (i, t) with idx[b][i][t] == j of weight[b][i][t] * grad_out[b][c][i]   (interpolation_cuda_kernel.cu:198-230).
+// The scatter form pays one LDS float atomic per (channel, point, neighbour) -- 57 M of them at the finest level of the training step, and LDS
+// float atomics retire about one lane per cycle (0.18 ms per launch).  The gather form inverts the index list ONCE per launch (it is the same
+// for every channel): a counting sort of the 3 n references by target point gives each target its list of (source point, weight); a workgroup
+// then stages four channel rows of grad_out in LDS and every thread sums its targets' lists with plain LDS reads and owns its outputs.
+namespace {
+
+// grid (b), 256 threads; LDS (m + 1) ints.  off: (b, m + 1) list starts; ent: (b, 3 n) int2 = (source point, weight bits)
+__global__ __launch_bounds__(256) void interp_csr_build_kernel(int n, int m, const int *__restrict__ idx_all, const float *__restrict__ w_all,
+                                                                 int *__restrict__ off_all, int2 *__restrict__ ent_all)
+{
+    extern __shared__ int cnt[];                 // [m + 1]
+    __shared__ int part[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int *idx = idx_all + (size_t)b * n * 3;
+    const float *w = w_all + (size_t)b * n * 3;
+    int *off = off_all + (size_t)b * (m + 1);
+    int2 *ent = ent_all + (size_t)b * n * 3;
+    for (int j = tid; j <= m; j += 256) cnt[j] = 0;
+    __syncthreads();
+    for (int i = tid; i < 3 * n; i += 256) atomicAdd(&cnt[min(max(idx[i], 0), m - 1)], 1);
+    __syncthreads();
+    // exclusive scan of cnt[0 .. m]: every thread owns a run of consecutive bins
+    const int per = (m + 1 + 255) / 256, lo = tid * per, hi = min(lo + per, m + 1);
+    int sum = 0;
+    for (int j = lo; j < hi; ++j) sum += cnt[j];
+    part[tid] = sum;
+    __syncthreads();
+    if (tid < 64) {                              // 256 partial sums: 4 per lane of one wavefront
+        int v[4], s4 = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { v[t] = part[tid * 4 + t]; s4 += v[t]; }
+        int incl = s4;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (tid >= o) incl += u; }
+        int run = incl - s4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { part[tid * 4 + t] = run; run += v[t]; }
+    }
+    __syncthreads();
+    int run = part[tid];
+    for (int j = lo; j < hi; ++j) { const int c = cnt[j]; cnt[j] = run; off[j] = run; run += c; }
+    __syncthreads();
+    for (int i = tid; i < 3 * n; i += 256) {
+        const int pos = atomicAdd(&cnt[min(max(idx[i], 0), m - 1)], 1);
+        ent[pos] = make_int2(i / 3, __float_as_int(w[i]));
+    }
+}
+
+// grid (ceil(c / 4), b), 256 threads; LDS 4 n floats
+__global__ __launch_bounds__(256) void interp_bwd_gather_kernel(int c, int n, int m, const float *__restrict__ grad_out, const int *__restrict__ off_all,
+                                                                  const int2 *__restrict__ ent_all, float *__restrict__ grad_points)
+{
+    extern __shared__ __attribute__((aligned(16))) float rows[];      // [4][n]
+    const int b = blockIdx.y, c0 = blockIdx.x * 4, tid = threadIdx.x;
+    const int nc = min(4, c - c0);
+    const float *src = grad_out + ((size_t)b * c + c0) * n;
+    if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const float4 *s4 = reinterpret_cast<const float4 *>(src);
+        float4 *d4 = reinterpret_cast<float4 *>(rows);
+        for (int i = tid; i < nc * (n >> 2); i += 256) d4[i] = s4[i];
+    } else {
+        for (int i = tid; i < nc * n; i += 256) rows[i] = src[i];
+    }
+    for (int i = nc * n + tid; i < 4 * n; i += 256) rows[i] = 0.f;
+    __syncthreads();
+    const int *off = off_all + (size_t)b * (m + 1);
+    const int2 *ent = ent_all + (size_t)b * n * 3;
+    float *dst = grad_points + ((size_t)b * c + c0) * m;
+    for (int j = tid; j < m; j += 256) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const int beg = off[j], end = off[j + 1];
+        for (int e = beg; e < end; ++e) {
+            const int2 en = ent[e];
+            const float w = __int_as_float(en.y);
+            a0 += w * rows[en.x];
+            a1 += w * rows[n + en.x];
+            a2 += w * rows[2 * n + en.x];
+            a3 += w * rows[3 * n + en.x];
+        }
+        dst[j] += a0;                                                  // the reference accumulates into the caller's buffer
+        if (nc > 1) dst[(size_t)m + j] += a1;
+        if (nc > 2) dst[2 * (size_t)m + j] += a2;
+        if (nc > 3) dst[3 * (size_t)m + j] += a3;
+    }
+}
+
+}  // namespace
+
+// ints of scratch pa_interpolation_backward_gather needs (list starts + (source, weight) pairs)
+PA_API long pa_interpolation_backward_scratch_ints(int b, int n, int m) { return (long)b * ((long)m + 1 + 6L * n) + 4; }
+
+// Same result as pa_interpolation_backward up to the order of the float sums (neither is ordered like the reference's atomics); needs
+// n <= 4096 (four channel rows in LDS), m <= 8192; scratch: pa_interpolation_backward_scratch_ints ints, 8-byte aligned.
+PA_API int pa_interpolation_backward_gather(int b, int c, int n, int m, const float *grad_out, const int *idx, const float *weight, float *grad_points,
+                                            int *scratch, pa_stream_t stream)
+{
+    PA_REQUIRE(b > 0 && c > 0 && m > 0 && n > 0, "pa_interpolation_backward_gather: sizes must be positive");
+    PA_REQUIRE(grad_out && idx && weight && grad_points && scratch, "pa_interpolation_backward_gather: null pointer");
+    PA_REQUIRE(b <= 65535 && (c + 3) / 4 <= 2147483647, "pa_interpolation_backward_gather: b=%d exceeds the grid limit", b);
+    if (n > 4096 || m > 8192) { pa_set_error("pa_interpolation_backward_gather: built for n <= 4096, m <= 8192 (got n=%d m=%d)", n, m); return PA_EUNSUPPORTED; }
+    PA_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 7) == 0, "pa_interpolation_backward_gather: scratch must be 8-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    int *off = scratch;
+    int2 *ent = reinterpret_cast<int2 *>(scratch + (((size_t)b * (m + 1) + 1) & ~(size_t)1));
+    hipLaunchKernelGGL(interp_csr_build_kernel, dim3(b), dim3(256), (size_t)(m + 1) * 4, st, n, m, idx, weight, off, ent);
+    const size_t lds = (size_t)4 * n * 4;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&interp_bwd_gather_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(interp_bwd_gather_kernel, dim3((c + 3) / 4, b), dim3(256), lds, st, c, n, m, grad_out, off, ent, grad_points);
+    PA_CHECK_LAUNCH("pa_interpolation_backward_gather");
+    return PA_OK;
+}
+
 PA_API int pa_interpolation_backward(int b, int c, int n, int m, const float *grad_out, const int *idx, const float *weight, float *grad_points, pa_stream_t stream)
 {
     PA_REQUIRE(b > 0 && c > 0 && m > 0 && n > 0, "pa_interpolation_backward: sizes must be positive");

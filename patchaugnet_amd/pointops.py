@@ -122,7 +122,12 @@ class Interpolation(Function):
         grad = torch.zeros((b, c, m), dtype=torch.float32, device=grad_out.device)
         g = grad_out.contiguous()
         with _guard(g):
-            call("pa_interpolation_backward", b, c, n, m, ptr(g), ptr(idx), ptr(weight), ptr(grad))
+            if 1024 <= n <= 4096 and m <= 8192 and c >= 16:      # atomics-free form: one inversion of the index list, then plain sums
+                from . import _lib
+                scratch = torch.empty(_lib.lib().pa_interpolation_backward_scratch_ints(b, n, m), dtype=torch.int32, device=g.device)
+                call("pa_interpolation_backward_gather", b, c, n, m, ptr(g), ptr(idx), ptr(weight), ptr(grad), ptr(scratch))
+            else:
+                call("pa_interpolation_backward", b, c, n, m, ptr(g), ptr(idx), ptr(weight), ptr(grad))
         return grad, None, None
 
 

@@ -325,6 +325,29 @@ def test_backward_ops_at_scale(P, b, c, n, m, k):
     assert np.allclose(f.grad.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("b,c,n,m", [(2, 256, 4096, 1024), (3, 18, 1023, 77), (1, 5, 1, 1), (2, 7, 2500, 8000), (1, 64, 4096, 16)])
+def test_interpolation_backward_gather_form(b, c, n, m):
+    """pa_interpolation_backward_gather (index list inverted once, plain sums) against the oracle; it ACCUMULATES into the caller's buffer like
+    the reference's kernel, ragged sizes included; targets that nobody references keep their value."""
+    from patchaugnet_amd import _lib
+    g = np.random.default_rng(b * 1000 + n)
+    go = g.standard_normal((b, c, n), dtype=np.float32)
+    idx = g.integers(0, m, (b, n, 3), dtype=np.int32)
+    if m > 4:
+        idx[idx == 3] = 2                                     # target 3 is never referenced
+    w = g.random((b, n, 3), dtype=np.float32)
+    init = g.standard_normal((b, c, m), dtype=np.float32)
+    out = dev(init.copy())
+    scratch = torch.empty(_lib.lib().pa_interpolation_backward_scratch_ints(b, n, m), dtype=torch.int32, device="cuda")
+    god, idxd, wd = dev(go), dev(idx), dev(w)                 # keep the device tensors alive across the asynchronous launch
+    _lib.call("pa_interpolation_backward_gather", b, c, n, m, _lib.ptr(god), _lib.ptr(idxd), _lib.ptr(wd), _lib.ptr(out), _lib.ptr(scratch))
+    torch.cuda.synchronize()
+    ref = init + o.interpolation_backward(go, idx, w, m)
+    assert np.allclose(out.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+    if m > 4:
+        assert np.array_equal(out.cpu().numpy()[:, :, 3], init[:, :, 3])
+
+
 @pytest.mark.parametrize("n,m,r,k", [(4096, 1024, 0.2, 32), (200, 20, 0.5, 8), (3000, 300, 0.05, 16), (100, 10, 1e-4, 4)])
 def test_ballquery_bit_exact(P, n, m, r, k):
     x = cloud(2, n)
