@@ -42,6 +42,7 @@ def parse():
     p.add_argument("--mlp-dtype", choices=["f32", "f16"], default="f32",
                    help="f16: shared-MLP chains on fp16 MFMA (fp32 accumulate; cosine >= 0.999 contract) -- not the headline configuration")
     p.add_argument("--no-graphs", action="store_true", help="issue every step's launches from Python instead of replaying one captured hipGraph per stream")
+    p.add_argument("--no-prefetch", action="store_true", help="--config train: no geometry prefetch of the next batch (one graph per step)")
     p.add_argument("--streams", type=int, default=4, help="HIP streams the consecutive steps are issued on (1 = strictly sequential)")
     p.add_argument("--config", choices=["extract", "train"], default="extract",
                    help="extract = BASELINE.json configs[1] (the headline metric); train = configs[3], one quadruplet training step per step")
@@ -267,8 +268,11 @@ def train_bench(a):
     if graphed:     # forward + losses + backward + Adam captured once (train.GraphedTrainer), one replay per step
         from patchaugnet_amd.train import GraphedTrainer
         try:
-            trainer = GraphedTrainer(model, opt, q, pos, neg, oth, nn_dict, num_points=n)
-            step = lambda: trainer.step(q, pos, neg, oth)
+            # prefetch: the coordinate-only launches (sampling, neighbour search, 3-NN) of the NEXT batch run on a side stream under the
+            # current step (a data loader knows the next batch); here the next batch is the same synthetic tuple, recomputed every step
+            trainer = GraphedTrainer(model, opt, q, pos, neg, oth, nn_dict, num_points=n, prefetch=not a.no_prefetch)
+            nb = None if a.no_prefetch else (q, pos, neg, oth)
+            step = lambda: trainer.step(q, pos, neg, oth, next_batch=nb)
         except Exception as ex:
             print(f"bench.py: hipGraph capture of the training step failed ({ex!r}); eager launches instead", file=sys.stderr)
             graphed = False
@@ -304,7 +308,8 @@ def train_bench(a):
                                "through the decoder, patch Chamfer + quadruplet loss, backward, Adam (BASELINE.json configs[3]), 1xMI355X",
                    "clouds_per_step": clouds, "points": n, "path": "HIP point ops + HIP training GEMMs (csrc/train_gemm.hip), autograd graph in torch",
                    "weights": "key-seeded random init", "parallelism": "dp1",
-                   "launch": "one hipGraph replay per step (forward + losses + backward + Adam)" if graphed else "python launches"},
+                   "launch": ("one hipGraph replay per step (forward + losses + backward + Adam)" + ("" if a.no_prefetch else
+                              "; sampling / neighbour search / 3-NN of the next batch replayed on a side stream under it")) if graphed else "python launches"},
         "losses_last_step": losses,
         "roofline": {"kernel": "tgemm_nn_kernel<64,16,true,1> (pa_tgemm_nn: 256 -> 256 layer of the finest FP level, forward: BatchNorm + ReLU of the "
                                "previous layer in the loader, statistics in the epilogue)", "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS,

@@ -78,11 +78,23 @@ class SAModule(nn.Module):
         if attention:
             self.sas = nn.ModuleList([SALayer(spec[-1], gp)])
 
-    def forward(self, xyz, features):
+    @torch.no_grad()
+    def geometry(self, xyz):
+        """Everything of this level that depends on the coordinates only: (centre indices, centre coordinates, neighbour indices) -- the
+        sampling and the grouper's search / permutation, exactly as forward() computes them."""
         center_idx = pointops.furthestsampling(xyz, self.npoint)
         new_xyz = pointops.gathering(xyz.transpose(1, 2).contiguous(), center_idx).transpose(1, 2).contiguous()
+        return center_idx, new_xyz, self.groupers[0].neighbours(xyz, new_xyz)
+
+    def forward(self, xyz, features, geo=None):
+        if geo is None:
+            center_idx = pointops.furthestsampling(xyz, self.npoint)
+            new_xyz = pointops.gathering(xyz.transpose(1, 2).contiguous(), center_idx).transpose(1, 2).contiguous()
+            idx = None
+        else:
+            center_idx, new_xyz, idx = geo
         center_features = pointops.gathering(features, center_idx)
-        grouped, sample_idx = self.groupers[0](xyz, new_xyz, features, center_features)
+        grouped, sample_idx = self.groupers[0](xyz, new_xyz, features, center_features, idx=idx)
         y = self.mlps[0].forward_maxpool(grouped)
         if hasattr(self, "sas"):
             y = self.sas[0](y)
@@ -96,10 +108,21 @@ class FPModule(nn.Module):
         super().__init__()
         self.mlp = SharedMLP(mlp, bn=True)
 
-    def forward(self, unknown, known, unknown_feats, known_feats):
+    @staticmethod
+    @torch.no_grad()
+    def geometry(unknown, known):
+        """(3-NN indices, inverse-distance weights): the coordinate-only part of forward()."""
         dist, idx = pointops.nearestneighbor(unknown, known)
         dist_recip = 1.0 / (dist + 1e-8)
-        weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+        return idx, dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+
+    def forward(self, unknown, known, unknown_feats, known_feats, geo=None):
+        if geo is None:
+            dist, idx = pointops.nearestneighbor(unknown, known)
+            dist_recip = 1.0 / (dist + 1e-8)
+            weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+        else:
+            idx, weight = geo
         x = pointops.interpolation(known_feats, idx, weight)
         if unknown_feats is not None:
             x = torch.cat([x, unknown_feats], dim=1)
@@ -126,11 +149,27 @@ class PyramidBackbone(nn.Module):
                                         for m, s, k in zip(sa_mlps, sampling, knn))
         self.FP_modules = nn.ModuleList(FPModule(mlp=m) for m in fp_mlps)
 
-    def forward(self, pointcloud):
+    @torch.no_grad()
+    def geometry(self, pointcloud):
+        """The coordinate-only part of forward(): sampling, neighbour search (with the groupers' permutation) and 3-NN weights of every level.
+        Depends on the input cloud, not on the weights, so a training loop can compute it for the NEXT batch while the current one trains
+        (train.GraphedTrainer); forward(pointcloud, geometry=...) then skips those launches.  {"sa": [...], "fp": [...]} of tensors."""
+        l_xyz, sa_geo = [pointcloud], []
+        for sa in self.SA_modules:
+            g = sa.geometry(l_xyz[-1])
+            sa_geo.append(g)
+            l_xyz.append(g[1])
+        nfp = len(self.FP_modules)
+        fp_geo = [None] * nfp
+        for i in range(-1, -(nfp + 1), -1):
+            fp_geo[i] = FPModule.geometry(l_xyz[i - 1], l_xyz[i])
+        return {"sa": sa_geo, "fp": fp_geo}
+
+    def forward(self, pointcloud, geometry=None):
         l_xyz, l_feat = [pointcloud], [pointcloud.transpose(1, 2).contiguous()]
         l_c, l_s = [], []
         for i, sa in enumerate(self.SA_modules):
-            nx, ci, si, f = sa(l_xyz[i], l_feat[i])
+            nx, ci, si, f = sa(l_xyz[i], l_feat[i], geo=None if geometry is None else geometry["sa"][i])
             l_xyz.append(nx); l_feat.append(f); l_c.append(ci); l_s.append(si)
         sa_features = list(l_feat[1:])
         c_o, s_o = origin_indices(l_c, l_s)
@@ -139,7 +178,7 @@ class PyramidBackbone(nn.Module):
             skip = l_feat[i - 1]
             if i == -nfp and not self.use_origin_pc_in_fp:
                 skip = None
-            l_feat[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], skip, l_feat[i])
+            l_feat[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], skip, l_feat[i], geo=None if geometry is None else geometry["fp"][i])
         fp = [l_feat[j].unsqueeze(-1) for j in range(nfp - 1, -1, -1)]          # coarse -> fine
         return {"center_idx_origin": c_o, "sample_idx_origin": s_o, "sa_features": sa_features, "fp_features": fp,
                 "l_xyz": l_xyz}

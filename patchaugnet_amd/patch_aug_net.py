@@ -109,8 +109,9 @@ class Network(nn.Module):
         st.pop("_related_idx", None)
         return st
 
-    def forward(self, x, nn_dict=None, return_feat=True, use_engine=None):
-        """x: (B, 1, N, 3)."""
+    def forward(self, x, nn_dict=None, return_feat=True, use_engine=None, geometry=None):
+        """x: (B, 1, N, 3).  geometry: the result of ``self.backbone.geometry(x.squeeze(1))`` for this x (module path only): the sampling /
+        grouping / 3-NN launches are then skipped (train.GraphedTrainer computes it for the next batch while the current one trains)."""
         if use_engine is None:
             use_engine = self.fused_eval and not self.training and not torch.is_grad_enabled() and nn_dict is None
         fused = use_engine
@@ -118,7 +119,7 @@ class Network(nn.Module):
             desc, (fp_features, center_idx) = self._fused(x, views=return_feat)
             return (desc, fp_features, center_idx) if return_feat else desc
         xyz = x.squeeze(1)
-        res = self.backbone(xyz)
+        res = self.backbone(xyz, geometry=geometry)
         center_idx, sample_idx, fp_features = res["center_idx_origin"], res["sample_idx_origin"], res["fp_features"]
         out = self.aggregation(fp_features)
         if nn_dict is not None:                                   # patch reconstruction branch (:68-104)

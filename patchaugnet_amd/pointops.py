@@ -450,14 +450,19 @@ class QueryAndGroup_Edge(nn.Module):
         self.ret_gxyz, self.ret_sample_idx = ret_gxyz, ret_sample_idx
         self.perm_buffer = None     # hipGraph capture (train.GraphedTrainer): a device tensor the caller refreshes with torch.randperm per step
 
+    def neighbours(self, xyz, new_xyz):
+        """The neighbour lists forward() groups by (search + the reference's column permutation when knn_dilation > 1)."""
+        idx = _neighbours(self.radius, self.nsample, xyz, new_xyz)
+        if self.radius is None and self.knn_dilation > 1:
+            # a host-generated permutation cannot be drawn inside a captured graph: the capturing caller owns a device buffer instead
+            perm = self.perm_buffer if self.perm_buffer is not None else torch.randperm(self.nsample).to(idx.device)
+            idx = idx.index_select(2, perm).contiguous()
+        return idx
+
     def forward(self, xyz, new_xyz=None, features=None, center_features=None, idx=None):
         new_xyz = xyz if new_xyz is None else new_xyz
         if idx is None:
-            idx = _neighbours(self.radius, self.nsample, xyz, new_xyz)
-            if self.radius is None and self.knn_dilation > 1:
-                # a host-generated permutation cannot be drawn inside a captured graph: the capturing caller owns a device buffer instead
-                perm = self.perm_buffer if self.perm_buffer is not None else torch.randperm(self.nsample).to(idx.device)
-                idx = idx.index_select(2, perm).contiguous()
+            idx = self.neighbours(xyz, new_xyz)
         new_features, o_grouped_xyz, _ = _centred_groups(xyz, new_xyz, features, center_features, idx, self.use_xyz)
         res = new_features
         if self.ret_gxyz:

@@ -22,7 +22,8 @@ def _as_tensor(a):
     return torch.from_numpy(a).float() if isinstance(a, np.ndarray) else a.float()
 
 
-def run_model(model, queries, positives, negatives, other_neg, nn_dict=None, num_points=4096, require_grad=True, device=None, args=DEFAULTS):
+def run_model(model, queries, positives, negatives, other_neg, nn_dict=None, num_points=4096, require_grad=True, device=None, args=DEFAULTS,
+              geometry=None):
     """train_place_recognition.py:142-164.  queries (bs,1,N,3), positives (bs,P,N,3), negatives (bs,Nn,N,3), other_neg (bs,1,N,3);
     returns {'global_desc': (q, pos, neg, other) split along dim 1, 'patch_recon': dict or None}."""
     device = device or next(model.parameters()).device
@@ -30,8 +31,9 @@ def run_model(model, queries, positives, negatives, other_neg, nn_dict=None, num
     # the four groups go to the device first and are concatenated there (a host-side cat spins the ATen thread pool, hostcpu.py)
     feed = torch.cat([_as_tensor(t).to(device, non_blocking=True) for t in (q, positives, negatives, other_neg)], 1)
     feed = feed.view((-1, 1, num_points, 3)).requires_grad_(require_grad)
+    kw = {} if geometry is None else {"geometry": geometry}      # coordinate-only launches done ahead of time (GraphedTrainer(prefetch=True))
     with torch.set_grad_enabled(require_grad):
-        out = model(feed, nn_dict, return_feat=False) if nn_dict is not None else model(feed, return_feat=False)
+        out = model(feed, nn_dict, return_feat=False, **kw) if nn_dict is not None else model(feed, return_feat=False, **kw)
     desc, recon = out if nn_dict is not None else (out, None)
     desc = desc.view(q.shape[0], -1, args["FEATURE_OUTPUT_DIM"])
     split = torch.split(desc, [1, args["TRAIN_POSITIVES_PER_QUERY"], args["TRAIN_NEGATIVES_PER_QUERY"], 1], dim=1)
@@ -115,7 +117,11 @@ class GraphedTrainer:
     Losses come back as device scalars (no synchronisation unless the caller reads them)."""
 
     def __init__(self, model, optimizer, queries, positives, negatives, other_neg, nn_dict, num_points=4096, args=DEFAULTS, loss_alpha=None,
-                 place_loss="quadruplet", recon_loss="patch_chamfer", warmup=3):
+                 place_loss="quadruplet", recon_loss="patch_chamfer", warmup=3, prefetch=False):
+        """prefetch=True: sampling, neighbour search and 3-NN weights -- everything that depends on the coordinates but not on the weights,
+        ~1 ms of an 8 ms step, most of it the serial furthest point sampling on 18 CUs -- are captured as a SECOND graph and replayed for the
+        NEXT batch on a side stream while the current batch trains (``step(..., next_batch=...)``); two buffer sets alternate.  The step
+        graph then starts from the prefetched indices.  Same arithmetic, same losses and parameters as prefetch=False."""
         from . import pointops
         self.model, self.optimizer, self.args, self.num_points = model, optimizer, dict(args), num_points
         self.nn_dict = nn_dict
@@ -125,34 +131,63 @@ class GraphedTrainer:
         assert dev.type == "cuda", "GraphedTrainer runs on the MI355X"
         assert all(g.get("capturable", True) for g in optimizer.param_groups), "build the optimizer with capturable=True (Adam / AdamW ...)"
         self.device = dev
-        self.static = [_as_tensor(t).to(dev).clone() for t in (queries, positives, negatives, other_neg)]
+        self.prefetch = bool(prefetch) and hasattr(getattr(model, "backbone", None), "geometry")
+        nsets = 2 if self.prefetch else 1
+        self.statics = [[_as_tensor(t).to(dev).clone() for t in (queries, positives, negatives, other_neg)] for _ in range(nsets)]
+        self.static = self.statics[0]
         self.groupers = [m for m in model.modules() if isinstance(m, pointops.QueryAndGroup_Edge) and m.radius is None and m.knn_dilation > 1]
-        self._perms = [torch.randperm(g.nsample).to(dev) for g in self.groupers]
-        for g, buf in zip(self.groupers, self._perms):
-            g.perm_buffer = buf                        # read by the forward during warm-up and capture only (reset below)
+        self._perm_sets = [[torch.randperm(g.nsample).to(dev) for g in self.groupers] for _ in range(nsets)]
+        self._perms = self._perm_sets[0]
         model.train()
         cur = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(device=dev)
+        self._side = side
+        self._set_perm_buffers(0)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             for _ in range(warmup):                    # allocator pools, lazy buffers and the optimizer state exist before capture
                 optimizer.zero_grad(set_to_none=True)
-                self._body()
+                self._body(0, self._geometry(0) if self.prefetch else None)
         cur.wait_stream(side)
         torch.cuda.synchronize(dev)
-        optimizer.zero_grad(set_to_none=True)          # the captured backward then CREATES the gradients inside the graph's pool
-        self.graph = torch.cuda.CUDAGraph()
+        self.graphs, self.geo_graphs, self.geo, self.losses_k = [], [], [], []
         try:
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                self.losses = self._body()
+            for k in range(nsets):
+                self._set_perm_buffers(k)
+                geo = None
+                if self.prefetch:
+                    gg = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gg, capture_error_mode="thread_local"):
+                        geo = self._geometry(k)
+                    self.geo_graphs.append(gg)
+                    self.geo.append(geo)
+                optimizer.zero_grad(set_to_none=True)  # the captured backward then CREATES the gradients inside this graph's pool
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self.losses_k.append(self._body(k, geo))
+                self.graphs.append(g)
         finally:
-            for g in self.groupers:                    # the graph has the buffers' addresses; eager forwards of the model draw their own again
-                g.perm_buffer = None
+            for gr in self.groupers:                   # the graphs have the buffers' addresses; eager forwards of the model draw their own again
+                gr.perm_buffer = None
+        self.graph, self.losses = self.graphs[0], self.losses_k[0]
+        self._k = 0                                    # buffer set of the next step
+        self._ready = None                             # (set, ids of the batch tensors) whose geometry the side stream has produced
+        self._ev_side = None
         torch.cuda.synchronize(dev)
 
-    def _body(self):
-        q, p, n, o = self.static
-        out = run_model(self.model, q, p, n, o, self.nn_dict, self.num_points, True, device=self.device, args=self.args)
+    def _set_perm_buffers(self, k):
+        for g, buf in zip(self.groupers, self._perm_sets[k]):
+            g.perm_buffer = buf                        # read by the forward during warm-up and capture only (reset after capture)
+
+    def _feed(self, k):
+        return torch.cat(self.statics[k], 1).view((-1, 1, self.num_points, 3))
+
+    def _geometry(self, k):
+        return self.model.backbone.geometry(self._feed(k).squeeze(1))
+
+    def _body(self, k=0, geometry=None):
+        q, p, n, o = self.statics[k]
+        out = run_model(self.model, q, p, n, o, self.nn_dict, self.num_points, True, device=self.device, args=self.args, geometry=geometry)
         oq, op, on, oo = out["global_desc"]
         a = self.args
         cur = {"place_recognition": losses.get_loss_func(self.place_loss)(oq, op, on, oo, a["MARGIN_1"], a["MARGIN_2"], use_min=a["TRIPLET_USE_BEST_POSITIVES"],
@@ -161,24 +196,58 @@ class GraphedTrainer:
         if recon is not None and getattr(self.model, "use_a2a_recon", False):
             cur["patch_recon_a2a"] = losses.get_loss_func(self.recon_loss)(recon["origin_patches"], recon["reconstructed_patches"])
         total = 0.0
-        for k in cur:
-            cur[k] = cur[k] * self.loss_alpha.get(k, 1.0)
-            total = total + cur[k]
+        for k2 in cur:
+            cur[k2] = cur[k2] * self.loss_alpha.get(k2, 1.0)
+            total = total + cur[k2]
         total.backward()
         self.optimizer.step()
         cur["total"] = total
-        return {k: v.detach() for k, v in cur.items()}
+        return {k2: v.detach() for k2, v in cur.items()}
 
-    def step(self, queries, positives, negatives, other_neg):
-        """Copy the batch into the graph's input buffers, draw the step's kNN permutations, replay.  Returns the dict of weighted losses
-        (device scalars owned by the graph: valid until the next step)."""
-        for dst, src in zip(self.static, (queries, positives, negatives, other_neg)):
+    def _load(self, k, batch):
+        for dst, src in zip(self.statics[k], batch):
             dst.copy_(_as_tensor(src), non_blocking=True)
-        for g, buf in zip(self.groupers, self._perms):
+        for g, buf in zip(self.groupers, self._perm_sets[k]):
             buf.copy_(torch.randperm(g.nsample), non_blocking=True)
-        self.graph.replay()
+
+    def step(self, queries, positives, negatives, other_neg, next_batch=None):
+        """Copy the batch into the graph's input buffers, draw the step's kNN permutations, replay.  Returns the dict of weighted losses
+        (device scalars owned by the graph: valid until that buffer set's next step).  prefetch=True: next_batch = the (queries, positives,
+        negatives, other_neg) of the FOLLOWING call; its coordinate-only launches run on a side stream under this step.  A call whose batch
+        was not announced that way computes them first, on the main stream."""
+        batch = (queries, positives, negatives, other_neg)
+        if not self.prefetch:
+            self._load(0, batch)
+            self.graph.replay()
+            return self.losses
+        main = torch.cuda.current_stream(self.device)
+        k = self._k
+        ids = tuple(id(t) for t in batch)
+        if self._ready == (k, ids):
+            main.wait_event(self._ev_side)             # the side stream has filled this set's inputs, permutations and geometry
+        else:
+            if self._ev_side is not None:
+                main.wait_event(self._ev_side)         # never overlap a stale prefetch into the set we are about to write
+            self._load(k, batch)
+            self.geo_graphs[k].replay()
+        self._ready = None
+        ev = torch.cuda.Event()
+        ev.record(main)                                # everything before this step (the other set's previous step) is ordered before it
+        self.graphs[k].replay()
+        if next_batch is not None:
+            o = 1 - k
+            self._side.wait_event(ev)
+            with torch.cuda.stream(self._side):
+                self._load(o, next_batch)
+                self.geo_graphs[o].replay()
+                self._ev_side = torch.cuda.Event()
+                self._ev_side.record(self._side)
+            self._ready = (o, tuple(id(t) for t in next_batch))
+        self._k = 1 - k
+        self.losses = self.losses_k[k]
         return self.losses
 
     def close(self):
         """Nothing to undo on the model (the permutation buffers are the trainer's own); kept for symmetry with GraphedExtractor."""
         self.graph = None
+        self.graphs, self.geo_graphs = [], []

@@ -293,3 +293,48 @@ def test_graphed_training_step_equals_the_eager_step():
             assert ((a - c).norm() / a.norm().clamp_min(1.0)).item() <= 5e-3, k
             assert ((a - c).abs().max() / a.abs().max().clamp_min(1e-2)).item() <= 3e-2, k
         tr.close()
+
+
+def test_graphed_trainer_with_geometry_prefetch_equals_the_eager_steps():
+    """GraphedTrainer(prefetch=True): sampling / neighbour search / 3-NN of the NEXT batch replayed on a side stream under the current step,
+    two buffer sets alternating.  Three SGD steps on three different batches against train.training_step from the same weights; the host
+    RNG is seeded once per run, so both draw the same sequence of kNN permutations (the trainer draws batch i + 1's during call i).  Also: a
+    call whose batch was NOT announced (the first one, and one after a skipped announcement) computes its geometry inline."""
+    import copy
+    from patchaugnet_amd import configs, patch_aug_net
+    from patchaugnet_amd.train import DEFAULTS, GraphedTrainer, training_step
+    from patchaugnet_amd.weights import seeded_state_dict
+    n = 1024
+    cfg = configs.scaled_config(configs.patch_aug_net_config(), n)
+    base = patch_aug_net.Network(param=cfg, use_a2a_recon=True, use_l2_norm=True)
+    base.load_state_dict(seeded_state_dict(base.state_dict()))
+    base = base.cuda()
+    g = torch.Generator().manual_seed(4)
+    # three steps: two runs of the EAGER step already differ by ~2 % in the fourth step's hinge loss (order of the fp32 atomics)
+    batches = [tuple((torch.rand(1, k, n, 3, generator=g) * 2 - 1).cuda() for k in (1, 2, 4, 1)) for _ in range(3)]
+    nn_dict = {(0, 1): None, (0, 2): None}
+    args = dict(DEFAULTS, TRAIN_NEGATIVES_PER_QUERY=4)
+    m0, m1 = copy.deepcopy(base), copy.deepcopy(base)
+    o0, o1 = torch.optim.SGD(m0.parameters(), lr=2e-3), torch.optim.SGD(m1.parameters(), lr=2e-3)
+    tr = GraphedTrainer(m1, o1, *batches[0], nn_dict, num_points=n, args=args, warmup=2, prefetch=True)
+    assert tr.prefetch and len(tr.graphs) == 2 and len(tr.geo_graphs) == 2
+    m1.load_state_dict(base.state_dict())
+    torch.manual_seed(21)
+    eager = [training_step(m0, o0, *b, nn_dict=nn_dict, num_points=n, args=args) for b in batches]
+    torch.manual_seed(21)
+    got = []
+    for i, b in enumerate(batches):
+        # call 0 computes its geometry inline and announces batch 1; call 1 runs on the prefetched set and announces nothing; call 2 must
+        # notice that and compute its geometry itself (on the set whose stale prefetch it first waits for)
+        nb = batches[i + 1] if i == 0 else None
+        got.append({k: float(v) for k, v in tr.step(*b, next_batch=nb).items()})
+    torch.cuda.synchronize()
+    for i, (e, gl) in enumerate(zip(eager, got)):
+        for k in e:
+            assert abs(e[k] - gl[k]) <= (2e-5 if i == 0 else 1e-2) * max(1.0, abs(e[k])), (i, k, e[k], gl[k])
+    sd0, sd1 = m0.state_dict(), m1.state_dict()
+    for k in sd0:
+        a, c = sd0[k].double(), sd1[k].double()
+        assert ((a - c).norm() / a.norm().clamp_min(1.0)).item() <= 5e-3, k
+        assert ((a - c).abs().max() / a.abs().max().clamp_min(1e-2)).item() <= 3e-2, k
+    tr.close()
