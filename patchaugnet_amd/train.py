@@ -214,7 +214,8 @@ class GraphedTrainer:
         """Copy the batch into the graph's input buffers, draw the step's kNN permutations, replay.  Returns the dict of weighted losses
         (device scalars owned by the graph: valid until that buffer set's next step).  prefetch=True: next_batch = the (queries, positives,
         negatives, other_neg) of the FOLLOWING call; its coordinate-only launches run on a side stream under this step.  A call whose batch
-        was not announced that way computes them first, on the main stream."""
+        was not announced that way computes them first, on the main stream.  An announced batch is COPIED at the announcement (inputs and
+        geometry stay consistent): the following call must pass the same tensor objects and is trained on their contents as announced."""
         batch = (queries, positives, negatives, other_neg)
         if not self.prefetch:
             self._load(0, batch)
