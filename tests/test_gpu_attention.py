@@ -83,3 +83,26 @@ def test_ppt_head_fc_and_gating(b, norm):
         h = _FcHead(agg.hidden_weights, agg.bn2, ks, per_scale=True, l2=0, device=flat.device).run(rows)
         got = _Gate(agg.context_gating, l2=1 if norm else 0, device=flat.device).run(h)
     assert (got - ref).abs().max().item() <= 3e-5 * max(ref.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("b,kdim,nout", [(32, 21504, 256), (5, 1000, 80), (70, 516, 128), (3, 130, 16)])
+def test_pa_fc_both_operand_paths(b, kdim, nout):
+    """pa_fc (split-K FC + BatchNorm fold + optional L2 normalise): the 16-byte operand path (nout % 64 == 0, kdim % 4 == 0) and the 4-byte
+    fallback (any nout % 16 == 0, ragged kdim) against fp64 torch."""
+    from patchaugnet_amd import _lib
+    from patchaugnet_amd._lib import call, ptr
+    g = torch.Generator(device="cuda").manual_seed(kdim + nout)
+    y = torch.randn(b, kdim, device="cuda", generator=g)
+    wt = torch.randn(kdim, nout, device="cuda", generator=g) * 0.05
+    bias = torch.randn(nout, device="cuda", generator=g)
+    scale = torch.rand(nout, device="cuda", generator=g) + 0.5
+    shift = torch.randn(nout, device="cuda", generator=g)
+    scratch = torch.empty(_lib.lib().pa_fc_scratch_floats(b, kdim, nout), device="cuda")
+    for l2 in (0, 1):
+        out = torch.empty(b, nout, device="cuda")
+        call("pa_fc", b, kdim, nout, ptr(y), ptr(wt), ptr(bias), ptr(scale), ptr(shift), l2, None, ptr(scratch), ptr(out))
+        ref = (y.double() @ wt.double() + bias.double()) * scale.double() + shift.double()
+        if l2:
+            ref = torch.nn.functional.normalize(ref, dim=1)
+        err = ((out.double() - ref).abs().max() / ref.abs().max()).item()
+        assert err <= 2e-5, (l2, err)

@@ -171,3 +171,37 @@ def test_fused_engine_matches_module_path_at_other_cloud_sizes(npts, sampling):
     _check_desc(d_eng, d_mod.cpu().numpy())
     for a, b in zip(fp_eng, fp_mod):
         assert (a - b).abs().max().item() <= 2e-4 * max(b.abs().max().item(), 1.0)
+
+
+def test_forward_with_precomputed_geometry_equals_the_plain_forward():
+    """backbone.geometry(x) (sampling, neighbour search with the groupers' permutation, 3-NN weights) handed to forward(geometry=...) gives
+    exactly the forward that computes them itself: module path, train mode statistics, patch-reconstruction branch included."""
+    from patchaugnet_amd import configs, patch_aug_net, pointops
+    from patchaugnet_amd.weights import seeded_state_dict, synthetic_submaps
+    n = 1024
+    cfg = configs.scaled_config(configs.patch_aug_net_config(), n)
+    m = patch_aug_net.Network(param=cfg, use_a2a_recon=True, use_l2_norm=True)
+    m.load_state_dict(seeded_state_dict(m.state_dict()))
+    m = m.cuda().train()
+    x = synthetic_submaps(4, n, seed=3).cuda()
+    groupers = [g for g in m.modules() if isinstance(g, pointops.QueryAndGroup_Edge) and g.radius is None and g.knn_dilation > 1]
+    for g in groupers:
+        g.perm_buffer = torch.randperm(g.nsample).cuda()          # the same permutation in both forwards
+    nn_dict = {(0, 1): None, (0, 2): None}
+    try:
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        with torch.no_grad():
+            (d0, r0), fp0, c0 = m(x, nn_dict)
+            m.load_state_dict(sd)                                 # undo the running-statistics update of the first forward
+            geo = m.backbone.geometry(x.squeeze(1))
+            (d1, r1), fp1, c1 = m(x, nn_dict, geometry=geo)
+    finally:
+        for g in groupers:
+            g.perm_buffer = None
+    # indices and pure gathers: exactly equal; dense outputs: train-mode BatchNorm statistics are summed with atomics, so two forwards of the
+    # SAME kind already differ in the last bits
+    assert all(torch.equal(a, b) for a, b in zip(c0, c1))
+    assert all(torch.equal(a, b) for a, b in zip(r0["origin_patches"], r1["origin_patches"]))
+    close = lambda a, b: (a - b).abs().max().item() <= 1e-5 * max(1.0, a.abs().max().item())
+    assert close(d0, d1) and all(close(a, b) for a, b in zip(fp0, fp1))
+    assert all(close(a, b) for a, b in zip(r0["reconstructed_patches"], r1["reconstructed_patches"]))
