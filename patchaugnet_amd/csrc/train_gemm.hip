@@ -549,15 +549,13 @@ __global__ void bn_bwd_finalize_kernel(int nch, int batch, double count, const d
 
 // out = relu(y * scale + shift) on (B, C, P); with pool > 0: max over groups of `pool` consecutive points -> out (B, C, P / pool), arg (int8 slot)
 __global__ __launch_bounds__(256) void bn_apply_kernel(int C, long P, int pool, int relu, const float *__restrict__ y, const float *__restrict__ p, float *__restrict__ out,
-                                                        signed char *__restrict__ arg, long sPb)
+                                                        signed char *__restrict__ arg, long sPb, long rows)
 {
     const long Pout = pool > 0 ? P / pool : P;
-    const long total = (long)gridDim.y * Pout;   // gridDim.y = B * C rows
-    (void)total;
-    const long row = blockIdx.y;
+    for (long row = blockIdx.y; row < rows; row += gridDim.y) {     // B * C rows, grid-stride over y (gridDim.y <= 65535)
     const int c = (int)(row % C);
-    p += (size_t)(row / C) * sPb;
-    const float scale = p[c], shift = p[C + c];
+    const float *pr = p + (size_t)(row / C) * sPb;
+    const float scale = pr[c], shift = pr[C + c];
     const float *src = y + (size_t)row * P;
     float *dst = out + (size_t)row * Pout;
     for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < Pout; j += (long)gridDim.x * 256) {
@@ -576,12 +574,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(int C, long P, int pool, 
             arg[(size_t)row * Pout + j] = (signed char)bi;
         }
     }
+    }
 }
 
 // gradient of the pooled output scattered back to the full (B, C, P) grid: g[j*pool + s] = (s == arg[j]) ? gp[j] : 0
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(long Pout, int pool, const float *__restrict__ gp, const signed char *__restrict__ arg, float *__restrict__ g)
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(long Pout, int pool, const float *__restrict__ gp, const signed char *__restrict__ arg, float *__restrict__ g, long rows)
 {
-    const long row = blockIdx.y;
+    for (long row = blockIdx.y; row < rows; row += gridDim.y)
     for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < Pout; j += (long)gridDim.x * 256) {
         const float v = gp[(size_t)row * Pout + j];
         const int a = arg[(size_t)row * Pout + j];
@@ -747,21 +746,23 @@ PA_API int pa_bn_bwd_finalize(int nch, int groups, double count, const double *s
 // (out (B, C, P/pool), arg (B, C, P/pool) int8 = winning slot; patch_aug_net.py:236).
 PA_API int pa_bn_apply(int B, int C, long P, int pool, int relu, const float *y, const float *p, float *out, signed char *arg, int per_batch_stats, pa_stream_t stream)
 {
-    PA_REQUIRE(B > 0 && C > 0 && P > 0 && y && p && out && (pool <= 0 || (arg && P % pool == 0 && pool < 128)) && (long)B * C <= 65535L * 1, "pa_bn_apply: bad arguments");
+    PA_REQUIRE(B > 0 && C > 0 && P > 0 && y && p && out && (pool <= 0 || (arg && P % pool == 0 && pool < 128)), "pa_bn_apply: bad arguments");
     const long Pout = pool > 0 ? P / pool : P;
     long gx = (Pout + 255) / 256;
     if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)gx, B * C), dim3(256), 0, (hipStream_t)stream, C, P, pool, relu, y, p, out, arg, per_batch_stats ? 7L * C : 0L);
+    const long rows = (long)B * C;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)gx, (unsigned)(rows < 65535 ? rows : 65535)), dim3(256), 0, (hipStream_t)stream, C, P, pool, relu, y, p, out, arg,
+                       per_batch_stats ? 7L * C : 0L, rows);
     PA_CHECK_LAUNCH("pa_bn_apply");
     return PA_OK;
 }
 
 PA_API int pa_maxpool_bwd(int rows, long Pout, int pool, const float *gp, const signed char *arg, float *g, pa_stream_t stream)
 {
-    PA_REQUIRE(rows > 0 && rows <= 65535 && Pout > 0 && pool > 0 && gp && arg && g, "pa_maxpool_bwd: bad arguments");
+    PA_REQUIRE(rows > 0 && Pout > 0 && pool > 0 && gp && arg && g, "pa_maxpool_bwd: bad arguments");
     long gx = (Pout + 255) / 256;
     if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)gx, rows), dim3(256), 0, (hipStream_t)stream, Pout, pool, gp, arg, g);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)gx, (unsigned)(rows < 65535 ? rows : 65535)), dim3(256), 0, (hipStream_t)stream, Pout, pool, gp, arg, g, (long)rows);
     PA_CHECK_LAUNCH("pa_maxpool_bwd");
     return PA_OK;
 }

@@ -91,7 +91,10 @@ import pickle
 def save_descriptor_cache(g_desc_dir, l_desc_dir, beg_idx, global_descs, feed=None, fp_features=None, center_idx=None, norm_metas=None):
     """scene_dataset.py:689-707.  global_descs (B, C); feed (B, 1, N, 3) or (B, N, 3) = the batch that went into the model;
     fp_features / center_idx = the model's other two outputs (local descriptors = fp_features[-2], centres = center_idx[0]).  The local
-    files are written only when center_idx is given, like the reference.  Device tensors are brought to the host in ONE copy each."""
+    files are written only when center_idx is given, like the reference.  Device tensors are brought to the host in ONE copy each.
+    norm_metas: one {'scale', 'trans'} dict per submap (normalize_point_cloud's second result); None = the identity meta the reference
+    stores for submaps that were not normalised ({'scale': 1.0, 'trans': zeros (1, 3)}, scene_dataset.py:723), so that
+    load_local_descriptor(unify_coord=True) -- and the reference's get_l_kpt_desc -- can always read the file."""
     g = global_descs.detach().cpu().numpy() if torch.is_tensor(global_descs) else np.asarray(global_descs)
     g = np.squeeze(g).reshape([-1, g.shape[-1]])
     os.makedirs(g_desc_dir, exist_ok=True)
@@ -106,7 +109,7 @@ def save_descriptor_cache(g_desc_dir, l_desc_dir, beg_idx, global_descs, feed=No
         with open(os.path.join(g_desc_dir, f"{beg_idx + b_i}.pickle"), "wb") as handle:
             pickle.dump(g[b_i].reshape(1, -1), handle, protocol=pickle.HIGHEST_PROTOCOL)
         if l_pos is not None:
-            meta = norm_metas[b_i] if norm_metas is not None else None
+            meta = norm_metas[b_i] if norm_metas is not None else {"scale": 1.0, "trans": np.zeros([1, 3])}
             with open(os.path.join(l_desc_dir, f"{beg_idx + b_i}.pickle"), "wb") as handle:
                 pickle.dump((l_pos[b_i], l_desc[b_i], meta), handle, protocol=pickle.HIGHEST_PROTOCOL)
 

@@ -105,9 +105,25 @@ class Network(nn.Module):
         """The engine holds ctypes pointer arrays into device buffers: never copied or pickled (copy.deepcopy / torch.save of the module)."""
         st = self.__dict__.copy()
         st["_engine"] = None
-        st.pop("_related_key", None)
-        st.pop("_related_idx", None)
+        st.pop("_related_cache", None)
         return st
+
+    def related_index(self, device, related):
+        """Device index tensor of the related-cloud list, made once per (device, key set): no host -> device copy per step.  Entries are
+        kept per key set -- a forward with ANOTHER key set (validation, a second trainer) never replaces or frees one that a captured
+        hipGraph has baked the address of; train.GraphedTrainer additionally holds its own reference for the graph's lifetime, so the
+        bounded eviction below cannot free it either."""
+        cache = self.__dict__.setdefault("_related_cache", {})
+        key = (str(device), tuple(related))
+        t = cache.get(key)
+        if t is None:
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("patch_aug_net.Network: nn_dict key set %r first seen while a hipGraph is being captured; run one eager "
+                                   "forward with it first (GraphedTrainer's warm-up does)" % (tuple(related),))
+            while len(cache) >= 64:
+                cache.pop(next(iter(cache)))
+            t = cache[key] = torch.tensor(list(related), dtype=torch.long, device=device)
+        return t
 
     def forward(self, x, nn_dict=None, return_feat=True, use_engine=None, geometry=None):
         """x: (B, 1, N, 3).  geometry: the result of ``self.backbone.geometry(x.squeeze(1))`` for this x (module path only): the sampling /
@@ -128,10 +144,7 @@ class Network(nn.Module):
             data = {"cloud_indices": related, "center_indices": [], "origin_patches": [], "patch_features": [],
                     "reconstructed_patches": []}
             hip_dec = self.use_a2a_recon and x.is_cuda and self.training and train_ops.hip_dense_enabled()
-            key = (x.device, tuple(related))
-            if getattr(self, "_related_key", None) != key:      # device index tensor made once per key set (no host -> device copy per step)
-                self._related_key, self._related_idx = key, torch.tensor(related, dtype=torch.long, device=x.device)
-            feats_cm = fp_features[1].squeeze(-1).index_select(0, self._related_idx)         # (R, 256, m0): one patch feature per column
+            feats_cm = fp_features[1].squeeze(-1).index_select(0, self.related_index(x.device, related))   # (R, 256, m0): one patch feature per column
             if self.use_l2_norm:
                 feats_cm = F.normalize(feats_cm, dim=1)
             recon = self.decoder.forward_cm(feats_cm.contiguous()) if hip_dec else None      # all related clouds in one set of launches

@@ -42,10 +42,14 @@ def run_model(model, queries, positives, negatives, other_neg, nn_dict=None, num
 
 def training_step(model, optimizer, queries, positives, negatives, other_neg, nn_dict=None, num_points=4096, args=DEFAULTS,
                   loss_alpha=None, place_loss="quadruplet", recon_loss="patch_chamfer", use_patch_feature_contrast=False, epoch=0,
-                  use_hard_negative_patch_mining=False, hard_neg_epoch_for_patch_align=10, step_seed=0):
+                  use_hard_negative_patch_mining=False, hard_neg_epoch_for_patch_align=10, step_seed=None):
     """train_one_epoch's body for one batch (:255-392): returns the dict of weighted losses.  use_patch_feature_contrast adds the
     contrastive patch-feature term over nn_dict's overlap tables (:308-385; hard-negative patches only once
-    epoch > hard_neg_epoch_for_patch_align with use_hard_negative_patch_mining, :345)."""
+    epoch > hard_neg_epoch_for_patch_align with use_hard_negative_patch_mining, :345).  step_seed seeds the device-side draw of the far
+    (negative) patches; None (default) = a fresh seed per call derived from torch's seed and a call counter, as the reference draws
+    np.random.choice from the global generator on every step (:366) -- a fixed seed would repeat the same negatives every step."""
+    if step_seed is None:
+        step_seed = next_step_seed()
     loss_alpha = loss_alpha or {"place_recognition": 1.0, "patch_recon_a2a": 1.0, "patch_recon_a2b": 1.0}
     model.train()
     optimizer.zero_grad(set_to_none=True)
@@ -74,6 +78,16 @@ def training_step(model, optimizer, queries, positives, negatives, other_neg, nn
     return {k: float(v.detach()) for k, v in cur.items()}
 
 
+_step_counter = [0]
+
+
+def next_step_seed():
+    """Seed of the next step's negative-patch draw: torch's initial seed mixed with a per-process call counter (reproducible under
+    torch.manual_seed, different on every call)."""
+    _step_counter[0] += 1
+    return (int(torch.initial_seed()) * 6364136223846793005 + _step_counter[0] * 1442695040888963407) & (2 ** 63 - 1)
+
+
 def hard_negative_refresh_due(count, batch_size, epoch, hard_neg_epoch, use_hard_neg=True):
     """train_place_recognition.py:401-406 -- after `count` batches of this epoch: re-extract every training submap's descriptor once the
     model is robust enough (epoch > hard_neg_epoch), every 1400 // batch_size batches, at phase 29."""
@@ -81,27 +95,36 @@ def hard_negative_refresh_due(count, batch_size, epoch, hard_neg_epoch, use_hard
 
 
 @torch.no_grad()
-def update_global_descs(model, load_batch, n_total, batch_size=36, save_dirs=None, n_streams=4):
+def update_global_descs(model, load_batch, n_total, batch_size=36, save_dirs=None, n_streams=4, norm_metas=None):
     """``PlaceRecognitionDataSet.update_global_descs`` -> ``SceneDataSet.make_descs`` (place_recognition_dataset.py:37-39,
     scene_dataset.py:494-711) as the training loop uses it (:403-406, batch_size 36): descriptors of all n_total submaps through the fused
     HIP engine (sharded over the ranks when a process group is up: patchaugnet_amd/distributed.py), the model left in the mode it was in.
-    save_dirs = (g_desc_dir, l_desc_dir) also writes the reference's per-submap pickle cache (patchaugnet_amd/io.py).  Returns the
-    (n_total, 256) matrix on the device: the input of retrieval.get_hard_negatives_batch."""
-    from .distributed import extract_dataset
+    save_dirs = (g_desc_dir, l_desc_dir) also writes the reference's per-submap pickle cache (patchaugnet_amd/io.py): ONE pass, every rank
+    writes the files of its own shard only; norm_metas(lo, hi) -> the list of {'scale', 'trans'} dicts of records lo..hi-1 (or a list
+    indexed by record; None = un-normalised submaps, identity meta).  Returns the (n_total, 256) matrix on the device: the input of
+    retrieval.get_hard_negatives_batch."""
+    from .distributed import all_gather_descriptors, dist_info, extract_dataset, shard_bounds
     from .io import save_descriptor_cache
     was_training = model.training
     model.eval()
     try:
-        descs = extract_dataset(model, load_batch, n_total, batch_size=batch_size, n_streams=n_streams)
-        if save_dirs is not None:
-            for b0 in range(0, n_total, batch_size):
-                b1 = min(b0 + batch_size, n_total)
-                x = load_batch(b0, b1)
-                d, fp, ci = model(x)
-                save_descriptor_cache(save_dirs[0], save_dirs[1], b0, d, x, fp, ci)
+        if save_dirs is None:
+            return extract_dataset(model, load_batch, n_total, batch_size=batch_size, n_streams=n_streams)
+        _, rank, world = dist_info()
+        lo, hi = shard_bounds(n_total, rank, world)
+        blocks = []
+        for b0 in range(lo, hi, batch_size):
+            b1 = min(b0 + batch_size, hi)
+            x = load_batch(b0, b1)
+            d, fp, ci = model(x)
+            metas = None if norm_metas is None else (norm_metas(b0, b1) if callable(norm_metas) else norm_metas[b0:b1])
+            save_descriptor_cache(save_dirs[0], save_dirs[1], b0, d, x, fp, ci, norm_metas=metas)
+            blocks.append(d)
+        dev = next(model.parameters()).device
+        local = torch.cat(blocks, 0) if blocks else torch.empty((0, DEFAULTS["FEATURE_OUTPUT_DIM"]), device=dev)
+        return all_gather_descriptors(local, n_total)
     finally:
         model.train(was_training)
-    return descs
 
 
 class GraphedTrainer:
@@ -169,6 +192,8 @@ class GraphedTrainer:
         finally:
             for gr in self.groupers:                   # the graphs have the buffers' addresses; eager forwards of the model draw their own again
                 gr.perm_buffer = None
+        # the graphs read the model's related-cloud index tensor(s) by address: hold them for the graphs' lifetime (patch_aug_net.related_index)
+        self._pinned = list(getattr(model, "_related_cache", {}).values())
         self.graph, self.losses = self.graphs[0], self.losses_k[0]
         self._k = 0                                    # buffer set of the next step
         self._ready = None                             # (set, ids of the batch tensors) whose geometry the side stream has produced
@@ -215,7 +240,9 @@ class GraphedTrainer:
         (device scalars owned by the graph: valid until that buffer set's next step).  prefetch=True: next_batch = the (queries, positives,
         negatives, other_neg) of the FOLLOWING call; its coordinate-only launches run on a side stream under this step.  A call whose batch
         was not announced that way computes them first, on the main stream.  An announced batch is COPIED at the announcement (inputs and
-        geometry stay consistent): the following call must pass the same tensor objects and is trained on their contents as announced."""
+        geometry stay consistent): the following call must pass the same tensor objects and is trained on their contents as announced.
+        The copies are asynchronous on the side stream: pinned host sources must stay untouched until that following call has been
+        issued (pageable sources are staged by the runtime before the copy call returns)."""
         batch = (queries, positives, negatives, other_neg)
         if not self.prefetch:
             self._load(0, batch)
@@ -223,8 +250,8 @@ class GraphedTrainer:
             return self.losses
         main = torch.cuda.current_stream(self.device)
         k = self._k
-        ids = tuple(id(t) for t in batch)
-        if self._ready == (k, ids):
+        # the announced batch is held by strong reference and matched by identity (an id() of a dropped array can be reused by a new one)
+        if self._ready is not None and self._ready[0] == k and all(a is b for a, b in zip(self._ready[1], batch)):
             main.wait_event(self._ev_side)             # the side stream has filled this set's inputs, permutations and geometry
         else:
             if self._ev_side is not None:
@@ -243,7 +270,7 @@ class GraphedTrainer:
                 self.geo_graphs[o].replay()
                 self._ev_side = torch.cuda.Event()
                 self._ev_side.record(self._side)
-            self._ready = (o, tuple(id(t) for t in next_batch))
+            self._ready = (o, tuple(next_batch))
         self._k = 1 - k
         self.losses = self.losses_k[k]
         return self.losses

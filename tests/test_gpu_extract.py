@@ -188,7 +188,20 @@ def test_update_global_descs_refresh_and_pickle_cache(tmp_path):
     assert np.array_equal(got, want.cpu().numpy())
     kpt, desc, meta = pio.load_local_descriptor(ld, 13)
     assert np.array_equal(kpt, x[13, 0][ci[0][13].long()].cpu().numpy().astype(np.float64))
-    assert np.array_equal(desc, fp[-2][13, :, :, 0].t().cpu().numpy()) and meta is None
+    assert np.array_equal(desc, fp[-2][13, :, :, 0].t().cpu().numpy())
+    # un-normalised submaps carry the identity meta of scene_dataset.py:723, so the unify_coord read path works on these files
+    assert meta["scale"] == 1.0 and np.array_equal(meta["trans"], np.zeros([1, 3]))
+    kpt_w, _, _ = pio.load_local_descriptor(ld, 13, unify_coord=True)
+    assert np.array_equal(kpt_w, kpt)
+    # normalised submaps: the caller's metas ride into the files of exactly the records they belong to
+    metas = [{"scale": 2.0 + i, "trans": np.full([1, 3], float(i))} for i in range(22)]
+    gd2, ld2 = str(tmp_path / "g2"), str(tmp_path / "l2")
+    update_global_descs(m, lambda lo, hi: x[lo:hi], 22, batch_size=8, save_dirs=(gd2, ld2), norm_metas=lambda lo, hi: metas[lo:hi])
+    for i in (0, 7, 8, 21):
+        kpt_i, _, meta_i = pio.load_local_descriptor(ld2, i)
+        assert meta_i["scale"] == 2.0 + i and np.array_equal(meta_i["trans"], np.full([1, 3], float(i)))
+        kw, _, _ = pio.load_local_descriptor(ld2, i, unify_coord=True)
+        assert np.allclose(kw, kpt_i * (2.0 + i) + float(i))
 
 
 def test_latency_mode_is_bit_identical():

@@ -1,0 +1,146 @@
+"""The grouping MODULES of the op layer on the HIP path against the CPU oracle's restatement of the same classes
+(libs/pointops/functions/pointops.py:476-516 QueryAndGroup ball + kNN, :519-582 QueryAndGroup_Edge, :584-635 QueryAndGroup_Edge_Split,
+:637-661 GroupAll).  Neighbour lists are index outputs -> bit-exact; the grouped tensors are pure gathers and one fp32 subtraction in
+the reference's order -> bit-exact as well; the feature gradients are sums of atomics -> 1e-6 relative."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pointops_cpu as C
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P():
+    from patchaugnet_amd import pointops
+    return pointops
+
+
+def _inputs(b, n, m, c, seed, lattice=False):
+    g = torch.Generator().manual_seed(seed)
+    xyz = torch.rand(b, n, 3, generator=g) * 2 - 1
+    if lattice:                       # exact distance ties: the (d2, index) order decides
+        xyz = torch.round(xyz * 4) / 4
+    sel = torch.stack([torch.randperm(n, generator=g)[:m] for _ in range(b)])
+    new_xyz = torch.gather(xyz, 1, sel.unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    feats = torch.randn(b, c, n, generator=g)
+    cfeat = torch.gather(feats, 2, sel.unsqueeze(1).expand(-1, c, -1)).contiguous()
+    return xyz, new_xyz, feats, cfeat
+
+
+def _same(a, b):
+    assert a.shape == b.shape and a.dtype == b.dtype, (a.shape, b.shape, a.dtype, b.dtype)
+    assert torch.equal(a, b), f"max|diff| {(a.double() - b.double()).abs().max().item():.3e}"
+
+
+CASES = [(2, 512, 64, 16, 20, False), (1, 1000, 37, 5, 8, True), (3, 128, 128, 32, 32, False), (2, 64, 16, 3, 1, False)]
+
+
+@pytest.mark.parametrize("b,n,m,c,ns,lattice", CASES)
+@pytest.mark.parametrize("radius", [None, 0.35])
+@pytest.mark.parametrize("use_xyz", [True, False])
+def test_query_and_group_ball_and_knn(P, b, n, m, c, ns, lattice, radius, use_xyz):
+    xyz, new_xyz, feats, _ = _inputs(b, n, m, c, seed=100 + n + ns, lattice=lattice)
+    ref = C.QueryAndGroup(radius, ns, use_xyz)(xyz, new_xyz, feats)
+    got = P.QueryAndGroup(radius, ns, use_xyz)(xyz.cuda(), new_xyz.cuda(), feats.cuda())
+    _same(got.cpu(), ref)
+    # features=None -> centred coordinates only; new_xyz=None -> the cloud queries itself (pointops.py:492-493)
+    ref = C.QueryAndGroup(radius, ns, True)(xyz, None, None)
+    got = P.QueryAndGroup(radius, ns, True)(xyz.cuda(), None, None)
+    _same(got.cpu(), ref)
+    # a caller-supplied neighbour list bypasses the search
+    idx = (C.ballquery(radius, ns, xyz, new_xyz) if radius is not None else C.knnquery(ns, xyz, new_xyz))
+    got = P.QueryAndGroup(radius, ns, use_xyz)(xyz.cuda(), new_xyz.cuda(), feats.cuda(), idx.cuda())
+    _same(got.cpu(), C.QueryAndGroup(radius, ns, use_xyz)(xyz, new_xyz, feats, idx))
+
+
+def test_query_and_group_needs_xyz_or_features(P):
+    xyz, new_xyz, _, _ = _inputs(1, 64, 8, 4, seed=3)
+    with pytest.raises(AssertionError):
+        P.QueryAndGroup(None, 4, use_xyz=False)(xyz.cuda(), new_xyz.cuda(), None)
+
+
+@pytest.mark.parametrize("b,n,m,c,ns,lattice", CASES)
+@pytest.mark.parametrize("radius", [None, 0.35])
+@pytest.mark.parametrize("ret_gxyz", [False, True])
+def test_query_and_group_edge_split(P, b, n, m, c, ns, lattice, radius, ret_gxyz):
+    xyz, new_xyz, feats, cfeat = _inputs(b, n, m, c, seed=200 + n + ns, lattice=lattice)
+    r_feat, r_xyz = C.QueryAndGroup_Edge_Split(radius, ns, True, ret_gxyz)(xyz, new_xyz, feats, cfeat)
+    g_feat, g_xyz = P.QueryAndGroup_Edge_Split(radius, ns, True, ret_gxyz)(xyz.cuda(), new_xyz.cuda(), feats.cuda(), cfeat.cuda())
+    _same(g_feat.cpu(), r_feat)
+    _same(g_xyz.cpu(), r_xyz)
+    r_feat, r_xyz = C.QueryAndGroup_Edge_Split(radius, ns, False, ret_gxyz)(xyz, new_xyz, feats, cfeat)
+    g_feat, g_xyz = P.QueryAndGroup_Edge_Split(radius, ns, False, ret_gxyz)(xyz.cuda(), new_xyz.cuda(), feats.cuda(), cfeat.cuda())
+    _same(g_feat.cpu(), r_feat)
+    _same(g_xyz.cpu(), r_xyz)
+    r_feat, r_xyz = C.QueryAndGroup_Edge_Split(radius, ns, True, ret_gxyz)(xyz, new_xyz, None, None)
+    g_feat, g_xyz = P.QueryAndGroup_Edge_Split(radius, ns, True, ret_gxyz)(xyz.cuda(), new_xyz.cuda(), None, None)
+    _same(g_feat.cpu(), r_feat)
+    _same(g_xyz.cpu(), r_xyz)
+
+
+@pytest.mark.parametrize("radius", [None, 0.4])
+def test_query_and_group_edge_ball_and_returns(P, radius):
+    """QueryAndGroup_Edge outside the configuration the models use: ball neighbourhoods, no dilation, every return combination."""
+    xyz, new_xyz, feats, cfeat = _inputs(2, 300, 40, 12, seed=77)
+    for ret_gxyz in (False, True):
+        for ret_idx in (False, True):
+            ref = C.QueryAndGroup_Edge(radius, 16, 1, True, ret_gxyz, ret_idx)(xyz, new_xyz, feats, cfeat)
+            got = P.QueryAndGroup_Edge(radius, 16, 1, True, ret_gxyz, ret_idx)(xyz.cuda(), new_xyz.cuda(), feats.cuda(), cfeat.cuda())
+
+            def flat(r):
+                out = []
+                while isinstance(r, tuple):
+                    out.append(r[1])
+                    r = r[0]
+                return [r] + out[::-1]
+            for a, e in zip(flat(got), flat(ref)):
+                _same(a.cpu(), e)
+
+
+def test_query_and_group_edge_dilated_matches_reference_permutation(P):
+    """knn_dilation > 1: the reference searches dilation x nsample and keeps columns randperm(nsample) (pointops.py:553-555); the same
+    CPU-generator draw selects the same columns here."""
+    xyz, new_xyz, feats, cfeat = _inputs(2, 512, 64, 8, seed=5)
+    torch.manual_seed(123)
+    r_feat, r_idx = C.QueryAndGroup_Edge(None, 20, 2, True, False, True)(xyz, new_xyz, feats, cfeat)
+    torch.manual_seed(123)
+    g_feat, g_idx = P.QueryAndGroup_Edge(None, 20, 2, True, False, True)(xyz.cuda(), new_xyz.cuda(), feats.cuda(), cfeat.cuda())
+    _same(g_idx.cpu(), r_idx)
+    _same(g_feat.cpu(), r_feat)
+
+
+@pytest.mark.parametrize("use_xyz", [True, False])
+def test_group_all(P, use_xyz):
+    xyz, new_xyz, feats, _ = _inputs(3, 200, 1, 24, seed=9)
+    _same(P.GroupAll(use_xyz)(xyz.cuda(), new_xyz.cuda(), feats.cuda()).cpu(), C.GroupAll(use_xyz)(xyz, new_xyz, feats))
+    _same(P.GroupAll(use_xyz)(xyz.cuda(), new_xyz.cuda(), None).cpu(), C.GroupAll(use_xyz)(xyz, new_xyz, None))
+
+
+@pytest.mark.parametrize("mod", ["QueryAndGroup", "QueryAndGroup_Edge_Split", "GroupAll"])
+def test_group_module_feature_gradients(P, mod):
+    """Backward through the modules: the feature gradient is the grouping backward (grouping_cuda_kernel.cu:33-52), the centre-feature
+    gradient the plain sum over the neighbourhood; coordinates carry no gradient into the neighbour search."""
+    xyz, new_xyz, feats, cfeat = _inputs(2, 256, 32, 10, seed=31)
+    g = torch.Generator().manual_seed(8)
+
+    def run(M, dev):
+        f = feats.to(dev).requires_grad_(True)
+        cf = cfeat.to(dev).requires_grad_(True)
+        if mod == "QueryAndGroup":
+            out = M.QueryAndGroup(None, 12, True)(xyz.to(dev), new_xyz.to(dev), f)
+        elif mod == "QueryAndGroup_Edge_Split":
+            out = M.QueryAndGroup_Edge_Split(0.5, 12, True)(xyz.to(dev), new_xyz.to(dev), f, cf)[0]
+        else:
+            out = M.GroupAll(True)(xyz.to(dev), new_xyz.to(dev), f)
+        w = torch.randn(out.shape, generator=torch.Generator().manual_seed(8)).to(dev)
+        (out * w).sum().backward()
+        return f.grad.cpu(), (cf.grad.cpu() if cf.grad is not None else None)
+
+    rf, rc = run(C, "cpu")
+    gf, gc = run(P, "cuda")
+    assert torch.allclose(gf, rf, rtol=1e-6, atol=1e-6), (gf - rf).abs().max()
+    assert (gc is None) == (rc is None)
+    if rc is not None:
+        assert torch.allclose(gc, rc, rtol=1e-5, atol=1e-5), (gc - rc).abs().max()
