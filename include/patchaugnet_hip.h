@@ -255,6 +255,21 @@ long pa_afa_rows_scratch_floats(int b, int c, int ktot, int nout);
 int pa_afa_rows(int b, int c, int ktot, int nout, const float *vt, const float *watt_t, const float *watt_p, const float *zero_bias,
                 const float *fc_wt, const float *fc_bias, const float *scale, const float *shift, int l2norm, float *scratch,
                 float *desc, pa_stream_t stream);
+/* The whole pyramid in one call (what SpatialPyramidNetVLAD.forward does scale by scale, loupe.py:284-303): arrays of nscales (<= 4)
+ * entries, coarse to fine; x[s] (b, n[s], 256) point-major; wc_t / wc_p / bias / w2 / scratch per scale as for pa_netvlad_rows
+ * (wc_p may be NULL, wc_p[s] is used only where k[s] > 48).  out (b, ktot, 256) cluster-major rows, ktot = sum k[s].  One accumulate
+ * launch per scale and ONE finalize launch for all of them; bit-identical to per-scale pa_netvlad_rows.
+ * phases: bit 0 = the launches of the <= 16-cluster scales, bit 1 = the other scales' launches, bit 2 = finalize (7 = all); x[s] may be
+ * NULL for scales the requested phases do not read, so the coarse scales can be issued as soon as their feature maps exist.
+ * pa_afa_fused: the APFA head (loupe.py:24-41, :57-66) on those rows in two launches.  Because 1 + w[k] > 0, relu(x + x*w[k]) =
+ * (1 + w[k]) relu(x): the per-cluster partial products relu(v[k]) . Wfc[k] are computed once, beside the attention logits, and the
+ * soft-max over clusters only scales them.  Arguments as pa_afa_rows (no packed / zero-bias operands); nout % 64 == 0;
+ * scratch: pa_afa_fused_scratch_floats(b, ktot, nout) floats.  Same function as pa_afa_rows up to fp32 re-association of the FC sum. */
+int pa_netvlad_pyramid(int b, int nscales, const int *n, const int *k, const float *const *x, const float *const *wc_t, const float *const *wc_p,
+                       const float *const *bias, const float *const *w2, float *const *scratch, float *out, int phases, pa_stream_t stream);
+long pa_afa_fused_scratch_floats(int b, int ktot, int nout);
+int pa_afa_fused(int b, int c, int ktot, int nout, const float *vt, const float *watt_t, const float *fc_wt, const float *fc_bias,
+                 const float *scale, const float *shift, int l2norm, float *scratch, float *desc, pa_stream_t stream);
 long pa_afa_scratch_floats(int b, int c, int ktot, int nout);
 int pa_afa(int b, int c, int ktot, int nout, const float *v, const float *watt, const float *fc_wt, const float *fc_bias,
            const float *scale, const float *shift, int l2norm, float *scratch, float *desc, pa_stream_t stream);

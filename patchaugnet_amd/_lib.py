@@ -61,6 +61,8 @@ _SIGS = {
     "pa_netvlad_pack_weights": "iipp",
     "pa_afa_rows": "iiiippppppppipp",
     "pa_fc": "iiipppppippp",
+    "pa_netvlad_pyramid": "iipppppppppi",
+    "pa_afa_fused": "iiiippppppipp",
     "pa_vlad_maxpool": "iiipip",
     "pa_tgemm_nn": "iiiipliipliipppliippipi",
     "pa_tgemm_kk": "iiilpliipppliippliii",
@@ -111,7 +113,8 @@ def lib():
         l = ctypes.CDLL(LIB_PATH)
         l.pa_last_error.restype = ctypes.c_char_p
         l.pa_abi_version.restype = _I
-        for name, nargs in (("pa_interpolation_backward_scratch_ints", 3), ("pa_netvlad_scratch_floats", 3), ("pa_afa_scratch_floats", 4), ("pa_fc_scratch_floats", 3), ("pa_afa_rows_scratch_floats", 4), ("pa_pack_weights_f16_halfs", 2)):
+        for name, nargs in (("pa_interpolation_backward_scratch_ints", 3), ("pa_netvlad_scratch_floats", 3), ("pa_afa_scratch_floats", 4), ("pa_fc_scratch_floats", 3), ("pa_afa_rows_scratch_floats", 4), ("pa_pack_weights_f16_halfs", 2),
+                            ("pa_afa_fused_scratch_floats", 3)):
             getattr(l, name).argtypes = [_I] * nargs
             getattr(l, name).restype = ctypes.c_long
         _declare(l, _SIGS)

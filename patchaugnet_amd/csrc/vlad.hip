@@ -306,6 +306,8 @@ __global__ __launch_bounds__(256, KT == 4 ? PA_VLAD_WGS : 1) void vlad_accum_ker
     VSTAMPK(12);
 }
 
+constexpr int VLAD_MAX_SCALES = 4;
+
 // wc_t [256][64] K-major -> the fragment order of the assignment GEMM above: wc_p[(s * 64 + lane) * 4 + ct] = wc_t[vlad_chan(s, lane / 16)][16 ct + lane % 16]
 __global__ __launch_bounds__(256) void vlad_pack_kernel(const float *__restrict__ wc_t, float *__restrict__ wc_p)
 {
@@ -791,6 +793,320 @@ PA_API int pa_vlad_maxpool(int b, int ktot, int c, const float *vt, int l2norm, 
     if (c != VC) { pa_set_error("pa_vlad_maxpool: built for 256 channels (got c=%d)", c); return PA_EUNSUPPORTED; }
     hipLaunchKernelGGL(vlad_maxpool_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, ktot, vt, l2norm, out);
     PA_CHECK_LAUNCH("pa_vlad_maxpool");
+    return PA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ whole pyramid + fused APFA head
+namespace {
+
+// finalize of ALL scales in one launch: grid (ktot, B); cluster row kk of the concatenation belongs to scale s with koff[s] <= kk < koff[s+1]
+struct VladFinalizeMulti {
+    int nscales;
+    int koff[VLAD_MAX_SCALES + 1], k[VLAD_MAX_SCALES], kp[VLAD_MAX_SCALES], nchunks[VLAD_MAX_SCALES];
+    const float *part[VLAD_MAX_SCALES], *asum[VLAD_MAX_SCALES], *w2[VLAD_MAX_SCALES];
+};
+
+__global__ __launch_bounds__(256) void vlad_finalize_multi_kernel(VladFinalizeMulti m, float *__restrict__ out, int ktot)
+{
+    __shared__ float red[4];
+    const int kk = blockIdx.x, b = blockIdx.y, c = threadIdx.x;
+    int s = 0;
+#pragma unroll
+    for (int t = 1; t < VLAD_MAX_SCALES; ++t)
+        if (t < m.nscales && kk >= m.koff[t]) s = t;
+    int koff = m.koff[0], k_true = m.k[0], kp = m.kp[0], nchunks = m.nchunks[0];
+    const float *part = m.part[0], *asum_part = m.asum[0], *w2 = m.w2[0];
+#pragma unroll
+    for (int t = 1; t < VLAD_MAX_SCALES; ++t)
+        if (s == t) { koff = m.koff[t]; k_true = m.k[t]; kp = m.kp[t]; nchunks = m.nchunks[t]; part = m.part[t]; asum_part = m.asum[t]; w2 = m.w2[t]; }
+    const int k = kk - koff;
+    float v = 0.f, a = 0.f;
+    // same chunk order as vlad_finalize_kernel (bit-identical rows), but sixteen partial rows are IN FLIGHT before the first add: the pass
+    // is 33 MB of reads at B = 32 and a dependent load -> add chain per chunk ran at a third of the cache bandwidth
+    for (int c0 = 0; c0 < nchunks; c0 += 16) {
+        float pv[16], pa[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const bool live = c0 + u < nchunks;
+            const size_t row = ((size_t)b * nchunks + (live ? c0 + u : c0)) * kp + k;
+            pv[u] = live ? part[row * VC + c] : 0.f;
+            pa[u] = live ? asum_part[row] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (c0 + u < nchunks) { v += pv[u]; a += pa[u]; }
+    }
+    v = v - a * w2[(size_t)c * k_true + k];          // loupe.py:213-219
+    float ss = v * v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) ss += __shfl_xor(ss, o);
+    if ((c & 63) == 0) red[c >> 6] = ss;
+    __syncthreads();
+    const float nrm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+    out[((size_t)b * ktot + kk) * VC + c] = v / fmaxf(nrm, 1e-12f);        // F.normalize(dim=1), loupe.py:221
+}
+
+// APFA head, stage 1.  grid (ktot, NS column slices of 64, batch tiles of 32): for cluster row k and a tile of <= 32 clouds
+//   logits[b][o]  = sum_c v[b][k][c] * Watt_t[c][o]                    o in the slice  -> mpart[b][k][slice] = max_o      (loupe.py:33-34)
+//   P[b][k][n]    = sum_c relu(v[b][k][c]) * Wfc[k*256 + c][n]         n in the slice
+// The reference computes y = relu(x + x*w[k]) and desc = y_flat . Wfc (loupe.py:36-38, :60-62).  1 + w[k] > 0 (w is a soft-max output), so
+// y[k][c] = (1 + w[k]) * relu(v[k][c]) and desc = sum_k (1 + w[k]) * P[k]: P does not depend on the attention weights, so the 22 MB FC
+// weight is streamed ONCE, here, by the same workgroups that compute the attention logits, and the soft-max over clusters only scales
+// 84 rows of 256 afterwards (stage 2).  Five launches (logits, re-weight, split-K FC, finalize: 53 us at B = 32) become two.
+// The contraction (256 channels) is split over the four waves (64 channels each) and reduced through LDS; operands are fetched 16 bytes
+// per lane: a lane's float4 of v feeds four k-steps (k-step (j, e) of k-group q contracts channel 16 j + 4 q + e), its float4 of W is four
+// consecutive columns of one k row (MFMA tile t holds column 4 i + t in its column i).
+constexpr int HB = 32;                 // clouds per tile
+constexpr int HAS = VC + 4;            // LDS row stride of the v tile (16-byte aligned rows)
+// grid (ktot, 4 attention slices + nout / 64 FC slices, batch tiles): ONE (cluster, 64-column slice, pass) unit per workgroup -- 672 equal
+// units of 128 MFMAs per wave at B = 32, 33 KB of LDS each, all resident at once (a workgroup doing both passes of a slice was 336 units of
+// twice the work: the CUs that drew two of them set the kernel's time).
+__global__ __launch_bounds__(256, 2) void afa_cluster_kernel(int bsz, int ktot, int nout, const float *__restrict__ vt,   // (B, ktot, VC)
+                                                               const float *__restrict__ watt_t,                            // (VC, VC) K-major (c, o)
+                                                               const float *__restrict__ fc_wt,                             // (ktot*VC, nout) rows k*VC + c
+                                                               float *__restrict__ mpart,                                   // (B, ktot, 4)
+                                                               float *__restrict__ P)                                       // (B, ktot, nout)
+{
+    __shared__ __attribute__((aligned(16))) float smem[HB * HAS];      // the v tile; after the MFMAs the four waves' partial tiles (4 x 32 x 64 floats)
+    float *As = smem, *red = smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
+    const int k = blockIdx.x, b0 = blockIdx.z * HB;
+    const bool fc = blockIdx.y >= VC / 64;                             // block-uniform: attention logits (raw v) or FC partial (relu(v))
+    const int y = fc ? blockIdx.y - VC / 64 : blockIdx.y;
+    const int cnt = min(HB, bsz - b0);
+    // A workgroup is one dependent chain (operands -> MFMAs -> reduce -> store) and the FC weights come from HBM: every global load of the
+    // chain -- the v tile and the weight fragments (16 x 16 bytes per lane) -- is issued before the first use: one memory latency, not two.
+    float4 vreg[HB * (VC / 4) / 256];
+#pragma unroll
+    for (int u = 0; u < HB * (VC / 4) / 256; ++u) {
+        const int q = tid + u * 256, r = q >> 6, p4 = q & 63;
+        vreg[u] = r < cnt ? *reinterpret_cast<const float4 *>(vt + ((size_t)(b0 + r) * ktot + k) * VC + p4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float *w = fc ? fc_wt + (size_t)k * VC * nout + y * 64 : watt_t + y * 64;
+    const int ldw = fc ? nout : VC;
+    float4 bw[16];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            bw[jj * 4 + e] = *reinterpret_cast<const float4 *>(w + (size_t)(16 * (wave * 4 + jj) + 4 * lq + e) * ldw + 4 * li);
+#pragma unroll
+    for (int u = 0; u < HB * (VC / 4) / 256; ++u) {
+        const int q = tid + u * 256, r = q >> 6, p4 = q & 63;
+        float4 v = vreg[u];
+        if (fc) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        *reinterpret_cast<float4 *>(As + r * HAS + p4 * 4) = v;
+    }
+    __syncthreads();
+    floatx4 acc[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[rt][t] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    // the contraction (256 channels) is split over the four waves, 64 channels each
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        float4 a4[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) a4[rt] = *reinterpret_cast<const float4 *>(As + (rt * 16 + li) * HAS + 16 * (wave * 4 + jj) + 4 * lq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float4 b4 = bw[jj * 4 + e];
+            const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const float av = e == 0 ? a4[rt].x : e == 1 ? a4[rt].y : e == 2 ? a4[rt].z : a4[rt].w;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[t], acc[rt][t], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();                                     // every wave has read its A fragments: the tile becomes the reduction buffer
+    // this wave's partial: row rt*16 + 4 lq + r, columns 4 li .. 4 li + 3 (tile t = column 4 li + t)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<float4 *>(red + (size_t)wave * HB * 64 + (rt * 16 + 4 * lq + r) * 64 + 4 * li) =
+                make_float4(acc[rt][0][r], acc[rt][1][r], acc[rt][2][r], acc[rt][3][r]);
+    __syncthreads();
+    // thread (row = tid / 8, column group = tid % 8): 8 columns, summed over the four waves in wave order
+    const int row = tid >> 3, cg = tid & 7;
+    float o[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float4 sum = *reinterpret_cast<const float4 *>(red + row * 64 + cg * 8 + h * 4);
+#pragma unroll
+        for (int wv = 1; wv < 4; ++wv) {
+            const float4 t4 = *reinterpret_cast<const float4 *>(red + (size_t)wv * HB * 64 + row * 64 + cg * 8 + h * 4);
+            sum.x += t4.x; sum.y += t4.y; sum.z += t4.z; sum.w += t4.w;
+        }
+        o[h * 4] = sum.x; o[h * 4 + 1] = sum.y; o[h * 4 + 2] = sum.z; o[h * 4 + 3] = sum.w;
+    }
+    if (!fc) {
+        float mx = fmaxf(fmaxf(fmaxf(o[0], o[1]), fmaxf(o[2], o[3])), fmaxf(fmaxf(o[4], o[5]), fmaxf(o[6], o[7])));
+        mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 4));
+        if (cg == 0 && row < cnt) mpart[((size_t)(b0 + row) * ktot + k) * 4 + y] = mx;
+    } else if (row < cnt) {
+        float *dst = P + ((size_t)(b0 + row) * ktot + k) * nout + y * 64 + cg * 8;
+        *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4 *>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+}
+
+// APFA head, stage 2.  grid B x 1024 threads: w = softmax_k(max over the 4 slices of mpart) (loupe.py:34-36); desc = BN(sum_k (1 + w[k]) P[k] +
+// bias) (loupe.py:60-62), optional F.normalize (:63-64).  nout <= 1024.  The sum over the ktot rows is pure load latency: thread group
+// g = tid / 256 takes the rows k = g mod 4 with independent accumulators and the groups meet in LDS (fixed order: deterministic).
+__global__ __launch_bounds__(1024) void afa_combine_kernel(int ktot, int nout, const float *__restrict__ mpart, const float *__restrict__ P,
+                                                             const float *__restrict__ fc_bias, const float *__restrict__ scale, const float *__restrict__ shift,
+                                                             int l2norm, float *__restrict__ desc)
+{
+    __shared__ float wk[256];
+    __shared__ float red[32];
+    __shared__ float grp[3 * 1024];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = tid >> 8, t = tid & 255;
+    const float *Pb = P + (size_t)b * ktot * nout;
+    // the P rows do not depend on the soft-max: start the first loads of every thread before the reductions
+    float m = -3.0e38f;
+    if (tid < ktot) {
+        const float4 mp = *reinterpret_cast<const float4 *>(mpart + ((size_t)b * ktot + tid) * 4);
+        m = fmaxf(fmaxf(mp.x, mp.y), fmaxf(mp.z, mp.w));
+    }
+    float mx = m;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));       // ktot <= 256: waves 0..3 hold every live row
+    const float e = tid < ktot ? __expf(m - mx) : 0.f;
+    float s = e;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+    if (lane == 0) red[16 + wave] = s;
+    __syncthreads();
+    s = (red[16] + red[17]) + (red[18] + red[19]);
+    if (tid < 256) wk[tid] = 1.0f + e / s;
+    __syncthreads();
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int n = t + u * 256;
+        if (n < nout) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int k = g;
+            for (; k + 12 < ktot; k += 16) {
+                a0 = fmaf(wk[k], Pb[(size_t)k * nout + n], a0);
+                a1 = fmaf(wk[k + 4], Pb[(size_t)(k + 4) * nout + n], a1);
+                a2 = fmaf(wk[k + 8], Pb[(size_t)(k + 8) * nout + n], a2);
+                a3 = fmaf(wk[k + 12], Pb[(size_t)(k + 12) * nout + n], a3);
+            }
+            for (; k < ktot; k += 4) a0 = fmaf(wk[k], Pb[(size_t)k * nout + n], a0);
+            v[u] = (a0 + a1) + (a2 + a3);
+        }
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (u * 256 >= nout) break;                                   // block-uniform
+        if (g > 0) grp[(g - 1) * 1024 + u * 256 + t] = v[u];
+    }
+    __syncthreads();
+    if (g == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int n = t + u * 256;
+            if (n < nout) {
+                const float acc = ((v[u] + grp[u * 256 + t]) + grp[1024 + u * 256 + t]) + grp[2048 + u * 256 + t];
+                v[u] = (acc + fc_bias[n]) * scale[n] + shift[n];
+                ss += v[u] * v[u];
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) ss += __shfl_xor(ss, o);
+        if (lane == 0) red[wave] = ss;
+    }
+    __syncthreads();
+    if (g == 0) {
+        const float inv = l2norm ? 1.0f / fmaxf(sqrtf((red[0] + red[1]) + (red[2] + red[3])), 1e-12f) : 1.0f;     // F.normalize
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (t + u * 256 < nout) desc[(size_t)b * nout + t + u * 256] = v[u] * inv;
+    }
+}
+
+}  // namespace
+
+// The whole NetVLAD pyramid (loupe.py:191-222 per scale, :301-303 concatenation) -> out (b, ktot, 256) cluster-major rows, ktot = sum k[s].
+// Arrays of nscales (<= 4) entries, coarse to fine; x[s] (b, n[s], 256) point-major; wc_t / wc_p / bias / w2 as for pa_netvlad_rows (wc_p[s]
+// NULL except for k[s] > 48); scratch[s]: pa_netvlad_scratch_floats(b, n[s], k[s]) floats.  Launches: one accumulate kernel per scale, then ONE
+// finalize launch for every scale (pa_netvlad_rows per scale: 2 launches each; 21.7 -> 18.6 us for the three finalize passes at B = 32).
+// Measured and dropped: the <= 16-cluster scales sharing one accumulate launch -- 576 workgroups of 70 KB of LDS on the chip's 512 two-per-CU
+// slots run as two rounds (28.4 us against 13.7 + 7.7 us for the two launches).  Results are bit-identical to pa_netvlad_rows.
+// phases: bit 0 = the accumulate launches of the scales with <= 16 clusters, bit 1 = the accumulate launches of the other scales,
+// bit 2 = the finalize launch (7 = everything).  A caller whose coarse feature maps are ready early (the decoder writes them first) issues
+// phase 1 right behind their producer, while they are still cache-resident, and phases 2 | 4 after the finest level; x[s] of a scale that
+// the requested phases do not read may be NULL.
+PA_API int pa_netvlad_pyramid(int b, int nscales, const int *n, const int *k, const float *const *x, const float *const *wc_t, const float *const *wc_p,
+                              const float *const *bias, const float *const *w2, float *const *scratch, float *out, int phases, pa_stream_t stream)
+{
+    PA_REQUIRE(b > 0 && b <= 65535 && nscales > 0 && nscales <= VLAD_MAX_SCALES && n && k && x && wc_t && bias && w2 && scratch && (out || !(phases & 4)) && (phases & 7),
+               "pa_netvlad_pyramid: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    VladFinalizeMulti fm;
+    memset(&fm, 0, sizeof(fm));
+    fm.nscales = nscales;
+    int ktot = 0;
+    for (int s = 0; s < nscales; ++s) {
+        const int kp = (k[s] + 15) & ~15, kt = kp / 16, chunks = vlad_chunks(n[s]), rows = vlad_rows_per_wg(n[s]);
+        const bool run = kp == 16 ? (phases & 1) : (phases & 2);
+        PA_REQUIRE(n[s] > 0 && k[s] > 0 && k[s] <= 64 && (x[s] || !run) && wc_t[s] && bias[s] && w2[s] && scratch[s],
+                   "pa_netvlad_pyramid: scale %d: bad arguments (<= 64 clusters)", s);
+        float *part = scratch[s], *asum = scratch[s] + (size_t)b * chunks * kp * VC;
+        fm.koff[s] = ktot; fm.k[s] = k[s]; fm.kp[s] = kp; fm.nchunks[s] = chunks; fm.part[s] = part; fm.asum[s] = asum; fm.w2[s] = w2[s];
+        ktot += k[s];
+        if (!run) continue;
+        const size_t lds = (size_t)(VROWS * VC + VROWS * (kt == 4 ? kp : kp + 2)) * 4;
+        const float *wp = (wc_p && k[s] > 48) ? wc_p[s] : nullptr;
+#define PA_VLAD_LAUNCH(KT)                                                                                                              \
+    do {                                                                                                                                \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vlad_accum_kernel<KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(vlad_accum_kernel<KT>, dim3(chunks, b), dim3(256), lds, st, n[s], k[s], rows, x[s], wc_t[s], wp, bias[s], part, asum);  \
+    } while (0)
+        if (kt == 1) PA_VLAD_LAUNCH(1);
+        else if (kt == 2) PA_VLAD_LAUNCH(2);
+        else if (kt == 3) PA_VLAD_LAUNCH(3);
+        else PA_VLAD_LAUNCH(4);
+#undef PA_VLAD_LAUNCH
+    }
+    fm.koff[nscales] = ktot;
+    for (int s = nscales; s < VLAD_MAX_SCALES; ++s) fm.koff[s + 1] = ktot;
+    if (phases & 4) hipLaunchKernelGGL(vlad_finalize_multi_kernel, dim3(ktot, b), dim3(256), 0, st, fm, out, ktot);
+    PA_CHECK_LAUNCH("pa_netvlad_pyramid");
+    return PA_OK;
+}
+
+PA_API long pa_afa_fused_scratch_floats(int b, int ktot, int nout) { return (long)b * ktot * 4 + (long)b * ktot * nout; }
+
+// Cluster-major APFA head in two launches (afa_cluster_kernel / afa_combine_kernel above).  vt (b, ktot, 256) from pa_netvlad_pyramid /
+// pa_netvlad_rows; watt_t: the attention conv as a K-major (in, out) matrix; fc_wt: K-major (ktot*256, nout) with rows ordered k*256 + c;
+// scratch: pa_afa_fused_scratch_floats(b, ktot, nout) floats.  Same function as pa_afa_rows; the FC sum is re-associated (per-cluster
+// partial sums scaled by 1 + w[k]), so descriptors agree to fp32 rounding, not bit for bit.
+PA_API int pa_afa_fused(int b, int c, int ktot, int nout, const float *vt, const float *watt_t, const float *fc_wt, const float *fc_bias,
+                        const float *scale, const float *shift, int l2norm, float *scratch, float *desc, pa_stream_t stream)
+{
+    PA_REQUIRE(b > 0 && ktot > 0 && nout > 0 && vt && watt_t && fc_wt && fc_bias && scale && shift && scratch && desc, "pa_afa_fused: bad arguments");
+    if (c != VC || ktot > 256 || nout % 64 || nout > 1024 || ktot > 65535) {
+        pa_set_error("pa_afa_fused: built for 256 channels, <= 256 clusters, nout %% 64 == 0, nout <= 1024 (got c=%d ktot=%d nout=%d)", c, ktot, nout);
+        return PA_EUNSUPPORTED;
+    }
+    PA_REQUIRE(((uintptr_t)vt & 15) == 0 && ((uintptr_t)watt_t & 15) == 0 && ((uintptr_t)fc_wt & 15) == 0 && ((uintptr_t)scratch & 15) == 0,
+               "pa_afa_fused: operands must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    float *mpart = scratch, *P = scratch + (size_t)b * ktot * 4;
+    hipLaunchKernelGGL(afa_cluster_kernel, dim3(ktot, VC / 64 + nout / 64, (b + HB - 1) / HB), dim3(256), 0, st, b, ktot, nout, vt, watt_t, fc_wt, mpart, P);
+    hipLaunchKernelGGL(afa_combine_kernel, dim3(b), dim3(1024), 0, st, ktot, nout, mpart, P, fc_bias, scale, shift, l2norm, desc);
+    PA_CHECK_LAUNCH("pa_afa_fused");
     return PA_OK;
 }
 

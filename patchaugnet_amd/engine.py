@@ -261,6 +261,45 @@ class _Vlad:
             call("pa_netvlad", b, self.n, self.c, self.k, ptr(x), ptr(self.wc_t), ptr(self.bias), ptr(self.w2), ptr(scratch), ptr(out), ldo, koff)
 
 
+class _Pyramid:
+    """All scales of the NetVLAD pyramid through pa_netvlad_pyramid: the coarse scales share one accumulate launch and every scale
+    shares one finalize launch (per-scale _Vlad.run: two launches each).  Pointer arrays of the weights are built once."""
+
+    def __init__(self, vlads):
+        self.vlads = vlads
+        ns = len(vlads)
+        self.ns = ns
+        self.ktot = sum(v.k for v in vlads)
+        arr = lambda ts: (ctypes.c_void_p * ns)(*[(t.data_ptr() if t is not None else None) for t in ts])
+        self.n = (ctypes.c_int * ns)(*[v.n for v in vlads])
+        self.k = (ctypes.c_int * ns)(*[v.k for v in vlads])
+        self.wc_t, self.wc_p = arr([v.wc_t for v in vlads]), arr([v.wc_p for v in vlads])
+        self.bias, self.w2 = arr([v.bias for v in vlads]), arr([v.w2 for v in vlads])
+
+        self.small = [v.k <= 16 for v in vlads]       # scales that share the early accumulate launch
+
+    def begin(self, b, dev):
+        """Per-forward state: the partial-sum scratch of every scale."""
+        lib = _lib.lib()
+        scr = [torch.empty(lib.pa_netvlad_scratch_floats(b, v.n, v.k), dtype=torch.float32, device=dev) for v in self.vlads]
+        return {"b": b, "scr": scr, "sc": (ctypes.c_void_p * self.ns)(*[t.data_ptr() for t in scr])}
+
+    def launch(self, state, feats, out, phases):
+        """feats: per scale (B, n_s, 256) point-major, coarse -> fine (None where `phases` does not read the scale); phases as pa_netvlad_pyramid."""
+        for v, f in zip(self.vlads, feats):
+            if f is not None and (f.shape[1] != v.n or f.shape[2] != v.c):
+                raise ValueError(f"NetVLAD scale built for ({v.n}, {v.c}) features, got {tuple(f.shape[1:])}")
+        cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
+        xs = (ctypes.c_void_p * self.ns)(*[(f.data_ptr() if f is not None else None) for f in feats])
+        state["keep"] = feats                         # the launches read these buffers asynchronously
+        call("pa_netvlad_pyramid", state["b"], self.ns, cast(self.n), cast(self.k), cast(xs), cast(self.wc_t), cast(self.wc_p), cast(self.bias),
+             cast(self.w2), cast(state["sc"]), ptr(out), phases)
+
+    def run(self, feats, out):
+        """All phases at once: feats per scale (B, n_s, 256) point-major, coarse -> fine; out (B, ktot, 256)."""
+        self.launch(self.begin(out.shape[0], out.device), feats, out, 7)
+
+
 class _Afa:
     """AdaptiveFeatureAggregator for pa_afa: K-major FC weight, BatchNorm folded to scale/shift."""
 
@@ -282,8 +321,18 @@ class _Afa:
         self.zero = torch.zeros(c, dtype=torch.float32, device=device)
         self.fc_wt_rows = afa.fc.weight.detach().float().view(self.nout, c, k).permute(2, 1, 0).reshape(k * c, self.nout).contiguous().to(device)
 
+    def run_fused(self, vt):
+        """vt (B, ktot, C) cluster-major rows -> desc: two launches (pa_afa_fused: per-cluster attention logits + FC partials, then the
+        soft-max over clusters scales the partials).  Needs nout % 64 == 0."""
+        b, ktot, c = vt.shape
+        scratch = torch.empty(_lib.lib().pa_afa_fused_scratch_floats(b, ktot, self.nout), dtype=torch.float32, device=vt.device)
+        desc = torch.empty((b, self.nout), dtype=torch.float32, device=vt.device)
+        call("pa_afa_fused", b, c, ktot, self.nout, ptr(vt), ptr(self.watt_t), ptr(self.fc_wt_rows), ptr(self.fc_bias), ptr(self.scale),
+             ptr(self.shift), self.l2, ptr(scratch), ptr(desc))
+        return desc
+
     def run_rows(self, vt):
-        """vt (B, ktot, C) from _Vlad.run(rows=True)."""
+        """vt (B, ktot, C) from _Vlad.run(rows=True): the five-launch form (dense logits, re-weight, split-K FC, finalize)."""
         b, ktot, c = vt.shape
         nfl = _lib.lib().pa_afa_rows_scratch_floats(b, c, ktot, self.nout)
         scratch = torch.empty(nfl, dtype=torch.float32, device=vt.device)
@@ -428,6 +477,8 @@ class PatchAugNetEngine:
         ks = [v.cluster_size for v in vl]
         with torch.no_grad():
             self.vlads = [_Vlad(v, self.device) for v in vl]
+            self.pyramid = _Pyramid(self.vlads) if os.environ.get("PA_ENGINE_VLAD_PER_SCALE") is None else None     # A/B knob
+            self._vlad_early = os.environ.get("PA_ENGINE_VLAD_LATE") is None                                       # A/B knob
             self.afa = self.head = self.gate = None
             if self.ppt:
                 self.head_kind = "fc"
@@ -440,6 +491,7 @@ class PatchAugNetEngine:
                         raise ValueError("fused APFA head supports the single-conv attention layer and an output width that is a multiple of 16")
                     self.head_kind = "afa"
                     self.afa = _Afa(agg.afa, self.device)
+                    self._afa_fused = self.afa.nout % 64 == 0 and os.environ.get("PA_ENGINE_AFA_ROWS") is None      # A/B knob: the five-launch head
                 elif agg.aggregation_type == 0:       # loupe.py:298-300: FC over the C-major flattening of (B, C, sum K), BN, L2 normalise
                     self.head_kind = "fc"
                     self.head = _FcHead(agg.hidden_weights, agg.bn, ks, per_scale=False, l2=1, device=self.device)
@@ -507,8 +559,9 @@ class PatchAugNetEngine:
     def stale(self, model):
         return self._key != self._params_key(model)
 
-    def backbone(self, xyz):
-        """xyz (B, N, 3) -> point-major features per level + level-0 centre indices.
+    def backbone(self, xyz, early=None):
+        """xyz (B, N, 3) -> point-major features per level + level-0 centre indices.  early(l_feat): called once the decoder has written every
+        level but the finest (the engine issues the coarse NetVLAD scales there).
 
         Everything that depends on coordinates only -- sampling, kNN and 3-NN of every level -- is independent of the feature chains.
         Level 0 (the long one: 1024 serial FPS rounds) has to come first; the coarser levels' sampling / kNN and all three 3-NN launches
@@ -622,6 +675,8 @@ class PatchAugNetEngine:
                 y = chain.fp(known_feat.contiguous(), idx3_l, w3_l, skip.contiguous() if skip is not None else None, B, n_u, m_k, c2, c1)
             self._mark(f"fp{nfp + i}.chain")
             l_feat[i - 1] = y.view(B, n_u, chain.n_last)
+            if early is not None and nfp + i == 1:
+                early(l_feat)        # every decoder level but the finest exists: the coarse NetVLAD scales read them while they are cache-resident
         return l_feat, l_c
 
     def forward(self, x, views=True):
@@ -634,18 +689,31 @@ class PatchAugNetEngine:
     def _forward(self, x, views):
         xyz = x.squeeze(1).contiguous()
         self._mark("start")
-        l_feat, l_c = self.backbone(xyz)
         nfp = len(self.fp)
-        feats = [l_feat[j] for j in range(nfp - 1, -1, -1)]                                   # coarse -> fine, (B, N_i, 256)
         ktot = sum(v.k for v in self.vlads)
         v = torch.empty((x.shape[0], ktot, 256), dtype=torch.float32, device=self.device)     # cluster-major rows
-        koff = 0
-        for vl, f in zip(self.vlads, feats):
-            vl.run(f.contiguous(), v, ktot, koff, rows=True)
-            koff += vl.k
+        pyr = self.pyramid
+        # coarse scales right behind the decoder level that completes their inputs (their feature maps are still cache-resident; after the
+        # finest level's 134 MB they are not) -- when every scale but the finest is a <= 16-cluster scale, i.e. both shipped models
+        split = pyr is not None and self.timer is None and nfp >= 2 and all(pyr.small[:-1]) and not pyr.small[-1] and self._vlad_early
+        st = pyr.begin(x.shape[0], self.device) if pyr is not None else None
+
+        def early(l_feat):
+            coarse = [l_feat[j].contiguous() for j in range(nfp - 1, 0, -1)]
+            pyr.launch(st, coarse + [None], v, 1)
+        l_feat, l_c = self.backbone(xyz, early if split else None)
+        feats = [l_feat[j] for j in range(nfp - 1, -1, -1)]                                   # coarse -> fine, (B, N_i, 256)
+        if pyr is not None:
+            fc = [f.contiguous() for f in feats]
+            pyr.launch(st, ([None] * (nfp - 1) + fc[-1:]) if split else fc, v, 6 if split else 7)
+        else:
+            koff = 0
+            for vl, f in zip(self.vlads, feats):
+                vl.run(f.contiguous(), v, ktot, koff, rows=True)
+                koff += vl.k
         self._mark("vlad")
         if self.head_kind == "afa":
-            desc = self.afa.run_rows(v)
+            desc = self.afa.run_fused(v) if self._afa_fused else self.afa.run_rows(v)
         elif self.head_kind == "fc":
             desc = self.head.run(v)
         else:

@@ -140,6 +140,8 @@ def load_local_descriptor(l_desc_dir, idx, unify_coord=False, global_offset=0.0)
     K = l_kpt.shape[0]
     l_kpt, l_desc = l_kpt.reshape(K, -1), l_desc.reshape(K, -1)
     if unify_coord:
-        trans = norm_meta["trans"].reshape(1, norm_meta["trans"].shape[0]) - global_offset
+        # the reference reshapes to (1, trans.shape[0]) (scene_dataset.py:827), which only fits the (3,) centroid of normalize_point_cloud and
+        # raises on the (1, 3) zeros it stores for un-normalised submaps (:723); reshape(1, -1) reads both
+        trans = np.asarray(norm_meta["trans"]).reshape(1, -1) - global_offset
         l_kpt = l_kpt * norm_meta["scale"] + trans
     return l_kpt, l_desc, norm_meta

@@ -194,12 +194,12 @@ def test_update_global_descs_refresh_and_pickle_cache(tmp_path):
     kpt_w, _, _ = pio.load_local_descriptor(ld, 13, unify_coord=True)
     assert np.array_equal(kpt_w, kpt)
     # normalised submaps: the caller's metas ride into the files of exactly the records they belong to
-    metas = [{"scale": 2.0 + i, "trans": np.full([1, 3], float(i))} for i in range(22)]
+    metas = [{"scale": 2.0 + i, "trans": np.full([3], float(i))} for i in range(22)]          # normalize_point_cloud's form: (3,) centroid
     gd2, ld2 = str(tmp_path / "g2"), str(tmp_path / "l2")
     update_global_descs(m, lambda lo, hi: x[lo:hi], 22, batch_size=8, save_dirs=(gd2, ld2), norm_metas=lambda lo, hi: metas[lo:hi])
     for i in (0, 7, 8, 21):
         kpt_i, _, meta_i = pio.load_local_descriptor(ld2, i)
-        assert meta_i["scale"] == 2.0 + i and np.array_equal(meta_i["trans"], np.full([1, 3], float(i)))
+        assert meta_i["scale"] == 2.0 + i and np.array_equal(meta_i["trans"], np.full([3], float(i)))
         kw, _, _ = pio.load_local_descriptor(ld2, i, unify_coord=True)
         assert np.allclose(kw, kpt_i * (2.0 + i) + float(i))
 

@@ -123,11 +123,10 @@ def test_group_module_feature_gradients(P, mod):
     """Backward through the modules: the feature gradient is the grouping backward (grouping_cuda_kernel.cu:33-52), the centre-feature
     gradient the plain sum over the neighbourhood; coordinates carry no gradient into the neighbour search."""
     xyz, new_xyz, feats, cfeat = _inputs(2, 256, 32, 10, seed=31)
-    g = torch.Generator().manual_seed(8)
 
     def run(M, dev):
-        f = feats.to(dev).requires_grad_(True)
-        cf = cfeat.to(dev).requires_grad_(True)
+        f = feats.detach().clone().to(dev).requires_grad_(True)          # fresh leaves per run (.to("cpu") alone would alias the input)
+        cf = cfeat.detach().clone().to(dev).requires_grad_(True)
         if mod == "QueryAndGroup":
             out = M.QueryAndGroup(None, 12, True)(xyz.to(dev), new_xyz.to(dev), f)
         elif mod == "QueryAndGroup_Edge_Split":

@@ -46,13 +46,59 @@ def test_afa(b, ktot):
         ref = afa(v).squeeze(-1)
         eng = _Afa(afa, v.device)
         got = eng.run(v.contiguous())
-        got_rows = eng.run_rows(v.transpose(1, 2).contiguous())                            # cluster-major path of the fused engine
+        got_rows = eng.run_rows(v.transpose(1, 2).contiguous())                            # cluster-major, five launches
+        got_fused = eng.run_fused(v.transpose(1, 2).contiguous())                          # cluster-major, two launches: what the engine runs
     err = (got - ref).abs().max().item()
     assert err <= 2e-5, err
     assert (got_rows - ref).abs().max().item() <= 2e-5
+    assert (got_fused - ref).abs().max().item() <= 2e-5 and (got_fused - got_rows).abs().max().item() <= 1e-5
+    ref64 = afa.double()(v.double()).squeeze(-1)                                           # the fused form is as close to fp64 as the others
+    assert (got_fused.double() - ref64).abs().max().item() <= 1.5 * max((got_rows.double() - ref64).abs().max().item(), 2e-7)
+    afa.float()
     from oracle import models_cpu
     orc = models_cpu.adaptive_feature_aggregator({"a." + kk: t.cpu() for kk, t in afa.state_dict().items()}, "a", v.cpu())
     assert (got.cpu() - orc).abs().max().item() <= 2e-5 and (got_rows.cpu() - orc).abs().max().item() <= 2e-5
+    assert (got_fused.cpu() - orc).abs().max().item() <= 2e-5
+
+
+def test_afa_fused_attention_extremes():
+    """The soft-max over clusters inside the fused head: one cluster with a dominant logit (w -> 1 for it, ~0 elsewhere), all-negative
+    rows (relu kills them) and a zero row -- against the module in fp64."""
+    from patchaugnet_amd import loupe
+    from patchaugnet_amd.engine import _Afa
+    afa = _seed_module(loupe.AdaptiveFeatureAggregator(256, 84, 256), seed=5)
+    v = torch.nn.functional.normalize(torch.randn(6, 256, 84, device="cuda"), dim=1)
+    v[0, :, 7] *= 40.0
+    v[1, :, :] = -v[1].abs()
+    v[2, :, 3] = 0.0
+    v[3] = 0.0
+    with torch.no_grad():
+        got = _Afa(afa, v.device).run_fused(v.transpose(1, 2).contiguous())
+        ref = afa.double()(v.double()).squeeze(-1)
+    assert torch.isfinite(got).all()
+    assert (got.double() - ref).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("b,scales", [(3, [(128, 4), (1024, 16), (4096, 64)]), (2, [(64, 1), (256, 4), (1024, 16), (4096, 64)]),
+                                      (2, [(100, 7), (700, 33)]), (1, [(2048, 64)]), (33, [(128, 4), (1024, 16)])])
+def test_netvlad_pyramid_is_bit_identical_to_the_per_scale_calls(b, scales):
+    """pa_netvlad_pyramid (coarse scales in one accumulate launch, every scale in one finalize launch) = pa_netvlad_rows per scale, bit for bit."""
+    from patchaugnet_amd import loupe
+    from patchaugnet_amd.engine import _Pyramid, _Vlad
+    vl, xs = [], []
+    for n, k in scales:
+        v = _seed_module(loupe.NetVLADBase(256, n, k, 256, gating=False), seed=n + k)
+        vl.append(_Vlad(v, torch.device("cuda")))
+        xs.append(torch.randn(b, n, 256, device="cuda") * 0.7)
+    ktot = sum(k for _, k in scales)
+    ref = torch.full((b, ktot, 256), 7.0, device="cuda")
+    koff = 0
+    for v, x in zip(vl, xs):
+        v.run(x, ref, ktot, koff, rows=True)
+        koff += v.k
+    got = torch.full((b, ktot, 256), -3.0, device="cuda")
+    _Pyramid(vl).run(xs, got)
+    assert torch.equal(got, ref)
 
 
 @pytest.mark.parametrize("agg_type,gating", [(0, False), (0, True), (2, True), (3, False), (3, True)])
