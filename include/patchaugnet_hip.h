@@ -316,6 +316,11 @@ int pa_tgemm_kk(int batch, int M, int N, long K, const float *A, long sAb, int l
 /* BatchNorm (training): statistics -> rows 0..3 of p, running statistics updated in place (momentum, unbiased variance) when given. */
 int pa_bn_finalize(int nch, int groups, double count, const double *stats, const float *gamma, const float *beta, float eps, float momentum,
                    float *running_mean, float *running_var, float *p, pa_stream_t stream);
+/* BatchNorm (evaluation): the parameter block from the RUNNING statistics (rows 0..3; rows 4, 5 zero, row 6 = scale), `groups` identical copies --
+ * the module path in eval() mode runs on the same GEMM kernels, forward and backward (the input gradient then has no batch-statistics terms:
+ * pa_bn_bwd_finalize with count = +inf leaves rows 4, 5 at zero and still returns dgamma / dbeta). */
+int pa_bn_eval_params(int nch, int groups, const float *gamma, const float *beta, const float *running_mean, const float *running_var, float eps,
+                      float *p, pa_stream_t stream);
 /* sums (2*C doubles, zero-filled) += per-channel sum of mask(g) and of mask(g)*xhat over g, y (B, C, P); relu != 0: mask = BN(y) > 0. */
 int pa_bn_bwd_reduce(int B, int C, long P, const float *g, const float *y, const float *p, int relu, double *sums, int per_batch_stats, pa_stream_t stream);
 /* rows 4..6 of p from the sums; dgamma / dbeta (nch floats) written when given. */
@@ -324,6 +329,14 @@ int pa_bn_bwd_finalize(int nch, int groups, double count, const double *sums, fl
  * out (B, C, P/pool) and arg (int8 winning slot, first maximum).  pa_maxpool_bwd scatters a pooled gradient back: rows = B*C. */
 int pa_bn_apply(int B, int C, long P, int pool, int relu, const float *y, const float *p, float *out, signed char *arg, int per_batch_stats, pa_stream_t stream);
 int pa_maxpool_bwd(int rows, long Pout, int pool, const float *gp, const signed char *arg, float *g, pa_stream_t stream);
+
+/* ---- Grouped self-attention in training / autograd mode (csrc/attention_train.hip; pptnet.py:261-282): the part between the two GEMMs.
+ * pa_attn_softmax_renorm: energy (b, n, n) -> A = softmax_rows(energy) / (1e-9 + column sums) IN PLACE; colsum (b, n) receives the
+ * denominators.  pa_attn_softmax_renorm_backward: grad (b, n, n) holds dL/dA on entry and dL/dEnergy on return.
+ * scratch: pa_attn_train_scratch_floats(b, n) floats for the forward call, that + b*n for the backward call.  Deterministic. */
+long pa_attn_train_scratch_floats(int b, int n);
+int pa_attn_softmax_renorm(int b, int n, float *energy, float *colsum, float *scratch, pa_stream_t stream);
+int pa_attn_softmax_renorm_backward(int b, int n, const float *attn, const float *colsum, float *grad, float *scratch, pa_stream_t stream);
 
 /* ---- Patch overlap-pair selection of the training step's contrastive patch-feature term (the Python loops of train_one_epoch,
  * place_recognition/train_place_recognition.py:308-372), csrc/patch_pairs.hip.  Records in CSR form: idx1 (nrec), near_off / far_off

@@ -68,6 +68,9 @@ _SIGS = {
     "pa_tgemm_kk": "iiilpliipppliippliii",
     "pa_bn_finalize": "iidpppffppp",
     "pa_bn_bwd_reduce": "iilpppipi",
+    "pa_bn_eval_params": "iippppfp",
+    "pa_attn_softmax_renorm": "iippp",
+    "pa_attn_softmax_renorm_backward": "iipppp",
     "pa_bn_bwd_finalize": "iidpppp",
     "pa_bn_apply": "iiliippppi",
     "pa_maxpool_bwd": "ilippp",
@@ -114,7 +117,7 @@ def lib():
         l.pa_last_error.restype = ctypes.c_char_p
         l.pa_abi_version.restype = _I
         for name, nargs in (("pa_interpolation_backward_scratch_ints", 3), ("pa_netvlad_scratch_floats", 3), ("pa_afa_scratch_floats", 4), ("pa_fc_scratch_floats", 3), ("pa_afa_rows_scratch_floats", 4), ("pa_pack_weights_f16_halfs", 2),
-                            ("pa_afa_fused_scratch_floats", 3)):
+                            ("pa_afa_fused_scratch_floats", 3), ("pa_attn_train_scratch_floats", 2)):
             getattr(l, name).argtypes = [_I] * nargs
             getattr(l, name).restype = ctypes.c_long
         _declare(l, _SIGS)

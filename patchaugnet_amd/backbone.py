@@ -51,10 +51,27 @@ class SALayer(nn.Module):
         st.pop("_attn_key", None)
         return st
 
+    def _autograd_hip(self, x):
+        """train(), or eval() with autograd, on the MI355X: the same function on the MFMA GEMM kernels of csrc/train_gemm.hip and the
+        soft-max / re-normalisation kernels of csrc/attention_train.hip, forward and backward (patchaugnet_amd/train_ops.py).  The tied
+        grouped q / k convolution is evaluated as its block-diagonal dense matrix (gp x the multiply-adds of the grouped form, C <= 512: the
+        N x N products dominate); its gradient flows back to the (C, C/gp) parameter through the block selection."""
+        from . import train_ops
+        w = self.k_conv.weight.squeeze(-1)                                        # (C, C/gp): output o reads the inputs of group o // cg
+        cg = w.shape[1]
+        dense = torch.block_diag(*w.view(self.gp, cg, cg))                          # (C, C)
+        y = train_ops.linear_cm(x, dense)
+        x_v = train_ops.linear_cm(x, self.v_conv.weight, self.v_conv.bias)
+        x_r = train_ops.sa_attention_train(y, x_v)
+        layer = train_ops.BNLayer(self.trans_conv.weight, self.after_norm, bias=self.trans_conv.bias)
+        return x + train_ops.chain_train((x - x_r).contiguous(), [layer], training=self.training)
+
     def forward(self, x):
-        if x.is_cuda and not self.training and not torch.is_grad_enabled() and x.shape[1] in (64, 128, 256, 512):
-            return self._fused(x)
-        bs, ch, n = x.shape
+        if x.is_cuda:
+            if not self.training and not torch.is_grad_enabled() and x.shape[1] in (64, 128, 256, 512):
+                return self._fused(x)
+            return self._autograd_hip(x)
+        bs, ch, n = x.shape                         # CPU form
         y = self.k_conv(x).reshape(bs, self.gp, ch // self.gp, n)
         energy = torch.matmul(y.permute(0, 1, 3, 2), y).sum(dim=1)
         attn = torch.softmax(energy, dim=-1)

@@ -477,6 +477,29 @@ __global__ void bn_finalize_kernel(int nch, int batch, double count, const doubl
     if (running_mean) { running_mean[c] = rm; running_var[c] = rv; }
 }
 
+// Evaluation-mode BatchNorm as the same parameter block: rows 0..3 from the RUNNING statistics (scale = gamma / sqrt(running_var + eps), shift = beta -
+// running_mean * scale, mean, rstd), rows 4, 5 (the batch-statistics terms of the input gradient) zero, row 6 = scale; `groups` identical copies.
+__global__ void bn_eval_params_kernel(int nch, int groups, const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ running_mean,
+                                      const float *__restrict__ running_var, float eps, float *__restrict__ p)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nch) return;
+    const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+    const float mean = running_mean[c];
+    const float rstd = (float)(1.0 / sqrt((double)running_var[c] + (double)eps));
+    const float scale = g * rstd;
+    for (int b = 0; b < groups; ++b) {
+        float *pb = p + (size_t)b * 7 * nch;
+        pb[c] = scale;
+        pb[nch + c] = bt - mean * scale;
+        pb[2 * nch + c] = mean;
+        pb[3 * nch + c] = rstd;
+        pb[4 * nch + c] = 0.f;
+        pb[5 * nch + c] = 0.f;
+        pb[6 * nch + c] = scale;
+    }
+}
+
 // backward reduction over a channel-major (B, C, P) pair (g = gradient w.r.t. the post-activation, y = raw pre-BatchNorm output):
 // sums[c] += sum mask(g), sums[C + c] += sum mask(g) * xhat   (fp64 atomics); grid (chunks of P, C, B)
 template <bool RELU>
@@ -714,6 +737,15 @@ PA_API int pa_bn_finalize(int nch, int groups, double count, const double *stats
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(pa_div_up(nch, 256)), dim3(256), 0, (hipStream_t)stream, nch, groups, count, stats, gamma, beta, eps, momentum,
                        running_mean, running_var, p);
     PA_CHECK_LAUNCH("pa_bn_finalize");
+    return PA_OK;
+}
+
+PA_API int pa_bn_eval_params(int nch, int groups, const float *gamma, const float *beta, const float *running_mean, const float *running_var, float eps,
+                             float *p, pa_stream_t stream)
+{
+    PA_REQUIRE(nch > 0 && groups > 0 && running_mean && running_var && p, "pa_bn_eval_params: bad arguments");
+    hipLaunchKernelGGL(bn_eval_params_kernel, dim3(pa_div_up(nch, 256)), dim3(256), 0, (hipStream_t)stream, nch, groups, gamma, beta, running_mean, running_var, eps, p);
+    PA_CHECK_LAUNCH("pa_bn_eval_params");
     return PA_OK;
 }
 

@@ -17,9 +17,10 @@ from . import train_ops
 from .backbone import SALayer
 
 
-def _hip_train(mod, x):
-    """train() mode on the MI355X: the dense layers run on the MFMA GEMM kernels of csrc/train_gemm.hip (patchaugnet_amd/train_ops.py)."""
-    return x.is_cuda and mod.training and train_ops.hip_dense_enabled()
+def _hip(x):
+    """On the MI355X -- train() or eval(), with or without autograd -- the dense layers run on the MFMA GEMM kernels of csrc/train_gemm.hip
+    (patchaugnet_amd/train_ops.py); the plain torch statements below are the modules' CPU form."""
+    return train_ops.on_device(x)
 
 GroupSALayer = SALayer      # patch_aug_net/models/loupe.py:69-114 -- the same grouped self-attention as pptnet.py's SA_Layer (disabled in
                             # the shipped PatchAugNet config, patch_aug_net.py:239; kept so code that names it keeps importing)
@@ -36,8 +37,8 @@ class GatingContext(nn.Module):
         self.bn1 = nn.BatchNorm1d(dim)
 
     def forward(self, x):
-        if _hip_train(self, x) and x.dim() == 2:
-            return x * torch.sigmoid(train_ops.bn_rows_train(self.bn1, train_ops.matmul_rows(x, self.gating_weights)))
+        if _hip(x) and x.dim() == 2:
+            return x * torch.sigmoid(train_ops.bn_rows(self.bn1, train_ops.matmul_rows(x, self.gating_weights), self.training))
         return x * torch.sigmoid(self.bn1(torch.matmul(x, self.gating_weights)))
 
 
@@ -63,8 +64,8 @@ class NetVLADBase(nn.Module):
 
     def forward(self, x):
         """x: (B, C, N, 1) -> (B, C, K) (or (B, C*K))."""
-        if _hip_train(self, x):
-            return self._forward_hip_train(x.squeeze(-1))
+        if _hip(x):
+            return self._forward_hip(x.squeeze(-1))
         x = x.squeeze(-1).transpose(1, 2)                                  # (B, N, C) view
         act = torch.matmul(x, self.cluster_weights)                        # (B, N, K)
         act = self.bn1(act.reshape(-1, self.cluster_size)).view(-1, self.max_samples, self.cluster_size)
@@ -75,17 +76,17 @@ class NetVLADBase(nn.Module):
         return vlad.view(-1, self.cluster_size * self.feature_size) if self.flatten else vlad
 
 
-def _netvlad_hip_train(self, x):
-    """Channel-major statement of NetVLADBase.forward for train(): x (B, C, N).  The assignment GEMM + BatchNorm is a one-layer chain
+def _netvlad_hip(self, x):
+    """Channel-major statement of NetVLADBase.forward on the MI355X: x (B, C, N).  The assignment GEMM + BatchNorm is a one-layer chain
     (cluster-major (B, K, N) output, statistics fused into the GEMM epilogue), the aggregation X . act^T a batched k-contiguous GEMM."""
     layer = train_ops.BNLayer(self.cluster_weights, self.bn1, relu=False, transposed=True)
-    act = torch.softmax(train_ops.chain_train(x, [layer]), dim=1)          # (B, K, N)
+    act = torch.softmax(train_ops.chain_train(x, [layer], training=self.training), dim=1)          # (B, K, N)
     a = act.sum(-1).unsqueeze(1) * self.cluster_weights2                   # (B, C, K)
     vlad = F.normalize(train_ops.bmm_nt(x, act) - a, dim=1, p=2).contiguous()
     return vlad.view(-1, self.cluster_size * self.feature_size) if self.flatten else vlad
 
 
-NetVLADBase._forward_hip_train = _netvlad_hip_train
+NetVLADBase._forward_hip = _netvlad_hip
 
 
 class MLPAttentionLayer(nn.Module):
@@ -100,7 +101,7 @@ class MLPAttentionLayer(nn.Module):
     def forward(self, x):
         r = x
         for mlp in self.mlps:
-            r = train_ops.linear_cm(r, mlp.weight) if _hip_train(self, x) else torch.matmul(mlp.weight.squeeze(-1), r)
+            r = train_ops.linear_cm(r, mlp.weight) if _hip(x) else torch.matmul(mlp.weight.squeeze(-1), r)
         w = torch.softmax(r.max(dim=1)[0], dim=-1).unsqueeze(1)      # (B, 1, K)
         return F.relu(x + x * w)
 
@@ -117,8 +118,8 @@ class AdaptiveFeatureAggregator(nn.Module):
 
     def forward(self, x):
         x = self.mlpa(x)
-        if _hip_train(self, x):
-            x = train_ops.bn_rows_train(self.bn, train_ops.linear_rows(x.flatten(1), self.fc.weight, self.fc.bias))
+        if _hip(x):
+            x = train_ops.bn_rows(self.bn, train_ops.linear_rows(x.flatten(1), self.fc.weight, self.fc.bias), self.training)
         else:
             x = self.bn(self.fc(x.flatten(1)))
         if self.l2_norm:
@@ -150,8 +151,8 @@ class SpatialPyramidNetVLAD(nn.Module):
 
     def forward(self, features):
         v = torch.cat([vlad(f) for vlad, f in zip(self.vlads, features)], dim=-1)   # (B, C, sum K)
-        if self.aggregation_type == 0 and _hip_train(self, v):
-            out = F.normalize(train_ops.bn_rows_train(self.bn, train_ops.matmul_rows(v.flatten(1), self.hidden_weights)))
+        if self.aggregation_type == 0 and _hip(v):
+            out = F.normalize(train_ops.bn_rows(self.bn, train_ops.matmul_rows(v.flatten(1), self.hidden_weights), self.training))
         elif self.aggregation_type == 0:
             out = F.normalize(self.bn(torch.matmul(v.flatten(1), self.hidden_weights)))
         elif self.aggregation_type == 2:
@@ -177,8 +178,8 @@ class SpatialPyramidNetVLAD4(nn.Module):
 
     def forward(self, f0, f1, f2, f3):
         v = torch.cat([self.vlad0(f0), self.vlad1(f1), self.vlad2(f2), self.vlad3(f3)], dim=-1)
-        if _hip_train(self, v):
-            v = train_ops.bn_rows_train(self.bn2, train_ops.matmul_rows(v, self.hidden_weights))
+        if _hip(v):
+            v = train_ops.bn_rows(self.bn2, train_ops.matmul_rows(v, self.hidden_weights), self.training)
         else:
             v = self.bn2(torch.matmul(v, self.hidden_weights))
         return self.context_gating(v) if self.gating else v

@@ -7,7 +7,9 @@ or with ``nn_dict`` the training tuple ``((desc, patch_recon_data), fp_features,
 State-dict keys equal the reference's (tests/golden/patch_aug_net_state_dict_keys.json).
 
 In ``eval()`` mode under ``torch.no_grad()`` the forward pass runs the fused HIP engine
-(patchaugnet_amd/engine.py); otherwise the autograd-capable module path (patchaugnet_amd/backbone.py).
+(patchaugnet_amd/engine.py); otherwise -- train(), or eval() with autograd -- the autograd-capable module path
+(patchaugnet_amd/backbone.py), whose dense layers run on the HIP GEMM kernels too (patchaugnet_amd/train_ops.py):
+no forward of a model on the MI355X reaches torch.matmul / rocBLAS / MIOpen.
 """
 import torch
 import torch.nn as nn
@@ -39,12 +41,12 @@ class PointNetDecoder(nn.Module):
         over the P columns fused into the GEMM epilogues, BatchNorm + ReLU applied by the next GEMM's loader), the output layer a GEMM
         with bias + tanh epilogue."""
         layers = [train_ops.BNLayer(self.fc1.weight, self.bn1, bias=self.fc1.bias), train_ops.BNLayer(self.fc2.weight, self.bn2, bias=self.fc2.bias)]
-        h = train_ops.chain_train(xt, layers, groups=True)
+        h = train_ops.chain_train(xt, layers, groups=True, training=self.training)
         y = train_ops.linear_cm(h, self.fc3.weight, self.fc3.bias, act=1)             # (R, num_points*3, P)
         return y.transpose(1, 2).contiguous().view(xt.shape[0], xt.shape[2], self.num_points, self.output_channels)
 
     def forward(self, x):
-        if x.is_cuda and self.training and train_ops.hip_dense_enabled():
+        if train_ops.on_device(x):
             return self.forward_cm(x.t().contiguous().unsqueeze(0))[0]
         x = F.relu(self.bn1(self.fc1(x)))
         x = F.relu(self.bn2(self.fc2(x)))
@@ -143,7 +145,7 @@ class Network(nn.Module):
             origin = pointops.grouping(xyz.transpose(1, 2).contiguous(), sample_idx[0])      # (B, 3, m0, k)
             data = {"cloud_indices": related, "center_indices": [], "origin_patches": [], "patch_features": [],
                     "reconstructed_patches": []}
-            hip_dec = self.use_a2a_recon and x.is_cuda and self.training and train_ops.hip_dense_enabled()
+            hip_dec = self.use_a2a_recon and train_ops.on_device(x)
             feats_cm = fp_features[1].squeeze(-1).index_select(0, self.related_index(x.device, related))   # (R, 256, m0): one patch feature per column
             if self.use_l2_norm:
                 feats_cm = F.normalize(feats_cm, dim=1)

@@ -4,8 +4,9 @@ Model API and state-dict keys of ``place_recognition/pointnet_vlad/PointNetVlad.
 ``place_recognition/evaluate.py:88-90``:
 ``PointNetVlad(global_feat=True, feature_transform=True, max_pool=False, output_dim=256, num_points=4096)``;
 ``forward(x: (B,1,N,3)) -> (B, output_dim)``.  The reference has no CUDA extension on this path -- it is dense torch ops only
--- so this class is torch as well (rocBLAS/MIOpen on the MI355X, ATen on CPU); 1x1 convolutions are written as matmuls
-on point-major activations.  Keys: tests/golden/pointnet_vlad_state_dict_keys.json.
+-- so this class is torch as well, and it is the CPU configuration ONLY: a tensor on the MI355X is refused (it would run on
+rocBLAS / MIOpen library kernels, which no model of this package is allowed to reach silently; the device models are PatchAugNet and
+PPT-Net).  1x1 convolutions are written as matmuls on point-major activations.  Keys: tests/golden/pointnet_vlad_state_dict_keys.json.
 """
 import math
 
@@ -132,4 +133,8 @@ class PointNetVlad(nn.Module):
                                      gating=True, add_batch_norm=True, is_training=True)
 
     def forward(self, x):
+        if x.is_cuda:
+            raise RuntimeError("PointNetVlad is BASELINE configs[0], the CPU-only PyTorch configuration: there is no HIP path for it and the "
+                               "package never routes a device tensor through library GEMM / convolution kernels; run it on CPU tensors "
+                               "(the MI355X models are patch_aug_net.Network and pptnet.Network)")
         return self.net_vlad(self.point_net(x))

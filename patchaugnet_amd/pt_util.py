@@ -48,22 +48,20 @@ class SharedMLP(nn.Sequential):
         for i in range(len(args) - 1):
             self.add_module(f"layer{i}", ConvBNReLU(args[i], args[i + 1], dims))
 
-    def _hip_train(self, x):
-        return x.is_cuda and self.training and train_ops.hip_dense_enabled()
-
     def _chain(self, x, pool):
-        """train() mode on the MI355X: the whole stack, forward and backward, on the MFMA GEMM kernels of csrc/train_gemm.hip
-        (BatchNorm + ReLU applied inside the next layer's operand loader, statistics accumulated in the epilogue)."""
+        """On the MI355X, train() and eval(): the whole stack, forward and backward, on the MFMA GEMM kernels of csrc/train_gemm.hip
+        (BatchNorm + ReLU applied inside the next layer's operand loader; train(): statistics accumulated in the epilogue,
+        eval(): the running statistics)."""
         layers = [train_ops.BNLayer(l.conv.weight, l.bn.bn) for l in self]
-        return train_ops.chain_train(x.flatten(2), layers, pool)
+        return train_ops.chain_train(x.flatten(2), layers, pool, training=self.training)
 
     def forward(self, x):
-        if self._hip_train(x):
+        if train_ops.on_device(x):
             return self._chain(x, 0).view(x.shape[0], self.channels[-1], *x.shape[2:])
-        return super().forward(x)
+        return super().forward(x)                   # CPU form
 
     def forward_maxpool(self, x):
         """(B, C, m, k) -> max over k of the stack's output, (B, C_out, m) (patch_aug_net.py:236): fused into the last BatchNorm pass."""
-        if self._hip_train(x):
+        if train_ops.on_device(x):
             return self._chain(x, x.shape[3])
-        return super().forward(x).max(dim=3)[0]
+        return super().forward(x).max(dim=3)[0]     # CPU form

@@ -13,31 +13,22 @@ BatchNorm + ReLU, the epilogue accumulates the statistics, and in the backward p
 gradient from (dZ, raw Y) on the fly.  Only the raw (pre-BatchNorm) layer outputs are kept for the backward pass.
 
 Everything here calls libpatchaugnet_hip.so (pa_tgemm_nn / pa_tgemm_kk / pa_bn_*); there is no torch.matmul / rocBLAS / MIOpen in it.
-"""
-import contextlib
 
+The module path takes these functions for EVERY tensor on the MI355X -- train() or eval(), with or without autograd (eval(): BatchNorm
+with the running statistics, ``training=False`` below) -- so a model on the device never reaches a library GEMM / convolution; the modules'
+plain torch statements remain only as their CPU form (PointNetVLAD's CPU configuration, and the fp64 reference side of the tests).
+"""
 import torch
 from torch.autograd import Function
 
 from ._lib import call, check_device, ptr
 
-_hip_dense = True
 STAT_SLOTS = 32          # PA_BN_STAT_SLOTS (include/patchaugnet_hip.h): replicas of a layer's statistics block
 
 
-def hip_dense_enabled():
-    return _hip_dense
-
-
-@contextlib.contextmanager
-def torch_dense_path():
-    """TEST HOOK: run the module path's dense layers through torch autograd instead (the comparison side of tests/test_gpu_train_ops.py)."""
-    global _hip_dense
-    old, _hip_dense = _hip_dense, False
-    try:
-        yield
-    finally:
-        _hip_dense = old
+def on_device(x):
+    """True when `x` lives on the MI355X: the dense layers of the module path then run on the HIP kernels of this file."""
+    return x.is_cuda
 
 
 def _guard(t):
@@ -84,7 +75,7 @@ class _ChainTrain(Function):
     groups = True: every batch entry is its own BatchNorm batch (the decoder run over R related clouds in one set of launches)."""
 
     @staticmethod
-    def forward(ctx, x, layers, pool, groups, *tensors):
+    def forward(ctx, x, layers, pool, groups, training, *tensors):
         check_device(x)
         B, cin, P = x.shape
         dev = x.device
@@ -98,7 +89,7 @@ class _ChainTrain(Function):
         G = B if groups else 1                    # statistics groups
         outs = [L.out_channels for L in layers]
         # one zero-filled arena for every layer's statistics replicas, one for the parameter blocks
-        stats_all = torch.zeros(G * STAT_SLOTS * 2 * sum(outs), dtype=torch.float64, device=dev)
+        stats_all = torch.zeros(G * STAT_SLOTS * 2 * sum(outs), dtype=torch.float64, device=dev) if training else None
         p_all = torch.empty(G * 7 * sum(outs), dtype=torch.float32, device=dev)
         ys, ps = [], []
         prev, prevp = x, None
@@ -111,16 +102,20 @@ class _ChainTrain(Function):
                 assert C == cin, f"layer {i}: weight has {C} input channels, activation has {cin}"
                 assert L.relu or i == len(layers) - 1, "only the last layer of a chain may come without ReLU"
                 y = torch.empty((B, O, P), dtype=torch.float32, device=dev)
-                stats = stats_all[so:so + G * STAT_SLOTS * 2 * O]
+                stats = stats_all[so:so + G * STAT_SLOTS * 2 * O] if training else None
                 p = p_all[po:po + G * 7 * O]
                 so += G * STAT_SLOTS * 2 * O
                 po += G * 7 * O
                 tgemm_nn(B, O, P, C, W, 0, O if L.transposed else C, not L.transposed, prev, C * P, P, y, O * P, P,
                          bmode=0 if i == 0 else 1, bp=prevp, bias=biases[i], stats=stats, per_batch_stats=groups)
-                rm, rv, mom = _bn_buffers(L.bn)
-                call("pa_bn_finalize", O, G, float(B * P // G), ptr(stats), ptr(gammas[i]), ptr(betas[i]), float(L.bn.eps), mom, ptr(rm), ptr(rv), ptr(p))
-                if rm is not None and L.bn.num_batches_tracked is not None:
-                    counters.append(L.bn.num_batches_tracked)
+                if training:
+                    rm, rv, mom = _bn_buffers(L.bn)
+                    call("pa_bn_finalize", O, G, float(B * P // G), ptr(stats), ptr(gammas[i]), ptr(betas[i]), float(L.bn.eps), mom, ptr(rm), ptr(rv), ptr(p))
+                    if rm is not None and L.bn.num_batches_tracked is not None:
+                        counters.append(L.bn.num_batches_tracked)
+                else:       # eval(): the running statistics, nothing updated (torch.nn.BatchNorm in eval mode)
+                    assert L.bn.running_mean is not None, "eval-mode BatchNorm without running statistics uses batch statistics: call with training=True"
+                    call("pa_bn_eval_params", O, G, ptr(gammas[i]), ptr(betas[i]), ptr(L.bn.running_mean), ptr(L.bn.running_var), float(L.bn.eps), ptr(p))
                 ys.append(y)
                 ps.append(p)
                 prev, prevp, cin = y, p, O
@@ -134,7 +129,7 @@ class _ChainTrain(Function):
             call("pa_bn_apply", B, cin, P, int(pool), int(layers[-1].relu), ptr(prev), ptr(prevp), ptr(out), ptr(arg), int(groups))
         ctx.save_for_backward(x, *Ws)
         ctx.layers, ctx.pool, ctx.groups, ctx.ys, ctx.ps, ctx.arg = layers, pool, groups, ys, ps, arg
-        ctx.bias_like = biases
+        ctx.bias_like, ctx.training = biases, training
         return out
 
     @staticmethod
@@ -173,7 +168,8 @@ class _ChainTrain(Function):
                 call("pa_bn_bwd_reduce", B, O, P, ptr(g), ptr(y), ptr(p), int(L.relu), ptr(sums), int(groups))
                 dgamma = grads[go + 2 * sum(outs[:i]):go + 2 * sum(outs[:i]) + O]
                 dbeta = grads[go + 2 * sum(outs[:i]) + O:go + 2 * sum(outs[:i]) + 2 * O]
-                call("pa_bn_bwd_finalize", O, G, float(B * P // G), ptr(sums), ptr(p), ptr(dgamma), ptr(dbeta))
+                # eval(): no batch-statistics terms in the input gradient -- count = +inf leaves rows 4, 5 of p at zero
+                call("pa_bn_bwd_finalize", O, G, float(B * P // G) if ctx.training else float("inf"), ptr(sums), ptr(p), ptr(dgamma), ptr(dbeta))
                 mode = 2 if L.relu else 3
                 dW = grads[wo[i]:wo[i + 1]].view(O, C)
                 tgemm_kk(B, O, C, P, g, O * P, P, prev, C * P, P, dW, 0, C, amode=mode, aaux=y, ap=p,
@@ -187,22 +183,30 @@ class _ChainTrain(Function):
                 else:
                     g = None
                 dWr = (dW.t().contiguous() if L.transposed else dW).view_as(W)
-                # a bias in front of a BatchNorm has an identically zero gradient (the mean subtraction removes it)
-                per_layer[i] = [dWr] + ([torch.zeros_like(ctx.bias_like[i])] if ctx.bias_like[i] is not None else []) + [dgamma, dbeta]
+                # a bias in front of a training-mode BatchNorm has an identically zero gradient (the mean subtraction removes it); in
+                # eval() it is d/dz of scale*z + shift summed over the points: scale * dbeta
+                if ctx.bias_like[i] is None:
+                    dbias = []
+                elif ctx.training:
+                    dbias = [torch.zeros_like(ctx.bias_like[i])]
+                else:
+                    dbias = [dbeta * p[:O]]
+                per_layer[i] = [dWr] + dbias + [dgamma, dbeta]
         ctx.ys = ctx.ps = ctx.arg = None
         flat = [t for pl in per_layer for t in pl]
-        return (g, None, None, None, *flat)
+        return (g, None, None, None, None, *flat)
 
 
-def chain_train(x, layers, pool=0, groups=False):
-    """x: (B, C0, P) contiguous fp32 on the MI355X; layers: [BNLayer]; returns (B, C_L, P // pool or P)."""
+def chain_train(x, layers, pool=0, groups=False, training=True):
+    """x: (B, C0, P) contiguous fp32 on the MI355X; layers: [BNLayer]; returns (B, C_L, P // pool or P).  training=False: BatchNorm with
+    the running statistics (eval() mode), same kernels, forward and backward."""
     tensors = []
     for L in layers:
         tensors.append(L.weight)
         if L.bias is not None:
             tensors.append(L.bias)
         tensors += [L.bn.weight, L.bn.bias]
-    return _ChainTrain.apply(x.contiguous(), layers, int(pool), bool(groups), *tensors)
+    return _ChainTrain.apply(x.contiguous(), layers, int(pool), bool(groups), bool(training), *tensors)
 
 
 class _LinearCM(Function):
@@ -283,6 +287,106 @@ def bmm_nt(a, b):
     return _BmmNT.apply(a.contiguous(), b.contiguous())
 
 
+class _BmmNN(Function):
+    """C_b (M x N) = A_b (M x K) . B_b (K x N), row-major operands (grouped self-attention: x_v (C x n) . attn (n x n))."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        check_device(a, b)
+        batch, M, K = a.shape
+        N = b.shape[2]
+        assert b.shape[0] == batch and b.shape[1] == K
+        c = torch.empty((batch, M, N), dtype=torch.float32, device=a.device)
+        with _guard(a):
+            tgemm_nn(batch, M, N, K, a, M * K, K, True, b, K * N, N, c, M * N, N)
+        ctx.save_for_backward(a, b)
+        return c
+
+    @staticmethod
+    def backward(ctx, gc):
+        a, b = ctx.saved_tensors
+        batch, M, K = a.shape
+        N = b.shape[2]
+        g = gc.contiguous()
+        da = db = None
+        with _guard(a):
+            if ctx.needs_input_grad[0]:      # dA (M x K) = dC (M x N) . B (K x N)^T: both contiguous along n
+                da = torch.zeros_like(a)
+                tgemm_kk(batch, M, K, N, g, M * N, N, b, K * N, N, da, M * K, K, per_batch=1)
+            if ctx.needs_input_grad[1]:      # dB (K x N) = A^T (K x M) . dC (M x N)
+                db = torch.empty_like(b)
+                tgemm_nn(batch, K, N, M, a, M * K, K, False, g, M * N, N, db, K * N, N)
+        return da, db
+
+
+def bmm_nn(a, b):
+    return _BmmNN.apply(a.contiguous(), b.contiguous())
+
+
+class _GramTN(Function):
+    """E_b (N x N) = Y_b^T Y_b for Y (B, C, N): the attention energy (the sum over the groups of the per-group Grams, pptnet.py:273-275)."""
+
+    @staticmethod
+    def forward(ctx, y):
+        check_device(y)
+        batch, C, N = y.shape
+        e = torch.empty((batch, N, N), dtype=torch.float32, device=y.device)
+        with _guard(y):
+            tgemm_nn(batch, N, N, C, y, C * N, N, False, y, C * N, N, e, N * N, N)      # A(m, k) = Y[k][m]
+        ctx.save_for_backward(y)
+        return e
+
+    @staticmethod
+    def backward(ctx, ge):
+        (y,) = ctx.saved_tensors
+        batch, C, N = y.shape
+        g = ge.contiguous()
+        dy = torch.zeros_like(y)
+        with _guard(y):
+            # dY = Y (dE + dE^T):  Y . dE^T (contiguous along the contraction: split-K kernel, accumulates into the zero-filled dy) ...
+            tgemm_kk(batch, C, N, N, y, C * N, N, g, N * N, N, dy, C * N, N, per_batch=1)
+            # ... + Y . dE (beta = 1)
+            tgemm_nn(batch, C, N, N, y, C * N, N, True, g, N * N, N, dy, C * N, N, beta=1)
+        return dy
+
+
+class _SoftmaxRenorm(Function):
+    """A = softmax_rows(E) / (1e-9 + column sums) (pptnet.py:276-277) on the kernels of csrc/attention_train.hip; E is consumed (in place)."""
+
+    @staticmethod
+    def forward(ctx, e):
+        check_device(e)
+        from . import _lib
+        batch, N, _ = e.shape
+        a = e                                                    # in place: the energy is dead after the soft-max
+        colsum = torch.empty((batch, N), dtype=torch.float32, device=e.device)
+        scratch = torch.empty(_lib.lib().pa_attn_train_scratch_floats(batch, N), dtype=torch.float32, device=e.device)
+        with _guard(e):
+            call("pa_attn_softmax_renorm", batch, N, ptr(a), ptr(colsum), ptr(scratch))
+        ctx.mark_dirty(e)
+        ctx.save_for_backward(a, colsum)
+        return a
+
+    @staticmethod
+    def backward(ctx, ga):
+        from . import _lib
+        a, colsum = ctx.saved_tensors
+        batch, N, _ = a.shape
+        g = ga.contiguous().clone()                              # becomes dE in place
+        scratch = torch.empty(_lib.lib().pa_attn_train_scratch_floats(batch, N) + batch * N, dtype=torch.float32, device=a.device)
+        with _guard(a):
+            call("pa_attn_softmax_renorm_backward", batch, N, ptr(a), ptr(colsum), ptr(g), ptr(scratch))
+        return g
+
+
+def sa_attention_train(y, x_v):
+    """Grouped self-attention core under autograd (pptnet.py:273-278): y = k_conv(x) (B, C, N) (q and k are tied), x_v = v_conv(x) (B, C, N)
+    -> x_r = x_v @ A, A = column-renormalised row soft-max of Y^T Y.  GEMMs on train_gemm.hip, the rest on attention_train.hip; one
+    (B, N, N) matrix is kept for the backward pass."""
+    attn = _SoftmaxRenorm.apply(_GramTN.apply(y.contiguous()))
+    return bmm_nn(x_v, attn)
+
+
 class _LinearRows(Function):
     """Y (R x O) = X (R x K) . W (O x K)^T + bias -- nn.Linear on a few rows and a long contraction (APFA's 21504 -> 256 FC): split-K."""
 
@@ -354,6 +458,13 @@ class _MatmulRows(Function):
 
 def matmul_rows(x, W):
     return _MatmulRows.apply(x.contiguous(), W)
+
+
+def bn_rows(bn, x, training):
+    """BatchNorm1d over the rows of a small (R, F) matrix in the module's mode (elementwise: no dense kernel either way)."""
+    if training:
+        return bn_rows_train(bn, x)
+    return (x - bn.running_mean) * torch.rsqrt(bn.running_var + bn.eps) * bn.weight + bn.bias
 
 
 def bn_rows_train(bn, x):

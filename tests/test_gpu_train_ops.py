@@ -3,10 +3,13 @@
 1. the two GEMM kernels with every operand transform, against fp64 torch statements of include/patchaugnet_hip.h's definitions
    (ragged shapes: nothing a multiple of a tile);
 2. the autograd layer: SharedMLP (pt_util.py:16-41 in train() mode) with and without the fused max-pool, PointNetDecoder
-   (pointnet_autoencoder.py:85-111), NetVLADBase / APFA / context gating (loupe.py) -- outputs, input / parameter gradients and BatchNorm
-   running statistics against torch autograd of the SAME modules (train_ops.torch_dense_path()), tolerance 1e-4 relative to the
-   tensor's scale (fp32 MFMA vs rocBLAS summation order).
+   (pointnet_autoencoder.py:85-111), NetVLADBase / APFA / context gating (loupe.py), the grouped self-attention of PPT-Net
+   (pptnet.py:246-282) -- outputs, input / parameter gradients and BatchNorm running statistics, in train() AND in eval() mode, against
+   torch autograd of a float64 CPU copy of the SAME module (the modules' CPU form is plain torch; on the device they have no torch-dense
+   branch to switch to), tolerance 2e-4 relative to the tensor's scale.
 """
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -132,25 +135,36 @@ def _grads(mod, x, fn, gout_seed=3):
     for p in mod.parameters():
         p.grad = None
     xx = x.clone().requires_grad_(True)
-    out = fn(xx)
-    go = torch.randn(out.shape, generator=torch.Generator().manual_seed(gout_seed)).to(out.device)
+    out = fn(mod, xx)
+    go = torch.randn(out.shape, generator=torch.Generator().manual_seed(gout_seed)).to(out.device, out.dtype)
     out.backward(go)
     gr = {k: p.grad.clone() for k, p in mod.named_parameters() if p.grad is not None}
     return out.detach(), xx.grad.clone(), gr, {k: v.clone() for k, v in mod.state_dict().items() if "running" in k or "tracked" in k}
 
 
-def _compare(mod, x, fn, tol=2e-4, skip=()):
-    from patchaugnet_amd import train_ops
-    state = {k: v.clone() for k, v in mod.state_dict().items()}
+def _randomize_running_stats(mod, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in mod.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.3)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+
+
+def _compare(mod, x, fn, tol=2e-4, skip=(), train=True):
+    """fn(module, input) on the device module (HIP kernels) against the same call on a float64 CPU copy (plain torch autograd)."""
+    mod.train(train)
+    ref = copy.deepcopy(mod).cpu().double()
     o1, dx1, g1, s1 = _grads(mod, x, fn)
-    mod.load_state_dict(state)
     near = []
     hooks = [m.register_forward_hook(lambda _m, _i, o: near.append(o.detach().abs().min().item()))
-             for m in mod.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
-    with train_ops.torch_dense_path():
-        o0, dx0, g0, s0 = _grads(mod, x, fn)
+             for m in ref.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+    o0, dx0, g0, s0 = _grads(ref, x.detach().cpu().double(), fn)
     for h in hooks:
         h.remove()
+    o1, dx1 = o1.cpu(), dx1.cpu()
+    g1 = {k: v.cpu() for k, v in g1.items()}
+    s1 = {k: v.cpu() for k, v in s1.items()}
     flip = min(near, default=1.0) < 2e-6          # a ReLU input at rounding distance from zero: its mask may differ between the two runs
     def close(a, b):
         return _rel_robust(a, b, tol) if flip else (_rel(a, b) <= tol, _rel(a, b))
@@ -180,9 +194,14 @@ def test_shared_mlp_train_matches_torch_autograd(spec, shape):
             l.bn.bn.weight.uniform_(0.5, 1.5)
             l.bn.bn.bias.normal_(0, 0.2)
     x = torch.randn(shape, device="cuda")
-    _compare(m, x, lambda t: m(t))
+    _compare(m, x, lambda mod, t: mod(t))
     if shape[3] > 1:
-        _compare(m, x, lambda t: m.forward_maxpool(t))
+        _compare(m, x, lambda mod, t: mod.forward_maxpool(t))
+    # eval() with autograd: the running statistics, same kernels (no torch.matmul / MIOpen route on the device)
+    _randomize_running_stats(m)
+    _compare(m, x, lambda mod, t: mod(t), train=False)
+    if shape[3] > 1:
+        _compare(m, x, lambda mod, t: mod.forward_maxpool(t), train=False)
 
 
 def test_decoder_train_matches_torch_autograd():
@@ -190,16 +209,19 @@ def test_decoder_train_matches_torch_autograd():
     torch.manual_seed(2)
     d = PointNetDecoder(embedding_size=256, num_points=20).cuda().train()
     x = torch.nn.functional.normalize(torch.randn(1024, 256, device="cuda"))
-    _compare(d, x, lambda t: d(t), skip=("fc1.bias", "fc2.bias"))
+    _compare(d, x, lambda mod, t: mod(t), skip=("fc1.bias", "fc2.bias"))
     # R related clouds in one set of launches (every cloud its own BatchNorm batch) == the decoder called once per cloud, in order
-    from patchaugnet_amd import train_ops
     x3 = torch.nn.functional.normalize(torch.randn(3, 256, 1024, device="cuda"), dim=1)
 
-    def run(t):
-        if train_ops.hip_dense_enabled():
-            return d.forward_cm(t)
-        return torch.stack([d(t[r].t()) for r in range(t.shape[0])])
+    def run(mod, t):
+        if t.is_cuda:
+            return mod.forward_cm(t)
+        return torch.stack([mod(t[r].t()) for r in range(t.shape[0])])
     _compare(d, x3, run, skip=("fc1.bias", "fc2.bias"))
+    # eval(): running statistics; the biases in front of the BatchNorms now HAVE a gradient (no mean subtraction)
+    _randomize_running_stats(d)
+    _compare(d, x, lambda mod, t: mod(t), train=False)
+    _compare(d, x3, run, train=False)
 
 
 @pytest.mark.parametrize("C,N,K", [(256, 4096, 64), (256, 1024, 16), (256, 128, 4), (64, 100, 5)])
@@ -208,7 +230,9 @@ def test_netvlad_train_matches_torch_autograd(C, N, K):
     torch.manual_seed(3)
     v = NetVLADBase(C, N, K, C).cuda().train()
     x = torch.randn(3, C, N, 1, device="cuda")
-    _compare(v, x, lambda t: v(t))
+    _compare(v, x, lambda mod, t: mod(t))
+    _randomize_running_stats(v)
+    _compare(v, x, lambda mod, t: mod(t), train=False)
 
 
 def test_heads_train_match_torch_autograd():
@@ -216,41 +240,114 @@ def test_heads_train_match_torch_autograd():
     torch.manual_seed(4)
     afa = AdaptiveFeatureAggregator(256, 84, 256).cuda().train()
     x = torch.randn(18, 256, 84, device="cuda")
-    _compare(afa, x, lambda t: afa(t), skip=("fc.bias",))
+    _compare(afa, x, lambda mod, t: mod(t), skip=("fc.bias",))
+    _randomize_running_stats(afa)
+    _compare(afa, x, lambda mod, t: mod(t), train=False)
     gate = GatingContext(256).cuda().train()
     x = torch.randn(18, 256, device="cuda")
-    _compare(gate, x, lambda t: gate(t))
+    _compare(gate, x, lambda mod, t: mod(t))
+    _randomize_running_stats(gate)
+    _compare(gate, x, lambda mod, t: mod(t), train=False)
     for agg in (0, 2, 3):
         sp = SpatialPyramidNetVLAD([256, 256, 256], [64, 256, 512], [4, 8, 16], [256, 256, 256], gating=True, aggregation_type=agg).cuda().train()
         feats = [torch.randn(4, 256, n, 1, device="cuda") for n in (64, 256, 512)]
 
-        def run(t, sp=sp, feats=feats):
-            return sp([t] + feats[1:])
+        def run(mod, t, feats=feats):
+            return mod([t] + [f.to(t.device, t.dtype) for f in feats[1:]])
         _compare(sp, feats[0], run, tol=5e-4, skip=("fc.bias",))
+        _randomize_running_stats(sp)
+        _compare(sp, feats[0], run, tol=5e-4, train=False)
 
 
-def test_training_dense_path_has_no_library_gemm():
-    """One train() forward + backward of the PatchAugNet module path: the profiler sees no rocBLAS / MIOpen / hipBLASLt kernel."""
-    from patchaugnet_amd import configs, patch_aug_net
-    from patchaugnet_amd.weights import seeded_state_dict
-    m = patch_aug_net.Network(param=configs.patch_aug_net_config(), use_a2a_recon=True, use_l2_norm=True)
-    m.load_state_dict(seeded_state_dict(m.state_dict()))
-    m = m.cuda().train()
-    x = (torch.rand(3, 1, 4096, 3, generator=torch.Generator().manual_seed(0)) * 2 - 1).cuda().requires_grad_(True)
-    nn_dict = {(0, 1): np.zeros((4, 1), np.int64)}
+@pytest.mark.parametrize("C,N,B", [(64, 1024, 2), (128, 256, 3), (256, 64, 2), (512, 16, 4), (64, 100, 1)])
+def test_grouped_self_attention_autograd_matches_torch(C, N, B):
+    """SA_Layer (pptnet.py:246-282) in train() and in eval()-with-autograd on the MI355X: csrc/train_gemm.hip GEMMs + csrc/attention_train.hip
+    soft-max / column re-normalisation, forward and backward, against the module's CPU form in float64."""
+    from patchaugnet_amd.backbone import SALayer
+    torch.manual_seed(6)
+    sa = SALayer(C, 8).cuda().train()
+    with torch.no_grad():
+        sa.k_conv.weight.mul_(0.5)                  # keep the soft-max away from one-hot rows (O(C) logits otherwise)
+        sa.after_norm.weight.uniform_(0.5, 1.5)
+        sa.after_norm.bias.normal_(0, 0.2)
+    x = torch.randn(B, C, N, device="cuda") * 0.5
+    # train(): trans_conv.bias sits in front of a BatchNorm, and v_conv.bias enters x_r as bias x (column sums of A = 1), a per-channel constant
+    # along the points that the same BatchNorm removes: both gradients are mathematically zero
+    _compare(sa, x, lambda mod, t: mod(t), tol=5e-4, skip=("trans_conv.bias", "v_conv.bias"))
+    _randomize_running_stats(sa)
+    _compare(sa, x, lambda mod, t: mod(t), tol=5e-4, train=False)
+    # eval() under no_grad is the fused two-pass kernel of csrc/attention.hip: same function
+    sa.eval()
+    with torch.no_grad():
+        fused = sa(x)
+    ref = copy.deepcopy(sa).cpu().double()(x.cpu().double())
+    assert _rel(fused.cpu(), ref) <= 5e-4
 
-    def step():
-        (desc, recon), _, _ = m(x, nn_dict)
-        loss = desc.square().sum() + sum(r.square().mean() for r in recon["reconstructed_patches"])
-        loss.backward()
+
+def test_attention_softmax_renorm_kernels_against_fp64():
+    """pa_attn_softmax_renorm / _backward (csrc/attention_train.hip) on ragged sizes, against torch fp64 autograd of pptnet.py:276-277."""
+    from patchaugnet_amd import train_ops
+    g = torch.Generator().manual_seed(9)
+    for b, n in [(2, 1024), (3, 100), (1, 257), (4, 16)]:
+        e = (torch.randn(b, n, n, generator=g) * 2).cuda()
+        e64 = e.cpu().double().requires_grad_(True)
+        p = torch.softmax(e64, dim=-1)
+        a64 = p / (1e-9 + p.sum(dim=1, keepdim=True))
+        go = torch.randn(b, n, n, generator=g)
+        a64.backward(go.double())
+        ed = e.clone().requires_grad_(True)
+        a = train_ops._SoftmaxRenorm.apply(ed * 1.0)
+        a.backward(go.cuda())
+        assert _rel(a.detach().cpu(), a64.detach()) <= 1e-5
+        assert _rel(ed.grad.cpu(), e64.grad) <= 2e-5
+
+
+def _library_kernels(step):
     step()
     with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
         step()
         torch.cuda.synchronize()
     names = [e.key for e in prof.key_averages()]
-    assert any("tgemm_nn_kernel" in n for n in names) and any("tgemm_kk_kernel" in n for n in names), names[:40]
-    lib = [n for n in names if any(s in n for s in ("Cijk", "rocblas", "miopen", "MIOpen", "hipblas", "gemm_kernel", "batch_norm", "BatchNorm"))]
+    lib = [n for n in names if any(s in n for s in ("Cijk", "rocblas", "miopen", "MIOpen", "hipblas", "gemm_kernel", "batch_norm", "BatchNorm",
+                                                      "naive_conv", "igemm", "Conv", "conv"))]
+    return names, lib
+
+
+@pytest.mark.parametrize("family,mode", [("patch_aug_net", "train"), ("patch_aug_net", "eval_grad"), ("patch_aug_net", "eval_nograd_module"),
+                                         ("pptnet", "train"), ("pptnet", "eval_grad")])
+def test_module_path_has_no_library_gemm(family, mode):
+    """Forward (+ backward) of the module path on the MI355X -- train(), eval() with autograd, eval() under no_grad with the fused engine switched
+    off; PatchAugNet and PPT-Net (grouped self-attention) -- the profiler sees no rocBLAS / MIOpen / hipBLASLt kernel, only the HIP GEMMs."""
+    from patchaugnet_amd import configs, patch_aug_net, pptnet
+    from patchaugnet_amd.weights import seeded_state_dict
+    if family == "patch_aug_net":
+        m = patch_aug_net.Network(param=configs.patch_aug_net_config(), use_a2a_recon=True, use_l2_norm=True)
+    else:
+        m = pptnet.Network(param=configs.pptnet_config(), use_normalize=True)
+    m.load_state_dict(seeded_state_dict(m.state_dict()))
+    m = m.cuda()
+    m.train(mode == "train")
+    grad = mode != "eval_nograd_module"
+    x = (torch.rand(3, 1, 4096, 3, generator=torch.Generator().manual_seed(0)) * 2 - 1).cuda().requires_grad_(grad)
+    nn_dict = {(0, 1): np.zeros((4, 1), np.int64)} if family == "patch_aug_net" else None
+
+    def step():
+        with torch.set_grad_enabled(grad):
+            if nn_dict is not None:
+                (desc, recon), _, _ = m(x, nn_dict)
+                loss = desc.square().sum() + sum(r.square().mean() for r in recon["reconstructed_patches"])
+            else:
+                out = m(x, use_engine=False) if family == "patch_aug_net" else m(x)
+                desc = out[0] if isinstance(out, tuple) else out
+                loss = desc.square().sum()
+            if grad:
+                loss.backward()
+    names, lib = _library_kernels(step)
+    assert any("tgemm_nn_kernel" in n for n in names), names[:40]
+    assert not grad or any("tgemm_kk_kernel" in n for n in names), names[:40]
     assert not lib, lib
+    if family == "pptnet":
+        assert any("at_row_softmax_kernel" in n for n in names) and (not grad or any("at_bwd_row_kernel" in n for n in names)), names[:60]
 
 
 def test_graphed_training_step_equals_the_eager_step():

@@ -21,7 +21,7 @@ with torch.no_grad():
     for which in (sys.argv[1:] or ["fp0"]):
         kind, lvl = which[:2], int(which[2])
         chain = (eng.sa if kind == "sa" else eng.fp)[lvl]
-        name = "sa" if kind == "sa" else ("fp_premul" if (eng.premul and lvl == 0) else "fp")
+        name = "sa" if kind == "sa" else ("fp_premul" if (eng.premul and eng._fold_static[lvl]) else "fp")
         orig = getattr(chain, name)
         buf = torch.zeros(512 * 8, dtype=torch.int64, device="cuda")
 
@@ -36,8 +36,11 @@ with torch.no_grad():
         setattr(chain, name, orig)
         t = buf.view(512, 8).cpu().numpy()
         t = t[t[:, 0] > 0]
-        nl = chain.n - (1 if name == "fp_premul" else 0)
+        nl = chain.n - (1 if (name == "fp_premul" and lvl == 0) else 0)
         d = t[:, 1:nl + 2] - t[:, 0:nl + 1]
         parts = ["prologue"] + [f"layer{i}" for i in range(nl)]
         print(which, f"({len(t)} tiles stamped)", "  ".join(f"{p} {np.median(d[:, i]):.0f}" for i, p in enumerate(parts)),
               " total", np.median(t[:, nl + 1] - t[:, 0]))
+        st, en = t[:, 0] - t[:, 0].min(), t[:, nl + 1] - t[:, 0].min()
+        q = lambda a: " ".join(f"{np.percentile(a, p):.0f}" for p in (0, 10, 25, 50, 75, 90, 100))
+        print("   start offsets (cycles, percentiles 0/10/25/50/75/90/100):", q(st), "| end offsets:", q(en))
