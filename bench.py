@@ -44,6 +44,9 @@ def parse():
     p.add_argument("--no-graphs", action="store_true", help="issue every step's launches from Python instead of replaying one captured hipGraph per stream")
     p.add_argument("--no-prefetch", action="store_true", help="--config train: no geometry prefetch of the next batch (one graph per step)")
     p.add_argument("--streams", type=int, default=4, help="HIP streams the consecutive steps are issued on (1 = strictly sequential)")
+    p.add_argument("--reps", type=int, default=5, help="repetitions of the timed K-step region; the headline value is their median (min / max reported)")
+    p.add_argument("--no-extras", action="store_true", help="skip the other BASELINE configurations that ride in the same JSON line at N = 1 "
+                                                              "(configs[0] CPU timing, training step, PPT-Net f32 / f16, EMD)")
     p.add_argument("--config", choices=["extract", "train"], default="extract",
                    help="extract = BASELINE.json configs[1] (the headline metric); train = configs[3], one quadruplet training step per step")
     return p.parse_args()
@@ -75,6 +78,8 @@ def grouping_roofline():
         ms = ev_time_ms(fn, iters=10 if b > 100 else 50)
         alg = 4.0 * (c * n + m * k + c * m * k) * b
         out[tag] = {"shape": [b, c, n, m, k], "ms": ms, "algorithmic_bytes": alg, "GBps": alg / ms / 1e6}
+        if alg < 200e6:      # the working set fits the 256 MiB Infinity Cache (and is re-read every iteration): a cache figure, NOT an HBM one
+            out[tag]["note"] = "cache-resident working set (< 256 MiB Infinity Cache): not an HBM bandwidth figure"
         del pts, idx, o
     return out
 
@@ -246,7 +251,7 @@ def pcie_inclusive(model, a, pipe):
                     "the K steps after one warm-up repetition (never the headline value)"}
 
 
-def train_bench(a):
+def train_bench(a, emit=True):
     """BASELINE.json configs[3]: one training step per bench step -- the reference's native tuple of 18 clouds (1 query + 2 positives +
     14 negatives + 1 other negative, configs/patch_aug_net.yaml:60-62; BASELINE.json says batch=16, the reference's loader only makes
     18), nn_dict with 2 (query, positive) pairs => 3 related clouds through the decoder and the patch Chamfer loss, quadruplet loss,
@@ -288,6 +293,8 @@ def train_bench(a):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     losses = {k: float(v) for k, v in losses.items()}
+    if graphed:
+        trainer.close()
     clouds = 18
     # dominant dense kernel: the 256 -> 256 layers of the finest feature-propagation level, forward form (BatchNorm + ReLU of the previous
     # layer in the operand loader, statistics in the epilogue), in isolation on the launch stream
@@ -311,11 +318,106 @@ def train_bench(a):
                    "launch": ("one hipGraph replay per step (forward + losses + backward + Adam)" + ("" if a.no_prefetch else
                               "; sampling / neighbour search / 3-NN of the next batch replayed on a side stream under it")) if graphed else "python launches"},
         "losses_last_step": losses,
+        "losses_note": "place_recognition = 0.0 means the hinge of the quadruplet loss is inactive on this synthetic tuple (random-init descriptors of "
+                       "unrelated clouds); the captured graph replays every kernel of the step regardless, so the timing is representative",
         "roofline": {"kernel": "tgemm_nn_kernel<64,16,true,1> (pa_tgemm_nn: 256 -> 256 layer of the finest FP level, forward: BatchNorm + ReLU of the "
                                "previous layer in the loader, statistics in the epilogue)", "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None, "algorithmic_flops_per_launch": flops, "ms_per_launch": ms},
     }
-    print(json.dumps(line))
+    if emit:
+        print(json.dumps(line))
+    return line
+
+
+def extras(a):
+    """The other BASELINE.json configurations, measured in the SAME run and carried in the same JSON line (N = 1 only): configs[0] PointNetVLAD
+    B = 1 on the host cores, configs[3] the training step (+ its dense kernel's roofline), configs[4] PPT-Net with
+    the fp32 and the fp16 MLP path, and the EMD call of the reference's reconstruction loss (16, 4096, 3) at 64 / 1024 iterations.  Each
+    entry is independent: a failure is reported in place, never raised."""
+    import copy
+    import gc
+    out = {}
+
+    def guarded(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as ex:
+            out[name] = {"error": repr(ex)}
+        gc.collect()
+        torch.cuda.empty_cache()
+
+    def pointnetvlad_cpu():
+        from patchaugnet_amd import pointnet_vlad
+        from patchaugnet_amd.hostcpu import limit_host_threads
+        from patchaugnet_amd.weights import seeded_state_dict, synthetic_submaps
+        cores = limit_host_threads()
+        m = pointnet_vlad.PointNetVlad(global_feat=True, feature_transform=True, max_pool=False, output_dim=256, num_points=4096)
+        m.load_state_dict(seeded_state_dict(m.state_dict()))
+        m.eval()
+        x = synthetic_submaps(1, 4096, seed=3)
+        with torch.no_grad():
+            for _ in range(3):
+                m(x)
+            ts = []
+            for _ in range(20):
+                t0 = time.perf_counter()
+                m(x)
+                ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return {"ms_per_submap": ts[len(ts) // 2] * 1e3, "min_ms": ts[0] * 1e3, "max_ms": ts[-1] * 1e3, "batch": 1, "cores": cores, "device": "cpu",
+                "workload": "PointNetVLAD, 4096 pts, batch = 1, CPU-only PyTorch path (BASELINE.json configs[0]); protocol of scene_dataset.py:672-686, 20 timed forwards, median"}
+
+    def train():
+        b = copy.copy(a)
+        b.steps, b.warmup, b.no_graphs, b.no_prefetch = 20, 3, False, False
+        line = train_bench(b, emit=False)
+        return {k: line[k] for k in ("ms_per_step", "value", "unit", "clouds_per_s", "roofline", "losses_last_step", "losses_note")} | {"workload": line["config"]["workload"]}
+
+    def extract_rate(model_name, mlp_dtype):
+        from patchaugnet_amd import configs, patch_aug_net, pptnet
+        from patchaugnet_amd.extract import GraphedExtractor
+        from patchaugnet_amd.weights import seeded_state_dict, synthetic_submaps
+        model = pptnet.Network(param=configs.pptnet_config(), use_normalize=True) if model_name == "pptnet" else \
+            patch_aug_net.Network(param=configs.patch_aug_net_config(), use_a2a_recon=True, use_l2_norm=True)
+        model.load_state_dict(seeded_state_dict(model.state_dict()))
+        model = model.cuda().eval()
+        model.mlp_dtype = mlp_dtype
+        x = synthetic_submaps(a.batch, a.points, seed=1234).cuda()
+        steps = 40
+        with torch.no_grad():
+            gx = GraphedExtractor(model, tuple(x.shape), a.streams)
+            rates = []
+            for rep in range(4):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                gx.begin()
+                for _ in range(steps):
+                    gx.run(x)
+                gx.end()
+                torch.cuda.synchronize()
+                if rep:
+                    rates.append(steps * a.batch / (time.perf_counter() - t0))
+        rates.sort()
+        return {"value": rates[1], "unit": "submaps/s", "min": rates[0], "max": rates[-1], "batch": a.batch, "steps": steps,
+                "dtype": "f32" if mlp_dtype == "f32" else "f16 MFMA operands in the shared-MLP chains, fp32 accumulate / everything else fp32"}
+
+    def emd():
+        from patchaugnet_amd import emd_module
+        g = torch.Generator().manual_seed(11)
+        p1, p2 = (torch.rand(16, 4096, 3, generator=g).cuda() for _ in range(2))
+        f = emd_module.emdModule()
+        res = {"shape": [16, 4096, 3], "eps": 0.02, "workload": "emdModule forward as patch_emd_loss calls it (pointnetvlad_loss.py:205-221)"}
+        for iters in (64, 1024):
+            ms = ev_time_ms(lambda: f(p1, p2, 0.02, iters), iters=3, warm=1)
+            res[f"ms_{iters}_iters"] = ms
+        return res
+
+    guarded("configs0_pointnetvlad_cpu", pointnetvlad_cpu)
+    guarded("configs3_training_step", train)
+    guarded("configs4_pptnet_f32", lambda: extract_rate("pptnet", "f32"))
+    guarded("configs4_pptnet_f16", lambda: extract_rate("pptnet", "f16"))
+    guarded("emd_16x4096", emd)
+    return out
 
 
 def self_launch(a):
@@ -430,32 +532,48 @@ def main():
             gathered = torch.empty(world * a.steps * a.batch, 256, device="cuda")
             dist.all_gather_into_tensor(gathered, descs.view(-1, 256))
             dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        pipe.begin()
-        for i in range(a.steps):
-            pipe.submit(one, i)
-        pipe.end()
-        ag_ms = None
-        if dist is not None:   # the one exchange step: every rank's descriptors to every rank (its own duration is reported beside the total)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            dist.all_gather_into_tensor(gathered, descs.view(-1, 256))
-            e1.record()
-        torch.cuda.synchronize()
-        if dist is not None:
-            ag_ms = e0.elapsed_time(e1)
-        if dist is not None:
-            dist.barrier()
-        dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+        # The timed region -- EXACTLY K steps between barrier + synchronize on both sides, ending (N > 1) with the one RCCL all-gather -- is
+        # repeated a.reps times; the headline is the MEDIAN repetition (max over ranks per repetition), min / max ride along.  One 19 ms
+        # region is at the mercy of a single scheduling hiccup; the spread says how much.
+        rep_dt, rep_local, rep_ag = [], [], []
+        for rep in range(max(a.reps, 1)):
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pipe.begin()
+            for i in range(a.steps):
+                pipe.submit(one, i)
+            pipe.end()
+            ag_ms = None
+            if dist is not None:   # the one exchange step: every rank's descriptors to every rank (its own duration is reported beside the total)
+                torch.cuda.synchronize()
+                t_local = time.perf_counter() - t0          # this rank's own extraction, before the exchange
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                dist.all_gather_into_tensor(gathered, descs.view(-1, 256))
+                e1.record()
+            torch.cuda.synchronize()
+            if dist is not None:
+                ag_ms = e0.elapsed_time(e1)
+                dist.barrier()
+            dt = time.perf_counter() - t0
+            if dist is None:
+                t_local = dt
+            rep_dt.append(dt)
+            rep_local.append(t_local)
+            rep_ag.append(ag_ms)
+    rccl_ranks = per_rank = None
+    if dist is not None:     # slowest rank per repetition, distinct rank ids seen through the all-gather, every rank's own rate
+        from patchaugnet_amd.distributed import run_stats
+        rep_dt, rccl_ranks, per_rank = run_stats(rep_dt, rep_local, a.steps * a.batch, "cuda")
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
+    order = sorted(range(len(rep_dt)), key=lambda i: rep_dt[i])
+    mid = order[len(order) // 2]
+    dt, ag_ms = rep_dt[mid], rep_ag[mid]
 
     submaps = world * a.steps * a.batch
     line = {
@@ -471,8 +589,12 @@ def main():
                    "weights": "key-seeded random init", "parallelism": f"dp{world}", "streams": a.streams,
                    "launch": "hipGraph replay per stream" if use_graphs else "python launches"},
     }
+    line["repetitions"] = {"count": len(rep_dt), "statistic": "median", "submaps_per_s": [round(submaps / t, 1) for t in rep_dt],
+                           "min": submaps / max(rep_dt), "max": submaps / min(rep_dt)}
     if ag_ms is not None:
-        line["all_gather_ms"] = ag_ms      # rank 0's view of the one RCCL collective that ends the timed region
+        line["all_gather_ms"] = ag_ms      # rank 0's view of the one RCCL collective that ends the timed region (median repetition)
+        line["rccl_ranks"] = rccl_ranks    # distinct rank ids received through the all-gather: must equal n_gpus
+        line["per_rank_submaps_per_s"] = [round(v, 1) for v in per_rank]
     if world == 1 and (a.model != "patch_aug_net" or a.mlp_dtype != "f32"):   # non-headline configurations: stage times only
         try:
             line["kernels"] = {"stages_ms": stage_pass(model, x)}
@@ -505,6 +627,9 @@ def main():
             line["pcie_inclusive"] = {"error": repr(ex)}
         if not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, {k: v.cpu() for k, v in sd.items()}, a.cpu_batch, a.points)
+        if not a.no_extras:
+            del pipe
+            line["other_configs"] = extras(a)
     print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

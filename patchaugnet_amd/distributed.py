@@ -82,3 +82,21 @@ def extract_dataset(model, load_batch, n_total, batch_size=32, n_streams=4, dim=
     if gx is not None:
         gx.end()
     return all_gather_descriptors(local, n_total)
+
+
+def run_stats(rep_dt, rep_local, units_per_rep, device):
+    """Cross-rank bookkeeping of a benchmark run (bench.py, N > 1): rep_dt / rep_local = this rank's wall time of every repetition of the
+    timed region, with / without the final exchange.  Returns (per-repetition MAX over ranks -- a repetition takes as long as its slowest
+    rank --, the number of DISTINCT rank ids received through an all-gather -- must equal the world size: proof that the collective saw
+    every rank --, every rank's own median rate in units/s -- imbalance shows here).  Without a process group: (rep_dt, 1, [own rate])."""
+    d, rank, world = dist_info()
+    med = lambda r: sorted(r)[len(r) // 2]
+    if d is None:
+        return list(rep_dt), 1, [units_per_rep / med(rep_local)]
+    t = torch.tensor(rep_dt, device=device, dtype=torch.float64)
+    d.all_reduce(t, op=d.ReduceOp.MAX)
+    ids = torch.empty(world, dtype=torch.int64, device=device)
+    d.all_gather_into_tensor(ids, torch.tensor([rank], dtype=torch.int64, device=device))
+    loc = torch.empty(world, len(rep_local), dtype=torch.float64, device=device)
+    d.all_gather_into_tensor(loc, torch.tensor([list(rep_local)], dtype=torch.float64, device=device))
+    return t.tolist(), int(torch.unique(ids).numel()), [units_per_rep / med(r) for r in loc.tolist()]

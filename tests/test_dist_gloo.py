@@ -63,6 +63,9 @@ def _worker(rank, world, port, n_total, ret):
             ret["descs"] = descs.numpy()
             ret["recall"] = {k: (v[0], v[2], v[6]) for k, v in res.items()}
         ret[f"bounds{rank}"] = distributed.shard_bounds(n_total, rank, world)
+        # bench.py's cross-rank bookkeeping: rank 1 is the slow one in repetition 0, rank 0 in repetition 2
+        rep_dt = [1.0 + rank, 2.0, 3.0 - rank]
+        ret[f"stats{rank}"] = distributed.run_stats(rep_dt, [t * 0.5 for t in rep_dt], 640, torch.device("cpu"))
     finally:
         dist.destroy_process_group()
 
@@ -87,12 +90,20 @@ def test_two_rank_extraction_and_recall_match_single_process(n_total):
     lo0, hi0 = ret["bounds0"]
     lo1, hi1 = ret["bounds1"]
     assert (lo0, hi1) == (0, n_total) and hi0 == lo1                      # contiguous, complete, disjoint
+    for r in range(2):      # slowest rank per repetition, both rank ids seen through the all-gather, each rank's own median rate -- on every rank
+        dt_max, seen, per_rank = ret[f"stats{r}"]
+        assert dt_max == [2.0, 2.0, 3.0] and seen == 2 and per_rank == [640 / 1.0, 640 / 1.0]
     sizes = [40, 33, 28]
     _, desc, tuples = synthetic_route(5, sizes)
     ref = retrieval.get_recall_precision(torch.from_numpy(desc), sizes, tuples, top_k=10, knn=_numpy_knn)
     assert sorted(ret["recall"]) == sorted(ref)
     for k, v in ref.items():
         assert np.array_equal(ret["recall"][k][0], v[0]) and ret["recall"][k][1:] == (v[2], v[6])
+
+
+def test_run_stats_without_a_process_group():
+    from patchaugnet_amd.distributed import run_stats
+    assert run_stats([3.0, 1.0, 2.0], [1.5, 0.5, 1.0], 100, torch.device("cpu")) == ([3.0, 1.0, 2.0], 1, [100.0])
 
 
 def test_shard_bounds_cover_everything():
