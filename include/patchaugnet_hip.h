@@ -330,6 +330,12 @@ int pa_bn_bwd_finalize(int nch, int groups, double count, const double *sums, fl
 int pa_bn_apply(int B, int C, long P, int pool, int relu, const float *y, const float *p, float *out, signed char *arg, int per_batch_stats, pa_stream_t stream);
 int pa_maxpool_bwd(int rows, long Pout, int pool, const float *gp, const signed char *arg, float *g, pa_stream_t stream);
 
+/* ---- Descriptor losses of the training step in one launch (csrc/losses.hip; losses/pointnetvlad_loss.py:18-45, :53-105): value and gradient.
+ * desc (b, 1 + p + nn + 1, d): per tuple the query, p positives, nn negatives, the other negative.  quad != 0: quadruplet_loss, else
+ * triplet_loss (m2 and the last row unused).  loss: 1 float; grad: same shape as desc, the gradient of the value.  b, p, nn <= 64. */
+int pa_quadruplet_loss(int b, int p, int nn, int d, const float *desc, float m1, float m2, int use_min, int lazy, int ignore_zero, int quad,
+                       float *loss, float *grad, pa_stream_t stream);
+
 /* ---- Grouped self-attention in training / autograd mode (csrc/attention_train.hip; pptnet.py:261-282): the part between the two GEMMs.
  * pa_attn_softmax_renorm: energy (b, n, n) -> A = softmax_rows(energy) / (1e-9 + column sums) IN PLACE; colsum (b, n) receives the
  * denominators.  pa_attn_softmax_renorm_backward: grad (b, n, n) holds dL/dA on entry and dL/dEnergy on return.

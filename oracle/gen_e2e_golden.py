@@ -28,18 +28,27 @@ ROUTE = 700.0
 FRESH = 0.30                      # share of a visit's returns that are re-drawn (transients, occlusion) instead of the place's fixed returns
 
 
-def trip_stops(seed=SEED, sizes=SIZES):
+# The Oxford-sized set of SURVEY.md section 8(d) config 3: 23 trips (datasets/dataset_info.py:127-132) of ~130 submaps each (the real count
+# is not in the repository), one shared road, positives closer than 25 m.
+OX_SIZES = [132, 127, 135, 129, 131, 126, 134, 130, 128, 133, 125, 136, 130, 129, 131, 127, 134, 132, 128, 130, 126, 135, 131]      # 2 999 submaps
+OX_SEED = 1234
+OX_PLACES = 160
+OX_ROUTE = 3200.0                 # 20 m between places
+OX_POS_RADIUS = 25.0
+
+
+def trip_stops(seed=SEED, sizes=SIZES, places=PLACES):
     """Which place every submap of every trip was taken at (sorted along the road within a trip)."""
     rng = np.random.default_rng(seed + 1)
-    return [np.sort(rng.choice(PLACES, n, replace=False)) for n in sizes]
+    return [np.sort(rng.choice(places, n, replace=False)) for n in sizes]
 
 
-def trip_positions(seed=SEED, sizes=SIZES):
+def trip_positions(seed=SEED, sizes=SIZES, places=PLACES, route=ROUTE):
     """(sum sizes, 2) northing / easting: the place's position on the road plus ~1.5 m of per-visit offset."""
     rng = np.random.default_rng(seed + 2)
-    stops = np.linspace(15.0, ROUTE - 15.0, PLACES)
+    stops = np.linspace(15.0, route - 15.0, places)
     return np.concatenate([np.stack([stops[st] + rng.normal(scale=1.5, size=len(st)), rng.normal(scale=0.6, size=len(st))], 1)
-                           for st in trip_stops(seed, sizes)])
+                           for st in trip_stops(seed, sizes, places)])
 
 
 def submap(place_seed, visit_seed, num_points=NUM_POINTS, fresh=FRESH):
@@ -69,9 +78,9 @@ def submap(place_seed, visit_seed, num_points=NUM_POINTS, fresh=FRESH):
     return np.clip(pts, -1.0, 1.0).astype(np.float32)
 
 
-def clouds(lo, hi, seed=SEED, sizes=SIZES, num_points=NUM_POINTS):
+def clouds(lo, hi, seed=SEED, sizes=SIZES, num_points=NUM_POINTS, places=PLACES):
     """Records lo..hi-1 as a (hi - lo, 1, N, 3) fp32 CPU tensor (the loader callback of distributed.extract_dataset)."""
-    st = np.concatenate(trip_stops(seed, sizes))
+    st = np.concatenate(trip_stops(seed, sizes, places))
     return torch.from_numpy(np.stack([submap(seed * 100003 + int(st[i]), seed * 7919 + 1000 + i, num_points) for i in range(lo, hi)])).unsqueeze(1)
 
 
@@ -122,5 +131,42 @@ def main():
     print("wrote e2e_recall.npz", os.path.getsize(os.path.join(GOLD, "e2e_recall.npz")) // 1024, "KiB")
 
 
+DESC_PROBES = 4
+
+
+def desc_probe(desc):
+    """(n, DESC_PROBES) float64 projections of the descriptors on fixed seeded unit directions: a few numbers per submap that pin the
+    descriptors of a 3 000-submap set without committing 3 MB of them."""
+    g = np.random.default_rng(4242)
+    d = g.normal(size=(desc.shape[1], DESC_PROBES))
+    d /= np.linalg.norm(d, axis=0, keepdims=True)
+    return np.asarray(desc, dtype=np.float64) @ d
+
+
+def main_oxford():
+    """tests/golden/e2e_recall_oxford.npz: the same chain on the Oxford-sized set (23 trips, 2 999 submaps, 506 trip pairs)."""
+    import time
+    from oracle.gen_recall_golden import run_reference
+    n = sum(OX_SIZES)
+    t0 = time.time()
+    desc = np.concatenate([oracle_descriptors(clouds(lo, min(lo + 64, n), OX_SEED, OX_SIZES, NUM_POINTS, OX_PLACES)) for lo in range(0, n, 64)])
+    print("oracle descriptors of", n, "submaps in %.0f s" % (time.time() - t0))
+    xy = trip_positions(OX_SEED, OX_SIZES, OX_PLACES, OX_ROUTE)
+    tuples = positives(xy, OX_SIZES, OX_POS_RADIUS)
+    res = run_reference(OX_SIZES, xy, desc, tuples, top_k=25, skip_trip_itself=True)
+    keys = sorted(res)
+    head = clouds(0, 1, OX_SEED, OX_SIZES, NUM_POINTS, OX_PLACES)
+    blob = {"sizes": np.array(OX_SIZES), "seed": np.array(OX_SEED), "top_k": np.array(25), "cloud_head": head[0, 0, :8].numpy(),
+            "desc_probe": desc_probe(desc),
+            "pairs": np.array(keys), "recall": np.stack([res[k][0] for k in keys]).astype(np.float32),
+            "precision": np.stack([res[k][1] for k in keys]).astype(np.float32),
+            "opr": np.array([res[k][2] for k in keys]), "num_eval": np.array([res[k][6] for k in keys])}
+    rec = np.mean([res[k][0] for k in keys], 0)
+    print("pairs", len(keys), "queries evaluated", blob["num_eval"].sum(), "recall@1 %.2f  @5 %.2f  top1%% %.2f" % (rec[0], rec[4], np.mean(blob["opr"])))
+    np.savez_compressed(os.path.join(GOLD, "e2e_recall_oxford.npz"), **blob)
+    print("wrote e2e_recall_oxford.npz", os.path.getsize(os.path.join(GOLD, "e2e_recall_oxford.npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    main()
+    import sys
+    main_oxford() if "oxford" in sys.argv[1:] else main()

@@ -69,6 +69,7 @@ _SIGS = {
     "pa_bn_finalize": "iidpppffppp",
     "pa_bn_bwd_reduce": "iilpppipi",
     "pa_bn_eval_params": "iippppfp",
+    "pa_quadruplet_loss": "iiiipffiiiipp",
     "pa_attn_softmax_renorm": "iippp",
     "pa_attn_softmax_renorm_backward": "iipppp",
     "pa_bn_bwd_finalize": "iidpppp",

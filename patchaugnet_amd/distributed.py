@@ -51,6 +51,7 @@ def extract_dataset(model, load_batch, n_total, batch_size=32, n_streams=4, dim=
     lo, hi = shard_bounds(n_total, rank, world)
     if device is None:
         device = next(model.parameters()).device if hasattr(model, "parameters") else torch.device("cpu")
+    device = torch.device(device)
     local = torch.empty((hi - lo, dim), dtype=torch.float32, device=device)
     pipe = None
     if n_streams > 0:
@@ -72,7 +73,10 @@ def extract_dataset(model, load_batch, n_total, batch_size=32, n_streams=4, dim=
             continue
 
         def step(b0=b0, b1=b1, dst=dst):
-            dst.copy_(model(load_batch(b0, b1), return_feat=False))
+            x = load_batch(b0, b1)
+            if device.type == "cuda" and not x.is_cuda:      # a (pinned) host batch outside the graph path -- the ragged tail: copied on the step's stream
+                x = x.to(device, non_blocking=True)
+            dst.copy_(model(x, return_feat=False))
         if pipe is not None:
             pipe.submit(step)
         else:

@@ -7,9 +7,39 @@ emd_module.py).  Shapes: q_vec (B,1,D), pos_vecs (B,P,D), neg_vecs (B,Nn,D), oth
 """
 import torch
 import torch.nn.functional as F
+from torch.autograd import Function
 
 from .chamfer_dist import ChamferDistanceL1
 from .emd_module import emdModule
+
+
+class _TupleLossFused(Function):
+    """triplet_loss / quadruplet_loss on the MI355X as ONE launch (csrc/losses.hip: value + gradient with respect to every descriptor); the
+    torch statements below are ~25 small kernels forward and ~40 backward on a few KB."""
+
+    @staticmethod
+    def forward(ctx, desc, P, Nn, m1, m2, use_min, lazy, ignore_zero, quad):
+        from ._lib import call, ptr
+        B, T, D = desc.shape
+        loss = torch.empty(1, dtype=torch.float32, device=desc.device)
+        grad = torch.empty_like(desc)
+        with torch.cuda.device(desc.device):
+            call("pa_quadruplet_loss", B, P, Nn, D, ptr(desc), float(m1), float(m2), int(use_min), int(lazy), int(ignore_zero), int(quad), ptr(loss), ptr(grad))
+        ctx.save_for_backward(grad)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None, None, None, None, None, None
+
+
+def _fused_tuple_loss(q_vec, pos_vecs, neg_vecs, other_neg, m1, m2, use_min, lazy, ignore_zero_loss, quad):
+    """None when the fused kernel does not apply (CPU tensors, more than 64 tuples / positives / negatives)."""
+    if not (q_vec.is_cuda and q_vec.dtype == torch.float32 and q_vec.shape[0] <= 64 and pos_vecs.shape[1] <= 64 and neg_vecs.shape[1] <= 64):
+        return None
+    parts = [q_vec, pos_vecs, neg_vecs, other_neg if other_neg is not None else q_vec]
+    return _TupleLossFused.apply(torch.cat(parts, 1).contiguous(), pos_vecs.shape[1], neg_vecs.shape[1], m1, m2, use_min, lazy, ignore_zero_loss, quad)
 
 
 def best_pos_distance(query, pos_vecs):
@@ -30,6 +60,9 @@ def _reduce(loss, lazy, ignore_zero_loss, lazy_false_mean):
 
 def triplet_loss(q_vec, pos_vecs, neg_vecs, margin, use_min=False, lazy=False, ignore_zero_loss=False):
     """pointnetvlad_loss.py:18-45"""
+    fused = _fused_tuple_loss(q_vec, pos_vecs, neg_vecs, None, margin, 0.0, use_min, lazy, ignore_zero_loss, quad=False)
+    if fused is not None:
+        return fused
     min_pos, max_pos = best_pos_distance(q_vec, pos_vecs)
     positive = (min_pos if use_min else max_pos).view(-1, 1)
     loss = (margin + positive - ((neg_vecs - q_vec) ** 2).sum(2)).clamp(min=0.0)
@@ -47,6 +80,10 @@ def _hinge(x, soft_margin):
 
 def quadruplet_loss(q_vec, pos_vecs, neg_vecs, other_neg, m1, m2, use_min=False, lazy=False, ignore_zero_loss=False, soft_margin=False):
     """pointnetvlad_loss.py:53-105 -- the training loss of configs/patch_aug_net.yaml (LOSS_FUNCTION quadruplet)."""
+    if not soft_margin:
+        fused = _fused_tuple_loss(q_vec, pos_vecs, neg_vecs, other_neg, m1, m2, use_min, lazy, ignore_zero_loss, quad=True)
+        if fused is not None:
+            return fused
     min_pos, max_pos = best_pos_distance(q_vec, pos_vecs)
     positive = (min_pos if use_min else max_pos).view(-1, 1)
     first = _hinge(m1 + positive - ((neg_vecs - q_vec) ** 2).sum(2), soft_margin)

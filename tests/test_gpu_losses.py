@@ -125,3 +125,44 @@ def test_batched_hard_negative_mining_equals_per_query_path():
     got = retrieval.get_hard_negatives_batch(qs, ref, negs, num_hard_neg=10, chunk=64)
     exp = [retrieval.get_hard_negatives(q, ref, n, 10) for q, n in zip(qs, negs)]
     assert got == exp and got[3] == []
+
+
+@pytest.mark.parametrize("i", [0, 1, 2, 3])
+def test_fused_tuple_losses_match_the_reference_run(i):
+    """triplet_loss / quadruplet_loss as one HIP launch (csrc/losses.hip: value + gradient) against the values and gradients the REFERENCE's
+    losses/pointnetvlad_loss.py produced for the same inputs in float64 (tests/golden/losses.npz, oracle/gen_loss_golden.py)."""
+    from oracle.gen_loss_golden import LOSS_CASES, loss_inputs
+    from patchaugnet_amd import losses
+    from tests._util import golden
+    g = golden("losses")
+    name, kw = LOSS_CASES[i]
+    assert not kw.get("soft_margin", False)
+    q, pos, neg, other = [t.float().cuda().requires_grad_(True) for t in loss_inputs()]
+    fn = getattr(losses, name)
+    v = fn(q, pos, neg, 0.5, **kw) if name == "triplet_loss" else fn(q, pos, neg, other, 0.5, 0.2, **kw)
+    assert v.grad_fn is not None and "TupleLossFused" in type(v.grad_fn).__name__, "the fused kernel did not take the call"
+    (v * 3.0).backward()                                        # a non-trivial upstream gradient
+    assert abs(float(v) - float(g[f"loss{i}_value"])) <= 2e-6 * max(1.0, abs(float(g[f"loss{i}_value"])))
+    for t, x in zip("qpno", (q, pos, neg, other)):
+        got = x.grad.cpu().numpy() / 3.0 if x.grad is not None else np.zeros_like(g[f"loss{i}_grad_{t}"])
+        assert np.allclose(got, g[f"loss{i}_grad_{t}"], rtol=2e-5, atol=2e-7), (name, t, np.abs(got - g[f"loss{i}_grad_{t}"]).max())
+
+
+def test_fused_quadruplet_loss_on_the_training_tuple_shape():
+    """One query, 2 positives, 14 negatives (configs/patch_aug_net.yaml:60-62), inactive and active hinges, against the torch statement in fp64."""
+    from patchaugnet_amd import losses
+    g = torch.Generator().manual_seed(2)
+    for scale in (0.05, 1.0):                       # 0.05: every negative far beyond the margin -> zero loss, zero gradient
+        q = torch.nn.functional.normalize(torch.randn(1, 1, 256, generator=g), dim=-1)
+        pos = torch.nn.functional.normalize(q + scale * 0.5 * torch.randn(1, 2, 256, generator=g), dim=-1)
+        neg = torch.nn.functional.normalize(q + (1.2 if scale == 1.0 else 30.0) * torch.randn(1, 14, 256, generator=g), dim=-1)
+        oth = torch.nn.functional.normalize(torch.randn(1, 1, 256, generator=g), dim=-1)
+        ref_in = [t.double().requires_grad_(True) for t in (q, pos, neg, oth)]
+        ref = losses.quadruplet_loss(*ref_in, 0.5, 0.2, use_min=False, lazy=True)
+        ref.backward()
+        dev_in = [t.cuda().requires_grad_(True) for t in (q, pos, neg, oth)]
+        got = losses.quadruplet_loss(*dev_in, 0.5, 0.2, use_min=False, lazy=True)
+        got.backward()
+        assert abs(float(got) - float(ref)) <= 2e-6
+        for a, b in zip(dev_in, ref_in):
+            assert torch.allclose(a.grad.cpu().double(), b.grad if b.grad is not None else torch.zeros_like(b), rtol=2e-5, atol=2e-7)
