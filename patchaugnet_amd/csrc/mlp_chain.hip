@@ -325,7 +325,58 @@ __device__ __forceinline__ void copy_rows_tap(const float *act, int stride, int 
     }
 }
 
-template <int RT, int NC, int MODE, bool POOLED, int WPT>
+// last layer of an UNPOOLED set-abstraction tiling with the max over the neighbourhood folded in (operand-swapped layout: a lane holds channels
+// col .. col + 3 of point 16 rt + l % 16).  The 16 points of a row tile belong to at most two groups of `ns` consecutive rows (ns >= 16): the max
+// over each group's points is a masked DPP-row reduction, and lanes 0 / 1 of every DPP row fold the two results into out[group][channel] with
+// an integer atomicMax on the float bit pattern -- exact and order-independent because the values are >= 0 after the ReLU (out is zero-filled by
+// the launcher).  Replaces writing the (groups * ns, C) tensor + the rowgroup_max pass over it.
+template <int RT, int NC>
+__device__ __forceinline__ void store_group_max_atomic(float *__restrict__ out, int ldo, long row0, long total_rows, int ns, const PaLayer &L, int c0, int lane,
+                                                         floatx4 (&acc)[RT][NC])
+{
+    const int i = lane & 15;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const long r0 = row0 + rt * 16;
+        if (r0 >= total_rows) continue;                                  // wave-uniform
+        const long gA = r0 / ns;
+        const int split = (int)min((gA + 1) * (long)ns - r0, 16L);       // rows of this tile in group gA; the rest (if any) belong to gA + 1
+        const bool valid = r0 + i < total_rows, inA = i < split;
+#pragma unroll
+        for (int ct = 0; ct < NC; ++ct) {
+            const int col = (c0 + ct) * 16 + (lane >> 4) * 4;
+            const float4 bias = *reinterpret_cast<const float4 *>(L.bias + col);
+            const float v[4] = {fmaxf(acc[rt][ct][0] + bias.x, 0.f), fmaxf(acc[rt][ct][1] + bias.y, 0.f), fmaxf(acc[rt][ct][2] + bias.z, 0.f),
+                                fmaxf(acc[rt][ct][3] + bias.w, 0.f)};
+            float ma[4], mb[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float a = (valid && inA) ? v[c] : 0.f, b = (valid && !inA) ? v[c] : 0.f;
+                a = fmaxf(a, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x120 + 8, 0xf, 0xf, true)));   // row_ror:8
+                a = fmaxf(a, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x120 + 4, 0xf, 0xf, true)));
+                a = fmaxf(a, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x120 + 2, 0xf, 0xf, true)));
+                a = fmaxf(a, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x120 + 1, 0xf, 0xf, true)));
+                b = fmaxf(b, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b), 0x120 + 8, 0xf, 0xf, true)));
+                b = fmaxf(b, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b), 0x120 + 4, 0xf, 0xf, true)));
+                b = fmaxf(b, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b), 0x120 + 2, 0xf, 0xf, true)));
+                b = fmaxf(b, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b), 0x120 + 1, 0xf, 0xf, true)));
+                ma[c] = a;
+                mb[c] = b;
+            }
+            if (i == 0) {
+                int *o = reinterpret_cast<int *>(out + gA * ldo + col);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) atomicMax(o + c, __float_as_int(ma[c]));
+            } else if (i == 1 && split < 16 && r0 + split < total_rows) {
+                int *o = reinterpret_cast<int *>(out + (gA + 1) * ldo + col);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) atomicMax(o + c, __float_as_int(mb[c]));
+            }
+        }
+    }
+}
+
+template <int RT, int NC, int MODE, bool POOLED, int WPT, bool APOOL = false>
 __device__ __forceinline__ void run_layer_chunks(float *act, const PaChain &a, const PaLayer &L, float *out, const float *residual, int l, long tile,
                                                  int lane, int c_begin, int c_end)
 {
@@ -349,10 +400,12 @@ __device__ __forceinline__ void run_layer_chunks(float *act, const PaChain &a, c
                 else store_hidden_nat<RT, NC, true>(act, a.lds_stride, L, c0, lane, acc);
             } else if (SWAP) store_hidden<RT, NC, false>(act, a.lds_stride, L, c0, lane, acc);
             else store_hidden_nat<RT, NC, false>(act, a.lds_stride, L, c0, lane, acc);
+        } else if (APOOL) {
+            store_group_max_atomic<RT, NC>(out, a.ldo, tile * (RT * 16), a.rows * a.ns, a.ns, L, c0, lane, acc);
         } else if (POOLED) {
             if (a.vec_out) store_pooled<RT, NC, true>(out, a.ldo, tile * 4, a.rows, L, c0, lane, acc);
             else store_pooled<RT, NC, false>(out, a.ldo, tile * 4, a.rows, L, c0, lane, acc);
-        } else if (a.ep_stride > 0) {   // host guarantees a single chunk per wave here
+        } else if (!APOOL && a.ep_stride > 0) {   // host guarantees a single chunk per wave here
             tile_sync<WPT>();           // every A read of the last layer has landed: the activation tile is dead
             if (SWAP) stage_rows_lds<RT, NC>(act, a.ep_stride, L, c0, lane, acc, a.relu_last);
             else stage_rows_lds_nat<RT, NC>(act, a.ep_stride, L, c0, lane, acc, a.relu_last);
@@ -369,7 +422,7 @@ __device__ __forceinline__ void run_layer_chunks(float *act, const PaChain &a, c
             const long total_rows = (MODE == MODE_SA) ? a.rows * a.ns : a.rows;
             copy_rows_tap<RT * 16>(act, a.lds_stride, L.n, a.tap, a.ldtap, tile * (RT * 16), total_rows, WPT == 1 ? lane : (int)threadIdx.x, WPT * 64);
         }
-    } else if (!POOLED && a.ep_stride > 0) {
+    } else if (!POOLED && !APOOL && a.ep_stride > 0) {
         tile_sync<WPT>();
         const long total_rows = (MODE == MODE_SA) ? a.rows * a.ns : a.rows;
         copy_rows_out<RT * 16>(act, a.ep_stride, L.n, out, a.ldo, tile * (RT * 16), total_rows, residual, a.ldr,
@@ -381,7 +434,7 @@ __device__ __forceinline__ void run_layer_chunks(float *act, const PaChain &a, c
 // (<= 256 registers) there; the plain row kernels trade occupancy for their 128 accumulator registers.
 // The 16-row wave-private variant (RT == 1, unpooled) runs EIGHT waves per workgroup, two per SIMD: while one wave of a SIMD gathers its
 // next tile or stores its last one, the other keeps the matrix pipe busy.
-template <int RT, int NCMAX, int MODE, bool POOLED, int WPT>
+template <int RT, int NCMAX, int MODE, bool POOLED, int WPT, bool APOOL = false>
 __global__ __launch_bounds__((RT == 1 && WPT == 1 && !POOLED) ? 512 : 256, (POOLED && RT <= 5) || (RT == 1 && WPT == 1) ? 2 : 1) void chain_kernel(PaChain a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -422,11 +475,11 @@ __global__ __launch_bounds__((RT == 1 && WPT == 1 && !POOLED) ? 512 : 256, (POOL
         const int nct = L.n >> 4;
         const int per = WPT == 1 ? nct : nct / WPT;          // column tiles this wave computes (host: nct % WPT == 0)
         const int cb = WPT == 1 ? 0 : wave * per, ce = cb + per;
-        if (NCMAX >= 16 && per % 16 == 0) run_layer_chunks<RT, (NCMAX >= 16 ? 16 : NCMAX), MODE, POOLED, WPT>(act, a, L, out, residual, l, tile, lane, cb, ce);
-        else if (NCMAX >= 8 && per % 8 == 0) run_layer_chunks<RT, (NCMAX >= 8 ? 8 : NCMAX), MODE, POOLED, WPT>(act, a, L, out, residual, l, tile, lane, cb, ce);
-        else if (NCMAX >= 4 && per % 4 == 0) run_layer_chunks<RT, (NCMAX >= 4 ? 4 : NCMAX), MODE, POOLED, WPT>(act, a, L, out, residual, l, tile, lane, cb, ce);
-        else if (per % 2 == 0) run_layer_chunks<RT, 2, MODE, POOLED, WPT>(act, a, L, out, residual, l, tile, lane, cb, ce);
-        else run_layer_chunks<RT, 1, MODE, POOLED, WPT>(act, a, L, out, residual, l, tile, lane, cb, ce);
+        if (NCMAX >= 16 && per % 16 == 0) run_layer_chunks<RT, (NCMAX >= 16 ? 16 : NCMAX), MODE, POOLED, WPT, APOOL>(act, a, L, out, residual, l, tile, lane, cb, ce);
+        else if (NCMAX >= 8 && per % 8 == 0) run_layer_chunks<RT, (NCMAX >= 8 ? 8 : NCMAX), MODE, POOLED, WPT, APOOL>(act, a, L, out, residual, l, tile, lane, cb, ce);
+        else if (NCMAX >= 4 && per % 4 == 0) run_layer_chunks<RT, (NCMAX >= 4 ? 4 : NCMAX), MODE, POOLED, WPT, APOOL>(act, a, L, out, residual, l, tile, lane, cb, ce);
+        else if (per % 2 == 0) run_layer_chunks<RT, 2, MODE, POOLED, WPT, APOOL>(act, a, L, out, residual, l, tile, lane, cb, ce);
+        else run_layer_chunks<RT, 1, MODE, POOLED, WPT, APOOL>(act, a, L, out, residual, l, tile, lane, cb, ce);
         PA_STAMP(2 + l);
     }
 #undef PA_STAMP
@@ -445,11 +498,11 @@ __global__ __launch_bounds__(256) void rowgroup_max_kernel(long groups, int ns, 
     out[t] = m;
 }
 
-template <int RT, int NCMAX, int MODE, bool POOLED, int WPT>
+template <int RT, int NCMAX, int MODE, bool POOLED, int WPT, bool APOOL = false>
 int launch_chain(const PaChain &a, int waves_per_wg, long ntiles, hipStream_t st)
 {
     const size_t lds = (size_t)(WPT == 1 ? waves_per_wg : 1) * a.wave_floats * 4;
-    auto kern = chain_kernel<RT, NCMAX, MODE, POOLED, WPT>;
+    auto kern = chain_kernel<RT, NCMAX, MODE, POOLED, WPT, APOOL>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (WPT == 1) hipLaunchKernelGGL(kern, dim3(pa_div_up(ntiles, waves_per_wg)), dim3(64 * waves_per_wg), lds, st, a);
     else hipLaunchKernelGGL(kern, dim3(ntiles, a.col_slices > 1 ? a.col_slices : 1), dim3(256), lds, st, a);
@@ -529,8 +582,12 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
     a.xcd_remap = no_xcd ? 0 : 1;
     hipStream_t st = (hipStream_t)stream;
 
-    const bool is_pooled = pooled != 0;
-    PA_REQUIRE(!is_pooled || mode == MODE_SA, "pa_mlp_chain: pooled output needs mode 1 (set-abstraction gather)");
+    // pooled = 2: the UNPOOLED shared-tile tiling with the max over the neighbourhood folded into the last layer's epilogue by atomics
+    // (store_group_max_atomic): out is (groups, n_last) and is zero-filled here
+    const bool atomic_pool = pooled == 2;
+    const bool is_pooled = pooled != 0 && !atomic_pool;
+    PA_REQUIRE(pooled == 0 || mode == MODE_SA, "pa_mlp_chain: pooled output needs mode 1 (set-abstraction gather)");
+    PA_REQUIRE(!atomic_pool || (ns >= 16 && !wp16 && residual == nullptr && tap == nullptr), "pa_mlp_chain: the atomic pooled epilogue needs nsample >= 16, fp32, no residual / tap");
     const long total_rows = (mode == MODE_SA) ? rows * ns : rows;
     // Tiling choice.  Wave-private tiles (WPT = 1) need >= ~2 tiles per SIMD to hide latency; with fewer row tiles the
     // four waves of a workgroup share one tile and split the columns (WPT = 4), optionally with 16-row tiles.
@@ -580,7 +637,7 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
     // LDS-staged epilogue: needs the last layer to be one chunk per wave (its A tile is dead when the results are staged), the staged
     // tile to fit the activation region (or 40 KB), and 16-byte aligned rows in the output / residual.
     int ep_floats = 0;
-    if (!is_pooled) {
+    if (!is_pooled && !atomic_pool) {
         const int nl = nout[nlayers - 1];
         const int per = split ? nl / 64 : nl / 16;
         const int nc = (ncmax >= 16 && per % 16 == 0) ? 16 : (ncmax >= 8 && per % 8 == 0) ? 8 : (ncmax >= 4 && per % 4 == 0) ? 4 : (per % 2 == 0) ? 2 : 1;
@@ -640,6 +697,11 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
                 pa_set_error("pa_mlp_chain: pooled tiling is built for nsample in (13..16], (17..20], (29..32]; got %d", ns);
                 return PA_EUNSUPPORTED;
         }
+    } else if (atomic_pool) {
+        PA_REQUIRE(split && (RTv == 1 || RTv == 2), "pa_mlp_chain: the atomic pooled epilogue is built for the shared-tile tilings (rows=%ld)", total_rows);
+        if (hipMemsetAsync(out, 0, (size_t)rows * ldo * sizeof(float), st) != hipSuccess) { pa_set_error("pa_mlp_chain: hipMemsetAsync failed"); return PA_EINVAL; }
+        if (RTv == 2) launch_chain<2, 8, MODE_SA, false, 4, true>(a, 4, ntiles, st);
+        else launch_chain<1, 8, MODE_SA, false, 4, true>(a, 4, ntiles, st);
     } else if (mode == MODE_PLAIN) launch_rows<MODE_PLAIN>(a, RTv, split, wpw, ntiles, st);
     else if (mode == MODE_SA) launch_rows<MODE_SA>(a, RTv, split, wpw, ntiles, st);
     else if (mode == MODE_FP) launch_rows<MODE_FP>(a, RTv, split, wpw, ntiles, st);

@@ -110,16 +110,26 @@ class _Chain:
         # fp32: below ~256 tiles the 16-row unpooled tiling (5x the workgroups) wins; both give the same bits (tests/test_gpu_chain.py)
         return self.hidden_ok_pooled or (self._split_widths_ok and 17 <= ns <= 20 and (0 if self.f16 else 256) <= tiles < 2048)
 
+    def atomic_pool_ok(self, groups, ns):
+        """The unpooled shared-tile tiling with the atomic-max epilogue applies (mlp_chain.hip: every layer splits four ways, few enough row
+        tiles for the shared-tile variant, fp32)."""
+        return (not self.f16 and ns >= 16 and all(l[4] % 64 == 0 for l in self.layers) and all(l[4] in (64, 128, 256, 512) for l in self.layers[:-1])
+                and (groups * ns + 31) // 32 < 2048)
+
     def _common(self):
         return (self.n, ctypes.cast(self.wt, ctypes.c_void_p), ctypes.cast(self.wpk, ctypes.c_void_p), ctypes.cast(self.bias, ctypes.c_void_p),
                 ctypes.cast(self.kpad, ctypes.c_void_p), ctypes.cast(self.nout, ctypes.c_void_p))
 
     def sa(self, xyz, feat, center_idx, nbr_idx, c_feat, pooled):
+        """pooled: False / 0 = every (group, neighbour) row; True / 1 = max over the neighbourhood in the pooled tiling; 2 = the same result
+        from the UNPOOLED shared-tile tiling with an atomic-max epilogue (few groups: the 16-row tiling fills the chip, the pooled one
+        does not; fp32 chains, nsample >= 16)."""
         B, n_src, _ = xyz.shape
         m, ns = nbr_idx.shape[1], nbr_idx.shape[2]
         groups = B * m
+        pooled = int(pooled)
         out = torch.empty((groups if pooled else groups * ns, self.n_last), dtype=torch.float32, device=xyz.device)
-        call(self._fn, 1, 1 if pooled else 0, *self._common(), groups, self.k0, None, 0,
+        call(self._fn, 1, pooled, *self._common(), groups, self.k0, None, 0,
              ptr(xyz), ptr(feat), ptr(center_idx), ptr(nbr_idx), n_src, m, ns, c_feat,
              None, None, None, None, 0, 0, 0, 0, ptr(out), self.n_last)
         return out
@@ -479,6 +489,7 @@ class PatchAugNetEngine:
             self.vlads = [_Vlad(v, self.device) for v in vl]
             self.pyramid = _Pyramid(self.vlads) if os.environ.get("PA_ENGINE_VLAD_PER_SCALE") is None else None     # A/B knob
             self._vlad_early = os.environ.get("PA_ENGINE_VLAD_LATE") is None                                       # A/B knob
+            self._atomic_pool = os.environ.get("PA_ENGINE_NO_ATOMIC_POOL") is None                                  # A/B knob
             self.afa = self.head = self.gate = None
             if self.ppt:
                 self.head_kind = "fc"
@@ -629,7 +640,10 @@ class PatchAugNetEngine:
             feat = l_feat[i]
             if chain.pooled_ok(B * m, ns):
                 y = chain.sa(src, feat, cidx[i], nbr[i], c_feat, pooled=True)                      # (B*m, C')
-            else:  # wide hidden layers: rows in group order, then the max over each group's ns rows
+            elif chain.atomic_pool_ok(B * m, ns) and self._atomic_pool:
+                # wide hidden layers, few groups: 16-row tiles in group order with the max folded into the last layer's epilogue (atomics)
+                y = chain.sa(src, feat, cidx[i], nbr[i], c_feat, pooled=2)
+            else:  # rows in group order, then the max over each group's ns rows
                 full = chain.sa(src, feat, cidx[i], nbr[i], c_feat, pooled=False)                  # (B*m*ns, C')
                 y = torch.empty((B * m, chain.n_last), dtype=torch.float32, device=self.device)
                 call("pa_rowgroup_max", B * m, ns, chain.n_last, ptr(full), ptr(y))

@@ -160,3 +160,25 @@ def test_register_resident_fpx_variant_matches_shipped_kernel(monkeypatch):
     tail = chain(True).fp_premul(known[:1], idx3[:1, :1000].contiguous(), w3[:1, :1000].contiguous(), skip[:1, :1000].contiguous(), 1, 1000, m, c2, c1)
     tail_ref = chain(False).fp_premul(known[:1], idx3[:1, :1000].contiguous(), w3[:1, :1000].contiguous(), skip[:1, :1000].contiguous(), 1, 1000, m, c2, c1)
     close(tail, tail_ref.double(), rtol=2e-5)                              # rows not a multiple of the 64-point workgroup tile
+
+
+@pytest.mark.parametrize("B,n,m,ns,C,dims", [(32, 128, 16, 20, 256, [259, 256, 256, 512]), (2, 128, 16, 20, 256, [259, 256, 256, 512]),
+                                              (5, 256, 37, 16, 128, [131, 128, 128, 256]), (3, 64, 7, 32, 61, [64, 64, 256, 128]),
+                                              (1, 40, 3, 19, 61, [64, 64, 64])])
+def test_sa_atomic_pooled_epilogue_equals_unpooled_then_max(B, n, m, ns, C, dims):
+    """pooled = 2: the unpooled 16-row tiling with the max over the neighbourhood folded into the last layer's epilogue (masked DPP-row maxima +
+    integer atomicMax on the non-negative float patterns) gives the SAME BITS as writing every row and running pa_rowgroup_max -- group
+    boundaries inside a row tile (ns = 20, 19), exactly on it (16, 32), and a ragged last tile."""
+    from patchaugnet_amd import _lib
+    from patchaugnet_amd.engine import _Chain
+    ref, eng = make_layers(dims, seed=13)
+    xyz, feat, cidx, nbr = sa_inputs(B, n, m, ns, C, seed=9)
+    chain = _Chain(eng)
+    assert chain.atomic_pool_ok(B * m, ns)
+    args = (xyz.cuda(), feat.cuda().contiguous(), cidx.cuda(), nbr.cuda(), C)
+    full = chain.sa(*args, pooled=False)
+    two_step = torch.empty(B * m, dims[-1], device="cuda")
+    _lib.call("pa_rowgroup_max", B * m, ns, dims[-1], _lib.ptr(full), _lib.ptr(two_step))
+    for _ in range(2):                      # the second call finds a dirty output buffer: the launcher zero-fills it
+        got = chain.sa(*args, pooled=2)
+        assert got.shape == two_step.shape and torch.equal(got, two_step)
