@@ -20,6 +20,8 @@
 // the last round bidders are applied in ascending order.  Arithmetic follows the source: value =
 // (float)(3.0 - (double)sqrtf(d2) - (double)price) (the literal 3.0 is a double, :146), increment =
 // (best - better) + eps in fp32.
+#include <stdlib.h>
+
 #include "pa_common.h"
 
 namespace {
@@ -193,6 +195,198 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_auction_kernel(int n, const f
     }
 }
 
+// ---- chip-wide form: ONE LAUNCH PER ROUND, G workgroups per cloud pair --------------------------------------------------------------------
+// The persistent kernel above keeps a cloud pair on ONE CU: at the reference's call shape (16, 4096, 3) that is 16 of 256 CUs, and a round costs
+// ~1 us per bidder (a wavefront scans all n objects) however few bidders are left -- 19.5 ms for 64 rounds, 53 ms for 1024.  Here the bidders of
+// a round are dealt to G workgroups per cloud (slices of the point range; Bid is independent per bidder, its only shared write is the atomic
+// maximum), and the per-object GetMax / Assign pass, which needs every bid of the cloud, is done by whichever of the G workgroups finishes LAST
+// (an arrival counter per cloud; producers release with __threadfence, the last arriver acquires).  The kernel boundary between rounds is the
+// only grid-wide synchronisation, so nothing can dead-lock against other streams' work.  Prices live in global memory between rounds (16 KB per
+// cloud from L2 per workgroup and round).  Same deterministic choices, same arithmetic, same state as the persistent kernel and the oracle.
+__global__ __launch_bounds__(EMD_THREADS) void emd_round_kernel(int n, const float *__restrict__ xyz1_all, const float *__restrict__ xyz2_all,
+                                                                 float *dist_all, int *assignment_all, float *price_all, int *assignment_inv_all,
+                                                                 int *bid_all, float *bid_inc_all, float *max_inc_all, int *max_idx_all, float eps,
+                                                                 int last)
+{
+    extern __shared__ float lds[];
+    float *x2 = lds, *y2 = lds + n, *z2 = lds + 2 * n, *pr = lds + 3 * n;
+    unsigned short *unass = (unsigned short *)(lds + 4 * n);
+    __shared__ int wcnt[EMD_WAVES];
+    __shared__ int is_last, list_base;
+    __shared__ Bid3 part_bid[EMD_WAVES];
+
+    const int i = blockIdx.y, g = blockIdx.x, G = gridDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t off = (size_t)i * n;
+    const float *xyz1 = xyz1_all + off * 3, *xyz2 = xyz2_all + off * 3;
+    int *ass = assignment_all + off, *ass_inv = assignment_inv_all + off, *bid = bid_all + off, *max_idx = max_idx_all + off;
+    float *price = price_all + off, *binc = bid_inc_all + off, *minc = max_inc_all + off, *dist = dist_all + off;
+    // Per-call round state in the cloud's `dist` row, which holds nothing until the squared distances are written after the last round (two calls in
+    // flight never share it): words 0 .. n/2 - 1 = this round's bidders (16-bit point indices, any order), word n/2 = arrival counter,
+    // word n/2 + 1 = number of bidders.  Both counters are zeroed by the launcher and left at zero by every round's last arriver.
+    unsigned short *glist = reinterpret_cast<unsigned short *>(dist);
+    int *arrive = reinterpret_cast<int *>(dist) + n / 2, *gcount = arrive + 1;
+
+    // ---- this workgroup's bidders: the unassigned points of its slice of the point range ---------------------------------------------------
+    const int per = (n + G - 1) / G, s0 = g * per, s1 = min(s0 + per, n);
+    int U = 0;
+    for (int c = s0; c < s1; c += EMD_THREADS) {
+        const int j = c + tid;
+        const bool un = j < s1 && ld_agent_i(ass + j) == -1;
+        const u64 mask = __ballot(un);
+        if (lane == 0) wcnt[wave] = __popcll(mask);
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int w = 0; w < EMD_WAVES; ++w) {
+            const int cw = wcnt[w];
+            before += (w < wave) ? cw : 0;
+            total += cw;
+        }
+        if (un) unass[U + before + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)j;
+        U += total;
+        __syncthreads();
+    }
+    if (U > 0) {
+        // the objects and this round's prices: only workgroups that have a bidder pay for the 16 n bytes
+        for (int k = tid; k < n; k += EMD_THREADS) {
+            x2[k] = xyz2[k * 3 + 0];
+            y2[k] = xyz2[k * 3 + 1];
+            z2[k] = xyz2[k * 3 + 2];
+            pr[k] = ld_agent_f(price + k);
+        }
+        if (tid == 0) list_base = atomicAdd(gcount, U);          // this workgroup's segment of the cloud's bidder list
+        __syncthreads();
+        for (int u = tid; u < U; u += EMD_THREADS) __hip_atomic_store(glist + list_base + u, unass[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- Bid (:95-179).  A wavefront per bidder; with fewer bidders than wavefronts (the long tail of the auction: a handful per round) W
+        // wavefronts share a bidder, each scanning 1/W of the objects, and the partial (best, second, index) triples are merged in object order.
+        int W = 1;
+        while (W < EMD_WAVES && U * W * 2 <= EMD_WAVES) W *= 2;
+        const int slice = n / W;                                  // n is a multiple of 1024
+        for (int u0 = 0; u0 < U; u0 += EMD_WAVES / W) {
+            const int u = u0 + wave / W, part = wave % W;
+            Bid3 b = {-1e9f, -1e9f, -1};
+            int j = -1;
+            if (u < U) {
+                j = unass[u];
+                const float x1 = xyz1[j * 3 + 0], y1 = xyz1[j * 3 + 1], z1 = xyz1[j * 3 + 2];
+                for (int k = part * slice + lane; k < (part + 1) * slice; k += 64) {
+                    const float dx = x2[k] - x1, dy = y2[k] - y1, dz = z2[k] - z1;
+                    const float d = (float)(3.0 - (double)sqrtf(dx * dx + dy * dy + dz * dz) - (double)pr[k]);
+                    if (d > b.best) {
+                        b.better = b.best;
+                        b.best = d;
+                        b.best_i = k;
+                    } else if (d > b.better) {
+                        b.better = d;
+                    }
+                }
+#pragma unroll
+                for (int s = 1; s < 64; s <<= 1) {
+                    const float ob = __shfl_xor(b.best, s), obt = __shfl_xor(b.better, s);
+                    const int oi = __shfl_xor(b.best_i, s);
+                    b = bid_merge(b, ob, obt, oi);
+                }
+            }
+            if (W > 1) {                                          // W is workgroup-uniform
+                if (lane == 0) part_bid[wave] = b;
+                __syncthreads();
+                if (part == 0 && u < U)
+                    for (int q = 1; q < W; ++q) { const Bid3 o = part_bid[wave + q]; b = bid_merge(b, o.best, o.better, o.best_i); }
+                __syncthreads();
+            }
+            if (lane == 0 && part == 0 && u < U) {
+                const float inc = b.best - b.better + eps;
+                st_agent_i(bid + j, b.best_i);
+                st_agent_f(binc + j, inc);
+                if (b.best_i >= 0) atomic_max_f(minc + b.best_i, inc);
+            }
+        }
+    }
+    // ---- arrival: the last of the cloud's G workgroups resolves the round --------------------------------------------------------------------
+    // Everything another workgroup reads from this one (bidder list, bid, increment, the atomic maximum) was written with agent-scope write-through
+    // stores / atomics and is read back with agent-scope loads that bypass the L1: publishing needs every wave's stores RETIRED (vmcnt 0), the
+    // workgroup barrier, and ONE lane's release in front of the arrival -- not 16 wavefronts x 512 workgroups of L2 write-back fences (that form
+    // measured 176 us per round).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (hipcc 7.2 may drop the wait behind the write-back when it thinks nothing is outstanding)
+        const int last_one = (atomicAdd(arrive, 1) == G - 1) ? 1 : 0;
+        if (last_one) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            st_agent_i(arrive, 0);                          // ready for the next round's launch
+        }
+        is_last = last_one;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    U = ld_agent_i(gcount);                                  // the cloud's bidders of this round
+    __syncthreads();
+    if (tid == 0) st_agent_i(gcount, 0);
+    for (int u = tid; u < U; u += EMD_THREADS) unass[u] = __hip_atomic_load(glist + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    // GetMax (:181-194): the highest-indexed bidder whose increment matches the maximum within 1e-6.  max_idx[k] is left at -1 by the winner
+    // that consumes it (Assign below) and starts at the caller's 0, which a real bidder index can only raise: no separate reset pass.
+    for (int u = tid; u < U; u += EMD_THREADS) {
+        const int j = unass[u];
+        const int bid_id = ld_agent_i(bid + j);
+        if (bid_id < 0) continue;
+        const double bi = (double)ld_agent_f(binc + j), mx = (double)ld_agent_f(minc + bid_id);
+        if (bi - 1e-6 <= mx && mx <= bi + 1e-6) atomicMax(max_idx + bid_id, j);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the atomics are at the L2 before anyone reads them
+    __syncthreads();
+    // Assign (:196-215): prices are updated in GLOBAL memory (the next round's workgroups load them)
+    if (!last) {
+        for (int u = tid; u < U; u += EMD_THREADS) {
+            const int j = unass[u];
+            const int bid_id = ld_agent_i(bid + j);
+            if (bid_id < 0 || ld_agent_i(max_idx + bid_id) != j) continue;
+            const int prev = ld_agent_i(ass_inv + bid_id);
+            if (prev != -1) st_agent_i(ass + prev, -1);
+            st_agent_i(ass_inv + bid_id, j);
+            st_agent_i(ass + j, bid_id);
+            st_agent_f(price + bid_id, ld_agent_f(price + bid_id) + ld_agent_f(binc + j));     // one winner per object: nobody else touches this price
+            st_agent_f(minc + bid_id, -1e9f);
+            st_agent_i(max_idx + bid_id, -1);
+        }
+    } else {
+        // last round: every bidder takes the object it bid for, applied in ASCENDING point order (several may take the same object): sort the list
+        // (any order until now) by counting ranks -- U is small by then, and n^2 / 1024 comparisons per thread even when it is not
+        for (int u = tid; u < U; u += EMD_THREADS) {
+            const unsigned short mine = unass[u];
+            int rank = 0;
+            for (int t = 0; t < U; ++t) rank += unass[t] < mine ? 1 : 0;
+            reinterpret_cast<unsigned short *>(pr)[rank] = mine;     // pr[] (LDS) is free: this workgroup may not even have loaded it
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned short *srt = reinterpret_cast<const unsigned short *>(pr);
+            for (int u = 0; u < U; ++u) {
+                const int j = srt[u];
+                const int bid_id = ld_agent_i(bid + j);
+                st_agent_i(ass + j, bid_id);
+                if (bid_id < 0) continue;
+                st_agent_i(ass_inv + bid_id, j);
+                st_agent_f(price + bid_id, ld_agent_f(price + bid_id) + ld_agent_f(binc + j));
+                st_agent_f(minc + bid_id, -1e9f);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // CalcDist (:217-226), straight from global memory (this workgroup may have had no bidder and no LDS copy of the objects)
+        for (int j = tid; j < n; j += EMD_THREADS) {
+            const int k = ld_agent_i(ass + j);
+            float d = 0.f;
+            if (k >= 0) {
+                const float dx = xyz1[j * 3 + 0] - xyz2[k * 3 + 0], dy = xyz1[j * 3 + 1] - xyz2[k * 3 + 1], dz = xyz1[j * 3 + 2] - xyz2[k * 3 + 2];
+                d = dx * dx + dy * dy + dz * dz;
+            }
+            dist[j] = d;
+        }
+    }
+}
+
 // NmDistanceGradKernel (:284-300): grad_xyz[i,j] += 2 g (xyz1[i,j] - xyz2[i,idx[i,j]]); one thread owns one point.
 __global__ void emd_backward_kernel(long total, int n, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
                                     const float *__restrict__ grad_dist, const int *__restrict__ idx, float *grad_xyz)
@@ -211,6 +405,10 @@ __global__ void emd_backward_kernel(long total, int n, const float *__restrict__
 
 }  // namespace
 
+static int g_emd_persistent = -1;
+// test / A/B switch: 1 = the persistent one-workgroup-per-cloud kernel, 0 = the chip-wide one-launch-per-round form (default; PA_EMD_PERSISTENT=1 flips it)
+PA_API void pa_emd_persistent_enable(int on) { g_emd_persistent = on ? 1 : 0; }
+
 PA_API int pa_emd_forward(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist, int *assignment, float *price,
                           int *assignment_inv, int *bid, float *bid_increments, float *max_increments, int *max_idx, float eps, int iters,
                           pa_stream_t stream)
@@ -224,12 +422,31 @@ PA_API int pa_emd_forward(int b, int n, int m, const float *xyz1, const float *x
     PA_REQUIRE(xyz1 && xyz2 && dist && assignment && price && assignment_inv && bid && bid_increments && max_increments && max_idx,
                "pa_emd_forward: null pointer");
     const size_t lds_bytes = (size_t)n * 16 + (size_t)n * 2;
-    {   // the opt-in is a per-DEVICE attribute of the function: set it on every call (a process may drive several GPUs)
+    static const bool persistent = getenv("PA_EMD_PERSISTENT") != nullptr;      // A/B and test knob: one workgroup per cloud, every round on chip
+    if (g_emd_persistent > 0 || (g_emd_persistent < 0 && persistent)) {
+        // the opt-in is a per-DEVICE attribute of the function: set it on every call (a process may drive several GPUs)
         hipError_t e = hipFuncSetAttribute((const void *)emd_auction_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         if (e != hipSuccess) { pa_set_error("pa_emd_forward: cannot raise the LDS limit: %s", hipGetErrorString(e)); return (int)e; }
+        hipLaunchKernelGGL(emd_auction_kernel, dim3(b), dim3(EMD_THREADS), lds_bytes, (hipStream_t)stream, n, xyz1, xyz2, dist, assignment, price,
+                           assignment_inv, bid, bid_increments, max_increments, max_idx, eps, iters);
+        PA_CHECK_LAUNCH("pa_emd_forward");
+        return PA_OK;
     }
-    hipLaunchKernelGGL(emd_auction_kernel, dim3(b), dim3(EMD_THREADS), lds_bytes, (hipStream_t)stream, n, xyz1, xyz2, dist, assignment, price,
-                       assignment_inv, bid, bid_increments, max_increments, max_idx, eps, iters);
+    // chip-wide: one launch per round, G workgroups per cloud (about two workgroups per CU in total)
+    hipError_t e = hipFuncSetAttribute((const void *)emd_round_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    if (e != hipSuccess) { pa_set_error("pa_emd_forward: cannot raise the LDS limit: %s", hipGetErrorString(e)); return (int)e; }
+    int G = 512 / b;
+    if (G > 32) G = 32;
+    if (G < 1) G = 1;
+    while (G > 1 && n / G < 64) G >>= 1;
+    // round state in every cloud's dist row (see the kernel): the arrival counter and the bidder count at words n/2, n/2 + 1 -- zero them, stream-ordered
+    if (hipMemset2DAsync(dist + n / 2, (size_t)n * sizeof(float), 0, 2 * sizeof(int), (size_t)b, (hipStream_t)stream) != hipSuccess) {
+        pa_set_error("pa_emd_forward: hipMemset2DAsync failed");
+        return PA_EINVAL;
+    }
+    for (int it = 0; it < iters; ++it)
+        hipLaunchKernelGGL(emd_round_kernel, dim3(G, b), dim3(EMD_THREADS), lds_bytes, (hipStream_t)stream, n, xyz1, xyz2, dist, assignment, price,
+                           assignment_inv, bid, bid_increments, max_increments, max_idx, eps, it == iters - 1 ? 1 : 0);
     PA_CHECK_LAUNCH("pa_emd_forward");
     return PA_OK;
 }

@@ -55,6 +55,15 @@ def test_knn_generic_contract(n, k, dim):
     assert D.shape == (1, len(qry), k) and np.array_equal(I[0].cpu().numpy(), (ri - 1).T)
 
 
+def _emd_form(persistent):
+    """Select the auction's launch form: True = one persistent workgroup per cloud, False = chip-wide, one launch per round (the default)."""
+    import ctypes
+    from patchaugnet_amd import _lib
+    lib = _lib.lib()
+    lib.pa_emd_persistent_enable.argtypes, lib.pa_emd_persistent_enable.restype = [ctypes.c_int], None
+    lib.pa_emd_persistent_enable(1 if persistent else 0)
+
+
 def _emd_gpu(a, c, eps, iters):
     """Run the HIP auction through the reference's module-level signature; returns status, dist, assignment and the state."""
     from patchaugnet_amd import emd_module
@@ -70,14 +79,21 @@ def _emd_gpu(a, c, eps, iters):
     return rc, {k: v.cpu().numpy() for k, v in st.items()}
 
 
+@pytest.mark.parametrize("persistent", [False, True])
 @pytest.mark.parametrize("b,n,eps,iters,lat", [(2, 1024, 0.005, 60, False), (3, 1024, 0.02, 1, False), (2, 2048, 0.01, 25, True),
-                                               (1, 4096, 0.02, 12, False), (2, 1024, 0.002, 400, False)])
-def test_emd_forward_matches_oracle_bit_exact(b, n, eps, iters, lat):
+                                               (1, 4096, 0.02, 12, False), (2, 1024, 0.002, 400, False), (20, 1024, 0.02, 30, False),
+                                               (1, 8192, 0.02, 5, False)])
+def test_emd_forward_matches_oracle_bit_exact(b, n, eps, iters, lat, persistent):
     """a-E: assignment, squared distances and the whole auction state equal the deterministic CPU restatement
-    (emd_cuda.cu:228-282; free choices fixed as documented in oracle_emd_forward)."""
+    (emd_cuda.cu:228-282; free choices fixed as documented in oracle_emd_forward) -- in both launch forms: chip-wide (one launch per round,
+    G workgroups per cloud, the round resolved by the last workgroup to arrive) and one persistent workgroup per cloud."""
     a, c = pts(b, n, lat), pts(b, n, lat)
     st, rd, ra, rs = o.emd_forward(a, c, eps, iters, full_state=True)
-    rc, g = _emd_gpu(a, c, eps, iters)
+    _emd_form(persistent)
+    try:
+        rc, g = _emd_gpu(a, c, eps, iters)
+    finally:
+        _emd_form(False)
     assert rc == 1 and st == 1
     assert np.array_equal(g["assignment"], ra)
     assert np.array_equal(g["dist"], rd)
