@@ -35,6 +35,13 @@ def _guard(t):
     return torch.cuda.device(t.device)
 
 
+def _f32(*ts):
+    """The kernels are fp32: any other dtype on the device is refused (it would be read as raw fp32 words), never converted silently."""
+    for t in ts:
+        if t is not None and t.dtype != torch.float32:
+            raise TypeError("patchaugnet_amd dense kernels are fp32 on the MI355X; got %s (run float64 references on CPU tensors)" % t.dtype)
+
+
 # ---------------------------------------------------------------------------------------------------- thin wrappers of the C ABI
 def tgemm_nn(batch, M, N, K, A, sAb, lda, a_kcontig, B, sBb, ldb, C, sCb, ldc, *, bmode=0, baux=None, bp=None, beta=0, bias=None, colv=None,
              act=0, stats=None, per_batch_stats=0):
@@ -77,6 +84,7 @@ class _ChainTrain(Function):
     @staticmethod
     def forward(ctx, x, layers, pool, groups, training, *tensors):
         check_device(x)
+        _f32(x, *tensors)
         B, cin, P = x.shape
         dev = x.device
         it = iter(tensors)
@@ -215,6 +223,7 @@ class _LinearCM(Function):
     @staticmethod
     def forward(ctx, x, W, bias, act):
         check_device(x, W)
+        _f32(x, W, bias)
         B, C, P = x.shape
         O = W.shape[0]
         assert W.numel() == O * C
@@ -257,6 +266,7 @@ class _BmmNT(Function):
     @staticmethod
     def forward(ctx, a, b):
         check_device(a, b)
+        _f32(a, b)
         batch, M, K = a.shape
         N = b.shape[1]
         assert b.shape[0] == batch and b.shape[2] == K
@@ -293,6 +303,7 @@ class _BmmNN(Function):
     @staticmethod
     def forward(ctx, a, b):
         check_device(a, b)
+        _f32(a, b)
         batch, M, K = a.shape
         N = b.shape[2]
         assert b.shape[0] == batch and b.shape[1] == K
@@ -329,6 +340,7 @@ class _GramTN(Function):
     @staticmethod
     def forward(ctx, y):
         check_device(y)
+        _f32(y)
         batch, C, N = y.shape
         e = torch.empty((batch, N, N), dtype=torch.float32, device=y.device)
         with _guard(y):
@@ -356,6 +368,7 @@ class _SoftmaxRenorm(Function):
     @staticmethod
     def forward(ctx, e):
         check_device(e)
+        _f32(e)
         from . import _lib
         batch, N, _ = e.shape
         a = e                                                    # in place: the energy is dead after the soft-max
@@ -393,9 +406,11 @@ class _LinearRows(Function):
     @staticmethod
     def forward(ctx, x, W, bias):
         check_device(x, W)
+        _f32(x, W, bias)
         R, K = x.shape
         O = W.shape[0]
-        y = bias.detach().expand(R, O).contiguous() if bias is not None else torch.zeros((R, O), dtype=torch.float32, device=x.device)
+        # the split-K kernel ACCUMULATES into y: start from the bias in a buffer of its own (expand(1, O).contiguous() would alias the parameter)
+        y = bias.detach().expand(R, O).clone() if bias is not None else torch.zeros((R, O), dtype=torch.float32, device=x.device)
         with _guard(x):
             tgemm_kk(1, R, O, K, x, 0, K, W, 0, K, y, 0, O)
         ctx.save_for_backward(x, W)
@@ -431,6 +446,7 @@ class _MatmulRows(Function):
     @staticmethod
     def forward(ctx, x, W):
         check_device(x, W)
+        _f32(x, W)
         R, K = x.shape
         N = W.shape[1]
         y = torch.empty((R, N), dtype=torch.float32, device=x.device)

@@ -436,3 +436,19 @@ def test_graphed_trainer_with_geometry_prefetch_equals_the_eager_steps():
         assert ((a - c).norm() / a.norm().clamp_min(1.0)).item() <= 5e-3, k
         assert ((a - c).abs().max() / a.abs().max().clamp_min(1e-2)).item() <= 3e-2, k
     tr.close()
+
+
+def test_linear_rows_single_row_leaves_the_bias_parameter_alone():
+    """nn.Linear on ONE row (a batch of one cloud through the APFA head): the split-K kernel accumulates into its output, which must start
+    from a copy of the bias -- bias.expand(1, O).contiguous() is a view of the parameter itself (found by the head fuzz family)."""
+    from patchaugnet_amd import train_ops
+    torch.manual_seed(0)
+    for rows in (1, 2):
+        x = torch.randn(rows, 256 * 93, device="cuda")
+        W = torch.randn(256, 256 * 93, device="cuda") * 0.01
+        bias = torch.randn(256, device="cuda")
+        keep = bias.clone()
+        for _ in range(2):
+            y = train_ops.linear_rows(x, W, bias)
+            assert torch.equal(bias, keep)
+            assert _rel(y, x.double() @ W.double().t() + keep.double()) <= 1e-5

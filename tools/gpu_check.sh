@@ -35,12 +35,12 @@ for f in sorted(glob.glob("gpurun_out/*_bench_*.json")):
         print(f, "unreadable", ex)
 PY
 rm -rf gpurun_out/${TAG}_prof
-timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_prof -o ${TAG} -- python bench.py --model pptnet --mlp-dtype f16 --streams 1 --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-pass > gpurun_out/${TAG}_prof_ppt.log 2>&1; echo "rocprof(ppt) rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_prof -o ${TAG} -- python bench.py --model pptnet --mlp-dtype f16 --streams 1 --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-pass --no-extras > gpurun_out/${TAG}_prof_ppt.log 2>&1; echo "rocprof(ppt) rc=$?"
 python tools/rocprof_summary.py $(ls gpurun_out/${TAG}_prof/*results.db | head -1) gpurun_out/${TAG}_kernel_stats_pptnet_f16_streams_1.csv
 for S in default 1; do
   rm -rf gpurun_out/${TAG}_prof
   EXTRA=""; [ "$S" = "1" ] && EXTRA="--streams 1"
-  timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_prof -o ${TAG} -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline $EXTRA > gpurun_out/${TAG}_prof_$S.log 2>&1; echo "rocprof($S) rc=$?"
+  timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_prof -o ${TAG} -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras $EXTRA > gpurun_out/${TAG}_prof_$S.log 2>&1; echo "rocprof($S) rc=$?"
   python tools/rocprof_summary.py $(ls gpurun_out/${TAG}_prof/*results.db | head -1) gpurun_out/${TAG}_kernel_stats_streams_$S.csv
   rm -rf gpurun_out/${TAG}_prof
 done
