@@ -525,6 +525,12 @@ void launch_rows(const PaChain &a, int rt, bool split, int wpw, long ntiles, hip
 // Generic entry point.  mode: 0 plain rows, 1 set-abstraction gather, 2 feature-propagation interpolate.
 // wt[l] is K-major (kpad[l] x n[l]) with BN folded in and zero rows beyond the true K; bias[l] has n[l] entries.
 int pa_chain16_launch(PaChain &a, int mode, bool is_pooled, bool split, int RTv, int scratch_floats, hipStream_t st);   // mlp_chain_f16.hip
+bool pa_sa_tiny_applies(const PaChain &a, int rt);                                                                      // sa_tiny.hip
+int pa_sa_tiny_launch(const PaChain &a, int rt, long ntiles, hipStream_t st);
+
+static int g_chain_tiny = -1;
+// test / A/B switch for the persistent first-level kernel (sa_tiny.hip): 1 = wherever its shape applies, 0 = never, -1 = the default rule
+PA_API void pa_chain_tiny_enable(int on) { g_chain_tiny = on; }
 
 static long long *g_chain_dbg = nullptr;
 // profiling hook (tools/chain_phases.py): device buffer of 512 x 8 int64 receiving s_memtime stamps of the next launches; NULL = off
@@ -687,7 +693,14 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
     while (wpw > 1 && wpw * per_wave > 156 * 1024) wpw = rt1 ? wpw - 1 : wpw >> 1;
     const long ntiles = is_pooled ? (rows + 3) / 4 : (total_rows + R - 1) / R;
 
-    if (is_pooled) {
+    // the finest set-abstraction level of both models (<= 8 -> 32 -> 32 -> 64): persistent workgroups with the weights resident in LDS and the
+    // gather pipelined across tiles (sa_tiny.hip); bit-identical to the generic pooled kernel, so which one runs is a matter of speed only
+    static const bool no_tiny = getenv("PA_CHAIN_NO_TINY") != nullptr;                                               // A/B knob
+    static const long tiny_min = getenv("PA_CHAIN_TINY_MIN_TILES") ? atol(getenv("PA_CHAIN_TINY_MIN_TILES")) : 1024;  // tuning knob
+    const bool tiny_on = g_chain_tiny < 0 ? (!no_tiny && ntiles >= tiny_min) : g_chain_tiny > 0;
+    if (is_pooled && !split && tiny_on && pa_sa_tiny_applies(a, RTv)) {
+        pa_sa_tiny_launch(a, RTv, ntiles, st);
+    } else if (is_pooled) {
         if (split) launch_chain<5, 4, MODE_SA, true, 4>(a, 4, ntiles, st);
         else switch (RTv) {
             case 4: launch_chain<4, 4, MODE_SA, true, 1>(a, wpw, ntiles, st); break;

@@ -182,3 +182,32 @@ def test_sa_atomic_pooled_epilogue_equals_unpooled_then_max(B, n, m, ns, C, dims
     for _ in range(2):                      # the second call finds a dirty output buffer: the launcher zero-fills it
         got = chain.sa(*args, pooled=2)
         assert got.shape == two_step.shape and torch.equal(got, two_step)
+
+
+@pytest.mark.parametrize("B,n,m,ns,C", [(8, 4096, 1024, 20, 3), (3, 1024, 250, 20, 3), (2, 333, 41, 17, 3), (5, 512, 128, 16, 3), (1, 100, 9, 13, 2),
+                                         (32, 4096, 1024, 20, 3)])
+def test_sa_first_level_persistent_kernel_is_bit_identical_to_the_generic_one(B, n, m, ns, C):
+    """sa_tiny.hip (weights resident in LDS, twelve looping wavefronts per workgroup, gather pipelined across tiles) against the generic pooled
+    chain kernel on the first level's shape <= 8 -> 32 -> 32 -> 64: same bits -- ragged group counts (the last tile partly empty, fewer tiles than
+    wavefronts), nsample 13 .. 20 (both row-tile counts), two feature channels."""
+    import ctypes
+    from patchaugnet_amd import _lib
+    from patchaugnet_amd.engine import _Chain
+    lib = _lib.lib()
+    lib.pa_chain_tiny_enable.argtypes, lib.pa_chain_tiny_enable.restype = [ctypes.c_int], None
+    ref, eng = make_layers([3 + C, 32, 32, 64], seed=17)
+    xyz, feat, cidx, nbr = sa_inputs(B, n, m, ns, C, seed=21)
+    chain = _Chain(eng)
+    args = (xyz.cuda(), feat.cuda().contiguous(), cidx.cuda(), nbr.cuda(), C)
+    try:
+        lib.pa_chain_tiny_enable(0)
+        generic = chain.sa(*args, pooled=True)
+        lib.pa_chain_tiny_enable(1)
+        tiny = chain.sa(*args, pooled=True)
+        tiny2 = chain.sa(*args, pooled=True)
+    finally:
+        lib.pa_chain_tiny_enable(-1)
+    assert torch.equal(tiny, generic) and torch.equal(tiny2, generic)
+    rows = sa_rows_ref(xyz, feat, cidx, nbr).double()
+    exp = mlp_ref(rows, [(w.float().double(), b.float().double()) for w, b in ref]).max(dim=2)[0].reshape(B * m, -1)
+    close(tiny, exp)
