@@ -138,7 +138,7 @@ def dominant_kernel_roofline(st, cfg, batch, points, grouping, pmc=None, pmc_not
     }
 
 
-DOMINANT_KERNEL_RE = r"chain_kernel<[12], 16, 3, false, 1>"     # fp0 feature-propagation chain (pa_fp_chain_premul): 16-row tiles (32 with PA_CHAIN_FPX_RT2)
+DOMINANT_KERNEL_RE = r"chain_kernel<[12], 16, 3, false, 1[,>]"     # fp0 feature-propagation chain (pa_fp_chain_premul): 16-row tiles (32 with PA_CHAIN_FPX_RT2)
 GROUPING_KERNEL_RE = r"group_lds_kernel<4>"
 
 

@@ -119,3 +119,22 @@ def test_bench_refuses_gpu_counts_it_cannot_honour():
     assert out.returncode != 0 and "refusing" in out.stderr and '"n_gpus"' not in out.stdout
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=dict(env, WORLD_SIZE="1", RANK="0"))
     assert out.returncode != 0 and "does not match WORLD_SIZE" in out.stderr
+
+
+def test_bench_kernel_regexes_match_the_built_kernels():
+    """bench.py finds the dominant kernel and the graded gather in rocprofv3's output by (demangled) name: a template signature change must not
+    silently turn roofline.traffic into null.  Checked against the kernel symbols of the built library."""
+    import re
+    import shutil
+    import subprocess
+    import bench
+    from patchaugnet_amd import _lib
+    filt = shutil.which("llvm-cxxfilt") or shutil.which("c++filt") or "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
+    if not os.path.exists(filt) or not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("no demangler / library")
+    data = open(_lib.LIB_PATH, "rb").read()
+    mangled = sorted({m.decode() for m in re.findall(rb"_ZN[0-9A-Za-z_]+(?:chain_kernel|group_lds_kernel)[0-9A-Za-z_]+", data)})
+    assert mangled, "no kernel symbols found in the library"
+    names = subprocess.run([filt], input="\n".join(mangled), capture_output=True, text=True, check=True).stdout.splitlines()
+    assert any(re.search(bench.DOMINANT_KERNEL_RE, n) for n in names), [n for n in names if "chain_kernel<1, 16, 3" in n]
+    assert any(re.search(bench.GROUPING_KERNEL_RE, n) for n in names)
