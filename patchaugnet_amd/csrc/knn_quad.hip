@@ -80,7 +80,12 @@ __device__ __forceinline__ void merge_pair(u32 (&a)[K], int mask)
     for (int j = 0; j < K; ++j) a[j] = c[j];
 }
 
-template <int K, int PTS, int NT>
+// KL: entries of a LANE's list.  The K nearest of a query are spread over the quad's four strided candidate streams about evenly (5 +- 2 of them per
+// lane at K = 20), so a lane keeps only its KL = 0.7 K smallest: every candidate costs KL instead of K v_med3 steps.  Exactness is unchanged: the
+// quad's K-th comes from the union of the four lists (>= the true K-th, so the candidate band and the stop rule only get more conservative), and a
+// lane whose WHOLE list falls inside the band may have dropped a candidate -> that query takes the exact slow path (4 sigma: a few queries per
+// batch).
+template <int K, int KL, int PTS, int NT>
 __global__ __launch_bounds__(NT) void knn_quad_kernel(int n, int m, int q_per_block, const float *__restrict__ xyz_all, const float *__restrict__ new_xyz_all,
                                                        int *__restrict__ idx_all, float *__restrict__ dist2_all, long long *dbg)
 {
@@ -197,20 +202,20 @@ __global__ __launch_bounds__(NT) void knn_quad_kernel(int n, int m, int q_per_bl
         // by the candidate's position in the sorted cloud: d >= 0, so unsigned order on the patterns is the order of the truncated distances
         // (ties broken by position), the lists stay plain 32-bit integers (v_med3_u32 / v_min_u32 / v_max_u32: no float modes involved), and the
         // positions of the survivors come back out of the list -- no second walk over the cells.
-        u32 L[K];
+        u32 L[KL];
 #pragma unroll
-        for (int j = 0; j < K; ++j) L[j] = KQ_NONE;
+        for (int j = 0; j < KL; ++j) L[j] = KQ_NONE;
         auto pass1 = [&](int pos, const float4 &p) {
             const u32 bits = __float_as_uint(dist(p));
             const u32 d = bits < KQ_NONE ? ((bits & ~((1u << KQ_TAG) - 1u)) | (u32)pos) : KQ_NONE;     // +inf / NaN (either sign): never admitted
 #pragma unroll
-            for (int j = K - 1; j >= 1; --j) L[j] = med3_u32(L[j - 1], d, L[j]);
+            for (int j = KL - 1; j >= 1; --j) L[j] = med3_u32(L[j - 1], d, L[j]);
             L[0] = min(L[0], d);
         };
         auto quad_kth = [&]() {                        // K-th smallest entry of the four lanes' lists (same value in all four lanes)
             u32 M[K];
 #pragma unroll
-            for (int j = 0; j < K; ++j) M[j] = L[j];
+            for (int j = 0; j < K; ++j) M[j] = j < KL ? L[j < KL ? j : 0] : KQ_NONE;
             merge_pair<K>(M, 1);                        // lanes {0,1} and {2,3}: K smallest of each pair, ascending
             u32 kth = 0u;
 #pragma unroll
@@ -236,19 +241,19 @@ __global__ __launch_bounds__(NT) void knn_quad_kernel(int n, int m, int q_per_bl
         const u32 tmax = kth >> KQ_TAG;
         int qn = 0;
 #pragma unroll
-        for (int j = 0; j < K; ++j) qn += (L[j] < KQ_NONE && (L[j] >> KQ_TAG) <= tmax) ? 1 : 0;
+        for (int j = 0; j < KL; ++j) qn += (L[j] < KQ_NONE && (L[j] >> KQ_TAG) <= tmax) ? 1 : 0;
         KQ_STAMP(4);
         const int base = (tid & 63) & ~3;
         const int c0 = __shfl(qn, base), c1 = __shfl(qn, base + 1), c2 = __shfl(qn, base + 2), c3 = __shfl(qn, base + 3);
         const int total = c0 + c1 + c2 + c3;
-        const bool overflow = c0 >= K || c1 >= K || c2 >= K || c3 >= K || total > KQ_TCAP;
+        const bool overflow = c0 >= KL || c1 >= KL || c2 >= KL || c3 >= KL || total > KQ_TCAP;
         const size_t o = ((size_t)b * m + q) * K;
         if (!overflow) {
             // ---- pass 3: exact keys to LDS, output slot = rank among the quad's keys
             const int off = (part > 0 ? c0 : 0) + (part > 1 ? c1 : 0) + (part > 2 ? c2 : 0);
             u64 *kq = keys + ql * (KQ_TCAP + 4);
 #pragma unroll
-            for (int j = 0; j < K; ++j) {
+            for (int j = 0; j < KL; ++j) {
                 if (!__any(j < qn)) break;
                 if (j < qn) {
                     const float4 p = sorted[L[j] & ((1u << KQ_TAG) - 1u)];
@@ -317,7 +322,11 @@ int launch_quad(int b, int n, int m, const float *xyz, const float *new_xyz, int
     constexpr int NT = KQ_NT, PTS = 4096 / KQ_NT;
     const int qpb = KQ_QPB;
     const size_t lds = (size_t)n * 16 + (size_t)KQ_AUX_FLOATS * 4 + (size_t)(KG_CELLS + 3) * 4 + (size_t)(NT / 4) * (KQ_TCAP + 4) * 8 + (size_t)qpb * 2;
-    auto kern = knn_quad_kernel<K, PTS, NT>;
+#ifndef KQ_KL_NUM
+#define KQ_KL_NUM 7      // lane list length = ceil(K * KQ_KL_NUM / 10); 10 = the full K
+#endif
+    constexpr int KL = (K * KQ_KL_NUM + 9) / 10;
+    auto kern = knn_quad_kernel<K, KL, PTS, NT>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(pa_div_up(m, qpb), b), dim3(NT), lds, st, n, m, qpb, xyz, new_xyz, idx, dist2, dbg);
     return 0;
