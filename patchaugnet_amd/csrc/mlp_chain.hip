@@ -527,6 +527,8 @@ void launch_rows(const PaChain &a, int rt, bool split, int wpw, long ntiles, hip
 int pa_chain16_launch(PaChain &a, int mode, bool is_pooled, bool split, int RTv, int scratch_floats, hipStream_t st);   // mlp_chain_f16.hip
 bool pa_sa_tiny_applies(const PaChain &a, int rt);                                                                      // sa_tiny.hip
 int pa_sa_tiny_launch(const PaChain &a, int rt, long ntiles, hipStream_t st);
+int pa_linear_lds_try(long rows, int k, int n, const float *x, int ldx, const float *wt, const float *bias, int relu, const float *residual, int ldr,
+                      float *out, int ldo, hipStream_t st);                                                                    // linear_lds.hip
 
 static int g_chain_tiny = -1;
 // test / A/B switch for the persistent first-level kernel (sa_tiny.hip): 1 = wherever its shape applies, 0 = never, -1 = the default rule
@@ -765,6 +767,10 @@ PA_API int pa_linear(long rows, int k, int n, const float *x, int ldx, const flo
                      const float *residual, int ldr, float *out, int ldo, pa_stream_t stream)
 {
     PA_REQUIRE(residual == nullptr || ldr >= n, "pa_linear: residual row stride %d < n=%d", ldr, n);
+    if (ldx >= k && ldo >= n && pa_linear_lds_try(rows, k, n, x, ldx, wt, bias, relu, residual, ldr, out, ldo, (hipStream_t)stream)) {
+        PA_CHECK_LAUNCH("pa_linear (LDS-resident weights)");
+        return 0;
+    }
     const int kpad = (k + 3) / 4 * 4;
     static const bool no_packed = getenv("PA_CHAIN_NO_PACKED") != nullptr;
     const int slices = linear_col_slices(rows, n, wpk != nullptr && !no_packed);

@@ -211,3 +211,38 @@ def test_sa_first_level_persistent_kernel_is_bit_identical_to_the_generic_one(B,
     rows = sa_rows_ref(xyz, feat, cidx, nbr).double()
     exp = mlp_ref(rows, [(w.float().double(), b.float().double()) for w, b in ref]).max(dim=2)[0].reshape(B * m, -1)
     close(tiny, exp)
+
+
+@pytest.mark.parametrize("rows,n,relu,res,ldx", [(4096, 256, 0, False, 256), (32768, 256, 0, False, 256), (5003, 512, 1, True, 300), (17, 128, 1, False, 256),
+                                                  (2048, 256, 1, True, 256)])
+def test_linear_with_lds_resident_weights_is_bit_identical_to_the_chain_kernel(rows, n, relu, res, ldx):
+    """pa_linear's k = 256 kernel with a 128-column weight half resident in LDS (linear_lds.hip) performs the chain kernel's arithmetic:
+    same fp32 MFMA, k ascending, bias, activation, residual -> identical bits, ragged last tile and strided rows included."""
+    import ctypes
+    from patchaugnet_amd import _lib
+    from patchaugnet_amd._lib import call, ptr
+    lib = _lib.lib()
+    lib.pa_linear_lds_enable.argtypes, lib.pa_linear_lds_enable.restype = [ctypes.c_int], None
+    g = torch.Generator().manual_seed(rows + n)
+    k = 256
+    x = torch.randn(rows, ldx, generator=g).cuda()
+    wt = (torch.randn(k, n, generator=g) * (2.0 / k) ** 0.5).cuda()
+    bias = (torch.randn(n, generator=g) * 0.1).cuda()
+    resid = torch.randn(rows, n, generator=g).cuda() if res else None
+    outs = []
+    try:
+        for on in (0, 1, 1):
+            lib.pa_linear_lds_enable(on)
+            out = torch.full((rows, n), float("nan"), device="cuda")
+            call("pa_linear", rows, k, n, ptr(x), ldx, ptr(wt), None, ptr(bias), relu, ptr(resid) if res else None, n if res else 0, ptr(out), n)
+            outs.append(out)
+    finally:
+        lib.pa_linear_lds_enable(-1)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[1], outs[0]) and torch.equal(outs[2], outs[0])
+    exp = x[:, :k].double() @ wt.double() + bias.double()
+    if relu:
+        exp = torch.relu(exp)
+    if res:
+        exp = exp + resid.double()
+    close(outs[1], exp)
