@@ -313,9 +313,10 @@ int pa_tgemm_nn(int batch, int M, int N, int K, const float *A, long sAb, int ld
 int pa_tgemm_kk(int batch, int M, int N, long K, const float *A, long sAb, int lda, int amode, const float *aaux, const float *ap,
                 const float *B, long sBb, int ldb, int bmode, const float *bp,
                 float *C, long sCb, int ldc, int per_batch, int per_batch_stats, pa_stream_t stream);
-/* BatchNorm (training): statistics -> rows 0..3 of p, running statistics updated in place (momentum, unbiased variance) when given. */
+/* BatchNorm (training): statistics -> rows 0..3 of p, running statistics updated in place (momentum, unbiased variance) when given;
+ * *num_batches_tracked += groups when given (torch.nn.BatchNorm's int64 counter, one forward pass per statistics group). */
 int pa_bn_finalize(int nch, int groups, double count, const double *stats, const float *gamma, const float *beta, float eps, float momentum,
-                   float *running_mean, float *running_var, float *p, pa_stream_t stream);
+                   float *running_mean, float *running_var, float *p, long long *num_batches_tracked, pa_stream_t stream);
 /* BatchNorm (evaluation): the parameter block from the RUNNING statistics (rows 0..3; rows 4, 5 zero, row 6 = scale), `groups` identical copies --
  * the module path in eval() mode runs on the same GEMM kernels, forward and backward (the input gradient then has no batch-statistics terms:
  * pa_bn_bwd_finalize with count = +inf leaves rows 4, 5 at zero and still returns dgamma / dbeta). */
@@ -343,6 +344,33 @@ int pa_quadruplet_loss(int b, int p, int nn, int d, const float *desc, float m1,
 long pa_attn_train_scratch_floats(int b, int n);
 int pa_attn_softmax_renorm(int b, int n, float *energy, float *colsum, float *scratch, pa_stream_t stream);
 int pa_attn_softmax_renorm_backward(int b, int n, const float *attn, const float *colsum, float *grad, float *scratch, pa_stream_t stream);
+
+/* ---- The aggregation heads' small non-GEMM steps in training / autograd mode, one launch each way (csrc/train_glue.hip); all deterministic.
+ * NetVLAD (patch_aug_net/models/loupe.py:196-222): pa_softmax_cols: act (b, k, n) = softmax over the k clusters of every point of `in`;
+ *   part (b, ceil(n / 256), k) = per-256-point partial sums of act over the points.  _backward: dpre = act (g - sum_k g act), g = dact + dasum[b][k]
+ *   (dasum NULL = no gradient reached the cluster sums).
+ * pa_vlad_residual_normalize: out (b, c, k) = v / max(||v||_c, 1e-12), v = raw - a_sum cw2 (cw2 (c, k) = cluster_weights2), a_sum (b, k) = the nblk
+ *   partials of `part` added up; a_sum and nrm (b, k: the norms before the clamp) are outputs kept for _backward, which returns dv (= draw), dasum (b, k)
+ *   and dcw2 (c, k; NULL = not wanted).
+ * pa_l2_normalize: torch.nn.functional.normalize(x, dim = 1) of x (b, c, m) (m = 1: the rows of a matrix); nrm (b, m) = the norms before the clamp.
+ * pa_bn_rows_train: torch.nn.BatchNorm1d in train mode over the rows of x (r, f): batch statistics, running statistics updated with the unbiased
+ *   variance and *num_batches_tracked += 1 when given; mean / rstd (f) kept for pa_bn_rows_backward (dx, dgamma, dbeta; the last two may be NULL).
+ * pa_afa_attention (patch_aug_net/models/loupe.py:8-41): w (b, k) = softmax over k of max over c of r (b, c, k); out = relu(x + x w); arg (b, k) = the
+ *   channel of each maximum.  _backward: dx, and dr (the soft-max gradient at the arg channels, 0 elsewhere; NULL = not wanted). */
+int pa_softmax_cols(int b, int k, int n, const float *in, float *act, float *part, pa_stream_t stream);
+int pa_softmax_cols_backward(int b, int k, int n, const float *act, const float *dact, const float *dasum, float *dpre, pa_stream_t stream);
+int pa_vlad_residual_normalize(int b, int c, int k, int nblk, const float *raw, const float *part, const float *cw2, float *out, float *asum, float *nrm,
+                               pa_stream_t stream);
+int pa_vlad_residual_normalize_backward(int b, int c, int k, const float *dout, const float *out, const float *nrm, const float *asum, const float *cw2, float *dv,
+                                        float *dasum, float *dcw2, pa_stream_t stream);
+int pa_l2_normalize(int b, int c, int m, const float *x, float *out, float *nrm, pa_stream_t stream);
+int pa_l2_normalize_backward(int b, int c, int m, const float *dout, const float *out, const float *nrm, float *dx, pa_stream_t stream);
+int pa_bn_rows_train(int r, int f, const float *x, const float *gamma, const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                     long long *num_batches_tracked, float *out, float *mean, float *rstd, pa_stream_t stream);
+int pa_bn_rows_backward(int r, int f, const float *dy, const float *x, const float *mean, const float *rstd, const float *gamma, float *dx, float *dgamma,
+                        float *dbeta, pa_stream_t stream);
+int pa_afa_attention(int b, int c, int k, const float *x, const float *r, float *out, float *w, int *arg, pa_stream_t stream);
+int pa_afa_attention_backward(int b, int c, int k, const float *dout, const float *x, const float *w, const int *arg, float *dx, float *dr, pa_stream_t stream);
 
 /* ---- Patch overlap-pair selection of the training step's contrastive patch-feature term (the Python loops of train_one_epoch,
  * place_recognition/train_place_recognition.py:308-372), csrc/patch_pairs.hip.  Records in CSR form: idx1 (nrec), near_off / far_off

@@ -1,0 +1,56 @@
+"""Zero-filled device buffers of one training step out of ONE filled allocation (used by train_ops.py and pointops.py's backward kernels)."""
+import contextlib
+
+import torch
+
+
+class _ZeroArena:
+    active = False
+    device = None
+    buf = None          # uint8 storage of this step, zero-filled by ONE launch
+    off = 0             # bytes handed out
+    used = 0            # bytes asked for in this step (the next step's size)
+    demand = {}         # device -> bytes
+
+
+_arena = _ZeroArena()
+
+
+@contextlib.contextmanager
+def zero_arena(device):
+    """Within the context (one training step: forward + backward), zeros() hands out slices of ONE buffer that a single launch has filled
+    instead of filling ~80 small buffers one launch each (BatchNorm statistics, split-K / atomic accumulators, scatter targets of the
+    backward kernels).  The buffer is allocated afresh per step with the size the previous step asked for (the first step fills its
+    buffers one by one and only measures); tensors that outlive the step -- parameter gradients -- keep it alive through their storage, so
+    nothing is ever handed out twice.  Requests beyond the buffer (a changed shape) fall back to torch.zeros."""
+    a = _arena
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    if a.active or device.type != "cuda":
+        yield
+        return
+    a.active, a.device, a.off, a.used = True, device, 0, 0
+    want = a.demand.get(device, 0)
+    a.buf = torch.zeros(want, dtype=torch.uint8, device=device) if want else None
+    try:
+        yield
+    finally:
+        a.demand[device] = a.used
+        a.buf, a.active = None, False
+
+
+def zeros(shape, dtype, device):
+    """torch.zeros(shape, dtype=dtype, device=device), out of the step's zero-filled buffer when one is open (zero_arena)."""
+    a = _arena
+    if a.active and torch.device(device) == a.device:
+        n = dtype.itemsize
+        for d in shape:
+            n *= d
+        span = (n + 255) // 256 * 256
+        a.used += span
+        if a.buf is not None and a.off + span <= a.buf.numel() and n > 0:
+            t = a.buf[a.off:a.off + n].view(dtype).view(shape)
+            a.off += span
+            return t
+    return torch.zeros(shape, dtype=dtype, device=device)

@@ -66,10 +66,20 @@ _SIGS = {
     "pa_vlad_maxpool": "iiipip",
     "pa_tgemm_nn": "iiiipliipliipppliippipi",
     "pa_tgemm_kk": "iiilpliipppliippliii",
-    "pa_bn_finalize": "iidpppffppp",
+    "pa_bn_finalize": "iidpppffpppp",
     "pa_bn_bwd_reduce": "iilpppipi",
     "pa_bn_eval_params": "iippppfp",
     "pa_quadruplet_loss": "iiiipffiiiipp",
+    "pa_softmax_cols": "iiippp",
+    "pa_softmax_cols_backward": "iiipppp",
+    "pa_vlad_residual_normalize": "iiiipppppp",
+    "pa_vlad_residual_normalize_backward": "iiipppppppp",
+    "pa_l2_normalize": "iiippp",
+    "pa_l2_normalize_backward": "iiipppp",
+    "pa_bn_rows_train": "iipppffpppppp",
+    "pa_bn_rows_backward": "iipppppppp",
+    "pa_afa_attention": "iiippppp",
+    "pa_afa_attention_backward": "iiipppppp",
     "pa_attn_softmax_renorm": "iippp",
     "pa_attn_softmax_renorm_backward": "iipppp",
     "pa_bn_bwd_finalize": "iidpppp",

@@ -450,9 +450,11 @@ __global__ __launch_bounds__(256) void tgemm_kk_kernel(KKArgs a)
 // p[2] mean, p[3] rstd (biased variance, as torch's training forward); running statistics updated in place with momentum and the
 // unbiased variance (torch.nn.BatchNorm semantics).
 __global__ void bn_finalize_kernel(int nch, int batch, double count, const double *__restrict__ stats, const float *__restrict__ gamma, const float *__restrict__ beta,
-                                   float eps, float momentum, float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ p)
+                                   float eps, float momentum, float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ p,
+                                   long long *__restrict__ counter)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && counter) *counter += batch;      // num_batches_tracked: one forward pass per statistics group
     if (c >= nch) return;
     const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
     float rm = running_mean ? running_mean[c] : 0.f, rv = running_mean ? running_var[c] : 0.f;
@@ -731,11 +733,11 @@ PA_API int pa_tgemm_kk(int batch, int M, int N, long K, const float *A, long sAb
 
 // BatchNorm (training) statistics -> per-channel parameter block p (7 * nch floats, rows 0..3 written here, 4..6 by pa_bn_bwd_finalize).
 PA_API int pa_bn_finalize(int nch, int groups, double count, const double *stats, const float *gamma, const float *beta, float eps, float momentum,
-                          float *running_mean, float *running_var, float *p, pa_stream_t stream)
+                          float *running_mean, float *running_var, float *p, long long *num_batches_tracked, pa_stream_t stream)
 {
     PA_REQUIRE(nch > 0 && groups > 0 && count > 0 && stats && p, "pa_bn_finalize: bad arguments");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(pa_div_up(nch, 256)), dim3(256), 0, (hipStream_t)stream, nch, groups, count, stats, gamma, beta, eps, momentum,
-                       running_mean, running_var, p);
+                       running_mean, running_var, p, num_batches_tracked);
     PA_CHECK_LAUNCH("pa_bn_finalize");
     return PA_OK;
 }

@@ -80,9 +80,8 @@ def _netvlad_hip(self, x):
     """Channel-major statement of NetVLADBase.forward on the MI355X: x (B, C, N).  The assignment GEMM + BatchNorm is a one-layer chain
     (cluster-major (B, K, N) output, statistics fused into the GEMM epilogue), the aggregation X . act^T a batched k-contiguous GEMM."""
     layer = train_ops.BNLayer(self.cluster_weights, self.bn1, relu=False, transposed=True)
-    act = torch.softmax(train_ops.chain_train(x, [layer], training=self.training), dim=1)          # (B, K, N)
-    a = act.sum(-1).unsqueeze(1) * self.cluster_weights2                   # (B, C, K)
-    vlad = F.normalize(train_ops.bmm_nt(x, act) - a, dim=1, p=2).contiguous()
+    pre = train_ops.chain_train(x, [layer], training=self.training)                                # (B, K, N) logits
+    vlad = train_ops.netvlad_tail(pre, x, self.cluster_weights2)          # soft-max, X . act^T - a_sum * cw2, intra-normalisation: (B, C, K)
     return vlad.view(-1, self.cluster_size * self.feature_size) if self.flatten else vlad
 
 
@@ -102,6 +101,8 @@ class MLPAttentionLayer(nn.Module):
         r = x
         for mlp in self.mlps:
             r = train_ops.linear_cm(r, mlp.weight) if _hip(x) else torch.matmul(mlp.weight.squeeze(-1), r)
+        if _hip(x):
+            return train_ops.afa_attention(x, r)                     # the two statements below in one launch (csrc/train_glue.hip)
         w = torch.softmax(r.max(dim=1)[0], dim=-1).unsqueeze(1)      # (B, 1, K)
         return F.relu(x + x * w)
 
@@ -123,7 +124,7 @@ class AdaptiveFeatureAggregator(nn.Module):
         else:
             x = self.bn(self.fc(x.flatten(1)))
         if self.l2_norm:
-            x = F.normalize(x)
+            x = train_ops.l2_normalize(x) if _hip(x) else F.normalize(x)
         return x.unsqueeze(-1)
 
 
@@ -152,7 +153,7 @@ class SpatialPyramidNetVLAD(nn.Module):
     def forward(self, features):
         v = torch.cat([vlad(f) for vlad, f in zip(self.vlads, features)], dim=-1)   # (B, C, sum K)
         if self.aggregation_type == 0 and _hip(v):
-            out = F.normalize(train_ops.bn_rows(self.bn, train_ops.matmul_rows(v.flatten(1), self.hidden_weights), self.training))
+            out = train_ops.l2_normalize(train_ops.bn_rows(self.bn, train_ops.matmul_rows(v.flatten(1), self.hidden_weights), self.training))
         elif self.aggregation_type == 0:
             out = F.normalize(self.bn(torch.matmul(v.flatten(1), self.hidden_weights)))
         elif self.aggregation_type == 2:

@@ -148,7 +148,7 @@ class Network(nn.Module):
             hip_dec = self.use_a2a_recon and train_ops.on_device(x)
             feats_cm = fp_features[1].squeeze(-1).index_select(0, self.related_index(x.device, related))   # (R, 256, m0): one patch feature per column
             if self.use_l2_norm:
-                feats_cm = F.normalize(feats_cm, dim=1)
+                feats_cm = train_ops.l2_normalize(feats_cm) if train_ops.on_device(x) else F.normalize(feats_cm, dim=1)
             recon = self.decoder.forward_cm(feats_cm.contiguous()) if hip_dec else None      # all related clouds in one set of launches
             for r, ci in enumerate(related):
                 feats = feats_cm[r].transpose(1, 0)                                          # (m0, 256)

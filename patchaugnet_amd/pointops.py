@@ -17,6 +17,7 @@ import torch.nn as nn
 from torch.autograd import Function
 
 from . import _lib
+from ._arena import zeros
 from ._lib import call, check_device, ptr
 
 
@@ -68,7 +69,7 @@ class Gathering(Function):
     def backward(ctx, grad_out):
         idx, c, n = ctx.for_backwards
         b, m = idx.shape
-        grad = torch.zeros((b, c, n), dtype=torch.float32, device=grad_out.device)
+        grad = zeros((b, c, n), torch.float32, grad_out.device)
         g = grad_out.contiguous()
         with _guard(g):
             call("pa_gathering_backward", b, c, n, m, ptr(g), ptr(idx), ptr(grad))
@@ -119,7 +120,7 @@ class Interpolation(Function):
     def backward(ctx, grad_out):
         idx, weight, m = ctx.interpolation_for_backward
         b, c, n = grad_out.shape
-        grad = torch.zeros((b, c, m), dtype=torch.float32, device=grad_out.device)
+        grad = zeros((b, c, m), torch.float32, grad_out.device)
         g = grad_out.contiguous()
         with _guard(g):
             if 1024 <= n <= 4096 and m <= 8192 and c >= 16:      # atomics-free form: one inversion of the index list, then plain sums
@@ -152,7 +153,7 @@ class Grouping(Function):
     def backward(ctx, grad_out):
         idx, n = ctx.for_backwards
         b, c, m, nsample = grad_out.shape
-        grad = torch.zeros((b, c, n), dtype=torch.float32, device=grad_out.device)
+        grad = zeros((b, c, n), torch.float32, grad_out.device)
         g = grad_out.contiguous()
         with _guard(g):
             call("pa_grouping_backward", b, c, n, m, nsample, ptr(g), ptr(idx), ptr(grad))
@@ -245,7 +246,7 @@ class FeatureGather(Function):
     def backward(ctx, grad):
         distribute_idx, n = ctx.for_backwards
         b, c, m = grad.shape
-        out = torch.zeros((b, c, n), dtype=torch.float32, device=grad.device)
+        out = zeros((b, c, n), torch.float32, grad.device)
         g = grad.contiguous()
         with _guard(g):
             call("pa_featuregather_backward", b, n, m, c, ptr(g), ptr(distribute_idx), ptr(out))

@@ -10,7 +10,7 @@ same four fields) and runs on the device (patchaugnet_amd/patch_pairs.py).
 import numpy as np
 import torch
 
-from . import losses, patch_pairs
+from . import losses, patch_pairs, train_ops
 
 DEFAULTS = {  # configs/patch_aug_net.yaml:55-75 (training section)
     "TRAIN_POSITIVES_PER_QUERY": 2, "TRAIN_NEGATIVES_PER_QUERY": 14, "MARGIN_1": 0.5, "MARGIN_2": 0.2,
@@ -53,27 +53,28 @@ def training_step(model, optimizer, queries, positives, negatives, other_neg, nn
     loss_alpha = loss_alpha or {"place_recognition": 1.0, "patch_recon_a2a": 1.0, "patch_recon_a2b": 1.0}
     model.train()
     optimizer.zero_grad(set_to_none=True)
-    out = run_model(model, queries, positives, negatives, other_neg, nn_dict, num_points, True, args=args)
-    oq, op, on, oo = out["global_desc"]
-    cur = {"place_recognition": losses.get_loss_func(place_loss)(oq, op, on, oo, args["MARGIN_1"], args["MARGIN_2"],
-                                                                 use_min=args["TRIPLET_USE_BEST_POSITIVES"], lazy=args["LOSS_LAZY"],
-                                                                 ignore_zero_loss=args["LOSS_IGNORE_ZERO_BATCH"])}
-    recon = out["patch_recon"]
-    if recon is not None and getattr(model, "use_a2a_recon", False):
-        cur["patch_recon_a2a"] = losses.get_loss_func(recon_loss)(recon["origin_patches"], recon["reconstructed_patches"])
-    if recon is not None and use_patch_feature_contrast:
-        a2b = patch_pairs.patch_feature_contrast_loss(nn_dict, recon, args["MARGIN_1"], num_points,
-                                                      hard_only=epoch > hard_neg_epoch_for_patch_align and use_hard_negative_patch_mining,
-                                                      seed=step_seed)
-        if a2b is not None:
-            cur["patch_recon_a2b"] = a2b
-    total = 0.0
-    for k in cur:
-        cur[k] = cur[k] * loss_alpha.get(k, 1.0)
-        total = total + cur[k]
-    if float(total.detach()) > 1e-10:                             # :390-392
-        total.backward()
-        optimizer.step()
+    with train_ops.zero_arena(next(model.parameters()).device):   # the step's zero-filled accumulators out of one filled buffer
+        out = run_model(model, queries, positives, negatives, other_neg, nn_dict, num_points, True, args=args)
+        oq, op, on, oo = out["global_desc"]
+        cur = {"place_recognition": losses.get_loss_func(place_loss)(oq, op, on, oo, args["MARGIN_1"], args["MARGIN_2"],
+                                                                     use_min=args["TRIPLET_USE_BEST_POSITIVES"], lazy=args["LOSS_LAZY"],
+                                                                     ignore_zero_loss=args["LOSS_IGNORE_ZERO_BATCH"])}
+        recon = out["patch_recon"]
+        if recon is not None and getattr(model, "use_a2a_recon", False):
+            cur["patch_recon_a2a"] = losses.get_loss_func(recon_loss)(recon["origin_patches"], recon["reconstructed_patches"])
+        if recon is not None and use_patch_feature_contrast:
+            a2b = patch_pairs.patch_feature_contrast_loss(nn_dict, recon, args["MARGIN_1"], num_points,
+                                                          hard_only=epoch > hard_neg_epoch_for_patch_align and use_hard_negative_patch_mining,
+                                                          seed=step_seed)
+            if a2b is not None:
+                cur["patch_recon_a2b"] = a2b
+        total = 0.0
+        for k in cur:
+            cur[k] = cur[k] * loss_alpha.get(k, 1.0)
+            total = total + cur[k]
+        if float(total.detach()) > 1e-10:                             # :390-392
+            total.backward()
+            optimizer.step()
     cur["total"] = total
     return {k: float(v.detach()) for k, v in cur.items()}
 
@@ -212,19 +213,20 @@ class GraphedTrainer:
 
     def _body(self, k=0, geometry=None):
         q, p, n, o = self.statics[k]
-        out = run_model(self.model, q, p, n, o, self.nn_dict, self.num_points, True, device=self.device, args=self.args, geometry=geometry)
-        oq, op, on, oo = out["global_desc"]
-        a = self.args
-        cur = {"place_recognition": losses.get_loss_func(self.place_loss)(oq, op, on, oo, a["MARGIN_1"], a["MARGIN_2"], use_min=a["TRIPLET_USE_BEST_POSITIVES"],
-                                                                          lazy=a["LOSS_LAZY"], ignore_zero_loss=a["LOSS_IGNORE_ZERO_BATCH"])}
-        recon = out["patch_recon"]
-        if recon is not None and getattr(self.model, "use_a2a_recon", False):
-            cur["patch_recon_a2a"] = losses.get_loss_func(self.recon_loss)(recon["origin_patches"], recon["reconstructed_patches"])
-        total = 0.0
-        for k2 in cur:
-            cur[k2] = cur[k2] * self.loss_alpha.get(k2, 1.0)
-            total = total + cur[k2]
-        total.backward()
+        with train_ops.zero_arena(self.device):
+            out = run_model(self.model, q, p, n, o, self.nn_dict, self.num_points, True, device=self.device, args=self.args, geometry=geometry)
+            oq, op, on, oo = out["global_desc"]
+            a = self.args
+            cur = {"place_recognition": losses.get_loss_func(self.place_loss)(oq, op, on, oo, a["MARGIN_1"], a["MARGIN_2"], use_min=a["TRIPLET_USE_BEST_POSITIVES"],
+                                                                              lazy=a["LOSS_LAZY"], ignore_zero_loss=a["LOSS_IGNORE_ZERO_BATCH"])}
+            recon = out["patch_recon"]
+            if recon is not None and getattr(self.model, "use_a2a_recon", False):
+                cur["patch_recon_a2a"] = losses.get_loss_func(self.recon_loss)(recon["origin_patches"], recon["reconstructed_patches"])
+            total = 0.0
+            for k2 in cur:
+                cur[k2] = cur[k2] * self.loss_alpha.get(k2, 1.0)
+                total = total + cur[k2]
+            total.backward()
         self.optimizer.step()
         cur["total"] = total
         return {k2: v.detach() for k2, v in cur.items()}

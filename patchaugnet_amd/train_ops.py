@@ -21,6 +21,7 @@ plain torch statements remain only as their CPU form (PointNetVLAD's CPU configu
 import torch
 from torch.autograd import Function
 
+from ._arena import zero_arena, zeros              # noqa: F401  (zero_arena is part of this module's interface)
 from ._lib import call, check_device, ptr
 
 STAT_SLOTS = 32          # PA_BN_STAT_SLOTS (include/patchaugnet_hip.h): replicas of a layer's statistics block
@@ -97,12 +98,11 @@ class _ChainTrain(Function):
         G = B if groups else 1                    # statistics groups
         outs = [L.out_channels for L in layers]
         # one zero-filled arena for every layer's statistics replicas, one for the parameter blocks
-        stats_all = torch.zeros(G * STAT_SLOTS * 2 * sum(outs), dtype=torch.float64, device=dev) if training else None
+        stats_all = zeros((G * STAT_SLOTS * 2 * sum(outs),), torch.float64, dev) if training else None
         p_all = torch.empty(G * 7 * sum(outs), dtype=torch.float32, device=dev)
         ys, ps = [], []
         prev, prevp = x, None
         so = po = 0
-        counters = []
         with _guard(x):
             for i, L in enumerate(layers):
                 W, O = Ws[i], outs[i]
@@ -118,17 +118,14 @@ class _ChainTrain(Function):
                          bmode=0 if i == 0 else 1, bp=prevp, bias=biases[i], stats=stats, per_batch_stats=groups)
                 if training:
                     rm, rv, mom = _bn_buffers(L.bn)
-                    call("pa_bn_finalize", O, G, float(B * P // G), ptr(stats), ptr(gammas[i]), ptr(betas[i]), float(L.bn.eps), mom, ptr(rm), ptr(rv), ptr(p))
-                    if rm is not None and L.bn.num_batches_tracked is not None:
-                        counters.append(L.bn.num_batches_tracked)
+                    nbt = L.bn.num_batches_tracked if rm is not None else None           # += G inside the kernel
+                    call("pa_bn_finalize", O, G, float(B * P // G), ptr(stats), ptr(gammas[i]), ptr(betas[i]), float(L.bn.eps), mom, ptr(rm), ptr(rv), ptr(p), ptr(nbt))
                 else:       # eval(): the running statistics, nothing updated (torch.nn.BatchNorm in eval mode)
                     assert L.bn.running_mean is not None, "eval-mode BatchNorm without running statistics uses batch statistics: call with training=True"
                     call("pa_bn_eval_params", O, G, ptr(gammas[i]), ptr(betas[i]), ptr(L.bn.running_mean), ptr(L.bn.running_var), float(L.bn.eps), ptr(p))
                 ys.append(y)
                 ps.append(p)
                 prev, prevp, cin = y, p, O
-            if counters:
-                torch._foreach_add_(counters, G)
             Pout = P // pool if pool else P
             if pool:
                 assert P % pool == 0
@@ -151,10 +148,10 @@ class _ChainTrain(Function):
         per_layer = [None] * len(layers)
         outs = [y.shape[1] for y in ys]
         ins = [x.shape[1]] + outs[:-1]
-        sums_all = torch.zeros(G * 2 * sum(outs), dtype=torch.float64, device=dev)
+        sums_all = zeros((G * 2 * sum(outs),), torch.float64, dev)
         # weight gradients (split-K partial tiles are added with atomics: zero-filled) and dgamma / dbeta, one arena
         nW = [o * c for o, c in zip(outs, ins)]
-        grads = torch.zeros(sum(nW) + 2 * sum(outs), dtype=torch.float32, device=dev)
+        grads = zeros((sum(nW) + 2 * sum(outs),), torch.float32, dev)
         wo = [0]
         for n in nW:
             wo.append(wo[-1] + n)
@@ -248,7 +245,7 @@ class _LinearCM(Function):
                 dx = torch.empty_like(x)
                 tgemm_nn(B, C, P, O, W, 0, C, False, g, O * P, P, dx, C * P, P)
             if ctx.needs_input_grad[1]:
-                dW = torch.zeros((O, C), dtype=torch.float32, device=x.device)
+                dW = zeros((O, C), torch.float32, x.device)
                 tgemm_kk(B, O, C, P, g, O * P, P, x, C * P, P, dW, 0, C)
                 dW = dW.view_as(W)
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -270,7 +267,7 @@ class _BmmNT(Function):
         batch, M, K = a.shape
         N = b.shape[1]
         assert b.shape[0] == batch and b.shape[2] == K
-        c = torch.zeros((batch, M, N), dtype=torch.float32, device=a.device)
+        c = zeros((batch, M, N), torch.float32, a.device)
         with _guard(a):
             tgemm_kk(batch, M, N, K, a, M * K, K, b, N * K, K, c, M * N, N, per_batch=1)
         ctx.save_for_backward(a, b)
@@ -322,7 +319,7 @@ class _BmmNN(Function):
         da = db = None
         with _guard(a):
             if ctx.needs_input_grad[0]:      # dA (M x K) = dC (M x N) . B (K x N)^T: both contiguous along n
-                da = torch.zeros_like(a)
+                da = zeros(a.shape, torch.float32, a.device)
                 tgemm_kk(batch, M, K, N, g, M * N, N, b, K * N, N, da, M * K, K, per_batch=1)
             if ctx.needs_input_grad[1]:      # dB (K x N) = A^T (K x M) . dC (M x N)
                 db = torch.empty_like(b)
@@ -353,7 +350,7 @@ class _GramTN(Function):
         (y,) = ctx.saved_tensors
         batch, C, N = y.shape
         g = ge.contiguous()
-        dy = torch.zeros_like(y)
+        dy = zeros(y.shape, torch.float32, y.device)
         with _guard(y):
             # dY = Y (dE + dE^T):  Y . dE^T (contiguous along the contraction: split-K kernel, accumulates into the zero-filled dy) ...
             tgemm_kk(batch, C, N, N, y, C * N, N, g, N * N, N, dy, C * N, N, per_batch=1)
@@ -464,7 +461,7 @@ class _MatmulRows(Function):
         dx = dW = None
         with _guard(x):
             if ctx.needs_input_grad[0]:      # dX (R x K) = dY (R x N) . W (K x N)^T
-                dx = torch.zeros_like(x)
+                dx = zeros(x.shape, torch.float32, x.device)
                 tgemm_kk(1, R, K, N, g, 0, N, W, 0, N, dx, 0, K)
             if ctx.needs_input_grad[1]:      # dW (K x N) = X^T (K x R) . dY (R x N)
                 dW = torch.empty_like(W)
@@ -476,6 +473,155 @@ def matmul_rows(x, W):
     return _MatmulRows.apply(x.contiguous(), W)
 
 
+class _NetVladTail(Function):
+    """NetVLAD after the assignment GEMM + BatchNorm (loupe.py:207-221): pre (B, K, N) logits, x (B, C, N) features, cw2 (1, C, K) ->
+    normalise_C(x . act^T - a_sum * cw2), act = softmax_K(pre), a_sum = act summed over the points.  Two launches of csrc/train_glue.hip around the
+    MFMA GEMM forward, three around the two GEMMs backward (the torch statement: 7 launches forward, ~20 backward)."""
+
+    @staticmethod
+    def forward(ctx, pre, x, cw2):
+        check_device(pre, x, cw2)
+        _f32(pre, x, cw2)
+        B, K, N = pre.shape
+        C = x.shape[1]
+        assert x.shape == (B, C, N) and cw2.numel() == C * K
+        dev = pre.device
+        nblk = (N + 255) // 256
+        act = torch.empty_like(pre)
+        part = torch.empty((B, nblk, K), dtype=torch.float32, device=dev)
+        raw = zeros((B, C, K), torch.float32, dev)                               # split-K accumulates
+        out = torch.empty((B, C, K), dtype=torch.float32, device=dev)
+        asum = torch.empty((B, K), dtype=torch.float32, device=dev)
+        nrm = torch.empty((B, K), dtype=torch.float32, device=dev)
+        with _guard(pre):
+            call("pa_softmax_cols", B, K, N, ptr(pre), ptr(act), ptr(part))
+            tgemm_kk(B, C, K, N, x, C * N, N, act, K * N, N, raw, C * K, K, per_batch=1)
+            call("pa_vlad_residual_normalize", B, C, K, nblk, ptr(raw), ptr(part), ptr(cw2), ptr(out), ptr(asum), ptr(nrm))
+        ctx.save_for_backward(x, act, cw2, out, asum, nrm)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, act, cw2, out, asum, nrm = ctx.saved_tensors
+        B, K, N = act.shape
+        C = x.shape[1]
+        g = gout.contiguous()
+        dv = torch.empty_like(out)
+        dasum = torch.empty_like(asum)
+        dcw2 = torch.empty_like(cw2) if ctx.needs_input_grad[2] else None
+        dx = dpre = None
+        with _guard(x):
+            call("pa_vlad_residual_normalize_backward", B, C, K, ptr(g), ptr(out), ptr(nrm), ptr(asum), ptr(cw2), ptr(dv), ptr(dasum), ptr(dcw2))
+            if ctx.needs_input_grad[1]:      # dX (C x N) = dV (C x K) . act (K x N)
+                dx = torch.empty_like(x)
+                tgemm_nn(B, C, N, K, dv, C * K, K, True, act, K * N, N, dx, C * N, N)
+            if ctx.needs_input_grad[0]:      # dact (K x N) = dV^T (K x C) . X (C x N), then through the soft-max in place
+                dpre = torch.empty_like(act)
+                tgemm_nn(B, K, N, C, dv, C * K, K, False, x, C * N, N, dpre, K * N, N)
+                call("pa_softmax_cols_backward", B, K, N, ptr(act), ptr(dpre), ptr(dasum), ptr(dpre))
+        return dpre, dx, dcw2
+
+
+def netvlad_tail(pre, x, cw2):
+    return _NetVladTail.apply(pre.contiguous(), x.contiguous(), cw2.contiguous())
+
+
+class _L2Normalize(Function):
+    """torch.nn.functional.normalize(x, dim=1) of a (B, C) or (B, C, M) tensor, one launch each way (csrc/train_glue.hip)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        check_device(x)
+        _f32(x)
+        B, C = x.shape[:2]
+        M = x.numel() // (B * C)
+        out = torch.empty_like(x)
+        nrm = torch.empty((B, M), dtype=torch.float32, device=x.device)
+        with _guard(x):
+            call("pa_l2_normalize", B, C, M, ptr(x), ptr(out), ptr(nrm))
+        ctx.save_for_backward(out, nrm)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        out, nrm = ctx.saved_tensors
+        B, C = out.shape[:2]
+        g = gout.contiguous()
+        dx = torch.empty_like(out)
+        with _guard(out):
+            call("pa_l2_normalize_backward", B, C, nrm.shape[1], ptr(g), ptr(out), ptr(nrm), ptr(dx))
+        return dx
+
+
+def l2_normalize(x):
+    """F.normalize(x, dim=1) (p = 2, eps = 1e-12) for x (B, C) or (B, C, ...)."""
+    return _L2Normalize.apply(x.contiguous())
+
+
+class _AfaAttention(Function):
+    """MLPAttentionLayer's tail (loupe.py:27-41): r = conv(x) (B, C, K) -> w = softmax_K(max_C r), out = relu(x + x * w)."""
+
+    @staticmethod
+    def forward(ctx, x, r):
+        check_device(x, r)
+        _f32(x, r)
+        B, C, K = x.shape
+        out = torch.empty_like(x)
+        w = torch.empty((B, K), dtype=torch.float32, device=x.device)
+        arg = torch.empty((B, K), dtype=torch.int32, device=x.device)
+        with _guard(x):
+            call("pa_afa_attention", B, C, K, ptr(x), ptr(r), ptr(out), ptr(w), ptr(arg))
+        ctx.save_for_backward(x, w, arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, w, arg = ctx.saved_tensors
+        B, C, K = x.shape
+        g = gout.contiguous()
+        dx = torch.empty_like(x)
+        dr = torch.empty_like(x) if ctx.needs_input_grad[1] else None
+        with _guard(x):
+            call("pa_afa_attention_backward", B, C, K, ptr(g), ptr(x), ptr(w), ptr(arg), ptr(dx), ptr(dr))
+        return dx, dr
+
+
+def afa_attention(x, r):
+    return _AfaAttention.apply(x.contiguous(), r.contiguous())
+
+
+class _BNRowsTrain(Function):
+    """torch.nn.BatchNorm1d in train mode over the rows of a small (R, F) matrix (the 256-wide heads: R = clouds in the step): one launch each way,
+    running statistics and num_batches_tracked updated by the forward kernel like the torch module does."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn):
+        check_device(x)
+        _f32(x, gamma, beta)
+        R, F_ = x.shape
+        out = torch.empty_like(x)
+        mean = torch.empty(F_, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(F_, dtype=torch.float32, device=x.device)
+        rm, rv, mom = _bn_buffers(bn)
+        nbt = bn.num_batches_tracked if (rm is not None and bn.num_batches_tracked is not None) else None
+        with _guard(x):
+            call("pa_bn_rows_train", R, F_, ptr(x), ptr(gamma), ptr(beta), float(bn.eps), mom, ptr(rm), ptr(rv), ptr(nbt), ptr(out), ptr(mean), ptr(rstd))
+        ctx.save_for_backward(x, mean, rstd, gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, mean, rstd, gamma = ctx.saved_tensors
+        R, F_ = x.shape
+        g = gout.contiguous()
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(F_, dtype=torch.float32, device=x.device) if gamma is not None and ctx.needs_input_grad[1] else None
+        dbeta = torch.empty(F_, dtype=torch.float32, device=x.device) if ctx.needs_input_grad[2] else None
+        with _guard(x):
+            call("pa_bn_rows_backward", R, F_, ptr(g), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dx), ptr(dgamma), ptr(dbeta))
+        return dx, dgamma, dbeta, None
+
+
 def bn_rows(bn, x, training):
     """BatchNorm1d over the rows of a small (R, F) matrix in the module's mode (elementwise: no dense kernel either way)."""
     if training:
@@ -484,14 +630,5 @@ def bn_rows(bn, x, training):
 
 
 def bn_rows_train(bn, x):
-    """BatchNorm1d in train mode over the rows of a small (R, F) matrix (the 256-wide heads: R = clouds in the step), as plain
-    elementwise tensor ops under autograd -- a few KB; running statistics updated like torch.nn.BatchNorm1d."""
-    mean = x.mean(0)
-    var = x.var(0, unbiased=False)
-    if bn.track_running_stats and bn.running_mean is not None:
-        with torch.no_grad():
-            n = x.shape[0]
-            bn.running_mean.mul_(1 - bn.momentum).add_(bn.momentum * mean)
-            bn.running_var.mul_(1 - bn.momentum).add_(bn.momentum * var * (n / max(n - 1, 1)))
-            bn.num_batches_tracked += 1
-    return (x - mean) * torch.rsqrt(var + bn.eps) * bn.weight + bn.bias
+    """BatchNorm1d in train mode over the rows of a small (R, F) matrix (csrc/train_glue.hip)."""
+    return _BNRowsTrain.apply(x.contiguous(), bn.weight, bn.bias, bn)

@@ -1,0 +1,144 @@
+"""csrc/train_glue.hip -- the aggregation heads' small non-GEMM steps under autograd (NetVLAD soft-max / residual / intra-normalisation,
+F.normalize, BatchNorm1d over a few rows, APFA attention) -- against the torch statements of the same steps evaluated in float64 on the CPU
+(patch_aug_net/models/loupe.py:8-66, :196-222).  Values and every gradient; tolerance 2e-5 of the tensor's scale (fp32 sums, different order)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def close(got, ref, rtol=2e-5):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    scale = ref.abs().max().item() + 1e-12
+    err = (got - ref).abs().max().item()
+    assert err <= rtol * scale, f"max err {err:.3e} vs scale {scale:.3e}"
+
+
+def run_both(fn_hip, fn_ref, inputs, seed=0):
+    """inputs: list of CPU fp32 tensors; returns after comparing the value and the gradient of every input under a random cotangent."""
+    hip_in = [t.detach().clone().cuda().requires_grad_(True) for t in inputs]
+    ref_in = [t.detach().clone().double().requires_grad_(True) for t in inputs]
+    out_h, out_r = fn_hip(*hip_in), fn_ref(*ref_in)
+    close(out_h, out_r)
+    w = torch.randn(out_r.shape, generator=torch.Generator().manual_seed(seed), dtype=torch.float64)
+    (out_h * w.float().cuda()).sum().backward()
+    (out_r * w).sum().backward()
+    for i, (a, b) in enumerate(zip(hip_in, ref_in)):
+        assert a.grad is not None, f"input {i} received no gradient"
+        close(a.grad, b.grad)
+
+
+@pytest.mark.parametrize("B,C,K,N", [(3, 32, 4, 128), (2, 256, 16, 1000), (2, 256, 64, 4096), (1, 8, 300, 70), (2, 16, 1, 64)])
+def test_netvlad_tail(B, C, K, N):
+    from patchaugnet_amd import train_ops
+    g = torch.Generator().manual_seed(B * 1000 + K)
+    pre, x, cw2 = torch.randn(B, K, N, generator=g) * 2, torch.randn(B, C, N, generator=g), torch.randn(1, C, K, generator=g) / C ** 0.5
+
+    def ref(pre, x, cw2):
+        act = torch.softmax(pre, dim=1)
+        a = act.sum(-1).unsqueeze(1) * cw2
+        return F.normalize(torch.matmul(x, act.transpose(1, 2)) - a, dim=1, p=2)
+    run_both(train_ops.netvlad_tail, ref, [pre, x, cw2])
+
+
+@pytest.mark.parametrize("shape", [(5, 256), (3, 64, 1000), (2, 256, 1024), (1, 7, 3)])
+def test_l2_normalize(shape):
+    from patchaugnet_amd import train_ops
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(len(shape)))
+    run_both(train_ops.l2_normalize, lambda t: F.normalize(t, dim=1), [x])
+
+
+def test_l2_normalize_of_a_zero_vector_is_zero_with_the_clamped_gradient():
+    from patchaugnet_amd import train_ops
+    x = torch.randn(4, 16)
+    x[2] = 0
+    run_both(train_ops.l2_normalize, lambda t: F.normalize(t, dim=1), [x])
+
+
+@pytest.mark.parametrize("B,C,K", [(4, 32, 84), (18, 256, 84), (2, 16, 300), (1, 5, 1)])
+def test_afa_attention(B, C, K):
+    from patchaugnet_amd import train_ops
+    g = torch.Generator().manual_seed(C + K)
+    x, r = torch.randn(B, C, K, generator=g), torch.randn(B, C, K, generator=g)
+
+    def ref(x, r):
+        w = torch.softmax(r.max(dim=1)[0], dim=-1).unsqueeze(1)
+        return F.relu(x + x * w)
+    run_both(train_ops.afa_attention, ref, [x, r])
+
+
+@pytest.mark.parametrize("R,Fdim", [(18, 256), (5, 40), (36, 1000)])
+def test_bn_rows_train_matches_batchnorm1d(R, Fdim):
+    from patchaugnet_amd import train_ops
+    g = torch.Generator().manual_seed(R)
+    bn_ref = torch.nn.BatchNorm1d(Fdim).double()
+    with torch.no_grad():
+        bn_ref.weight.copy_(torch.rand(Fdim, generator=g) + 0.5)
+        bn_ref.bias.copy_(torch.randn(Fdim, generator=g) * 0.1)
+        bn_ref.running_mean.copy_(torch.randn(Fdim, generator=g))
+        bn_ref.running_var.copy_(torch.rand(Fdim, generator=g) + 0.5)
+    bn_hip = torch.nn.BatchNorm1d(Fdim)
+    bn_hip.load_state_dict({k: (v.float() if v.is_floating_point() else v) for k, v in bn_ref.state_dict().items()})
+    bn_hip = bn_hip.cuda()
+    x = torch.randn(R, Fdim, generator=g) * 3 + 1
+    xh = x.clone().cuda().requires_grad_(True)
+    xr = x.clone().double().requires_grad_(True)
+    for _ in range(2):                                   # two steps: the running statistics and the counter move twice
+        oh = train_ops.bn_rows(bn_hip, xh, True)
+        orf = bn_ref(xr)
+    close(oh, orf)
+    w = torch.randn(R, Fdim, generator=g, dtype=torch.float64)
+    xh.grad = None
+    xr.grad = None
+    bn_hip.zero_grad()
+    bn_ref.zero_grad()
+    (oh * w.float().cuda()).sum().backward()
+    (orf * w).sum().backward()
+    close(xh.grad, xr.grad)
+    close(bn_hip.weight.grad, bn_ref.weight.grad)
+    close(bn_hip.bias.grad, bn_ref.bias.grad)
+    close(bn_hip.running_mean, bn_ref.running_mean)
+    close(bn_hip.running_var, bn_ref.running_var)
+    assert int(bn_hip.num_batches_tracked) == int(bn_ref.num_batches_tracked) == 2
+
+
+def test_chain_train_counts_batches_inside_the_finalize_kernel():
+    """num_batches_tracked of the chain's BatchNorm layers: += 1 per forward (+= B with per-cloud statistics groups), no library launch."""
+    from patchaugnet_amd import train_ops
+    bn = torch.nn.BatchNorm1d(16).cuda()
+    W = torch.randn(16, 8, device="cuda", requires_grad=True)
+    x = torch.randn(3, 8, 50, device="cuda")
+    train_ops.chain_train(x, [train_ops.BNLayer(W, bn)], training=True)
+    assert int(bn.num_batches_tracked) == 1
+    train_ops.chain_train(x, [train_ops.BNLayer(W, bn)], groups=True, training=True)
+    assert int(bn.num_batches_tracked) == 4
+    train_ops.chain_train(x, [train_ops.BNLayer(W, bn)], training=False)
+    assert int(bn.num_batches_tracked) == 4
+
+
+def test_zero_arena_hands_out_zero_filled_disjoint_buffers_and_learns_its_size():
+    """train_ops.zero_arena: the first step measures, later steps slice ONE filled buffer; escaped tensors stay valid after the step."""
+    from patchaugnet_amd import _arena, train_ops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    _arena._arena.demand.pop(dev, None)
+    kept = []
+    for step in range(3):
+        with train_ops.zero_arena("cuda"):
+            a = train_ops.zeros((5, 7), torch.float32, dev)
+            b = train_ops.zeros((33,), torch.float64, dev)
+            c = train_ops.zeros((2, 3, 4), torch.float32, dev)
+            assert a.dtype == torch.float32 and b.dtype == torch.float64 and a.shape == (5, 7) and c.shape == (2, 3, 4)
+            assert not a.any() and not b.any() and not c.any()
+            shared = a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+            assert shared == (step > 0), "the first step measures, the next ones share one buffer"
+            a += 1
+            b += 2
+            c += 3
+            assert (a == 1).all() and (b == 2).all() and (c == 3).all()          # disjoint
+            big = train_ops.zeros((1 << 16,), torch.float32, dev)                 # beyond what was measured only in step 0 .. then learnt
+            assert not big.any()
+            kept.append(a)
+    assert all((t == 1).all() for t in kept)                                      # an escaped tensor keeps its step's buffer alive
+    assert train_ops.zeros((4,), torch.float32, dev).untyped_storage().nbytes() == 16   # outside a step: plain torch.zeros

@@ -1,0 +1,55 @@
+"""Which Python lines of the training step's FORWARD call kernel-launching aten ops (TorchDispatchMode + traceback); the backward mirrors them.
+python tools/probes/train_glue_lines.py"""
+import collections
+import os
+import sys
+import traceback
+import torch
+from torch.utils._python_dispatch import TorchDispatchMode
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from patchaugnet_amd import configs, patch_aug_net
+from patchaugnet_amd.train import training_step
+from patchaugnet_amd.weights import seeded_state_dict
+
+VIEWS = {"view", "_unsafe_view", "expand", "reshape", "transpose", "t", "permute", "unsqueeze", "squeeze", "select", "slice", "alias", "detach", "as_strided",
+         "empty", "empty_like", "empty_strided", "new_empty", "unbind", "split", "split_with_sizes", "chunk", "narrow", "unflatten", "flatten", "is_same_size",
+         "_local_scalar_dense", "lift_fresh", "is_pinned", "stride", "size", "numel", "sym_size", "sym_numel", "sym_stride", "storage_offset", "sym_storage_offset", "dim",
+         "result_type", "can_cast", "_has_compatible_shallow_copy_type", "is_nonzero", "contiguous", "clone" if False else "__x", "movedim", "unsafe_split", "view_as", "_reshape_alias"}
+
+
+class Count(TorchDispatchMode):
+    def __init__(self):
+        super().__init__()
+        self.by = collections.defaultdict(collections.Counter)
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = func.overloadpacket.__name__
+        if name not in VIEWS:
+            fr = [f for f in traceback.extract_stack() if "/patchaugnet_amd/" in f.filename]
+            where = f"{os.path.relpath(fr[-1].filename, ROOT)}:{fr[-1].lineno} {fr[-1].name}" if fr else "(torch)"
+            self.by[where][name] += 1
+        return func(*args, **(kwargs or {}))
+
+
+cfg = configs.patch_aug_net_config()
+model = patch_aug_net.Network(param=cfg, use_a2a_recon=True, use_l2_norm=True)
+model.load_state_dict(seeded_state_dict(model.state_dict()))
+model = model.cuda()
+g = torch.Generator().manual_seed(5)
+n = 4096
+q, pos, neg, oth = ((torch.rand(1, k, n, 3, generator=g) * 2 - 1).cuda() for k in (1, 2, 14, 1))
+nn_dict = {(0, 1): torch.randint(0, n, (1024, 1), generator=g).numpy(), (0, 2): torch.randint(0, n, (1024, 1), generator=g).numpy()}
+opt = torch.optim.Adam(model.parameters(), lr=1e-5, fused=True)
+step = lambda: training_step(model, opt, q, pos, neg, oth, nn_dict=nn_dict, num_points=n)
+for _ in range(2):
+    step()
+with Count() as c:
+    step()
+tot = 0
+for where, ops in sorted(c.by.items(), key=lambda kv: -sum(kv[1].values())):
+    k = sum(ops.values())
+    tot += k
+    print(f"{k:4d}  {where:70s} {dict(ops.most_common(6))}")
+print("total ops", tot)
