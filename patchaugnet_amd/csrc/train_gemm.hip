@@ -602,6 +602,74 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(int C, long P, int pool, 
     }
 }
 
+// The un-pooled form with 16-byte accesses (P % 4 == 0, aligned rows): P4 = P / 4
+__global__ __launch_bounds__(256) void bn_apply_vec_kernel(int C, long P4, int relu, const float *__restrict__ y, const float *__restrict__ p, float *__restrict__ out, long sPb,
+                                                            long rows)
+{
+    for (long row = blockIdx.y; row < rows; row += gridDim.y) {
+        const int c = (int)(row % C);
+        const float *pr = p + (size_t)(row / C) * sPb;
+        const float scale = pr[c], shift = pr[C + c];
+        const float4 *src = reinterpret_cast<const float4 *>(y) + (size_t)row * P4;
+        float4 *dst = reinterpret_cast<float4 *>(out) + (size_t)row * P4;
+        for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < P4; j += (long)gridDim.x * 256) {
+            float4 v = src[j];
+            v.x = fmaf(v.x, scale, shift); v.y = fmaf(v.y, scale, shift); v.z = fmaf(v.z, scale, shift); v.w = fmaf(v.w, scale, shift);
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            dst[j] = v;
+        }
+    }
+}
+
+// The pooled form through LDS: a workgroup reads the 256 * pool consecutive inputs of 256 outputs with contiguous (16-byte when VEC) loads into rows of
+// pool + 1 floats, then thread j walks its own row.  (The direct form above reads `pool` floats per thread at a stride of `pool` floats: 1.1 TB/s on
+// the first set-abstraction level's 94 MB.)  Dynamic LDS: 256 * (pool + 1) floats.
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_apply_pool_lds_kernel(int C, long P, int pool, int relu, const float *__restrict__ y, const float *__restrict__ p,
+                                                                 float *__restrict__ out, signed char *__restrict__ arg, long sPb, long rows)
+{
+    extern __shared__ float tile[];
+    const long Pout = P / pool;
+    const int st = pool + 1;
+    for (long row = blockIdx.y; row < rows; row += gridDim.y) {
+        const int c = (int)(row % C);
+        const float *pr = p + (size_t)(row / C) * sPb;
+        const float scale = pr[c], shift = pr[C + c];
+        for (long j0 = (long)blockIdx.x * 256; j0 < Pout; j0 += (long)gridDim.x * 256) {
+            const int cnt = (int)(Pout - j0 < 256 ? Pout - j0 : 256), nel = cnt * pool;
+            const float *src = y + (size_t)row * P + j0 * pool;
+            if (VEC) {
+                for (int i = threadIdx.x; i < nel / 4; i += 256) {
+                    float4 v = reinterpret_cast<const float4 *>(src)[i];
+                    v.x = fmaf(v.x, scale, shift); v.y = fmaf(v.y, scale, shift); v.z = fmaf(v.z, scale, shift); v.w = fmaf(v.w, scale, shift);
+                    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    const int e = 4 * i, r = e / pool;
+                    float *d = tile + r * st + (e - r * pool);
+                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                }
+            } else {
+                for (int e = threadIdx.x; e < nel; e += 256) {
+                    float v = fmaf(src[e], scale, shift);
+                    if (relu) v = fmaxf(v, 0.f);
+                    const int r = e / pool;
+                    tile[r * st + (e - r * pool)] = v;
+                }
+            }
+            __syncthreads();
+            if ((int)threadIdx.x < cnt) {
+                const float *t = tile + threadIdx.x * st;
+                float best = -INFINITY;
+                int bi = 0;
+                for (int q = 0; q < pool; ++q)
+                    if (t[q] > best) { best = t[q]; bi = q; }     // first maximum, like torch.max
+                out[(size_t)row * Pout + j0 + threadIdx.x] = best;
+                arg[(size_t)row * Pout + j0 + threadIdx.x] = (signed char)bi;
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // gradient of the pooled output scattered back to the full (B, C, P) grid: g[j*pool + s] = (s == arg[j]) ? gp[j] : 0
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(long Pout, int pool, const float *__restrict__ gp, const signed char *__restrict__ arg, float *__restrict__ g, long rows)
 {
@@ -612,6 +680,19 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(long Pout, int pool, c
         float *dst = g + ((size_t)row * Pout + j) * pool;
         for (int s = 0; s < pool; ++s) dst[s] = s == a ? v : 0.f;
     }
+}
+
+// pool % 4 == 0 and aligned rows: 16-byte stores
+__global__ __launch_bounds__(256) void maxpool_bwd_vec_kernel(long Pout, int pool, const float *__restrict__ gp, const signed char *__restrict__ arg, float *__restrict__ g, long rows)
+{
+    for (long row = blockIdx.y; row < rows; row += gridDim.y)
+        for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < Pout; j += (long)gridDim.x * 256) {
+            const float v = gp[(size_t)row * Pout + j];
+            const int a = arg[(size_t)row * Pout + j];
+            float4 *dst = reinterpret_cast<float4 *>(g + ((size_t)row * Pout + j) * pool);
+            for (int q = 0; q < pool / 4; ++q)
+                dst[q] = make_float4(4 * q == a ? v : 0.f, 4 * q + 1 == a ? v : 0.f, 4 * q + 2 == a ? v : 0.f, 4 * q + 3 == a ? v : 0.f);
+        }
 }
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -785,8 +866,20 @@ PA_API int pa_bn_apply(int B, int C, long P, int pool, int relu, const float *y,
     long gx = (Pout + 255) / 256;
     if (gx > 64) gx = 64;
     const long rows = (long)B * C;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)gx, (unsigned)(rows < 65535 ? rows : 65535)), dim3(256), 0, (hipStream_t)stream, C, P, pool, relu, y, p, out, arg,
-                       per_batch_stats ? 7L * C : 0L, rows);
+    const dim3 grid((unsigned)gx, (unsigned)(rows < 65535 ? rows : 65535));
+    const long sPb = per_batch_stats ? 7L * C : 0L;
+    hipStream_t st = (hipStream_t)stream;
+    static const bool plain = getenv("PA_BN_APPLY_PLAIN") != nullptr;          // A/B switch: the direct kernels only
+    if (!plain && pool <= 0 && P % 4 == 0 && aligned16(y) && aligned16(out)) {
+        long g4 = (P / 4 + 255) / 256;
+        hipLaunchKernelGGL(bn_apply_vec_kernel, dim3((unsigned)(g4 > 64 ? 64 : g4), grid.y), dim3(256), 0, st, C, P / 4, relu, y, p, out, sPb, rows);
+    } else if (!plain && pool > 0 && pool <= 63) {
+        const size_t lds = 256 * (size_t)(pool + 1) * sizeof(float);
+        if (pool % 4 == 0 && aligned16(y)) hipLaunchKernelGGL(bn_apply_pool_lds_kernel<true>, grid, dim3(256), lds, st, C, P, pool, relu, y, p, out, arg, sPb, rows);
+        else hipLaunchKernelGGL(bn_apply_pool_lds_kernel<false>, grid, dim3(256), lds, st, C, P, pool, relu, y, p, out, arg, sPb, rows);
+    } else {
+        hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(256), 0, st, C, P, pool, relu, y, p, out, arg, sPb, rows);
+    }
     PA_CHECK_LAUNCH("pa_bn_apply");
     return PA_OK;
 }
@@ -796,7 +889,9 @@ PA_API int pa_maxpool_bwd(int rows, long Pout, int pool, const float *gp, const 
     PA_REQUIRE(rows > 0 && Pout > 0 && pool > 0 && gp && arg && g, "pa_maxpool_bwd: bad arguments");
     long gx = (Pout + 255) / 256;
     if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)gx, (unsigned)(rows < 65535 ? rows : 65535)), dim3(256), 0, (hipStream_t)stream, Pout, pool, gp, arg, g, (long)rows);
+    const dim3 grid((unsigned)gx, (unsigned)(rows < 65535 ? rows : 65535));
+    if (pool % 4 == 0 && aligned16(g)) hipLaunchKernelGGL(maxpool_bwd_vec_kernel, grid, dim3(256), 0, (hipStream_t)stream, Pout, pool, gp, arg, g, (long)rows);
+    else hipLaunchKernelGGL(maxpool_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, Pout, pool, gp, arg, g, (long)rows);
     PA_CHECK_LAUNCH("pa_maxpool_bwd");
     return PA_OK;
 }

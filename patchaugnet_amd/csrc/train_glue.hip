@@ -64,6 +64,35 @@ __global__ __launch_bounds__(256) void softmax_cols_kernel(int k, int n, const f
     for (int c = threadIdx.x; c < k; c += 256) part[((size_t)b * gridDim.x + blockIdx.x) * k + c] = (red[c] + red[k + c]) + (red[2 * k + c] + red[3 * k + c]);
 }
 
+// The same for K = KT known at compile time (NetVLAD's 1 / 4 / 16 / 64 clusters): a thread keeps its column in registers -- one pass of loads, all in
+// flight together, instead of three dependent walks.
+template <int KT>
+__global__ __launch_bounds__(256) void softmax_cols_reg_kernel(int n, const float *__restrict__ in, float *__restrict__ act, float *__restrict__ part)
+{
+    __shared__ float red[4 * KT];
+    const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x, wave = threadIdx.x >> 6;
+    const bool on = j < n;
+    const size_t base = (size_t)b * KT * n + (on ? j : 0);
+    float v[KT];
+#pragma unroll
+    for (int c = 0; c < KT; ++c) v[c] = in[base + (size_t)c * n];
+    float m = v[0];
+#pragma unroll
+    for (int c = 1; c < KT; ++c) m = fmaxf(m, v[c]);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < KT; ++c) { v[c] = expf(v[c] - m); s += v[c]; }
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+        const float a = on ? v[c] / s : 0.f;
+        if (on) act[base + (size_t)c * n] = a;
+        const float w = wave_sum(a);
+        if ((threadIdx.x & 63) == 0) red[wave * KT + c] = w;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < KT; c += 256) part[((size_t)b * gridDim.x + blockIdx.x) * KT + c] = (red[c] + red[KT + c]) + (red[2 * KT + c] + red[3 * KT + c]);
+}
+
 // dpre = act * (g - sum_k g act), g = dact + dasum[b][k] (the gradient that reached a_sum spreads over every point of the cluster's row); dpre may
 // be dact itself (a thread reads its whole column before it writes it)
 __global__ __launch_bounds__(256) void softmax_cols_bwd_kernel(int k, int n, const float *__restrict__ act, const float *dact, const float *__restrict__ dasum,
@@ -81,6 +110,28 @@ __global__ __launch_bounds__(256) void softmax_cols_bwd_kernel(int k, int n, con
         const float g = dact[base + (size_t)c * n] + (dasum ? dasum[b * k + c] : 0.f);
         dpre[base + (size_t)c * n] = act[base + (size_t)c * n] * (g - dot);
     }
+}
+
+template <int KT>
+__global__ __launch_bounds__(256) void softmax_cols_bwd_reg_kernel(int n, const float *__restrict__ act, const float *dact, const float *__restrict__ dasum, float *dpre)
+{
+    const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const size_t base = (size_t)b * KT * n + j;
+    float g[KT], a[KT];
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+        g[c] = dact[base + (size_t)c * n];
+        a[c] = act[base + (size_t)c * n];
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+        g[c] += dasum ? dasum[b * KT + c] : 0.f;
+        dot += g[c] * a[c];
+    }
+#pragma unroll
+    for (int c = 0; c < KT; ++c) dpre[base + (size_t)c * n] = a[c] * (g[c] - dot);
 }
 
 // ---- out = normalise over the channels of (raw - a_sum * cw2) -------------------------------------------------------------------------------------
@@ -134,13 +185,13 @@ __global__ __launch_bounds__(256) void vlad_resnorm_bwd_kernel(int c, int k, con
     if (threadIdx.x == 0) dasum[b * k + kk] = -da;
 }
 
-// The same two for k <= 256, one workgroup per cloud: thread t = (channel lane t / k, cluster t % k) walks the (C, K) slab with contiguous reads (the
-// (K, B) grid above strides by k floats); the 256 / k lanes of a cluster are added up in lane order through LDS.
-__global__ __launch_bounds__(256) void vlad_resnorm_slab_kernel(int c, int k, int nblk, const float *__restrict__ raw, const float *__restrict__ part,
+// The same two for k <= 1024, one 1024-thread workgroup per cloud: thread t = (channel lane t / k, cluster t % k) walks the (C, K) slab with contiguous
+// reads (the (K, B) grid above strides by k floats); the 1024 / k lanes of a cluster are added up in lane order through LDS.
+__global__ __launch_bounds__(1024) void vlad_resnorm_slab_kernel(int c, int k, int nblk, const float *__restrict__ raw, const float *__restrict__ part,
                                                                 const float *__restrict__ cw2, float *__restrict__ out, float *__restrict__ asum, float *__restrict__ nrm)
 {
-    __shared__ float red[256], as[256], ns[256];
-    const int b = blockIdx.x, lanes = 256 / k, cl = threadIdx.x / k, kk = threadIdx.x % k;
+    __shared__ float red[1024], as[1024], ns[1024];
+    const int b = blockIdx.x, lanes = 1024 / k, cl = threadIdx.x / k, kk = threadIdx.x % k;
     const bool on = cl < lanes;
     if (threadIdx.x < k) {
         float a = 0.f;
@@ -173,11 +224,11 @@ __global__ __launch_bounds__(256) void vlad_resnorm_slab_kernel(int c, int k, in
             out[((size_t)b * c + ch) * k + kk] = v / d;
         }
 }
-__global__ __launch_bounds__(256) void vlad_resnorm_slab_bwd_kernel(int c, int k, const float *__restrict__ dout, const float *__restrict__ out, const float *__restrict__ nrm,
+__global__ __launch_bounds__(1024) void vlad_resnorm_slab_bwd_kernel(int c, int k, const float *__restrict__ dout, const float *__restrict__ out, const float *__restrict__ nrm,
                                                                     const float *__restrict__ cw2, float *__restrict__ dv, float *__restrict__ dasum)
 {
-    __shared__ float red[256], ds[256];
-    const int b = blockIdx.x, lanes = 256 / k, cl = threadIdx.x / k, kk = threadIdx.x % k;
+    __shared__ float red[1024], ds[1024];
+    const int b = blockIdx.x, lanes = 1024 / k, cl = threadIdx.x / k, kk = threadIdx.x % k;
     const bool on = cl < lanes;
     const float norm = nrm[b * k + kk], d = fmaxf(norm, L2_EPS);
     float dot = 0.f;
@@ -241,29 +292,45 @@ __global__ __launch_bounds__(64) void l2_rows_bwd_kernel(int f, const float *__r
     for (int i = threadIdx.x; i < f; i += 64) dx[base + i] = (dout[base + i] - out[base + i] * dot) / d;
 }
 
-// the same over dim 1 of a (B, C, M) tensor, M > 1: grid (ceil(M / 256), B) x 256, one thread per column, channels in order
+// the same over dim 1 of a (B, C, M) tensor, M > 1: grid (ceil(M / 32), B) x 256 = 32 columns x 8 channel lanes (a lane walks every 8th channel, 128
+// contiguous bytes per channel row), the lanes of a column added up in lane order through LDS
 __global__ __launch_bounds__(256) void l2_dim1_kernel(int c, int m, const float *__restrict__ x, float *__restrict__ out, float *__restrict__ nrm)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (j >= m) return;
-    const size_t base = (size_t)b * c * m + j;
+    __shared__ float red[256];
+    const int col = threadIdx.x & 31, cl = threadIdx.x >> 5, j = blockIdx.x * 32 + col, b = blockIdx.y;
+    const bool on = j < m;
+    const size_t base = (size_t)b * c * m + (on ? j : 0);
     float ss = 0.f;
-    for (int ch = 0; ch < c; ++ch) ss += x[base + (size_t)ch * m] * x[base + (size_t)ch * m];
-    const float norm = sqrtf(ss), d = fmaxf(norm, L2_EPS);
-    for (int ch = 0; ch < c; ++ch) out[base + (size_t)ch * m] = x[base + (size_t)ch * m] / d;
-    nrm[(size_t)b * m + j] = norm;
+    if (on)
+        for (int ch = cl; ch < c; ch += 8) ss += x[base + (size_t)ch * m] * x[base + (size_t)ch * m];
+    red[threadIdx.x] = ss;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) t += red[l * 32 + col];
+    const float norm = sqrtf(t), d = fmaxf(norm, L2_EPS);
+    if (!on) return;
+    for (int ch = cl; ch < c; ch += 8) out[base + (size_t)ch * m] = x[base + (size_t)ch * m] / d;
+    if (cl == 0) nrm[(size_t)b * m + j] = norm;
 }
 __global__ __launch_bounds__(256) void l2_dim1_bwd_kernel(int c, int m, const float *__restrict__ dout, const float *__restrict__ out, const float *__restrict__ nrm,
                                                           float *__restrict__ dx)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (j >= m) return;
-    const size_t base = (size_t)b * c * m + j;
-    const float norm = nrm[(size_t)b * m + j], d = fmaxf(norm, L2_EPS);
+    __shared__ float red[256];
+    const int col = threadIdx.x & 31, cl = threadIdx.x >> 5, j = blockIdx.x * 32 + col, b = blockIdx.y;
+    const bool on = j < m;
+    const size_t base = (size_t)b * c * m + (on ? j : 0);
+    const float norm = on ? nrm[(size_t)b * m + j] : 1.f, d = fmaxf(norm, L2_EPS);
     float dot = 0.f;
-    if (norm >= L2_EPS)
-        for (int ch = 0; ch < c; ++ch) dot += dout[base + (size_t)ch * m] * out[base + (size_t)ch * m];
-    for (int ch = 0; ch < c; ++ch) dx[base + (size_t)ch * m] = (dout[base + (size_t)ch * m] - out[base + (size_t)ch * m] * dot) / d;
+    if (on && norm >= L2_EPS)
+        for (int ch = cl; ch < c; ch += 8) dot += dout[base + (size_t)ch * m] * out[base + (size_t)ch * m];
+    red[threadIdx.x] = dot;
+    __syncthreads();
+    dot = 0.f;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) dot += red[l * 32 + col];
+    if (!on) return;
+    for (int ch = cl; ch < c; ch += 8) dx[base + (size_t)ch * m] = (dout[base + (size_t)ch * m] - out[base + (size_t)ch * m] * dot) / d;
 }
 
 // ---- BatchNorm1d (train mode) over the rows of an (R, F) matrix: one thread per feature, rows in order ------------------------------------------------
@@ -384,13 +451,113 @@ __global__ __launch_bounds__(256) void afa_attn_bwd_kernel(int c, int k, const f
     }
 }
 
+// The same two for k <= 1024 with 1024 threads per cloud: thread t = (channel lane t / k, column t % k), contiguous reads, the lanes of a column
+// combined in lane order (the one-thread-per-column walks above take 70 / 170 us at 18 x 256 x 84; these 10 / 15).
+__device__ __forceinline__ float block1024_sum(float v, float *red)
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i];
+    return t;
+}
+__global__ __launch_bounds__(1024) void afa_attn_wide_kernel(int c, int k, const float *__restrict__ x, const float *__restrict__ r, float *__restrict__ out,
+                                                             float *__restrict__ w, int *__restrict__ arg)
+{
+    __shared__ float rv[1024], ws[1024], red[16];
+    __shared__ int ri[1024];
+    const int b = blockIdx.x, lanes = 1024 / k, cl = threadIdx.x / k, kk = threadIdx.x % k;
+    const float *rb = r + (size_t)b * c * k, *xb = x + (size_t)b * c * k;
+    float m = -INFINITY;
+    int am = 0x7fffffff;
+    if (cl < lanes)
+        for (int ch = cl; ch < c; ch += lanes) {
+            const float v = rb[ch * k + kk];
+            if (v > m) { m = v; am = ch; }
+        }
+    rv[threadIdx.x] = m;
+    ri[threadIdx.x] = am;
+    __syncthreads();
+    float best = -INFINITY;
+    if (threadIdx.x < k) {
+        int bi = 0x7fffffff;
+        for (int l = 0; l < lanes; ++l) {
+            const float v = rv[l * k + threadIdx.x];
+            const int i = ri[l * k + threadIdx.x];
+            if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+        }
+        arg[b * k + threadIdx.x] = bi == 0x7fffffff ? 0 : bi;
+    }
+    float mm = wave_max(best);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mm;
+    __syncthreads();
+    mm = red[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mm = fmaxf(mm, red[i]);
+    const float e = threadIdx.x < k ? expf(best - mm) : 0.f;
+    const float ssum = block1024_sum(e, red);
+    if (threadIdx.x < k) {
+        ws[threadIdx.x] = e / ssum;
+        w[b * k + threadIdx.x] = e / ssum;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < c * k; i += 1024) {
+        const float v = xb[i];
+        out[(size_t)b * c * k + i] = fmaxf(v + v * ws[i % k], 0.f);
+    }
+}
+__global__ __launch_bounds__(1024) void afa_attn_wide_bwd_kernel(int c, int k, const float *__restrict__ dout, const float *__restrict__ x, const float *__restrict__ w,
+                                                                 const int *__restrict__ arg, float *__restrict__ dx, float *__restrict__ dr)
+{
+    __shared__ float rv[1024], ws[1024], wsh[1024], red[16];
+    __shared__ int as[1024];
+    const int b = blockIdx.x, lanes = 1024 / k, cl = threadIdx.x / k, kk = threadIdx.x % k;
+    const size_t base = (size_t)b * c * k;
+    const float wk = w[b * k + kk];
+    float s = 0.f;
+    if (cl < lanes)
+        for (int ch = cl; ch < c; ch += lanes) {
+            const float v = x[base + ch * k + kk];
+            if (v + v * wk > 0.f) s += dout[base + ch * k + kk] * v;
+        }
+    rv[threadIdx.x] = s;
+    __syncthreads();
+    float dw = 0.f;
+    if (threadIdx.x < k)
+        for (int l = 0; l < lanes; ++l) dw += rv[l * k + threadIdx.x];
+    const float dot = block1024_sum(threadIdx.x < k ? dw * wk : 0.f, red);          // threadIdx.x < k: kk == threadIdx.x
+    if (threadIdx.x < k) {
+        ws[threadIdx.x] = wk * (dw - dot);
+        wsh[threadIdx.x] = wk;
+        as[threadIdx.x] = arg[b * k + threadIdx.x];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < c * k; i += 1024) {
+        const int q = i % k, ch = i / k;
+        const float v = x[base + i], wq = wsh[q];
+        dx[base + i] = v + v * wq > 0.f ? dout[base + i] * (1.f + wq) : 0.f;
+        if (dr) dr[base + i] = ch == as[q] ? ws[q] : 0.f;
+    }
+}
+
 }  // namespace
 
 // act (B, K, N) = softmax over K of in; part (B, ceil(N / 256), K) = per-block sums over the points (pa_vlad_residual_normalize adds them up)
 PA_API int pa_softmax_cols(int b, int k, int n, const float *in, float *act, float *part, pa_stream_t stream)
 {
     PA_REQUIRE(b > 0 && k > 0 && n > 0 && in && act && part && b <= 65535 && k <= 4096, "pa_softmax_cols: bad arguments");
-    hipLaunchKernelGGL(softmax_cols_kernel, dim3(pa_div_up(n, 256), b), dim3(256), 4 * k * sizeof(float), (hipStream_t)stream, k, n, in, act, part);
+    const dim3 grid(pa_div_up(n, 256), b);
+    hipStream_t st = (hipStream_t)stream;
+    switch (k) {
+        case 1: hipLaunchKernelGGL(softmax_cols_reg_kernel<1>, grid, dim3(256), 0, st, n, in, act, part); break;
+        case 4: hipLaunchKernelGGL(softmax_cols_reg_kernel<4>, grid, dim3(256), 0, st, n, in, act, part); break;
+        case 16: hipLaunchKernelGGL(softmax_cols_reg_kernel<16>, grid, dim3(256), 0, st, n, in, act, part); break;
+        case 64: hipLaunchKernelGGL(softmax_cols_reg_kernel<64>, grid, dim3(256), 0, st, n, in, act, part); break;
+        default: hipLaunchKernelGGL(softmax_cols_kernel, grid, dim3(256), 4 * k * sizeof(float), st, k, n, in, act, part);
+    }
     PA_CHECK_LAUNCH("pa_softmax_cols");
     return PA_OK;
 }
@@ -398,7 +565,15 @@ PA_API int pa_softmax_cols(int b, int k, int n, const float *in, float *act, flo
 PA_API int pa_softmax_cols_backward(int b, int k, int n, const float *act, const float *dact, const float *dasum, float *dpre, pa_stream_t stream)
 {
     PA_REQUIRE(b > 0 && k > 0 && n > 0 && act && dact && dpre && b <= 65535, "pa_softmax_cols_backward: bad arguments");
-    hipLaunchKernelGGL(softmax_cols_bwd_kernel, dim3(pa_div_up(n, 256), b), dim3(256), 0, (hipStream_t)stream, k, n, act, dact, dasum, dpre);
+    const dim3 grid(pa_div_up(n, 256), b);
+    hipStream_t st = (hipStream_t)stream;
+    switch (k) {
+        case 1: hipLaunchKernelGGL(softmax_cols_bwd_reg_kernel<1>, grid, dim3(256), 0, st, n, act, dact, dasum, dpre); break;
+        case 4: hipLaunchKernelGGL(softmax_cols_bwd_reg_kernel<4>, grid, dim3(256), 0, st, n, act, dact, dasum, dpre); break;
+        case 16: hipLaunchKernelGGL(softmax_cols_bwd_reg_kernel<16>, grid, dim3(256), 0, st, n, act, dact, dasum, dpre); break;
+        case 64: hipLaunchKernelGGL(softmax_cols_bwd_reg_kernel<64>, grid, dim3(256), 0, st, n, act, dact, dasum, dpre); break;
+        default: hipLaunchKernelGGL(softmax_cols_bwd_kernel, grid, dim3(256), 0, st, k, n, act, dact, dasum, dpre);
+    }
     PA_CHECK_LAUNCH("pa_softmax_cols_backward");
     return PA_OK;
 }
@@ -408,7 +583,7 @@ PA_API int pa_vlad_residual_normalize(int b, int c, int k, int nblk, const float
                                       pa_stream_t stream)
 {
     PA_REQUIRE(b > 0 && c > 0 && k > 0 && nblk > 0 && raw && part && cw2 && out && asum && nrm && b <= 65535, "pa_vlad_residual_normalize: bad arguments");
-    if (k <= 256) hipLaunchKernelGGL(vlad_resnorm_slab_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, c, k, nblk, raw, part, cw2, out, asum, nrm);
+    if (k <= 1024) hipLaunchKernelGGL(vlad_resnorm_slab_kernel, dim3(b), dim3(1024), 0, (hipStream_t)stream, c, k, nblk, raw, part, cw2, out, asum, nrm);
     else hipLaunchKernelGGL(vlad_resnorm_kernel, dim3(k, b), dim3(256), 0, (hipStream_t)stream, c, k, nblk, raw, part, cw2, out, asum, nrm);
     PA_CHECK_LAUNCH("pa_vlad_residual_normalize");
     return PA_OK;
@@ -419,7 +594,7 @@ PA_API int pa_vlad_residual_normalize_backward(int b, int c, int k, const float 
                                                float *dasum, float *dcw2, pa_stream_t stream)
 {
     PA_REQUIRE(b > 0 && c > 0 && k > 0 && dout && out && nrm && asum && cw2 && dv && dasum && b <= 65535, "pa_vlad_residual_normalize_backward: bad arguments");
-    if (k <= 256) hipLaunchKernelGGL(vlad_resnorm_slab_bwd_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, c, k, dout, out, nrm, cw2, dv, dasum);
+    if (k <= 1024) hipLaunchKernelGGL(vlad_resnorm_slab_bwd_kernel, dim3(b), dim3(1024), 0, (hipStream_t)stream, c, k, dout, out, nrm, cw2, dv, dasum);
     else hipLaunchKernelGGL(vlad_resnorm_bwd_kernel, dim3(k, b), dim3(256), 0, (hipStream_t)stream, c, k, dout, out, nrm, cw2, dv, dasum);
     if (dcw2) hipLaunchKernelGGL(vlad_resnorm_dcw2_kernel, dim3(pa_div_up(c * k, 256)), dim3(256), 0, (hipStream_t)stream, b, c * k, k, dv, asum, dcw2);
     PA_CHECK_LAUNCH("pa_vlad_residual_normalize_backward");
@@ -431,7 +606,7 @@ PA_API int pa_l2_normalize(int b, int c, int m, const float *x, float *out, floa
 {
     PA_REQUIRE(b > 0 && c > 0 && m > 0 && x && out && nrm && (m == 1 || b <= 65535), "pa_l2_normalize: bad arguments");
     if (m == 1) hipLaunchKernelGGL(l2_rows_kernel, dim3(b), dim3(64), 0, (hipStream_t)stream, c, x, out, nrm);
-    else hipLaunchKernelGGL(l2_dim1_kernel, dim3(pa_div_up(m, 256), b), dim3(256), 0, (hipStream_t)stream, c, m, x, out, nrm);
+    else hipLaunchKernelGGL(l2_dim1_kernel, dim3(pa_div_up(m, 32), b), dim3(256), 0, (hipStream_t)stream, c, m, x, out, nrm);
     PA_CHECK_LAUNCH("pa_l2_normalize");
     return PA_OK;
 }
@@ -440,7 +615,7 @@ PA_API int pa_l2_normalize_backward(int b, int c, int m, const float *dout, cons
 {
     PA_REQUIRE(b > 0 && c > 0 && m > 0 && dout && out && nrm && dx && (m == 1 || b <= 65535), "pa_l2_normalize_backward: bad arguments");
     if (m == 1) hipLaunchKernelGGL(l2_rows_bwd_kernel, dim3(b), dim3(64), 0, (hipStream_t)stream, c, dout, out, nrm, dx);
-    else hipLaunchKernelGGL(l2_dim1_bwd_kernel, dim3(pa_div_up(m, 256), b), dim3(256), 0, (hipStream_t)stream, c, m, dout, out, nrm, dx);
+    else hipLaunchKernelGGL(l2_dim1_bwd_kernel, dim3(pa_div_up(m, 32), b), dim3(256), 0, (hipStream_t)stream, c, m, dout, out, nrm, dx);
     PA_CHECK_LAUNCH("pa_l2_normalize_backward");
     return PA_OK;
 }
@@ -470,7 +645,8 @@ PA_API int pa_bn_rows_backward(int r, int f, const float *dy, const float *x, co
 PA_API int pa_afa_attention(int b, int c, int k, const float *x, const float *r, float *out, float *w, int *arg, pa_stream_t stream)
 {
     PA_REQUIRE(b > 0 && c > 0 && k > 0 && k <= 8192 && x && r && out && w && arg, "pa_afa_attention: bad arguments");
-    hipLaunchKernelGGL(afa_attn_kernel, dim3(b), dim3(256), k * sizeof(float), (hipStream_t)stream, c, k, x, r, out, w, arg);
+    if (k <= 1024) hipLaunchKernelGGL(afa_attn_wide_kernel, dim3(b), dim3(1024), 0, (hipStream_t)stream, c, k, x, r, out, w, arg);
+    else hipLaunchKernelGGL(afa_attn_kernel, dim3(b), dim3(256), k * sizeof(float), (hipStream_t)stream, c, k, x, r, out, w, arg);
     PA_CHECK_LAUNCH("pa_afa_attention");
     return PA_OK;
 }
@@ -478,7 +654,8 @@ PA_API int pa_afa_attention(int b, int c, int k, const float *x, const float *r,
 PA_API int pa_afa_attention_backward(int b, int c, int k, const float *dout, const float *x, const float *w, const int *arg, float *dx, float *dr, pa_stream_t stream)
 {
     PA_REQUIRE(b > 0 && c > 0 && k > 0 && k <= 8192 && dout && x && w && arg && dx, "pa_afa_attention_backward: bad arguments");
-    hipLaunchKernelGGL(afa_attn_bwd_kernel, dim3(b), dim3(256), k * sizeof(float), (hipStream_t)stream, c, k, dout, x, w, arg, dx, dr);
+    if (k <= 1024) hipLaunchKernelGGL(afa_attn_wide_bwd_kernel, dim3(b), dim3(1024), 0, (hipStream_t)stream, c, k, dout, x, w, arg, dx, dr);
+    else hipLaunchKernelGGL(afa_attn_bwd_kernel, dim3(b), dim3(256), k * sizeof(float), (hipStream_t)stream, c, k, dout, x, w, arg, dx, dr);
     PA_CHECK_LAUNCH("pa_afa_attention_backward");
     return PA_OK;
 }

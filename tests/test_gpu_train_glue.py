@@ -30,7 +30,7 @@ def run_both(fn_hip, fn_ref, inputs, seed=0):
         close(a.grad, b.grad)
 
 
-@pytest.mark.parametrize("B,C,K,N", [(3, 32, 4, 128), (2, 256, 16, 1000), (2, 256, 64, 4096), (1, 8, 300, 70), (2, 16, 1, 64)])
+@pytest.mark.parametrize("B,C,K,N", [(3, 32, 4, 128), (2, 256, 16, 1000), (2, 256, 64, 4096), (1, 8, 300, 70), (2, 16, 1, 64), (1, 6, 1100, 33), (2, 40, 7, 300)])
 def test_netvlad_tail(B, C, K, N):
     from patchaugnet_amd import train_ops
     g = torch.Generator().manual_seed(B * 1000 + K)
@@ -57,7 +57,7 @@ def test_l2_normalize_of_a_zero_vector_is_zero_with_the_clamped_gradient():
     run_both(train_ops.l2_normalize, lambda t: F.normalize(t, dim=1), [x])
 
 
-@pytest.mark.parametrize("B,C,K", [(4, 32, 84), (18, 256, 84), (2, 16, 300), (1, 5, 1)])
+@pytest.mark.parametrize("B,C,K", [(4, 32, 84), (18, 256, 84), (2, 16, 300), (1, 5, 1), (1, 3, 1100)])
 def test_afa_attention(B, C, K):
     from patchaugnet_amd import train_ops
     g = torch.Generator().manual_seed(C + K)

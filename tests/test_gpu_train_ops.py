@@ -184,6 +184,7 @@ def _compare(mod, x, fn, tol=2e-4, skip=(), train=True):
 
 @pytest.mark.parametrize("spec,shape", [([6, 32, 32, 64], (3, 6, 50, 20)), ([67, 64, 64, 256], (2, 67, 37, 20)), ([259, 256, 256], (2, 259, 300, 1)),
                                         ([768, 256, 256], (3, 768, 16, 1)),
+                                        ([6, 32], (2, 6, 300, 13)), ([6, 16, 32], (2, 6, 700, 20)),      # pooled outputs beyond one 256-wide block; nsample % 4 != 0
                                         ([8, 512], (144, 8, 4, 20))])     # 144 clouds x 512 channels = 73 728 (cloud, channel) rows > 65 535
 def test_shared_mlp_train_matches_torch_autograd(spec, shape):
     from patchaugnet_amd.pt_util import SharedMLP
