@@ -86,9 +86,20 @@ struct NNArgs {
     double *stats;                       // [PA_BN_STAT_SLOTS][2*M]: sum and sum of squares of the stored values per row m over (batch, n); or null
     long sPb, sStatb;                    // per-batch strides of tb.p (floats) and stats (doubles); 0 = one block shared by the batch
     int vecA, vecB;                      // 16-byte loads allowed (alignment / divisibility checked on the host)
+    int xcd_order;                       // XCD-contiguous tile order (xcd_contiguous_id)
 };
 
 constexpr int NN_BN = 128;
+
+// Workgroups are dealt to the eight XCDs round-robin in launch order (id % 8), and every XCD has its own L2.  This maps the launch-order id to a
+// tile id such that an XCD owns a CONTIGUOUS range of tile ids: tiles that share an operand (the M tiles of one column block; the tiles of one
+// split of a dW GEMM) are then neighbours in time on one XCD and the shared operand is fetched into that L2 once instead of once per XCD.
+// (The tail of a launch whose size is not a multiple of eight keeps its order.)  PA_TGEMM_XCD_ORDER = bit 0: tgemm_nn, bit 1: tgemm_kk (A/B knob).
+__device__ __forceinline__ unsigned xcd_contiguous_id(unsigned id, unsigned total)
+{
+    const unsigned t8 = total & ~7u;
+    return id < t8 ? (id & 7u) * (t8 >> 3) + (id >> 3) : id;
+}
 
 // NN_BK = 32 halves the number of (barrier, fetch) rounds of a long contraction: with few workgroups per CU a round is bound by the
 // latency of its global loads, not by its MFMAs; 16 stays for the short contractions (K <= 16: first layers, cluster counts).
@@ -105,7 +116,15 @@ __global__ __launch_bounds__(256) void tgemm_nn_kernel(NNArgs a)
     __shared__ __attribute__((aligned(16))) float Bs[2][NN_BK * SB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int n0 = blockIdx.x * NN_BN, m0 = blockIdx.y * BM, b = blockIdx.z;
+    // tile order: M tiles fastest (they share the column block of B, the big operand), then column blocks, then clouds
+    unsigned tix = blockIdx.x, tiy = blockIdx.y, tiz = blockIdx.z;
+    if (a.xcd_order) {
+        const unsigned t = xcd_contiguous_id(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
+        tiy = t % gridDim.y;
+        tix = (t / gridDim.y) % gridDim.x;
+        tiz = t / (gridDim.y * gridDim.x);
+    }
+    const int n0 = tix * NN_BN, m0 = tiy * BM, b = tiz;
     const float *A = a.A + (size_t)b * a.sAb;
     const float *B = a.B + (size_t)b * a.sBb;
     const float *B2 = (BMODE >= TF_BN_BWD_RELU) ? a.tb.aux + (size_t)b * a.sBb : nullptr;
@@ -300,7 +319,7 @@ __global__ __launch_bounds__(256) void tgemm_nn_kernel(NNArgs a)
             float t1 = 0.f, t2 = 0.f;
 #pragma unroll
             for (int w = 0; w < WN; ++w) { t1 += red[(w * BM + tid) * 2]; t2 += red[(w * BM + tid) * 2 + 1]; }
-            const unsigned slot = (blockIdx.x + blockIdx.z * gridDim.x) % PA_BN_STAT_SLOTS;
+            const unsigned slot = (tix + tiz * gridDim.x) % PA_BN_STAT_SLOTS;
             double *st = a.stats + (size_t)b * a.sStatb + (size_t)slot * 2 * a.M;
             atomicAdd(st + m0 + tid, (double)t1);
             atomicAdd(st + a.M + m0 + tid, (double)t2);
@@ -322,6 +341,7 @@ struct KKArgs {
     int per_batch;
     int vecA, vecB;
     long sAPb, sBPb;                     // per-batch strides of ta.p / tb.p (floats); 0 = shared
+    int xcd_order;
 };
 
 constexpr int KK_BM = 64, KK_BN = 64, KK_BK = 32, KK_S = KK_BK + 2;   // row stride 34: (2m + k) mod 32 distinct for m < 16, k < 2
@@ -334,8 +354,15 @@ __global__ __launch_bounds__(256) void tgemm_kk_kernel(KKArgs a)
     __shared__ __attribute__((aligned(16))) float Bs[2][KK_BN * KK_S];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;                 // 2 x 2 waves, 32 x 32 each
-    const int n0 = blockIdx.x * KK_BN, m0 = blockIdx.y * KK_BM;
-    const int b = blockIdx.z / a.ksplits, split = blockIdx.z % a.ksplits;
+    unsigned tix = blockIdx.x, tiy = blockIdx.y, tiz = blockIdx.z;
+    if (a.xcd_order) {                  // the tiles of one (cloud, k-split) share its two operand chunks: neighbours on one XCD
+        const unsigned t = xcd_contiguous_id(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
+        tix = t % gridDim.x;
+        tiy = (t / gridDim.x) % gridDim.y;
+        tiz = t / (gridDim.x * gridDim.y);
+    }
+    const int n0 = tix * KK_BN, m0 = tiy * KK_BM;
+    const int b = tiz / a.ksplits, split = tiz % a.ksplits;
     const int kbeg = split * a.kchunk, kend = min(kbeg + a.kchunk, a.K);
     const float *A = a.A + (size_t)b * a.sAb, *B = a.B + (size_t)b * a.sBb;
     const float *A2 = AMODE >= TF_BN_BWD_RELU ? a.ta.aux + (size_t)b * a.sAb : nullptr;
@@ -728,6 +755,8 @@ PA_API int pa_tgemm_nn(int batch, int M, int N, int K, const float *A, long sAb,
     a.sStatb = per_batch_stats ? (long)PA_BN_STAT_SLOTS * 2 * M : 0;
     a.vecA = aligned16(A) && lda % 4 == 0 && sAb % 4 == 0 && (a_kcontig ? (K % 4 == 0 && K >= 4) : (M % 4 == 0 && M >= 4));
     a.vecB = aligned16(B) && ldb % 4 == 0 && sBb % 4 == 0 && (bmode < 2 || aligned16(baux)) && N % 4 == 0 && N >= 4;
+    static const int xcd_mode = getenv("PA_TGEMM_XCD_ORDER") ? atoi(getenv("PA_TGEMM_XCD_ORDER")) : 2;      // bit 0: tgemm_nn, bit 1: tgemm_kk
+    a.xcd_order = xcd_mode & 1;
     // 64-row tiles (half the accumulators: 4-5 workgroups per CU instead of 3) for every shape.  128-row tiles remain behind
     // PA_TGEMM_BIG_MIN (minimum number of 128 x 128 tiles to use them): measured on MI355X they lose even where they fill the chip -- the
     // finest level's 256 x 4096 x 256 per cloud x 18 is 1152 such tiles on 768 resident slots = two rounds (153 us; 64-row tiles 145 us), the
@@ -775,6 +804,8 @@ PA_API int pa_tgemm_kk(int batch, int M, int N, long K, const float *A, long sAb
     a.sBPb = per_batch_stats ? 7L * N : 0;
     a.vecA = aligned16(A) && lda % 4 == 0 && sAb % 4 == 0 && (amode == 0 || aligned16(aaux)) && K % 4 == 0 && K >= 4;
     a.vecB = aligned16(B) && ldb % 4 == 0 && sBb % 4 == 0;
+    static const int xcd_mode = getenv("PA_TGEMM_XCD_ORDER") ? atoi(getenv("PA_TGEMM_XCD_ORDER")) : 2;
+    a.xcd_order = (xcd_mode >> 1) & 1;
     const long tiles = (long)((M + KK_BM - 1) / KK_BM) * ((N + KK_BN - 1) / KK_BN) * batch;
     long splits = (2048 + tiles - 1) / tiles;                  // aim at ~2048 workgroups
     const long maxsplits = (K + 4 * KK_BK - 1) / (4 * KK_BK);  // at least 4 k-tiles per split
