@@ -84,6 +84,9 @@ int pa_interpolation_backward(int b, int c, int n, int m, const float *grad_out,
 long pa_interpolation_backward_scratch_ints(int b, int n, int m);
 int pa_interpolation_backward_gather(int b, int c, int n, int m, const float *grad_out, const int *idx, const float *weight, float *grad_points,
                                      int *scratch, pa_stream_t stream);
+/* The list inversion of pa_interpolation_backward_gather alone (it depends on idx / weight only): scratch then serves any number of
+ * pa_interpolation_backward_gather calls with idx = weight = NULL for the same (b, n, m). */
+int pa_interpolation_backward_lists(int b, int n, int m, const int *idx, const float *weight, int *scratch, pa_stream_t stream);
 
 /* K9 with the FP module's inverse-distance weights fused in (patch_aug_net.py:350-353): weight (b,n,3), idx (b,n,3). */
 int pa_three_nn_weights(int b, int n, int m, const float *unknown, const float *known, float *weight, int *idx, pa_stream_t stream);

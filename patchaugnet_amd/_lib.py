@@ -28,6 +28,7 @@ _SIGS = {
     "pa_interpolation_forward": "iiiipppp",
     "pa_interpolation_backward": "iiiipppp",
     "pa_interpolation_backward_gather": "iiiippppp",
+    "pa_interpolation_backward_lists": "iiippp",
     "pa_ballquery": "iiifippp",
     "pa_featuredistribute": "iiippp",
     "pa_featuregather_forward": "iiiippp",

@@ -127,20 +127,26 @@ class FPModule(nn.Module):
 
     @staticmethod
     @torch.no_grad()
-    def geometry(unknown, known):
-        """(3-NN indices, inverse-distance weights): the coordinate-only part of forward()."""
+    def geometry(unknown, known, lists_for_channels=0):
+        """(3-NN indices, inverse-distance weights, backward lists or None): the coordinate-only part of forward().  lists_for_channels = the
+        channel count of the features that will be interpolated under autograd (0 = no backward pass follows)."""
         dist, idx = pointops.nearestneighbor(unknown, known)
         dist_recip = 1.0 / (dist + 1e-8)
-        return idx, dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+        weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+        lists = None
+        if lists_for_channels and pointops._gather_form(idx.shape[0], lists_for_channels, idx.shape[1], known.shape[1]):
+            lists = pointops.interpolation_backward_lists(idx, weight, known.shape[1])      # the backward pass's inverted lists, off the step's path
+        return idx, weight, lists
 
     def forward(self, unknown, known, unknown_feats, known_feats, geo=None):
         if geo is None:
             dist, idx = pointops.nearestneighbor(unknown, known)
             dist_recip = 1.0 / (dist + 1e-8)
             weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+            lists = None
         else:
-            idx, weight = geo
-        x = pointops.interpolation(known_feats, idx, weight)
+            idx, weight, lists = geo
+        x = pointops.interpolation(known_feats, idx, weight, lists)
         if unknown_feats is not None:
             x = torch.cat([x, unknown_feats], dim=1)
         return self.mlp(x.unsqueeze(-1)).squeeze(-1)
@@ -179,7 +185,9 @@ class PyramidBackbone(nn.Module):
         nfp = len(self.FP_modules)
         fp_geo = [None] * nfp
         for i in range(-1, -(nfp + 1), -1):
-            fp_geo[i] = FPModule.geometry(l_xyz[i - 1], l_xyz[i])
+            # channels of the coarser level's features this level interpolates (its backward lists are coordinate-only work too; train() only)
+            c_known = self.SA_modules[-1].mlps[0].channels[-1] if i == -1 else self.FP_modules[i + 1].mlp.channels[-1]
+            fp_geo[i] = FPModule.geometry(l_xyz[i - 1], l_xyz[i], lists_for_channels=c_known if self.training else 0)
         return {"sa": sa_geo, "fp": fp_geo}
 
     def forward(self, pointcloud, geometry=None):

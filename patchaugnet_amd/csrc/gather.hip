@@ -458,18 +458,32 @@ PA_API int pa_interpolation_backward_gather(int b, int c, int n, int m, const fl
                                             int *scratch, pa_stream_t stream)
 {
     PA_REQUIRE(b > 0 && c > 0 && m > 0 && n > 0, "pa_interpolation_backward_gather: sizes must be positive");
-    PA_REQUIRE(grad_out && idx && weight && grad_points && scratch, "pa_interpolation_backward_gather: null pointer");
+    PA_REQUIRE(grad_out && grad_points && scratch && ((idx == nullptr) == (weight == nullptr)), "pa_interpolation_backward_gather: null pointer");
     PA_REQUIRE(b <= 65535 && (c + 3) / 4 <= 2147483647, "pa_interpolation_backward_gather: b=%d exceeds the grid limit", b);
     if (n > 4096 || m > 8192) { pa_set_error("pa_interpolation_backward_gather: built for n <= 4096, m <= 8192 (got n=%d m=%d)", n, m); return PA_EUNSUPPORTED; }
     PA_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 7) == 0, "pa_interpolation_backward_gather: scratch must be 8-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     int *off = scratch;
     int2 *ent = reinterpret_cast<int2 *>(scratch + (((size_t)b * (m + 1) + 1) & ~(size_t)1));
-    hipLaunchKernelGGL(interp_csr_build_kernel, dim3(b), dim3(256), (size_t)(m + 1) * 4, st, n, m, idx, weight, off, ent);
+    if (idx) hipLaunchKernelGGL(interp_csr_build_kernel, dim3(b), dim3(256), (size_t)(m + 1) * 4, st, n, m, idx, weight, off, ent);      // else: pa_interpolation_backward_lists ran
     const size_t lds = (size_t)4 * n * 4;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&interp_bwd_gather_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(interp_bwd_gather_kernel, dim3((c + 3) / 4, b), dim3(256), lds, st, c, n, m, grad_out, off, ent, grad_points);
     PA_CHECK_LAUNCH("pa_interpolation_backward_gather");
+    return PA_OK;
+}
+
+// The inversion alone: scratch then serves any number of pa_interpolation_backward_gather(idx = weight = NULL) calls of the same (b, n, m).  It depends
+// on the neighbour lists only, i.e. on coordinates: a training loop runs it with the next batch's sampling / neighbour searches, off the step's path.
+PA_API int pa_interpolation_backward_lists(int b, int n, int m, const int *idx, const float *weight, int *scratch, pa_stream_t stream)
+{
+    PA_REQUIRE(b > 0 && m > 0 && n > 0 && idx && weight && scratch && b <= 65535, "pa_interpolation_backward_lists: bad arguments");
+    if (n > 4096 || m > 8192) { pa_set_error("pa_interpolation_backward_lists: built for n <= 4096, m <= 8192 (got n=%d m=%d)", n, m); return PA_EUNSUPPORTED; }
+    PA_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 7) == 0, "pa_interpolation_backward_lists: scratch must be 8-byte aligned");
+    int *off = scratch;
+    int2 *ent = reinterpret_cast<int2 *>(scratch + (((size_t)b * (m + 1) + 1) & ~(size_t)1));
+    hipLaunchKernelGGL(interp_csr_build_kernel, dim3(b), dim3(256), (size_t)(m + 1) * 4, (hipStream_t)stream, n, m, idx, weight, off, ent);
+    PA_CHECK_LAUNCH("pa_interpolation_backward_lists");
     return PA_OK;
 }
 

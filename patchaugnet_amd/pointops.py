@@ -102,15 +102,31 @@ class NearestNeighbor(Function):
 nearestneighbor = NearestNeighbor.apply
 
 
+def _gather_form(b, c, n, m):
+    """Shapes the atomics-free interpolation backward is built for (csrc/gather.hip)."""
+    return 1024 <= n <= 4096 and m <= 8192 and c >= 16
+
+
+def interpolation_backward_lists(idx, weight, m):
+    """The (point, neighbour) lists of interpolation's backward pass inverted per known point -- coordinate-only work a training loop can run
+    ahead of the step (backbone geometry(), prefetched with the neighbour searches); pass the result as interpolation's 4th argument."""
+    check_device(idx, weight)
+    b, n = idx.shape[:2]
+    scratch = torch.empty(_lib.lib().pa_interpolation_backward_scratch_ints(b, n, m), dtype=torch.int32, device=idx.device)
+    with _guard(idx):
+        call("pa_interpolation_backward_lists", b, n, m, ptr(idx), ptr(weight), ptr(scratch))
+    return scratch
+
+
 class Interpolation(Function):
-    """pointops.py:85-118 -- features (b,c,m), idx/weight (b,n,3) -> (b,c,n)."""
+    """pointops.py:85-118 -- features (b,c,m), idx/weight (b,n,3) -> (b,c,n).  lists: optional interpolation_backward_lists(idx, weight, m)."""
 
     @staticmethod
-    def forward(ctx, features, idx, weight):
+    def forward(ctx, features, idx, weight, lists=None):
         check_device(features, idx, weight)
         b, c, m = features.shape
         n = idx.shape[1]
-        ctx.interpolation_for_backward = (idx, weight, m)
+        ctx.interpolation_for_backward = (idx, weight, m, lists)
         out = _new(features, (b, c, n), torch.float32)
         with _guard(features):
             call("pa_interpolation_forward", b, c, m, n, ptr(features), ptr(idx), ptr(weight), ptr(out))
@@ -118,18 +134,20 @@ class Interpolation(Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        idx, weight, m = ctx.interpolation_for_backward
+        idx, weight, m, lists = ctx.interpolation_for_backward
         b, c, n = grad_out.shape
         grad = zeros((b, c, m), torch.float32, grad_out.device)
         g = grad_out.contiguous()
         with _guard(g):
-            if 1024 <= n <= 4096 and m <= 8192 and c >= 16:      # atomics-free form: one inversion of the index list, then plain sums
-                from . import _lib
-                scratch = torch.empty(_lib.lib().pa_interpolation_backward_scratch_ints(b, n, m), dtype=torch.int32, device=g.device)
-                call("pa_interpolation_backward_gather", b, c, n, m, ptr(g), ptr(idx), ptr(weight), ptr(grad), ptr(scratch))
+            if _gather_form(b, c, n, m):      # atomics-free form: one inversion of the index list, then plain sums
+                if lists is not None:
+                    call("pa_interpolation_backward_gather", b, c, n, m, ptr(g), None, None, ptr(grad), ptr(lists))
+                else:
+                    scratch = torch.empty(_lib.lib().pa_interpolation_backward_scratch_ints(b, n, m), dtype=torch.int32, device=g.device)
+                    call("pa_interpolation_backward_gather", b, c, n, m, ptr(g), ptr(idx), ptr(weight), ptr(grad), ptr(scratch))
             else:
                 call("pa_interpolation_backward", b, c, n, m, ptr(g), ptr(idx), ptr(weight), ptr(grad))
-        return grad, None, None
+        return grad, None, None, None
 
 
 interpolation = Interpolation.apply

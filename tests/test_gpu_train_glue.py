@@ -142,3 +142,31 @@ def test_zero_arena_hands_out_zero_filled_disjoint_buffers_and_learns_its_size()
             kept.append(a)
     assert all((t == 1).all() for t in kept)                                      # an escaped tensor keeps its step's buffer alive
     assert train_ops.zeros((4,), torch.float32, dev).untyped_storage().nbytes() == 16   # outside a step: plain torch.zeros
+
+
+def test_interpolation_backward_with_prebuilt_lists_is_identical():
+    """The inverted (point, neighbour) lists of interpolation's backward built ahead (backbone geometry(), prefetched with the neighbour
+    searches) give the gradient the inline build gives (up to the order within a point's list), and the fp64 scatter-add's."""
+    from patchaugnet_amd import pointops
+    g = torch.Generator().manual_seed(4)
+    b, c, n, m = 3, 32, 2048, 512
+    unknown, known = torch.rand(b, n, 3, generator=g).cuda(), torch.rand(b, m, 3, generator=g).cuda()
+    dist, idx = pointops.nearestneighbor(unknown, known)
+    w = 1.0 / (dist + 1e-8)
+    w = w / w.sum(2, keepdim=True)
+    assert pointops._gather_form(b, c, n, m)
+    lists = pointops.interpolation_backward_lists(idx, w, m)
+    cot = torch.randn(b, c, n, generator=g).cuda()
+    grads = []
+    for l in (None, lists, lists):
+        f = torch.randn(b, c, m, generator=torch.Generator().manual_seed(9)).cuda().requires_grad_(True)
+        out = pointops.interpolation(f, idx, w, l)
+        (out * cot).sum().backward()
+        grads.append(f.grad)
+    assert torch.equal(grads[1], grads[2])                   # the same lists: the same sums in the same order
+    close(grads[0], grads[1].double(), rtol=1e-6)            # another build orders a point's list differently (atomic slot counters): rounding only
+    ref = torch.zeros(b, c, m, dtype=torch.float64)
+    idc, wc, cc = idx.cpu().long(), w.cpu().double(), cot.cpu().double()
+    for j in range(3):
+        ref.scatter_add_(2, idc[:, :, j].unsqueeze(1).expand(-1, c, -1), cc * wc[:, :, j].unsqueeze(1))
+    close(grads[0], ref)
