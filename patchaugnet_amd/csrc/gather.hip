@@ -409,9 +409,12 @@ __global__ __launch_bounds__(256) void interp_csr_build_kernel(int n, int m, con
     }
 }
 
-// grid (ceil(c / 4), b), 256 threads; LDS 4 n floats
-__global__ __launch_bounds__(256) void interp_bwd_gather_kernel(int c, int n, int m, const float *__restrict__ grad_out, const int *__restrict__ off_all,
-                                                                  const int2 *__restrict__ ent_all, float *__restrict__ grad_points)
+// grid (ceil(c / 4), b), NT threads (1024 when there are that many known points: a thread walks its point's list with dependent global reads, so
+// the launch lives on the number of wavefronts in flight); LDS 4 n floats.  A list is read four entries at a time (clamped addresses, the tail
+// predicated off): one round trip per four neighbours instead of four.
+template <int NT>
+__global__ __launch_bounds__(NT) void interp_bwd_gather_kernel(int c, int n, int m, const float *__restrict__ grad_out, const int *__restrict__ off_all,
+                                                               const int2 *__restrict__ ent_all, float *__restrict__ grad_points)
 {
     extern __shared__ __attribute__((aligned(16))) float rows[];      // [4][n]
     const int b = blockIdx.y, c0 = blockIdx.x * 4, tid = threadIdx.x;
@@ -420,25 +423,31 @@ __global__ __launch_bounds__(256) void interp_bwd_gather_kernel(int c, int n, in
     if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
         const float4 *s4 = reinterpret_cast<const float4 *>(src);
         float4 *d4 = reinterpret_cast<float4 *>(rows);
-        for (int i = tid; i < nc * (n >> 2); i += 256) d4[i] = s4[i];
+        for (int i = tid; i < nc * (n >> 2); i += NT) d4[i] = s4[i];
     } else {
-        for (int i = tid; i < nc * n; i += 256) rows[i] = src[i];
+        for (int i = tid; i < nc * n; i += NT) rows[i] = src[i];
     }
-    for (int i = nc * n + tid; i < 4 * n; i += 256) rows[i] = 0.f;
+    for (int i = nc * n + tid; i < 4 * n; i += NT) rows[i] = 0.f;
     __syncthreads();
     const int *off = off_all + (size_t)b * (m + 1);
     const int2 *ent = ent_all + (size_t)b * n * 3;
     float *dst = grad_points + ((size_t)b * c + c0) * m;
-    for (int j = tid; j < m; j += 256) {
+    for (int j = tid; j < m; j += NT) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         const int beg = off[j], end = off[j + 1];
-        for (int e = beg; e < end; ++e) {
-            const int2 en = ent[e];
-            const float w = __int_as_float(en.y);
-            a0 += w * rows[en.x];
-            a1 += w * rows[n + en.x];
-            a2 += w * rows[2 * n + en.x];
-            a3 += w * rows[3 * n + en.x];
+        for (int e = beg; e < end; e += 4) {
+            int2 en[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) en[q] = ent[min(e + q, end - 1)];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (e + q < end) {
+                    const float w = __int_as_float(en[q].y);
+                    a0 += w * rows[en[q].x];
+                    a1 += w * rows[n + en[q].x];
+                    a2 += w * rows[2 * n + en[q].x];
+                    a3 += w * rows[3 * n + en[q].x];
+                }
         }
         dst[j] += a0;                                                  // the reference accumulates into the caller's buffer
         if (nc > 1) dst[(size_t)m + j] += a1;
@@ -467,8 +476,13 @@ PA_API int pa_interpolation_backward_gather(int b, int c, int n, int m, const fl
     int2 *ent = reinterpret_cast<int2 *>(scratch + (((size_t)b * (m + 1) + 1) & ~(size_t)1));
     if (idx) hipLaunchKernelGGL(interp_csr_build_kernel, dim3(b), dim3(256), (size_t)(m + 1) * 4, st, n, m, idx, weight, off, ent);      // else: pa_interpolation_backward_lists ran
     const size_t lds = (size_t)4 * n * 4;
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&interp_bwd_gather_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(interp_bwd_gather_kernel, dim3((c + 3) / 4, b), dim3(256), lds, st, c, n, m, grad_out, off, ent, grad_points);
+    if (m >= 1024) {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&interp_bwd_gather_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(interp_bwd_gather_kernel<1024>, dim3((c + 3) / 4, b), dim3(1024), lds, st, c, n, m, grad_out, off, ent, grad_points);
+    } else {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&interp_bwd_gather_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(interp_bwd_gather_kernel<256>, dim3((c + 3) / 4, b), dim3(256), lds, st, c, n, m, grad_out, off, ent, grad_points);
+    }
     PA_CHECK_LAUNCH("pa_interpolation_backward_gather");
     return PA_OK;
 }
