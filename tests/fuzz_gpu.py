@@ -322,13 +322,102 @@ def f_afa():
         eng = _Afa(afa, v.device)
         got = eng.run(v.contiguous())
         got_rows = eng.run_rows(v.transpose(1, 2).contiguous())
-    e1, e2 = (got - ref).abs().max().item(), (got_rows - ref).abs().max().item()
-    if not (e1 <= 3e-5 and e2 <= 3e-5):
-        return f"b={b} ktot={ktot} err={e1} err_rows={e2}"
+        got_fused = eng.run_fused(v.transpose(1, 2).contiguous())          # the two-launch head of the shipped engine
+    e1, e2, e3 = (got - ref).abs().max().item(), (got_rows - ref).abs().max().item(), (got_fused - ref).abs().max().item()
+    if not (e1 <= 3e-5 and e2 <= 3e-5 and e3 <= 3e-5):
+        return f"b={b} ktot={ktot} err={e1} err_rows={e2} err_fused={e3}"
+
+
+def f_linear_lds():
+    """pa_linear's k = 256 kernel with the weight half resident in LDS (linear_lds.hip): bit-identical to the chain kernel on any row count, row
+    strides, widths that are multiples of 128, bias / ReLU / residual; fp64 check on top"""
+    import ctypes
+    lib = _lib.lib()
+    lib.pa_linear_lds_enable.argtypes, lib.pa_linear_lds_enable.restype = [ctypes.c_int], None
+    rows, n = logint(1, 40000), 128 * int(rng.integers(1, 6))
+    ldx = 256 + 4 * int(rng.integers(0, 3)) * int(rng.integers(0, 12))
+    relu, res = int(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    ldr = n + 4 * int(rng.integers(0, 5)) if res else 0
+    x = torch.randn(rows, ldx, device="cuda")
+    wt = torch.randn(256, n, device="cuda") / 16
+    bias = torch.randn(n, device="cuda")
+    r = torch.randn(rows, ldr, device="cuda") if res else None
+    outs = []
+    try:
+        for on in (0, 1):
+            lib.pa_linear_lds_enable(on)
+            out = torch.full((rows, n), float("nan"), device="cuda")
+            call("pa_linear", rows, 256, n, ptr(x), ldx, ptr(wt), ptr(pack_weights(wt)), ptr(bias), relu, ptr(r), ldr, ptr(out), n)
+            outs.append(out)
+    finally:
+        lib.pa_linear_lds_enable(-1)
+    ref = x[:, :256].double() @ wt.double() + bias.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    if res:
+        ref = ref + r[:, :n].double()
+    err = (outs[1].double() - ref).abs().max().item()
+    if not (torch.equal(outs[0], outs[1]) and err <= 2e-5 * max(ref.abs().max().item(), 1.0)):
+        return f"rows={rows} n={n} ldx={ldx} relu={relu} res={res} ldr={ldr} identical={torch.equal(outs[0], outs[1])} err={err}"
+
+
+def _grad_check(fn_hip, fn_ref, inputs, tol=3e-5):
+    """value and every input gradient of an autograd function on the HIP kernels against the same torch statement in fp64 on the device"""
+    hin = [t.clone().requires_grad_(True) for t in inputs]
+    rin = [t.double().requires_grad_(True) for t in inputs]
+    oh, orf = fn_hip(*hin), fn_ref(*rin)
+    w = torch.randn_like(orf)
+    (oh * w.float()).sum().backward()
+    (orf * w).sum().backward()
+    # error relative to the tensor's scale, floored at 1 like the other GEMM families (a gradient that is zero in exact arithmetic has no scale)
+    worst = ((oh.double() - orf).abs().max() / orf.abs().max().clamp_min(1.0)).item()
+    for a, b in zip(hin, rin):
+        worst = max(worst, ((a.grad.double() - b.grad).abs().max() / b.grad.abs().max().clamp_min(1.0)).item())
+    return None if worst <= tol else worst
+
+
+def f_train_glue():
+    """csrc/train_glue.hip under autograd: NetVLAD tail, dim-1 normalise, APFA attention, BatchNorm1d rows -- random shapes, fp64 torch on the device"""
+    import torch.nn.functional as F
+    from patchaugnet_amd import train_ops
+    which = int(rng.integers(0, 4))
+    if which == 0:
+        b, c, k, n = int(rng.integers(1, 5)), 4 * int(rng.integers(1, 65)), int(rng.choice([1, 2, 4, 7, 16, 33, 64, 100])), logint(1, 5000)
+        pre, x, cw2 = torch.randn(b, k, n, device="cuda") * 2, torch.randn(b, c, n, device="cuda"), torch.randn(1, c, k, device="cuda") / c ** 0.5
+
+        def ref(pre, x, cw2):
+            act = torch.softmax(pre, dim=1)
+            return F.normalize(torch.matmul(x, act.transpose(1, 2)) - act.sum(-1).unsqueeze(1) * cw2, dim=1)
+        bad = _grad_check(train_ops.netvlad_tail, ref, [pre, x, cw2])
+        return None if bad is None else f"netvlad_tail b={b} c={c} k={k} n={n} rel={bad}"
+    if which == 1:
+        b, c, m = int(rng.integers(1, 20)), logint(1, 600), int(rng.choice([1, 1, 3, 31, 32, 33, 1000]))
+        x = torch.randn(b, c, m, device="cuda") if m > 1 else torch.randn(b, c, device="cuda")
+        bad = _grad_check(train_ops.l2_normalize, lambda t: F.normalize(t, dim=1), [x])
+        return None if bad is None else f"l2_normalize b={b} c={c} m={m} rel={bad}"
+    if which == 2:
+        b, c, k = int(rng.integers(1, 20)), logint(1, 300), logint(1, 1200)
+        x, r = torch.randn(b, c, k, device="cuda"), torch.randn(b, c, k, device="cuda")
+
+        def ref(x, r):
+            return F.relu(x + x * torch.softmax(r.max(dim=1)[0], dim=-1).unsqueeze(1))
+        bad = _grad_check(train_ops.afa_attention, ref, [x, r])
+        return None if bad is None else f"afa_attention b={b} c={c} k={k} rel={bad}"
+    r_, f_ = int(rng.integers(4, 64)), logint(1, 1500)
+    bn_h = torch.nn.BatchNorm1d(f_).cuda()
+    with torch.no_grad():
+        bn_h.weight.uniform_(0.5, 1.5)
+        bn_h.bias.normal_(0, 0.2)
+    bn_r = torch.nn.BatchNorm1d(f_).cuda().double()
+    bn_r.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bn_h.state_dict().items()})
+    x = torch.randn(r_, f_, device="cuda") * 2 + 0.5
+    bad = _grad_check(lambda t: train_ops.bn_rows(bn_h, t, True), lambda t: bn_r(t), [x], tol=2e-4)
+    ok = bad is None and torch.allclose(bn_h.running_var.double(), bn_r.running_var, rtol=1e-5, atol=1e-6) and int(bn_h.num_batches_tracked) == 1
+    return None if ok else f"bn_rows r={r_} f={f_} rel={bad}"
 
 
 FAMILIES = (("fps", f_fps), ("knn", f_knn), ("3nn", f_3nn), ("knn_grid", f_knn_grid), ("3nn_grid", f_3nn_grid), ("gather", f_gather), ("backward", f_backward), ("linear", f_linear),
-            ("attention", f_attention), ("chain_sa", f_chain_sa), ("chain_fp", f_chain_fp), ("netvlad", f_netvlad), ("afa", f_afa))
+            ("attention", f_attention), ("chain_sa", f_chain_sa), ("chain_fp", f_chain_fp), ("netvlad", f_netvlad), ("afa", f_afa), ("linear_lds", f_linear_lds), ("train_glue", f_train_glue))
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:
