@@ -89,6 +89,13 @@ struct NNArgs {
     int xcd_order;                       // XCD-contiguous tile order (xcd_contiguous_id)
 };
 
+#ifndef PA_TGEMM_PREFETCH2
+#define PA_TGEMM_PREFETCH2 0
+#endif
+#ifndef PA_TGEMM_LDS_AHEAD
+#define PA_TGEMM_LDS_AHEAD 1
+#endif
+
 constexpr int NN_BN = 128;
 
 // Workgroups are dealt to the eight XCDs round-robin in launch order (id % 8), and every XCD has its own L2.  This maps the launch-order id to a
@@ -142,16 +149,29 @@ __global__ __launch_bounds__(256) void tgemm_nn_kernel(NNArgs a)
     // stash(), after the MFMAs of the current tile -- so the loads of tile kt + 1 are in flight during the whole MFMA block of tile kt.
     // (Before: predicated loads compiled to a branch per load and the transform right behind them put s_waitcnt vmcnt(0) BEFORE the
     // MFMAs: the global latency of every k-tile was exposed in every wave.)
-    float ra[AE];
-    unsigned fa = 0;                                       // validity bits of ra
+    // Register stage(s) of the operand loads.  PA_TGEMM_PREFETCH2=1 (compile time; measured and NOT the default) requests tile kt + 2 while tile
+    // kt is multiplied and tile kt + 1 is stashed: hipcc 7.2 then drains the load queue (s_waitcnt vmcnt(0)) at the top of the second half of
+    // the unrolled loop and waits for the older stage in front of the MFMAs, and the second stage's registers cost a workgroup per CU: 122 ->
+    // 159 us at the fp0 shape (tools/probes/tgemm_scale.py).
     constexpr int BP = NN_BK / 8;                           // B staging passes of 8 rows
-    float rb[BP * 4], ry[BP * 4];
-    ChanP rcp[BP];
-    unsigned fb = 0;                                       // validity bits of rb
+    struct Stage {
+        float ra[AE];
+        unsigned fa;                                       // validity bits of ra
+        float rb[BP * 4], ry[BP * 4];
+        ChanP rcp[BP];
+        unsigned fb;                                       // validity bits of rb
+    };
+    Stage S0;
+#if PA_TGEMM_PREFETCH2
+    Stage S1;
+#endif
     // B staging: thread -> rows kb, kb + 8; 4 consecutive columns nb4
     const int kb = tid >> 5, nb4 = (tid & 31) * 4;
     const int Km1 = a.K - 1, Mm1 = a.M - 1, Nm1 = a.N - 1;
-    auto fetch = [&](int k0) {
+    auto fetch = [&](int k0, Stage &S) {
+        float (&ra)[AE] = S.ra, (&rb)[BP * 4] = S.rb, (&ry)[BP * 4] = S.ry;
+        ChanP (&rcp)[BP] = S.rcp;
+        unsigned &fa = S.fa, &fb = S.fb;
         fa = 0; fb = 0;
         // ---- A tile
         if (A_KCONTIG) {                                   // 4 consecutive k per load: m = q / (BK/4), k4 = (q % (BK/4)) * 4
@@ -218,7 +238,10 @@ __global__ __launch_bounds__(256) void tgemm_nn_kernel(NNArgs a)
             }
         }
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf, Stage &S) {
+        float (&ra)[AE] = S.ra, (&rb)[BP * 4] = S.rb, (&ry)[BP * 4] = S.ry;
+        ChanP (&rcp)[BP] = S.rcp;
+        const unsigned fa = S.fa, fb = S.fb;
         float *as = As[buf], *bs = Bs[buf];
 #pragma unroll
         for (int e = 0; e < AE; ++e) ra[e] = (fa >> e) & 1u ? ra[e] : 0.f;
@@ -249,14 +272,41 @@ __global__ __launch_bounds__(256) void tgemm_nn_kernel(NNArgs a)
     };
 
     const int nk = (a.K + NN_BK - 1) / NN_BK;
-    fetch(0);
-    stash(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) fetch((kt + 1) * NN_BK);
+    // The MFMA block of one k-tile.  The operand fragments of k-step ks + 1 are read from LDS BEFORE the MFMAs of k-step ks are issued and the
+    // scheduler is pinned to that order: left alone hipcc emits read -> s_waitcnt lgkmcnt(0) -> 4 MFMAs, eight times per tile, i.e. every wave
+    // pays the LDS round trip per 128 cycles of MFMA work (PA_TGEMM_LDS_AHEAD=0 keeps that form for A/B).
+    auto multiply = [&](int cur) {
         const float *as = As[cur] + (lane >> 4) * SA + wm * (BM / WM) + (lane & 15);
         const float *bs = Bs[cur] + (lane >> 4) * SB + wn * (NN_BN / WN) + (lane & 15);
+#if PA_TGEMM_LDS_AHEAD
+        float af[MT], bf[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = as[i * 16];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[j] = bs[j * 16];
+#pragma unroll
+        for (int ks = 0; ks < NN_BK / 4; ++ks) {
+            float an[MT], bn[NT];
+            if (ks + 1 < NN_BK / 4) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) an[i] = as[(ks + 1) * 4 * SA + i * 16];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bn[j] = bs[(ks + 1) * 4 * SB + j * 16];
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            if (ks + 1 < NN_BK / 4) {
+                __builtin_amdgcn_sched_group_barrier(0x100, (MT + NT + 1) / 2, 0);      // the next k-step's reads (pairs merge into ds_read2_b32) ...
+                __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);                // ... then this k-step's MFMAs
+#pragma unroll
+                for (int i = 0; i < MT; ++i) af[i] = an[i];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bf[j] = bn[j];
+            }
+        }
+#else
 #pragma unroll
         for (int ks = 0; ks < NN_BK / 4; ++ks) {
             float af[MT], bf[NT];
@@ -269,9 +319,36 @@ __global__ __launch_bounds__(256) void tgemm_nn_kernel(NNArgs a)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) stash(cur ^ 1);
+#endif
+    };
+#if PA_TGEMM_PREFETCH2
+    fetch(0, S0);
+    if (nk > 1) fetch(NN_BK, S1);
+    stash(0, S0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        if (kt + 2 < nk) fetch((kt + 2) * NN_BK, S0);       // S0 is free: tile kt was stashed from it
+        multiply(0);
+        if (kt + 1 < nk) stash(1, S1);
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        if (kt + 3 < nk) fetch((kt + 3) * NN_BK, S1);
+        multiply(1);
+        if (kt + 2 < nk) stash(0, S0);
         __syncthreads();
     }
+#else
+    fetch(0, S0);
+    stash(0, S0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) fetch((kt + 1) * NN_BK, S0);
+        multiply(cur);
+        if (kt + 1 < nk) stash(cur ^ 1, S0);
+        __syncthreads();
+    }
+#endif
 
     // ---- epilogue: C/D layout: column n = l % 16, row m = 4 * (l / 16) + r
     float s1[MT][4], s2[MT][4];
@@ -325,6 +402,125 @@ __global__ __launch_bounds__(256) void tgemm_nn_kernel(NNArgs a)
             atomicAdd(st + a.M + m0 + tid, (double)t2);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------ tgemm_nn, wave-private form
+// The same contraction for the aligned shapes that carry the step's FLOPs (M % 64 == 0, N % 64 == 0, K % 16 == 0, 16-byte aligned operands, no
+// tanh / distance epilogue): every WAVEFRONT owns a 64 x 64 output tile and runs its own software pipeline -- no LDS, no workgroup barrier.
+// (The LDS-tiled kernel above keeps 4-5 workgroups per CU whose four waves meet at a barrier every 32 MFMAs; at the 256 x 4096 x 256 layer the
+// workgroups convoy: 3.4 us per k-tile for 2.2 us of MFMA work on the CU, 51 % MFMA-busy, waves 57 % in s_waitcnt; deeper register prefetch
+// and LDS reads issued a k-step ahead changed nothing -- tools/probes/tgemm_scale.py, tools/pmc_tgemm.sh.)
+// Operands come straight from global memory / L2 in the MFMA fragment layout with 16-byte loads, eight loads per 64 MFMAs:
+//   * the contraction index is visited in the order k = 16 j + 4 (l / 16) + r (block j, MFMA step r = 0..3): a sum may take its terms in any order
+//     as long as both operands agree, and in this order a lane's four A values of a block (A k-contiguous) are ONE float4;
+//   * the tile's columns are n = n0 + 4 (l % 16) + u for MFMA column tile u: a lane's four B values of a step are ONE float4 of row k, and its
+//     four results per output row are four consecutive columns -> 16-byte stores.  With A m-contiguous (the dX GEMM) the rows are permuted the
+//     same way (m = m0 + 4 i + t) and a float4 of row k feeds the four row tiles.
+// The BatchNorm / ReLU operand transform is applied to the 16 B values of a block in registers (its per-channel parameters are float4 loads in the
+// same k order); statistics epilogue: 16-lane DPP-row sums, one fp64 atomic pair per row and wave.
+template <bool A_KCONTIG, int BMODE>
+__global__ __launch_bounds__(256) void tgemm_nnw_kernel(NNArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, q = lane >> 4;
+    const int nblk = blockIdx.x * (blockDim.x >> 6) + wave;
+    const int n0 = nblk * 64, m0 = blockIdx.y * 64, b = blockIdx.z;
+    if (n0 >= a.N) return;
+    const float *A = a.A + (size_t)b * a.sAb;
+    const float *B = a.B + (size_t)b * a.sBb + n0 + 4 * li;
+    const float *B2 = (BMODE >= TF_BN_BWD_RELU) ? a.tb.aux + (size_t)b * a.sBb + n0 + 4 * li : nullptr;
+    const float *P = a.tb.p + (size_t)b * a.sPb + 4 * q;
+    float *C = a.C + (size_t)b * a.sCb;
+    constexpr int NP = BMODE == TF_NONE ? 0 : (BMODE == TF_AFFINE_RELU ? 2 : 7);
+
+    floatx4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[i][u] = (floatx4){0.f, 0.f, 0.f, 0.f};
+
+    constexpr int NPA = NP > 0 ? NP : 1;
+    floatx4 ac[4], bc[4], yc[4], pc[NPA], an[4], bn[4], yn[4], pn[NPA];
+    // everything block jb needs, requested together (the transform's parameters too: a load issued AFTER the next block's would make the wait for
+    // it a wait for all of them -- the counter is in order)
+    auto load = [&](int jb, floatx4 (&aa)[4], floatx4 (&bb)[4], floatx4 (&yy)[4], floatx4 (&pp)[NPA]) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) pp[j] = *reinterpret_cast<const floatx4 *>(P + (size_t)j * a.tb.nch + 16 * jb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            aa[i] = A_KCONTIG ? *reinterpret_cast<const floatx4 *>(A + (size_t)(m0 + i * 16 + li) * a.lda + 16 * jb + 4 * q)
+                              : *reinterpret_cast<const floatx4 *>(A + (size_t)(16 * jb + 4 * q + i) * a.lda + m0 + 4 * li);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            bb[r] = *reinterpret_cast<const floatx4 *>(B + (size_t)(16 * jb + 4 * q + r) * a.ldb);
+            if (BMODE >= TF_BN_BWD_RELU) yy[r] = *reinterpret_cast<const floatx4 *>(B2 + (size_t)(16 * jb + 4 * q + r) * a.ldb);
+        }
+    };
+    // one block: transform the 16 B values in registers, then 64 MFMAs
+    auto compute = [&](floatx4 (&aa)[4], floatx4 (&bb)[4], floatx4 (&yy)[4], floatx4 (&pp)[NPA]) {
+        if (BMODE != TF_NONE) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ChanP c;
+#pragma unroll
+                for (int j = 0; j < 7; ++j) c.v[j] = j < NP ? pp[j < NP ? j : 0][r] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bb[r][u] = tf_apply<BMODE>(bb[r][u], BMODE >= TF_BN_BWD_RELU ? yy[r][u] : 0.f, c);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    acc[i][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_KCONTIG ? aa[i][r] : aa[r][i], bb[r][u], acc[i][u], 0, 0, 0);
+    };
+    // two register sets in turn (no copies: a copy placed after a component's last use made hipcc wait for the NEXT block's loads four MFMAs
+    // into the current block)
+    // into the current block); every load is UNCONDITIONAL (block index clamped: the last one or two are redundant) -- a load behind an `if` gives
+    // the two paths different numbers of outstanding loads, and hipcc then waits for all of them (s_waitcnt vmcnt(0)) in front of the MFMAs
+    const int nb = a.K / 16;
+    load(0, ac, bc, yc, pc);
+    int jb = 0;
+    for (; jb + 2 <= nb; jb += 2) {
+        load(min(jb + 1, nb - 1), an, bn, yn, pn);                 // in flight under this block's 64 MFMAs
+        __builtin_amdgcn_sched_barrier(0);                         // (left alone the scheduler sinks the loads into the MFMA stream, each into a
+        compute(ac, bc, yc, pc);                                   //  register that has just been freed, and waits for it a few MFMAs later)
+        __builtin_amdgcn_sched_barrier(0);
+        load(min(jb + 2, nb - 1), ac, bc, yc, pc);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(an, bn, yn, pn);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (jb < nb) compute(ac, bc, yc, pc);                          // odd number of blocks: the last one is already here
+
+    // ---- epilogue.  D layout of tile (i, u): column l % 16, row 4 (l / 16) + rr  ->  n = n0 + 4 (l % 16) + u (four consecutive columns per lane),
+    // m = m0 + 16 i + 4 (l / 16) + rr (A k-contiguous) or m0 + 4 (4 (l / 16) + rr) + i (A m-contiguous)
+    const unsigned slot = (unsigned)(nblk + b * (a.N / 64)) % PA_BN_STAT_SLOTS;
+    double *st = a.stats ? a.stats + (size_t)b * a.sStatb + (size_t)slot * 2 * a.M : nullptr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int m = A_KCONTIG ? m0 + 16 * i + 4 * q + rr : m0 + 4 * (4 * q + rr) + i;
+            const float bias = a.bias ? a.bias[m] : 0.f;
+            floatx4 v = {acc[i][0][rr] + bias, acc[i][1][rr] + bias, acc[i][2][rr] + bias, acc[i][3][rr] + bias};
+            floatx4 *dst = reinterpret_cast<floatx4 *>(C + (size_t)m * a.ldc + n0 + 4 * li);
+            if (a.beta) {
+                const floatx4 o = *dst;
+                v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+            }
+            *dst = v;
+            if (st) {
+                float t1 = (v[0] + v[1]) + (v[2] + v[3]), t2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { t1 += __shfl_xor(t1, o); t2 += __shfl_xor(t2, o); }
+                if (li == 0) {
+                    atomicAdd(st + m, (double)t1);
+                    atomicAdd(st + a.M + m, (double)t2);
+                }
+            }
+        }
 }
 
 // ------------------------------------------------------------------------------------------------ tgemm_kk
@@ -448,6 +644,27 @@ __global__ __launch_bounds__(256) void tgemm_kk_kernel(KKArgs a)
         if (kt + 1 < nk) fetch(kbeg + (kt + 1) * KK_BK);
         const float *as = As[cur] + (wm * 32 + (lane & 15)) * KK_S + (lane >> 4);
         const float *bs = Bs[cur] + (wn * 32 + (lane & 15)) * KK_S + (lane >> 4);
+#if PA_TGEMM_LDS_AHEAD
+        // the fragments of k-step ks + 1 are read before the MFMAs of k-step ks are issued (see tgemm_nn_kernel's multiply)
+        float a0 = as[0], a1 = as[16 * KK_S], b0 = bs[0], b1 = bs[16 * KK_S];
+#pragma unroll
+        for (int ks = 0; ks < KK_BK / 4; ++ks) {
+            float na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
+            if (ks + 1 < KK_BK / 4) {
+                na0 = as[(ks + 1) * 4]; na1 = as[16 * KK_S + (ks + 1) * 4];
+                nb0 = bs[(ks + 1) * 4]; nb1 = bs[16 * KK_S + (ks + 1) * 4];
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+            if (ks + 1 < KK_BK / 4) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+        }
+#else
 #pragma unroll
         for (int ks = 0; ks < KK_BK / 4; ++ks) {
             const float a0 = as[ks * 4], a1 = as[16 * KK_S + ks * 4];
@@ -457,6 +674,7 @@ __global__ __launch_bounds__(256) void tgemm_kk_kernel(KKArgs a)
             acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
         }
+#endif
         if (kt + 1 < nk) stash(cur ^ 1);
         __syncthreads();
     }
@@ -733,6 +951,10 @@ TOp make_top(int mode, const float *aux, const float *p, int nch)
 
 }  // namespace
 
+static int g_tgemm_wave = -1;
+// test / A/B switch: 1 = the wave-private kernel wherever its shape rules hold, 0 = never, -1 = the environment (PA_TGEMM_WAVE, default off)
+PA_API void pa_tgemm_wave_enable(int on) { g_tgemm_wave = on; }
+
 // C_b (M x N) = [beta C_b +] act(A_b . f(B_b) + bias): see tgemm_nn_kernel.  a_kcontig: A(m,k) = A[m*lda + k] (else A[k*lda + m]);
 // sAb = 0 shares A over the batch.  bmode 0 none / 1 affine+relu (bp: 2*K floats) / 2 bn-bwd with ReLU mask / 3 bn-bwd (baux = raw output,
 // bp: 7*K floats).  stats (PA_BN_STAT_SLOTS x 2*M doubles, accumulated; pa_bn_finalize adds the replicas up) or NULL.
@@ -766,8 +988,32 @@ PA_API int pa_tgemm_nn(int batch, int M, int N, int K, const float *A, long sAb,
     const bool big = M > 64 && t128 >= big_min;
     const long t64 = (long)((M + 63) / 64) * ((N + NN_BN - 1) / NN_BN) * batch;
     const bool deep = K > 16 && !big && t64 < 1024;     // few workgroups: latency-bound rounds, halve their number (measured: hurts the chip-filling launches)
-    dim3 grid((N + NN_BN - 1) / NN_BN, (M + (big ? 127 : 63)) / (big ? 128 : 64), batch);
     hipStream_t st = (hipStream_t)stream;
+    // the wave-private kernel for the aligned shapes (tgemm_nnw_kernel): OPT-IN (PA_TGEMM_WAVE=1 or pa_tgemm_wave_enable).  Measured against the
+    // LDS-tiled kernel on MI355X (tools/probes/tgemm_scale.py, 18 x (M x 4096 x 256)): M = 64: 54 vs 60 us, M = 256: 125 vs 123 us, M = 512: 211 vs
+    // 222 us; the training step 6.10 vs 6.15 ms -- a tie.  Both follow time = ~33 us + 21.5 us per 64 rows of M: the marginal rate is 112 TFLOP/s
+    // (0.71 of peak) and the constant is the first pass over the 75 MB activation operand, which neither form overlaps with its MFMAs.
+    static const bool wave_env = getenv("PA_TGEMM_WAVE") && atoi(getenv("PA_TGEMM_WAVE")) != 0;
+    const bool wave_on = g_tgemm_wave > 0 || (g_tgemm_wave < 0 && wave_env);
+    static const long wave_min = getenv("PA_TGEMM_WAVE_MIN") ? atol(getenv("PA_TGEMM_WAVE_MIN")) : 1;
+    const long wtiles = (long)(M / 64) * (N / 64) * batch;
+    if (wave_on && act == 0 && !colv && M % 64 == 0 && N % 64 == 0 && K % 16 == 0 && wtiles >= wave_min && aligned16(A) && lda % 4 == 0 && sAb % 4 == 0 &&
+        aligned16(B) && ldb % 4 == 0 && sBb % 4 == 0 && (bmode < 2 || aligned16(baux)) && aligned16(C) && ldc % 4 == 0 && sCb % 4 == 0 &&
+        (bmode == 0 || (aligned16(bp) && a.sPb % 4 == 0)) && batch <= 65535 && M / 64 <= 65535) {
+        const int nblocks = N / 64;
+        static const int wforce = getenv("PA_TGEMM_WAVE_W") ? atoi(getenv("PA_TGEMM_WAVE_W")) : 0;      // waves per workgroup (A/B knob)
+        int W = nblocks % 4 == 0 ? 4 : (nblocks % 2 == 0 ? 2 : 1);
+        if (wforce > 0 && nblocks % wforce == 0 && wforce <= 4) W = wforce;
+        const dim3 wgrid(nblocks / W, M / 64, batch);
+#define PA_NNW(KC, MODE) hipLaunchKernelGGL((tgemm_nnw_kernel<KC, MODE>), wgrid, dim3(64 * W), 0, st, a)
+#define PA_NNW_MODE(KC) switch (bmode) { case 0: PA_NNW(KC, 0); break; case 1: PA_NNW(KC, 1); break; case 2: PA_NNW(KC, 2); break; default: PA_NNW(KC, 3); break; }
+        if (a_kcontig) { PA_NNW_MODE(true) } else { PA_NNW_MODE(false) }
+#undef PA_NNW_MODE
+#undef PA_NNW
+        PA_CHECK_LAUNCH("pa_tgemm_nn (wave-private)");
+        return PA_OK;
+    }
+    dim3 grid((N + NN_BN - 1) / NN_BN, (M + (big ? 127 : 63)) / (big ? 128 : 64), batch);
 #define PA_NN(BMv, BKv, KC, MODE, VAv, VBv) hipLaunchKernelGGL((tgemm_nn_kernel<BMv, BKv, KC, MODE, VAv, VBv>), grid, dim3(256), 0, st, a)
 #define PA_NN_VEC(BMv, BKv, KC, MODE)                                                                       \
     if (a.vecA) { if (a.vecB) PA_NN(BMv, BKv, KC, MODE, true, true); else PA_NN(BMv, BKv, KC, MODE, true, false); } \
