@@ -343,10 +343,16 @@ __global__ __launch_bounds__(256) void tgemm_nn_kernel(NNArgs a)
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) fetch((kt + 1) * NN_BK, S0);
+#ifndef PA_TGEMM_DBG_NO_LOADS                              // decomposition probes (never built into the library): the k-loop without its global
+        if (kt + 1 < nk) fetch((kt + 1) * NN_BK, S0);      // loads / without its MFMAs -- tools/probes/tgemm_scale.py on a variant build
+#endif
+#ifndef PA_TGEMM_DBG_NO_MFMA
         multiply(cur);
+#endif
+#ifndef PA_TGEMM_DBG_NO_STASH
         if (kt + 1 < nk) stash(cur ^ 1, S0);
         __syncthreads();
+#endif
     }
 #endif
 
@@ -368,6 +374,9 @@ __global__ __launch_bounds__(256) void tgemm_nn_kernel(NNArgs a)
                     else if (a.act == 2) { v = (bias + a.colv[gn]) - 2.f * acc[i][j][r]; v = v > 0.f ? v : 0.f; }
                     float *dst = C + (size_t)gm * a.ldc + gn;
                     if (a.beta) v += *dst;
+#ifdef PA_TGEMM_DBG_NO_STORE
+                    if (v == 1.2345e33f)                    // decomposition probe: the epilogue without its stores (the value still has to exist)
+#endif
                     *dst = v;
                     t1 += v;
                     t2 += v * v;
