@@ -397,6 +397,16 @@ void pa_knn_quad_enable(int on);
  * instead of 12 n: the winner's coordinates come from the owning lane's registers).  Same samples bit for bit; slower per round (fps.hip). */
 void pa_fps_reg_xyz_enable(int on);
 
+/* A/B and test switches of round 3's kernels (1 = wherever the kernel's shape rules hold, 0 = never, -1 = the default rule / environment):
+ *   pa_chain_tiny_enable     the persistent first-set-abstraction kernel (csrc/sa_tiny.hip; default on; bit-identical to the generic chain kernel)
+ *   pa_linear_lds_enable     pa_linear at k = 256 on LDS-resident weights (csrc/linear_lds.hip; default from 8192 rows; bit-identical)
+ *   pa_tgemm_wave_enable     pa_tgemm_nn's wave-private kernel (default off: PA_TGEMM_WAVE=1; same sums in another order)
+ *   pa_emd_persistent_enable pa_emd_forward as one persistent workgroup per cloud instead of one launch per round (0 / 1; bit-identical) */
+void pa_chain_tiny_enable(int on);
+void pa_linear_lds_enable(int on);
+void pa_tgemm_wave_enable(int on);
+void pa_emd_persistent_enable(int on);
+
 /* pa_nearestneighbor / pa_three_nn_weights use a cell-grid kernel (csrc/three_nn_grid.hip, same results bit for bit) for 512..4096 known
  * points and >= 1024 queries; 0 forces the brute-force scan (A/B, tests). */
 void pa_three_nn_grid_enable(int on);
