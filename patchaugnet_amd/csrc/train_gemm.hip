@@ -87,8 +87,12 @@ struct NNArgs {
     long sPb, sStatb;                    // per-batch strides of tb.p (floats) and stats (doubles); 0 = one block shared by the batch
     int vecA, vecB;                      // 16-byte loads allowed (alignment / divisibility checked on the host)
     int xcd_order;                       // XCD-contiguous tile order (xcd_contiguous_id)
+    int vecC;                            // 16-byte stores of C allowed (alignment, N % 4 == 0)
 };
 
+#ifndef PA_TGEMM_VEC_STORE
+#define PA_TGEMM_VEC_STORE 1
+#endif
 #ifndef PA_TGEMM_PREFETCH2
 #define PA_TGEMM_PREFETCH2 0
 #endif
@@ -357,6 +361,8 @@ __global__ __launch_bounds__(256) void tgemm_nn_kernel(NNArgs a)
 #endif
 
     // ---- epilogue: C/D layout: column n = l % 16, row m = 4 * (l / 16) + r
+    // (vec_store: 64-row tiles with the plain epilogue and 16-byte-aligned output rows -- workgroup-uniform)
+    const bool vec_store = PA_TGEMM_VEC_STORE && BM == 64 && NN_BK * (NN_BN + 16) * 2 >= 4 * 32 * 36 && a.act == 0 && !a.beta && a.vecC;
     float s1[MT][4], s2[MT][4];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -377,7 +383,8 @@ __global__ __launch_bounds__(256) void tgemm_nn_kernel(NNArgs a)
 #ifdef PA_TGEMM_DBG_NO_STORE
                     if (v == 1.2345e33f)                    // decomposition probe: the epilogue without its stores (the value still has to exist)
 #endif
-                    *dst = v;
+                    if (!vec_store) *dst = v;
+                    if (vec_store) acc[i][j][r] = v;       // the stored value, for the transposed 16-byte store below
                     t1 += v;
                     t2 += v * v;
                 }
@@ -385,6 +392,29 @@ __global__ __launch_bounds__(256) void tgemm_nn_kernel(NNArgs a)
             s1[i][r] = t1;
             s2[i][r] = t2;
         }
+    if (vec_store) {
+        // 16-byte stores: the accumulator layout gives a lane ONE column of four rows (4-byte stores, 64 contiguous bytes per row and instruction:
+        // ~12 us of the 124 us launch at the fp0 shape).  Each wave passes its 64 x 32 tile through a private 32 x 36-float slab of the B stage
+        // (free after the loop's last barrier; a wave's LDS operations execute in order, no barrier needed) in two halves and writes rows of
+        // 128 contiguous bytes, 8 lanes per row.
+        float *slab = &Bs[0][0] + wave * (32 * 36);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) slab[(ii * 16 + (lane >> 4) * 4 + r) * 36 + j * 16 + (lane & 15)] = acc[half * 2 + ii][j][r];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int idx = it * 64 + lane, rl = idx >> 3, c4 = (idx & 7) * 4;
+                const int gm = m0 + half * 32 + rl, gn = n0 + wn * 32 + c4;
+                const float4 v = *reinterpret_cast<const float4 *>(slab + rl * 36 + c4);
+                if (gm < a.M && gn < a.N) *reinterpret_cast<float4 *>(C + (size_t)gm * a.ldc + gn) = v;      // N % 4 == 0: a group of four is in or out
+            }
+        }
+    }
     if (a.stats) {
         // per-row sums over this workgroup's columns: 16 lanes of a DPP row share a row m, the WN waves of a wave row meet in LDS (the
         // operand stage is free after the loop's last barrier), then ONE fp64 atomic pair per row and workgroup -- into one of
@@ -988,6 +1018,8 @@ PA_API int pa_tgemm_nn(int batch, int M, int N, int K, const float *A, long sAb,
     a.vecB = aligned16(B) && ldb % 4 == 0 && sBb % 4 == 0 && (bmode < 2 || aligned16(baux)) && N % 4 == 0 && N >= 4;
     static const int xcd_mode = getenv("PA_TGEMM_XCD_ORDER") ? atoi(getenv("PA_TGEMM_XCD_ORDER")) : 2;      // bit 0: tgemm_nn, bit 1: tgemm_kk
     a.xcd_order = xcd_mode & 1;
+    static const bool no_vec_store = getenv("PA_TGEMM_NO_VEC_STORE") != nullptr;                               // A/B knob
+    a.vecC = !no_vec_store && aligned16(C) && ldc % 4 == 0 && sCb % 4 == 0 && N % 4 == 0;
     // 64-row tiles (half the accumulators: 4-5 workgroups per CU instead of 3) for every shape.  128-row tiles remain behind
     // PA_TGEMM_BIG_MIN (minimum number of 128 x 128 tiles to use them): measured on MI355X they lose even where they fill the chip -- the
     // finest level's 256 x 4096 x 256 per cloud x 18 is 1152 such tiles on 768 resident slots = two rounds (153 us; 64-row tiles 145 us), the
