@@ -1032,8 +1032,10 @@ PA_API int pa_tgemm_nn(int batch, int M, int N, int K, const float *A, long sAb,
     hipStream_t st = (hipStream_t)stream;
     // the wave-private kernel for the aligned shapes (tgemm_nnw_kernel): OPT-IN (PA_TGEMM_WAVE=1 or pa_tgemm_wave_enable).  Measured against the
     // LDS-tiled kernel on MI355X (tools/probes/tgemm_scale.py, 18 x (M x 4096 x 256)): M = 64: 54 vs 60 us, M = 256: 125 vs 123 us, M = 512: 211 vs
-    // 222 us; the training step 6.10 vs 6.15 ms -- a tie.  Both follow time = ~33 us + 21.5 us per 64 rows of M: the marginal rate is 112 TFLOP/s
-    // (0.71 of peak) and the constant is the first pass over the 75 MB activation operand, which neither form overlaps with its MFMAs.
+    // 222 us; the training step 6.10 vs 6.15 ms -- a tie.  Both follow time = ~30 us + 21.5 us per 64 rows of M; the decomposition builds of the
+    // LDS-tiled kernel (PA_TGEMM_DBG_*) put its LDS-read + MFMA loop alone at 84-91 us of the 110-126 us: neither form is
+    // waiting for its operands, both sit at the ~0.75 of peak the MFMA pipe gives this chip's other kernels, plus launch, ramp, tail and the
+    // 75 MB of output traffic.
     static const bool wave_env = getenv("PA_TGEMM_WAVE") && atoi(getenv("PA_TGEMM_WAVE")) != 0;
     const bool wave_on = g_tgemm_wave > 0 || (g_tgemm_wave < 0 && wave_env);
     static const long wave_min = getenv("PA_TGEMM_WAVE_MIN") ? atol(getenv("PA_TGEMM_WAVE_MIN")) : 1;
