@@ -80,10 +80,11 @@ int pa_interpolation_forward(int b, int c, int m, int n, const float *points, co
 int pa_interpolation_backward(int b, int c, int n, int m, const float *grad_out, const int *idx, const float *weight, float *grad_points, pa_stream_t stream);
 /* The same gradient without atomics (csrc/gather.hip): the (point, neighbour) references are counting-sorted by target once per launch, then
  * every output element is a plain sum over its list.  Equal to pa_interpolation_backward up to the order of the float sums; n <= 4096,
- * m <= 8192; scratch: pa_interpolation_backward_scratch_ints(b, n, m) ints, 8-byte aligned. */
+ * m <= 8192; scratch: pa_interpolation_backward_scratch_ints(b, n, m) ints, 8-byte aligned.  grad_out_batch_stride: floats between consecutive
+ * clouds of grad_out (0 = c n; larger for a channel slice of a wider contiguous tensor, read in place). */
 long pa_interpolation_backward_scratch_ints(int b, int n, int m);
-int pa_interpolation_backward_gather(int b, int c, int n, int m, const float *grad_out, const int *idx, const float *weight, float *grad_points,
-                                     int *scratch, pa_stream_t stream);
+int pa_interpolation_backward_gather(int b, int c, int n, int m, const float *grad_out, long grad_out_batch_stride, const int *idx, const float *weight,
+                                     float *grad_points, int *scratch, pa_stream_t stream);
 /* The list inversion of pa_interpolation_backward_gather alone (it depends on idx / weight only): scratch then serves any number of
  * pa_interpolation_backward_gather calls with idx = weight = NULL for the same (b, n, m). */
 int pa_interpolation_backward_lists(int b, int n, int m, const int *idx, const float *weight, int *scratch, pa_stream_t stream);

@@ -27,7 +27,7 @@ _SIGS = {
     "pa_nearestneighbor": "iiipppp",
     "pa_interpolation_forward": "iiiipppp",
     "pa_interpolation_backward": "iiiipppp",
-    "pa_interpolation_backward_gather": "iiiippppp",
+    "pa_interpolation_backward_gather": "iiiiplpppp",
     "pa_interpolation_backward_lists": "iiippp",
     "pa_ballquery": "iiifippp",
     "pa_featuredistribute": "iiippp",

@@ -413,13 +413,13 @@ __global__ __launch_bounds__(256) void interp_csr_build_kernel(int n, int m, con
 // the launch lives on the number of wavefronts in flight); LDS 4 n floats.  A list is read four entries at a time (clamped addresses, the tail
 // predicated off): one round trip per four neighbours instead of four.
 template <int NT>
-__global__ __launch_bounds__(NT) void interp_bwd_gather_kernel(int c, int n, int m, const float *__restrict__ grad_out, const int *__restrict__ off_all,
+__global__ __launch_bounds__(NT) void interp_bwd_gather_kernel(int c, int n, int m, const float *__restrict__ grad_out, long gstride, const int *__restrict__ off_all,
                                                                const int2 *__restrict__ ent_all, float *__restrict__ grad_points)
 {
     extern __shared__ __attribute__((aligned(16))) float rows[];      // [4][n]
     const int b = blockIdx.y, c0 = blockIdx.x * 4, tid = threadIdx.x;
     const int nc = min(4, c - c0);
-    const float *src = grad_out + ((size_t)b * c + c0) * n;
+    const float *src = grad_out + (size_t)b * gstride + (size_t)c0 * n;      // gstride: floats between clouds (c n, or more for a channel slice)
     if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
         const float4 *s4 = reinterpret_cast<const float4 *>(src);
         float4 *d4 = reinterpret_cast<float4 *>(rows);
@@ -462,10 +462,14 @@ __global__ __launch_bounds__(NT) void interp_bwd_gather_kernel(int c, int n, int
 PA_API long pa_interpolation_backward_scratch_ints(int b, int n, int m) { return (long)b * ((long)m + 1 + 6L * n) + 4; }
 
 // Same result as pa_interpolation_backward up to the order of the float sums (neither is ordered like the reference's atomics); needs
-// n <= 4096 (four channel rows in LDS), m <= 8192; scratch: pa_interpolation_backward_scratch_ints ints, 8-byte aligned.
-PA_API int pa_interpolation_backward_gather(int b, int c, int n, int m, const float *grad_out, const int *idx, const float *weight, float *grad_points,
-                                            int *scratch, pa_stream_t stream)
+// n <= 4096 (four channel rows in LDS), m <= 8192; scratch: pa_interpolation_backward_scratch_ints ints, 8-byte aligned.  grad_out_batch_stride:
+// floats between consecutive clouds of grad_out (0 = c n): the gradient of a channel SLICE of a wider tensor (autograd's backward of the
+// torch.cat that appends the skip features) is read in place instead of through a contiguous copy (75 MB at the finest level).
+PA_API int pa_interpolation_backward_gather(int b, int c, int n, int m, const float *grad_out, long grad_out_batch_stride, const int *idx, const float *weight,
+                                            float *grad_points, int *scratch, pa_stream_t stream)
 {
+    const long gstride = grad_out_batch_stride > 0 ? grad_out_batch_stride : (long)c * n;
+    PA_REQUIRE(gstride >= (long)c * n, "pa_interpolation_backward_gather: batch stride %ld < c n", gstride);
     PA_REQUIRE(b > 0 && c > 0 && m > 0 && n > 0, "pa_interpolation_backward_gather: sizes must be positive");
     PA_REQUIRE(grad_out && grad_points && scratch && ((idx == nullptr) == (weight == nullptr)), "pa_interpolation_backward_gather: null pointer");
     PA_REQUIRE(b <= 65535 && (c + 3) / 4 <= 2147483647, "pa_interpolation_backward_gather: b=%d exceeds the grid limit", b);
@@ -478,10 +482,10 @@ PA_API int pa_interpolation_backward_gather(int b, int c, int n, int m, const fl
     const size_t lds = (size_t)4 * n * 4;
     if (m >= 1024) {
         if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&interp_bwd_gather_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(interp_bwd_gather_kernel<1024>, dim3((c + 3) / 4, b), dim3(1024), lds, st, c, n, m, grad_out, off, ent, grad_points);
+        hipLaunchKernelGGL(interp_bwd_gather_kernel<1024>, dim3((c + 3) / 4, b), dim3(1024), lds, st, c, n, m, grad_out, gstride, off, ent, grad_points);
     } else {
         if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&interp_bwd_gather_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(interp_bwd_gather_kernel<256>, dim3((c + 3) / 4, b), dim3(256), lds, st, c, n, m, grad_out, off, ent, grad_points);
+        hipLaunchKernelGGL(interp_bwd_gather_kernel<256>, dim3((c + 3) / 4, b), dim3(256), lds, st, c, n, m, grad_out, gstride, off, ent, grad_points);
     }
     PA_CHECK_LAUNCH("pa_interpolation_backward_gather");
     return PA_OK;

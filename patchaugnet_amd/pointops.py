@@ -137,14 +137,18 @@ class Interpolation(Function):
         idx, weight, m, lists = ctx.interpolation_for_backward
         b, c, n = grad_out.shape
         grad = zeros((b, c, m), torch.float32, grad_out.device)
-        g = grad_out.contiguous()
+        gather = _gather_form(b, c, n, m)
+        # a channel slice of a wider contiguous tensor (the backward of the torch.cat that appended the skip features) is read in place
+        sliced = gather and grad_out.dtype == torch.float32 and grad_out.stride(2) == 1 and grad_out.stride(1) == n and grad_out.stride(0) >= c * n
+        g = grad_out if sliced else grad_out.contiguous()
+        gstride = g.stride(0) if sliced else 0
         with _guard(g):
-            if _gather_form(b, c, n, m):      # atomics-free form: one inversion of the index list, then plain sums
+            if gather:      # atomics-free form: one inversion of the index list, then plain sums
                 if lists is not None:
-                    call("pa_interpolation_backward_gather", b, c, n, m, ptr(g), None, None, ptr(grad), ptr(lists))
+                    call("pa_interpolation_backward_gather", b, c, n, m, ptr(g), gstride, None, None, ptr(grad), ptr(lists))
                 else:
                     scratch = torch.empty(_lib.lib().pa_interpolation_backward_scratch_ints(b, n, m), dtype=torch.int32, device=g.device)
-                    call("pa_interpolation_backward_gather", b, c, n, m, ptr(g), ptr(idx), ptr(weight), ptr(grad), ptr(scratch))
+                    call("pa_interpolation_backward_gather", b, c, n, m, ptr(g), gstride, ptr(idx), ptr(weight), ptr(grad), ptr(scratch))
             else:
                 call("pa_interpolation_backward", b, c, n, m, ptr(g), ptr(idx), ptr(weight), ptr(grad))
         return grad, None, None, None

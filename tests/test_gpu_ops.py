@@ -340,7 +340,7 @@ def test_interpolation_backward_gather_form(b, c, n, m):
     out = dev(init.copy())
     scratch = torch.empty(_lib.lib().pa_interpolation_backward_scratch_ints(b, n, m), dtype=torch.int32, device="cuda")
     god, idxd, wd = dev(go), dev(idx), dev(w)                 # keep the device tensors alive across the asynchronous launch
-    _lib.call("pa_interpolation_backward_gather", b, c, n, m, _lib.ptr(god), _lib.ptr(idxd), _lib.ptr(wd), _lib.ptr(out), _lib.ptr(scratch))
+    _lib.call("pa_interpolation_backward_gather", b, c, n, m, _lib.ptr(god), 0, _lib.ptr(idxd), _lib.ptr(wd), _lib.ptr(out), _lib.ptr(scratch))
     torch.cuda.synchronize()
     ref = init + o.interpolation_backward(go, idx, w, m)
     assert np.allclose(out.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)

@@ -170,3 +170,11 @@ def test_interpolation_backward_with_prebuilt_lists_is_identical():
     for j in range(3):
         ref.scatter_add_(2, idc[:, :, j].unsqueeze(1).expand(-1, c, -1), cc * wc[:, :, j].unsqueeze(1))
     close(grads[0], ref)
+    # the interpolated features concatenated with skip features (backbone.py FPModule.forward): autograd hands the backward a channel SLICE of
+    # the wider gradient; it is read in place through the batch stride (no contiguous copy) and gives the same sums
+    f = torch.randn(b, c, m, generator=torch.Generator().manual_seed(9)).cuda().requires_grad_(True)
+    skip = torch.randn(b, 5, n, generator=g).cuda()
+    wide = torch.cat([pointops.interpolation(f, idx, w, lists), skip], dim=1)
+    cot_wide = torch.cat([cot, torch.randn(b, 5, n, generator=g).cuda()], dim=1)
+    (wide * cot_wide).sum().backward()
+    assert torch.equal(f.grad, grads[1])
