@@ -97,21 +97,22 @@ class SAModule(nn.Module):
 
     @torch.no_grad()
     def geometry(self, xyz):
-        """Everything of this level that depends on the coordinates only: (centre indices, centre coordinates, neighbour indices) -- the
+        """Everything of this level that depends on the coordinates only: (centre indices, centre coordinates, neighbour indices, grouped coordinates) -- the
         sampling and the grouper's search / permutation, exactly as forward() computes them."""
         center_idx = pointops.furthestsampling(xyz, self.npoint)
         new_xyz = pointops.gathering(xyz.transpose(1, 2).contiguous(), center_idx).transpose(1, 2).contiguous()
-        return center_idx, new_xyz, self.groupers[0].neighbours(xyz, new_xyz)
+        idx = self.groupers[0].neighbours(xyz, new_xyz)
+        return center_idx, new_xyz, idx, pointops.grouped_coordinates(xyz, new_xyz, idx)
 
     def forward(self, xyz, features, geo=None):
         if geo is None:
             center_idx = pointops.furthestsampling(xyz, self.npoint)
             new_xyz = pointops.gathering(xyz.transpose(1, 2).contiguous(), center_idx).transpose(1, 2).contiguous()
-            idx = None
+            idx = coords = None
         else:
-            center_idx, new_xyz, idx = geo
+            center_idx, new_xyz, idx, coords = geo
         center_features = pointops.gathering(features, center_idx)
-        grouped, sample_idx = self.groupers[0](xyz, new_xyz, features, center_features, idx=idx)
+        grouped, sample_idx = self.groupers[0](xyz, new_xyz, features, center_features, idx=idx, coords=coords)
         y = self.mlps[0].forward_maxpool(grouped)
         if hasattr(self, "sas"):
             y = self.sas[0](y)

@@ -423,10 +423,17 @@ def _neighbours(radius, nsample, xyz, new_xyz):
     return ballquery(radius, nsample, xyz, new_xyz) if radius is not None else knnquery(nsample, xyz, new_xyz)
 
 
-def _centred_groups(xyz, new_xyz, features, center_features, idx, use_xyz):
-    """Shared tail of the QueryAndGroup_Edge* modules (pointops.py:559-570 / :617-630)."""
+def grouped_coordinates(xyz, new_xyz, idx):
+    """(neighbour coordinates, neighbour coordinates minus their centre), (B, 3, m, k) each: the coordinate-only part of the QueryAndGroup_Edge*
+    modules (pointops.py:559-562) -- a training loop computes it with the prefetched neighbour searches (backbone geometry())."""
     o_grouped_xyz = grouping(xyz.transpose(1, 2).contiguous(), idx)
-    grouped_xyz = o_grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
+    return o_grouped_xyz, o_grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
+
+
+def _centred_groups(xyz, new_xyz, features, center_features, idx, use_xyz, coords=None):
+    """Shared tail of the QueryAndGroup_Edge* modules (pointops.py:559-570 / :617-630).  coords: grouped_coordinates(xyz, new_xyz, idx) when the
+    caller already has it."""
+    o_grouped_xyz, grouped_xyz = coords if coords is not None else grouped_coordinates(xyz, new_xyz, idx)
     if features is not None:
         grouped = grouping(features, idx)
         if grouped.size(3) > 1:
@@ -482,11 +489,11 @@ class QueryAndGroup_Edge(nn.Module):
             idx = idx.index_select(2, perm).contiguous()
         return idx
 
-    def forward(self, xyz, new_xyz=None, features=None, center_features=None, idx=None):
+    def forward(self, xyz, new_xyz=None, features=None, center_features=None, idx=None, coords=None):
         new_xyz = xyz if new_xyz is None else new_xyz
         if idx is None:
             idx = self.neighbours(xyz, new_xyz)
-        new_features, o_grouped_xyz, _ = _centred_groups(xyz, new_xyz, features, center_features, idx, self.use_xyz)
+        new_features, o_grouped_xyz, _ = _centred_groups(xyz, new_xyz, features, center_features, idx, self.use_xyz, coords)
         res = new_features
         if self.ret_gxyz:
             res = res, o_grouped_xyz
