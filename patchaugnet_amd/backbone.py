@@ -96,23 +96,33 @@ class SAModule(nn.Module):
             self.sas = nn.ModuleList([SALayer(spec[-1], gp)])
 
     @torch.no_grad()
-    def geometry(self, xyz):
-        """Everything of this level that depends on the coordinates only: (centre indices, centre coordinates, neighbour indices, grouped coordinates) -- the
-        sampling and the grouper's search / permutation, exactly as forward() computes them."""
+    def geometry(self, xyz, coordinate_features=None):
+        """Everything of this level that depends on the coordinates only: (centre indices, centre coordinates, neighbour indices, grouped coordinates,
+        grouped input or None) -- the sampling and the grouper's search / permutation, exactly as forward() computes them.  coordinate_features:
+        the level's input features when they are the coordinates themselves (the first level: (B, 3, n) = xyz transposed); the grouper's whole
+        output is then coordinate-only work too."""
         center_idx = pointops.furthestsampling(xyz, self.npoint)
         new_xyz = pointops.gathering(xyz.transpose(1, 2).contiguous(), center_idx).transpose(1, 2).contiguous()
         idx = self.groupers[0].neighbours(xyz, new_xyz)
-        return center_idx, new_xyz, idx, pointops.grouped_coordinates(xyz, new_xyz, idx)
+        coords = pointops.grouped_coordinates(xyz, new_xyz, idx)
+        grouped = None
+        if coordinate_features is not None:
+            center_features = pointops.gathering(coordinate_features, center_idx)
+            grouped = self.groupers[0](xyz, new_xyz, coordinate_features, center_features, idx=idx, coords=coords)[0]
+        return center_idx, new_xyz, idx, coords, grouped
 
     def forward(self, xyz, features, geo=None):
         if geo is None:
             center_idx = pointops.furthestsampling(xyz, self.npoint)
             new_xyz = pointops.gathering(xyz.transpose(1, 2).contiguous(), center_idx).transpose(1, 2).contiguous()
-            idx = coords = None
+            idx = coords = grouped = None
         else:
-            center_idx, new_xyz, idx, coords = geo
-        center_features = pointops.gathering(features, center_idx)
-        grouped, sample_idx = self.groupers[0](xyz, new_xyz, features, center_features, idx=idx, coords=coords)
+            center_idx, new_xyz, idx, coords, grouped = geo
+        if grouped is None:
+            center_features = pointops.gathering(features, center_idx)
+            grouped, sample_idx = self.groupers[0](xyz, new_xyz, features, center_features, idx=idx, coords=coords)
+        else:                       # first level, everything about its input was coordinate-only (geometry(..., coordinate_features=...))
+            sample_idx = idx
         y = self.mlps[0].forward_maxpool(grouped)
         if hasattr(self, "sas"):
             y = self.sas[0](y)
@@ -179,8 +189,8 @@ class PyramidBackbone(nn.Module):
         Depends on the input cloud, not on the weights, so a training loop can compute it for the NEXT batch while the current one trains
         (train.GraphedTrainer); forward(pointcloud, geometry=...) then skips those launches.  {"sa": [...], "fp": [...]} of tensors."""
         l_xyz, sa_geo = [pointcloud], []
-        for sa in self.SA_modules:
-            g = sa.geometry(l_xyz[-1])
+        for i, sa in enumerate(self.SA_modules):
+            g = sa.geometry(l_xyz[-1], coordinate_features=pointcloud.transpose(1, 2).contiguous() if i == 0 else None)
             sa_geo.append(g)
             l_xyz.append(g[1])
         nfp = len(self.FP_modules)
