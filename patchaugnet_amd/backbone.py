@@ -199,7 +199,9 @@ class PyramidBackbone(nn.Module):
             # channels of the coarser level's features this level interpolates (its backward lists are coordinate-only work too; train() only)
             c_known = self.SA_modules[-1].mlps[0].channels[-1] if i == -1 else self.FP_modules[i + 1].mlp.channels[-1]
             fp_geo[i] = FPModule.geometry(l_xyz[i - 1], l_xyz[i], lists_for_channels=c_known if self.training else 0)
-        return {"sa": sa_geo, "fp": fp_geo}
+        # level-local centre / neighbour indices mapped to indices of the input cloud: index arithmetic only
+        origin = origin_indices([g[0] for g in sa_geo], [g[2] for g in sa_geo])
+        return {"sa": sa_geo, "fp": fp_geo, "origin": origin}
 
     def forward(self, pointcloud, geometry=None):
         l_xyz, l_feat = [pointcloud], [pointcloud.transpose(1, 2).contiguous()]
@@ -208,7 +210,7 @@ class PyramidBackbone(nn.Module):
             nx, ci, si, f = sa(l_xyz[i], l_feat[i], geo=None if geometry is None else geometry["sa"][i])
             l_xyz.append(nx); l_feat.append(f); l_c.append(ci); l_s.append(si)
         sa_features = list(l_feat[1:])
-        c_o, s_o = origin_indices(l_c, l_s)
+        c_o, s_o = origin_indices(l_c, l_s) if geometry is None else geometry["origin"]
         nfp = len(self.FP_modules)
         for i in range(-1, -(nfp + 1), -1):
             skip = l_feat[i - 1]
@@ -217,4 +219,6 @@ class PyramidBackbone(nn.Module):
             l_feat[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], skip, l_feat[i], geo=None if geometry is None else geometry["fp"][i])
         fp = [l_feat[j].unsqueeze(-1) for j in range(nfp - 1, -1, -1)]          # coarse -> fine
         return {"center_idx_origin": c_o, "sample_idx_origin": s_o, "sa_features": sa_features, "fp_features": fp,
-                "l_xyz": l_xyz}
+                "l_xyz": l_xyz,
+                # the first level's grouped neighbour coordinates (B, 3, m0, k) when the geometry was precomputed (= grouping(xyz, sample_idx_origin[0]))
+                "origin_patches_cm": None if geometry is None else geometry["sa"][0][3][0]}

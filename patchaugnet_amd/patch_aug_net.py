@@ -142,7 +142,9 @@ class Network(nn.Module):
         out = self.aggregation(fp_features)
         if nn_dict is not None:                                   # patch reconstruction branch (:68-104)
             related = sorted({i for pair in nn_dict for i in pair})
-            origin = pointops.grouping(xyz.transpose(1, 2).contiguous(), sample_idx[0])      # (B, 3, m0, k)
+            origin = res.get("origin_patches_cm")                                           # (B, 3, m0, k): with the precomputed geometry
+            if origin is None:
+                origin = pointops.grouping(xyz.transpose(1, 2).contiguous(), sample_idx[0])
             data = {"cloud_indices": related, "center_indices": [], "origin_patches": [], "patch_features": [],
                     "reconstructed_patches": []}
             hip_dec = self.use_a2a_recon and train_ops.on_device(x)
