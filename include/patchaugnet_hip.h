@@ -159,25 +159,8 @@ int pa_mlp_chain(int mode, int pooled, int nlayers, const float *const *wt, cons
 int pa_fp_chain_premul(int nlayers, const float *const *wt, const float *const *wpk, const float *const *bias, const int *kpad, const int *nout,
                        long rows, const float *g, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2,
                        int c1, const float *wskip, const float *wskip_p, const float *bias0, float *out, int ldo, pa_stream_t stream);
-/* Same with a fused tail: the last layer (wt[nlayers - 1], zero bias, relu_last = 0) is the next finer level's pre-multiply applied to this
- * level's output; that output (the result of layer nlayers - 2) leaves through tap (ldtap), the pre-multiplied rows through out. */
-int pa_fp_chain_premul_tap(int nlayers, const float *const *wt, const float *const *wpk, const float *const *bias, const int *kpad, const int *nout,
-                           long rows, const float *g, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2,
-                           int c1, const float *wskip, const float *wskip_p, const float *bias0, float *out, int ldo, float *tap, int ldtap,
-                           int relu_last, pa_stream_t stream);
 /*   c1 > 4 (coarser levels, skip = encoder features, c1 % 4 == 0, nlayers <= 2): the first layer stays in the chain as a c1-wide
  *   contraction over the skip channels (wskip, optional packed copy wskip_p) whose output gets the interpolated term added. */
-
-/* EXPERIMENTAL, not used by default.  Finest feature-propagation level with register-resident activations (fpx_reg.hip):
- * pa_fp_chain_premul for 1 <= c1 <= 4 and exactly
- * two remaining 256 -> 256 layers (patch_aug_net.py:350-362 at the 4096-point level), computed with operand-swapped MFMAs so that a
- * layer's accumulators are the next layer's B operand (no activation tile in LDS; weights through a shared LDS stage; 16-point waves).  g (b*m_known, 256);
- * wp2 / wp3: the two layers' K-major (256 x 256) weights in the k-permuted packing
- *     wp[((q*16 + ot)*64 + l)*4 + s] = Wt[16q + 4(l/16) + s][16 ot + l%16],  q, ot in 0..15, l in 0..63, s in 0..3.
- * Contracts the channels in a different order than pa_fp_chain_premul: same values to fp32 rounding, not the same bits. */
-int pa_fpx256(long rows, const float *g, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c1,
-              const float *wskip, const float *bias0, const float *wp2, const float *b2, const float *wp3, const float *b3,
-              float *out, int ldo, pa_stream_t stream);
 
 /* ---- fp16-operand variants of the chain kernels (opt-in; BASELINE.json configs[4] "fp16 MFMA MLP path") ---------------------
  * Same fusion and fp32 inputs / outputs; inside the kernel activations are held as fp16 in LDS, weights are fp16 fragments
@@ -225,10 +208,6 @@ int pa_mlp_chain_packed(int mode, int pooled, int nlayers, const float *const *w
  * stats: scratch of 2*b*n floats (row max and 1/row-sum).  Any n >= 1; c in {64, 128, 256, 512}. */
 int pa_sa_attention(int b, int n, int c, const float *yv, const float *x, float *stats, float *d, pa_stream_t stream);
 
-/* Profiling hook: when set to a device buffer of 512 x 8 int64, the chain kernels store cycle-counter stamps at their phase
- * boundaries (tile start, prologue done, each layer done) for the first 512 tiles.  NULL (the default) turns it off. */
-void pa_chain_debug_buffer(long long *buf);
-void pa_knn_debug_buffer(long long *buf);   /* same for the pruned kNN kernel: 6 int64 (prologue cycles, query cycles, chunks visited, insertions, sort cycles, queries per wave) */
 
 /* out[g][c] = max over s < ns of in[g*ns + s][c]  (rows of c floats) */
 int pa_rowgroup_max(long groups, int ns, int c, const float *in, float *out, pa_stream_t stream);
@@ -386,31 +365,6 @@ int pa_patch_pairs_count(int nrec, const int *idx1, const int *near_off, const i
                          const int *center_m, const int *center_n, int *scratch_inv, int *counts, pa_stream_t stream);
 int pa_patch_pairs_fill(int nrec, const int *idx1, const int *near_off, const int *near_v, const int *far_off, const int *far_v, int npoints, int m0,
                         const int *scratch_inv, unsigned long long seed, const int *offsets, int *out_idx1, int *out_pos2, int *out_neg2, pa_stream_t stream);
-
-/* Opt-in alternative for pa_knnquery at 2048..4096 source points, >= 256 queries, nsample 16 / 20 / 32: one lane per query over an
- * 8 x 8 x 8 cell grid (csrc/knn_lane.hip; same results bit for bit; slower than the default at the model's problem size, see the file). */
-void pa_knn_lane_enable(int on);
-/* pa_knnquery at 2048..4096 source points, >= 256 queries, nsample 16 / 20 / 32 runs four lanes per query over the cell grid
- * (csrc/knn_quad.hip, same results bit for bit); 0 forces the wave-per-query kernels (A/B, tests). */
-void pa_knn_quad_enable(int on);
-
-/* Opt-in variant of the register-resident furthest point sampling kernels (n <= 8192) that keeps no copy of the cloud in LDS (256 bytes
- * instead of 12 n: the winner's coordinates come from the owning lane's registers).  Same samples bit for bit; slower per round (fps.hip). */
-void pa_fps_reg_xyz_enable(int on);
-
-/* A/B and test switches of round 3's kernels (1 = wherever the kernel's shape rules hold, 0 = never, -1 = the default rule / environment):
- *   pa_chain_tiny_enable     the persistent first-set-abstraction kernel (csrc/sa_tiny.hip; default on; bit-identical to the generic chain kernel)
- *   pa_linear_lds_enable     pa_linear at k = 256 on LDS-resident weights (csrc/linear_lds.hip; default from 8192 rows; bit-identical)
- *   pa_tgemm_wave_enable     pa_tgemm_nn's wave-private kernel (default off: PA_TGEMM_WAVE=1; same sums in another order)
- *   pa_emd_persistent_enable pa_emd_forward as one persistent workgroup per cloud instead of one launch per round (0 / 1; bit-identical) */
-void pa_chain_tiny_enable(int on);
-void pa_linear_lds_enable(int on);
-void pa_tgemm_wave_enable(int on);
-void pa_emd_persistent_enable(int on);
-
-/* pa_nearestneighbor / pa_three_nn_weights use a cell-grid kernel (csrc/three_nn_grid.hip, same results bit for bit) for 512..4096 known
- * points and >= 1024 queries; 0 forces the brute-force scan (A/B, tests). */
-void pa_three_nn_grid_enable(int on);
 
 /* ---- Retrieval kNN at database scale (csrc/knn_mfma.hip): the recall harness' brute-force search (datasets/scene_dataset.py:1016-1099,
  * KNN_CUDA knn.cu:232-269) with the distance matrix on MFMA and an exact re-rank: columns equal pa_knn_generic's bit for bit.

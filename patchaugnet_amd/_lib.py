@@ -11,7 +11,9 @@ import torch
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.environ.get("PA_LIB_PATH", os.path.join(_CSRC, "libpatchaugnet_hip.so"))   # override: A/B of two builds in one session
+EXP_LIB_PATH = os.path.join(_CSRC, "libpatchaugnet_hip_exp.so")   # test-only superset with the measured-slower variants (csrc/Makefile)
 _lib = None
+_exp = None
 
 _I, _F, _P = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
@@ -50,8 +52,6 @@ _SIGS = {
     "pa_linear_f16": "liipipppipipi",
     "pa_fp_chain_premul_f16": "ippppplppppiiiippppi",
     "pa_fp_chain_premul": "ippppplppppiiiippppi",
-    "pa_fp_chain_premul_tap": "ippppplppppiiiippppipii",
-    "pa_fpx256": "lppppiiipppppppi",
     "pa_mlp_chain_packed": "iiippppplipippppiiiippppiiiipi",
     "pa_sa_attention": "iiipppp",
     "pa_netvlad": "iiiippppppii",
@@ -90,6 +90,12 @@ _SIGS = {
     "pa_patch_pairs_count": "ipppppiipppp",
     "pa_patch_pairs_fill": "ipppppiipqpppp",
 }
+# entry points of the measured-slower variants: exported by the test-only library only (csrc/pa_internal.h section 2)
+_EXP_SIGS = {
+    "pa_fp_chain_premul_tap": "ippppplppppiiiippppipii",
+    "pa_fpx256": "lppppiiipppppppi",
+}
+_EXP_SWITCHES = ("pa_knn_lane_enable", "pa_fps_reg_xyz_enable", "pa_tgemm_wave_enable")
 _T = {"i": _I, "f": _F, "p": _P, "l": ctypes.c_long, "d": ctypes.c_double, "q": ctypes.c_ulonglong}
 
 
@@ -118,23 +124,54 @@ def _declare(lib, sigs):
         fn.restype = _I
 
 
+def _load(path):
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C patchaugnet_amd/csrc`). There is no CPU or PyTorch fallback for these ops.")
+    l = ctypes.CDLL(path)
+    l.pa_last_error.restype = ctypes.c_char_p
+    l.pa_abi_version.restype = _I
+    for name, nargs in (("pa_interpolation_backward_scratch_ints", 3), ("pa_netvlad_scratch_floats", 3), ("pa_afa_scratch_floats", 4), ("pa_fc_scratch_floats", 3), ("pa_afa_rows_scratch_floats", 4), ("pa_pack_weights_f16_halfs", 2),
+                        ("pa_afa_fused_scratch_floats", 3), ("pa_attn_train_scratch_floats", 2)):
+        getattr(l, name).argtypes = [_I] * nargs
+        getattr(l, name).restype = ctypes.c_long
+    _declare(l, _SIGS)
+    return l
+
+
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(
-                f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
-                "(or `make -C patchaugnet_amd/csrc`). There is no CPU or PyTorch fallback for these ops.")
-        l = ctypes.CDLL(LIB_PATH)
-        l.pa_last_error.restype = ctypes.c_char_p
-        l.pa_abi_version.restype = _I
-        for name, nargs in (("pa_interpolation_backward_scratch_ints", 3), ("pa_netvlad_scratch_floats", 3), ("pa_afa_scratch_floats", 4), ("pa_fc_scratch_floats", 3), ("pa_afa_rows_scratch_floats", 4), ("pa_pack_weights_f16_halfs", 2),
-                            ("pa_afa_fused_scratch_floats", 3), ("pa_attn_train_scratch_floats", 2)):
-            getattr(l, name).argtypes = [_I] * nargs
-            getattr(l, name).restype = ctypes.c_long
-        _declare(l, _SIGS)
-        _lib = l
+        _lib = _load(LIB_PATH)
     return _lib
+
+
+class experimental:
+    """Context manager (tests / probes only): inside it every call() goes to libpatchaugnet_hip_exp.so, the superset library that also
+    carries the measured-slower kernel variants and their switches (csrc/pa_internal.h section 2).  The product library never contains
+    them; nothing in the package enters this context on its own."""
+
+    def __enter__(self):
+        global _lib, _exp
+        if _exp is None:
+            _exp = _load(EXP_LIB_PATH)
+            _declare(_exp, _EXP_SIGS)
+            for name in _EXP_SWITCHES:
+                getattr(_exp, name).argtypes, getattr(_exp, name).restype = [_I], None
+        self._saved = _lib
+        _lib = _exp
+        return _exp
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._saved
+        return False
+
+
+def has(name):
+    """Does the active library export `name`?  (The experimental entry points exist only inside `with experimental():`.)"""
+    return hasattr(_lib or lib(), name)
 
 
 def check_device(*tensors):

@@ -207,20 +207,25 @@ __global__ __launch_bounds__(1024) void fps_stream_kernel(int n, int m, FpsOrder
 // on MI355X at b = 32: bit-identical samples, but the round is longer (n = 4096: 0.70 -> 0.86 us, 719 -> 876 us per launch: the register-set
 // select + three v_readlane + the wider slot exchange sit on the serial chain) and the four-stream extraction rate drops 33.3 k -> 30.8 k
 // submaps/s even though the chain workgroups can now share a CU with it -- the launch's own length matters more than the LDS it pins.
+// The variant is measured-slower and therefore compiled into the test-only library only (PA_EXPERIMENTAL: libpatchaugnet_hip_exp.so).
+#ifdef PA_EXPERIMENTAL
 int g_fps_reg_xyz = -1;
 bool fps_lds_xyz()
 {
     if (g_fps_reg_xyz < 0) { const char *e = getenv("PA_FPS_REG_XYZ"); g_fps_reg_xyz = (e && e[0] == '1') ? 1 : 0; }
     return g_fps_reg_xyz == 0;
 }
+#endif
 
 template <int NT, int PPT>
 int launch_reg(int b, int n, int m, FpsOrder ord, const float *xyz, float *temp, int *idx, float *new_xyz, hipStream_t st)
 {
+#ifdef PA_EXPERIMENTAL
     if (!fps_lds_xyz()) {
         hipLaunchKernelGGL((fps_reg_kernel<NT, PPT, false>), dim3(b), dim3(NT), 2 * (NT / 64) * sizeof(FpsSlot), st, n, m, ord, xyz, temp, idx, new_xyz);
         return 0;
     }
+#endif
     const size_t lds = (size_t)(3 * n + ((3 * n) & 1)) * 4 + 2 * (NT / 64) * 8;
     if (lds > 48 * 1024)  // opt in to the large-LDS carve-out (gfx950: 160 KiB per CU)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_reg_kernel<NT, PPT, true>),
@@ -261,7 +266,9 @@ static int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int 
     return PA_OK;
 }
 
+#ifdef PA_EXPERIMENTAL
 PA_API void pa_fps_reg_xyz_enable(int on) { g_fps_reg_xyz = on ? 1 : 0; }
+#endif
 
 PA_API int pa_furthestsampling(int b, int n, int m, const float *xyz, float *temp, int *idx, pa_stream_t stream)
 {

@@ -5,7 +5,7 @@
 #include <stdio.h>
 #include <cmath>
 
-#include "../../include/patchaugnet_hip.h"
+#include "pa_internal.h"
 
 #define PA_API extern "C" __attribute__((visibility("default")))
 

@@ -443,6 +443,7 @@ __global__ __launch_bounds__(256) void tgemm_nn_kernel(NNArgs a)
     }
 }
 
+#ifdef PA_EXPERIMENTAL   // measured a tie with the LDS-tiled kernel: test-only library (libpatchaugnet_hip_exp.so)
 // ------------------------------------------------------------------------------------------------ tgemm_nn, wave-private form
 // The same contraction for the aligned shapes that carry the step's FLOPs (M % 64 == 0, N % 64 == 0, K % 16 == 0, 16-byte aligned operands, no
 // tanh / distance epilogue): every WAVEFRONT owns a 64 x 64 output tile and runs its own software pipeline -- no LDS, no workgroup barrier.
@@ -561,6 +562,8 @@ __global__ __launch_bounds__(256) void tgemm_nnw_kernel(NNArgs a)
             }
         }
 }
+
+#endif  // PA_EXPERIMENTAL
 
 // ------------------------------------------------------------------------------------------------ tgemm_kk
 // C (M x N) += sum over (batch, k) of fA(A_b)(m,k) * fB(B_b)(n,k); both operands k-contiguous: A_b(m,k) = A[b*sAb + m*lda + k].
@@ -990,9 +993,11 @@ TOp make_top(int mode, const float *aux, const float *p, int nch)
 
 }  // namespace
 
+#ifdef PA_EXPERIMENTAL
 static int g_tgemm_wave = -1;
 // test / A/B switch: 1 = the wave-private kernel wherever its shape rules hold, 0 = never, -1 = the environment (PA_TGEMM_WAVE, default off)
 PA_API void pa_tgemm_wave_enable(int on) { g_tgemm_wave = on; }
+#endif
 
 // C_b (M x N) = [beta C_b +] act(A_b . f(B_b) + bias): see tgemm_nn_kernel.  a_kcontig: A(m,k) = A[m*lda + k] (else A[k*lda + m]);
 // sAb = 0 shares A over the batch.  bmode 0 none / 1 affine+relu (bp: 2*K floats) / 2 bn-bwd with ReLU mask / 3 bn-bwd (baux = raw output,
@@ -1030,6 +1035,7 @@ PA_API int pa_tgemm_nn(int batch, int M, int N, int K, const float *A, long sAb,
     const long t64 = (long)((M + 63) / 64) * ((N + NN_BN - 1) / NN_BN) * batch;
     const bool deep = K > 16 && !big && t64 < 1024;     // few workgroups: latency-bound rounds, halve their number (measured: hurts the chip-filling launches)
     hipStream_t st = (hipStream_t)stream;
+#ifdef PA_EXPERIMENTAL
     // the wave-private kernel for the aligned shapes (tgemm_nnw_kernel): OPT-IN (PA_TGEMM_WAVE=1 or pa_tgemm_wave_enable).  Measured against the
     // LDS-tiled kernel on MI355X (tools/probes/tgemm_scale.py, 18 x (M x 4096 x 256)): M = 64: 54 vs 60 us, M = 256: 125 vs 123 us, M = 512: 211 vs
     // 222 us; the training step 6.10 vs 6.15 ms -- a tie.  Both follow time = ~30 us + 21.5 us per 64 rows of M; the decomposition builds of the
@@ -1056,6 +1062,7 @@ PA_API int pa_tgemm_nn(int batch, int M, int N, int K, const float *A, long sAb,
         PA_CHECK_LAUNCH("pa_tgemm_nn (wave-private)");
         return PA_OK;
     }
+#endif  // PA_EXPERIMENTAL
     dim3 grid((N + NN_BN - 1) / NN_BN, (M + (big ? 127 : 63)) / (big ? 128 : 64), batch);
 #define PA_NN(BMv, BKv, KC, MODE, VAv, VBv) hipLaunchKernelGGL((tgemm_nn_kernel<BMv, BKv, KC, MODE, VAv, VBv>), grid, dim3(256), 0, st, a)
 #define PA_NN_VEC(BMv, BKv, KC, MODE)                                                                       \

@@ -523,12 +523,14 @@ class PatchAugNetEngine:
                 ok = bool(self.premul and ok and chain.n >= 2 and c2 % 4 == 0 and chain.layers[0][4] % 16 == 0 and chain.layers[0][2] == c2 + c1)
                 self._fold_static.append(ok)
                 if ok:
-                    chain.build_premul(c2, c1, kperm=os.environ.get("PA_ENGINE_FPX_REG", "0") == "1")
+                    # PA_ENGINE_FPX_REG / PA_ENGINE_TAIL select measured-slower variants that only the test-only library exports
+                    # (`with _lib.experimental():`, csrc/pa_internal.h section 2); with the product library they are refused, not ignored
+                    chain.build_premul(c2, c1, kperm=self._exp_knob("PA_ENGINE_FPX_REG", "pa_fpx256"))
             # a level whose chain runs as [skip layer | one 256-wide layer] can carry the next finer level's pre-multiply as a third layer
             # (pa_fp_chain_premul_tap).  Measured at B = 32 and NOT the default: the pre-multiply launch goes 0.050 -> 0.005 ms but the
             # shared-tile chain that now carries it 0.072 -> 0.112 ms (the stand-alone launch runs the faster eight-wave tiling) -- net zero.
             self._tail_static = [False] * nfp
-            if os.environ.get("PA_ENGINE_TAIL") is not None:
+            if self._exp_knob("PA_ENGINE_TAIL", "pa_fp_chain_premul_tap", flag=True):
                 for j in range(1, nfp):
                     c1 = self.sa[j - 1].n_last
                     fine, here = self.fp[j - 1], self.fp[j]
@@ -545,6 +547,14 @@ class PatchAugNetEngine:
         # applied while a stream is capturing.
         self.geo_overlap = os.environ.get("PA_ENGINE_GEO_OVERLAP") is not None
         self._geo_streams = {}
+
+    @staticmethod
+    def _exp_knob(env, symbol, flag=False):
+        on = (os.environ.get(env) is not None) if flag else (os.environ.get(env, "0") == "1")
+        if on and not _lib.has(symbol):
+            raise RuntimeError(f"{env} selects an experimental kernel variant ({symbol}) that only libpatchaugnet_hip_exp.so exports: "
+                               "build the engine inside `with patchaugnet_amd._lib.experimental():`")
+        return on
 
     def _mark(self, name):
         if self.timer is not None:

@@ -4,9 +4,11 @@ Model API and state-dict keys of ``place_recognition/pointnet_vlad/PointNetVlad.
 ``place_recognition/evaluate.py:88-90``:
 ``PointNetVlad(global_feat=True, feature_transform=True, max_pool=False, output_dim=256, num_points=4096)``;
 ``forward(x: (B,1,N,3)) -> (B, output_dim)``.  The reference has no CUDA extension on this path -- it is dense torch ops only
--- so this class is torch as well, and it is the CPU configuration ONLY: a tensor on the MI355X is refused (it would run on
-rocBLAS / MIOpen library kernels, which no model of this package is allowed to reach silently; the device models are PatchAugNet and
-PPT-Net).  1x1 convolutions are written as matmuls on point-major activations.  Keys: tests/golden/pointnet_vlad_state_dict_keys.json.
+-- so the CPU form below is torch as well (1x1 convolutions written as matmuls on point-major activations).  evaluate.py moves the model
+to the accelerator (``model.to(device)``), so a tensor on the MI355X is served too: the ``_hip`` methods state the same network
+channel-major on the hand-written MFMA GEMM / BatchNorm / NetVLAD kernels of ``train_ops`` (csrc/train_gemm.hip, train_glue.hip) -- the
+kernels PatchAugNet's module path trains on -- in train() and eval(), with autograd; no rocBLAS / MIOpen kernel is reached
+(tests/test_pointnet_vlad.py).  Keys: tests/golden/pointnet_vlad_state_dict_keys.json.
 """
 import math
 
@@ -14,6 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import train_ops
 from .loupe import GatingContext
 
 __all__ = ["PointNetVlad"]
@@ -58,6 +61,34 @@ class STN3d(nn.Module):
         return x.view(-1, self.k, self.k)
 
 
+def _conv_cm(conv, bn, x, training, relu=True):
+    """The same layer on channel-major (B, C_in, N) device rows: conv weight (O, 1, 1, C_in) or (O, C_in, 1, 1) is an (O, C_in) matrix either way."""
+    w = conv.weight.flatten(1)
+    if bn is not None:
+        return train_ops.chain_train(x, [train_ops.BNLayer(w, bn, bias=conv.bias, relu=relu)], training=training)
+    y = train_ops.linear_cm(x, w, conv.bias)
+    return F.relu(y) if relu else y
+
+
+def _stn_hip(self, x):
+    """STN3d.forward on the MI355X: x (B, k, N) channel-major -> (B, k, k)."""
+    tr = self.training
+    bn = (lambda i: getattr(self, f"bn{i}")) if self.use_bn else (lambda i: None)
+    x = _conv_cm(self.conv1, bn(1), x, tr)
+    x = _conv_cm(self.conv2, bn(2), x, tr)
+    x = _conv_cm(self.conv3, bn(3), x, tr)
+    x = x.max(dim=2)[0]                                               # (B, 1024)
+    x = train_ops.linear_rows(x, self.fc1.weight, self.fc1.bias)
+    x = F.relu(train_ops.bn_rows(self.bn4, x, tr) if self.use_bn else x)
+    x = train_ops.linear_rows(x, self.fc2.weight, self.fc2.bias)
+    x = F.relu(train_ops.bn_rows(self.bn5, x, tr) if self.use_bn else x)
+    x = train_ops.linear_rows(x, self.fc3.weight, self.fc3.bias) + torch.eye(self.k, dtype=x.dtype, device=x.device).flatten()
+    return x.view(-1, self.k, self.k)
+
+
+STN3d._forward_hip = _stn_hip
+
+
 class PointNetfeat(nn.Module):
     """PointNetVlad.py:181-232."""
 
@@ -75,6 +106,8 @@ class PointNetfeat(nn.Module):
 
     def forward(self, x):
         """x: (B, 1, N, 3) -> (B, 1024, N, 1) when max_pool is False (the evaluate.py configuration)."""
+        if train_ops.on_device(x):
+            return self._forward_hip(x)
         p = x.squeeze(1)
         trans = self.stn(p)
         p = torch.matmul(p, trans)
@@ -92,6 +125,31 @@ class PointNetfeat(nn.Module):
         if self.global_feat:
             return g, trans
         return torch.cat([g.unsqueeze(-1).expand(-1, -1, self.num_points), pointfeat.transpose(1, 2)], 1), trans
+
+
+def _feat_hip(self, x):
+    """PointNetfeat.forward on the MI355X, channel-major: p (B, 3, N); `p @ trans` of the point-major form is trans^T . p here."""
+    tr = self.training
+    p = x.squeeze(1).transpose(1, 2).contiguous()                     # (B, 3, N)
+    trans = self.stn._forward_hip(p)
+    p = train_ops.bmm_nn(trans.transpose(1, 2), p)
+    f = _conv_cm(self.conv1, self.bn1, p, tr)
+    f = _conv_cm(self.conv2, self.bn2, f, tr)
+    pointfeat = f
+    if self.apply_feature_trans:
+        f = train_ops.bmm_nn(self.feature_trans._forward_hip(f).transpose(1, 2), f)
+    f = _conv_cm(self.conv3, self.bn3, f, tr)
+    f = _conv_cm(self.conv4, self.bn4, f, tr)
+    f = _conv_cm(self.conv5, self.bn5, f, tr, relu=False)             # (B, 1024, N)
+    if not self.max_pool:
+        return f.unsqueeze(-1)
+    g = f.max(dim=2)[0]
+    if self.global_feat:
+        return g, trans
+    return torch.cat([g.unsqueeze(-1).expand(-1, -1, self.num_points), pointfeat], 1), trans
+
+
+PointNetfeat._forward_hip = _feat_hip
 
 
 class NetVLADLoupe(nn.Module):
@@ -113,6 +171,8 @@ class NetVLADLoupe(nn.Module):
 
     def forward(self, x):
         """x: (B, C, N, 1)."""
+        if train_ops.on_device(x):
+            return self._forward_hip(x.squeeze(-1))
         x = x.squeeze(-1).transpose(1, 2)                                           # (B, N, C)
         act = torch.matmul(x, self.cluster_weights)
         act = self.bn1(act.reshape(-1, self.cluster_size)).view(-1, self.max_samples, self.cluster_size)
@@ -125,6 +185,19 @@ class NetVLADLoupe(nn.Module):
         return self.context_gating(vlad) if self.gating else vlad
 
 
+def _loupe_hip(self, x):
+    """NetVLADLoupe.forward on the MI355X: x (B, C, N) channel-major (the layout loupe.NetVLADBase's device form uses)."""
+    tr = self.training
+    pre = train_ops.chain_train(x, [train_ops.BNLayer(self.cluster_weights, self.bn1, relu=False, transposed=True)], training=tr)   # (B, K, N)
+    vlad = train_ops.netvlad_tail(pre, x, self.cluster_weights2)                    # soft-max, X . act^T - a_sum * cw2, normalise over C: (B, C, K)
+    vlad = train_ops.l2_normalize(vlad.reshape(-1, self.cluster_size * self.feature_size))
+    vlad = train_ops.bn_rows(self.bn2, train_ops.matmul_rows(vlad, self.hidden1_weights), tr)
+    return self.context_gating(vlad) if self.gating else vlad
+
+
+NetVLADLoupe._forward_hip = _loupe_hip
+
+
 class PointNetVlad(nn.Module):
     def __init__(self, num_points=2500, global_feat=True, feature_transform=False, max_pool=True, output_dim=1024):
         super().__init__()
@@ -133,8 +206,4 @@ class PointNetVlad(nn.Module):
                                      gating=True, add_batch_norm=True, is_training=True)
 
     def forward(self, x):
-        if x.is_cuda:
-            raise RuntimeError("PointNetVlad is BASELINE configs[0], the CPU-only PyTorch configuration: there is no HIP path for it and the "
-                               "package never routes a device tensor through library GEMM / convolution kernels; run it on CPU tensors "
-                               "(the MI355X models are patch_aug_net.Network and pptnet.Network)")
         return self.net_vlad(self.point_net(x))

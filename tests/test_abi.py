@@ -39,9 +39,41 @@ def test_library_exports_every_declared_symbol(libpath):
 
 def test_bindings_cover_the_pa_entry_points(libpath):
     from patchaugnet_amd import _lib
-    pa = [n for n in declared_symbols() if n.startswith("pa_") and n not in ("pa_abi_version", "pa_last_error", "pa_chain_debug_buffer", "pa_knn_debug_buffer", "pa_knn_lane_enable", "pa_three_nn_grid_enable", "pa_knn_quad_enable", "pa_fps_reg_xyz_enable")
-          and not n.endswith("_enable") and not n.endswith("_scratch_floats") and n not in ("pa_pack_weights_f16_halfs", "pa_interpolation_backward_scratch_ints")]
+    pa = [n for n in declared_symbols() if n.startswith("pa_") and n not in ("pa_abi_version", "pa_last_error")
+          and not n.endswith("_scratch_floats") and n not in ("pa_pack_weights_f16_halfs", "pa_interpolation_backward_scratch_ints")]
     assert sorted(pa) == sorted(_lib._SIGS), set(pa) ^ set(_lib._SIGS)
+
+
+def internal_symbols():
+    """(product test hooks, experimental-only symbols) declared by the private header csrc/pa_internal.h."""
+    src = open(os.path.join(ROOT, "patchaugnet_amd", "csrc", "pa_internal.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    head, exp = src.split("#ifdef PA_EXPERIMENTAL", 1)
+    rx = r"\b(?:int|long|void)\s*\*?\s*([a-z_0-9]+)\s*\("
+    return sorted(set(re.findall(rx, head))), sorted(set(re.findall(rx, exp)))
+
+
+def test_public_header_is_the_boundary_only():
+    """include/patchaugnet_hip.h declares the reference's launcher names and the pa_* ops: no A/B switch, debug hook or experimental entry."""
+    names = declared_symbols()
+    assert not [n for n in names if n.endswith("_enable") or "debug" in n or n in ("pa_fpx256", "pa_fp_chain_premul_tap")]
+    text = open(os.path.join(ROOT, "include", "patchaugnet_hip.h")).read()
+    assert "getenv" not in text and not re.search(r"\bPA_[A-Z]+_[A-Z_]+=", text)
+
+
+def test_product_library_has_no_experimental_symbols(libpath):
+    """The measured-slower variants (csrc/pa_internal.h section 2) are exported by libpatchaugnet_hip_exp.so only."""
+    from patchaugnet_amd import _lib
+    hooks, exp = internal_symbols()
+    assert len(hooks) >= 5 and len(exp) >= 5
+    out = subprocess.run(["nm", "-D", "--defined-only", libpath], stdout=subprocess.PIPE, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if l.strip()}
+    assert not [n for n in exp if n in exported], [n for n in exp if n in exported]
+    assert not [n for n in exported if any(t in n for t in ("knn_lane", "fpx256", "tgemm_nnw", "reg_xyz"))]
+    assert all(n in exported for n in hooks), [n for n in hooks if n not in exported]
+    xout = subprocess.run(["nm", "-D", "--defined-only", _lib.EXP_LIB_PATH], stdout=subprocess.PIPE, text=True, check=True).stdout
+    xexp = {l.split()[-1] for l in xout.splitlines() if l.strip()}
+    assert all(n in xexp for n in exp) and {n for n in exported if not n.startswith("__hip")} <= xexp        # the test-only library is a superset
 
 
 def test_argument_validation_without_gpu(libpath):

@@ -46,12 +46,9 @@ def test_fps_bit_exact(P, b, n, m, kind):
 
 @pytest.mark.parametrize("b,n,m,kind", FPS_CASES)
 def test_fps_register_coordinate_variant_bit_exact(b, n, m, kind):
-    """pa_fps_reg_xyz_enable(1): no LDS copy of the cloud, winner coordinates from the owning lane's registers (fps.hip).  Same samples,
-    same gathered coordinates, same running minima as the oracle."""
-    import ctypes
+    """pa_fps_reg_xyz_enable(1), a measured-slower variant kept in the test-only library (libpatchaugnet_hip_exp.so): no LDS copy of the cloud,
+    winner coordinates from the owning lane's registers (fps.hip).  Same samples, same gathered coordinates as the oracle."""
     from patchaugnet_amd import _lib
-    lib = _lib.lib()
-    lib.pa_fps_reg_xyz_enable.argtypes, lib.pa_fps_reg_xyz_enable.restype = [ctypes.c_int], None
     x = cloud(b, n, kind)
     xd = dev(x)
     ref = o.furthestsampling(x, m)
@@ -59,14 +56,15 @@ def test_fps_register_coordinate_variant_bit_exact(b, n, m, kind):
     idx2 = torch.empty((b, m), dtype=torch.int32, device="cuda")
     nx = torch.empty((b, m, 3), device="cuda")
     temp = torch.full((b, n), 1e10, device="cuda")
-    lib.pa_fps_reg_xyz_enable(1)
-    try:
-        _lib.call("pa_furthestsampling", b, n, m, _lib.ptr(xd), _lib.ptr(temp), _lib.ptr(idx))
-        if n <= 8192:
-            _lib.call("pa_furthestsampling_gather", b, n, m, _lib.ptr(xd), _lib.ptr(idx2), _lib.ptr(nx))
-        torch.cuda.synchronize()
-    finally:
-        lib.pa_fps_reg_xyz_enable(0)
+    with _lib.experimental() as lib:
+        lib.pa_fps_reg_xyz_enable(1)
+        try:
+            _lib.call("pa_furthestsampling", b, n, m, _lib.ptr(xd), _lib.ptr(temp), _lib.ptr(idx))
+            if n <= 8192:
+                _lib.call("pa_furthestsampling_gather", b, n, m, _lib.ptr(xd), _lib.ptr(idx2), _lib.ptr(nx))
+            torch.cuda.synchronize()
+        finally:
+            lib.pa_fps_reg_xyz_enable(0)
     assert np.array_equal(idx.cpu().numpy(), ref)
     if n <= 8192:
         assert np.array_equal(idx2.cpu().numpy(), ref)
@@ -144,14 +142,14 @@ def test_knn_lane_kernel_bit_exact(P, kind, k):
         q[:, ::5] += (rng.random((b, len(range(0, m, 5)), 3), dtype=np.float32) * 0.01).astype(np.float32)   # queries that are not cloud points
     ri, rd = o.knnquery(k, x, q)
     from patchaugnet_amd import _lib
+    with _lib.experimental() as xlib:      # the lane-per-query kernel lives in the test-only library (measured slower at the model's size)
+        xlib.pa_knn_lane_enable(1)
+        try:
+            gi, gd = P.knnquery_with_dist(k, dev(x), dev(q))
+            torch.cuda.synchronize()
+        finally:
+            xlib.pa_knn_lane_enable(0)
     lib = _lib.lib()
-    lib.pa_knn_lane_enable.argtypes, lib.pa_knn_lane_enable.restype = [__import__("ctypes").c_int], None
-    lib.pa_knn_lane_enable(1)
-    try:
-        gi, gd = P.knnquery_with_dist(k, dev(x), dev(q))
-        torch.cuda.synchronize()
-    finally:
-        lib.pa_knn_lane_enable(0)
     assert np.array_equal(gi.cpu().numpy(), ri)
     assert np.array_equal(gd.cpu().numpy().view(np.uint32), rd.view(np.uint32))
     gi2, gd2 = P.knnquery_with_dist(k, dev(x), dev(q))                      # the default: four lanes per query (knn_quad.hip)

@@ -4,10 +4,12 @@
 set -e
 NAME=$1; FLAGS=$2; shift 2
 SRCS=${@:-mlp_chain.hip}
+EXP_ONLY=" fpx_reg.hip knn_lane.hip "
 cd "$(dirname "$0")/../patchaugnet_amd/csrc"
 mkdir -p ab/$NAME
 OBJS=""
 for f in *.hip; do
+  [[ "$EXP_ONLY" == *" $f "* ]] && continue
   if [[ " $SRCS " == *" $f "* ]]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -Wno-unused-function $FLAGS -c $f -o ab/$NAME/${f%.hip}.o
     OBJS="$OBJS ab/$NAME/${f%.hip}.o"
