@@ -133,6 +133,10 @@ int pa_emd_backward(int b, int n, const float *xyz1, const float *xyz2, float *g
 /* ---- Generic-dimension brute-force kNN  (libs/KNN_CUDA/knn_cuda/csrc/cuda/knn.cpp:23-56, knn.cu:232-269)
  * ref (dim,nr), query (dim,nq) -> dist (k,nq) fp32 L2 (sqrt applied), ind (k,nq) int64 1-BASED, order (dist asc, row asc). */
 int pa_knn_generic(const float *ref, int nr, const float *query, int nq, int dim, int k, float *dist, int64_t *ind, pa_stream_t stream);
+/* kNN over a per-query candidate list (the hard-negative refresh, datasets/scene_dataset.py:1101-1113): out (nq, k) int64 = for every query the
+ * k entries of ITS list cand[q][0..L) (row indices into ref_rows, -1 = padding) nearest to it, nearest first, ties to the earlier list position
+ * (what pa_knn_generic returns on the gathered rows, bit for bit); -1 where a list has fewer than k live entries.  Rows row-major; k <= 64. */
+int pa_knn_candidates(const float *ref_rows, int dim, const float *q_rows, int nq, const int64_t *cand, int L, int k, int64_t *out, pa_stream_t stream);
 
 /* ---- Fused shared-MLP chains (MFMA, fp32)  -- evaluation-time replacement of the unfused
  * grouping + subtract + cat (libs/pointops/functions/pointops.py:559-570), SharedMLP = Conv2d 1x1 + BatchNorm2d + ReLU
@@ -207,6 +211,11 @@ int pa_mlp_chain_packed(int mode, int pooled, int nlayers, const float *const *w
  * Writes d (b, n, c) = x - x_r, x_r = V^T attn, attn = row soft-max of Y Y^T re-normalised by (1e-9 + column sums).
  * stats: scratch of 2*b*n floats (row max and 1/row-sum).  Any n >= 1; c in {64, 128, 256, 512}. */
 int pa_sa_attention(int b, int n, int c, const float *yv, const float *x, float *stats, float *d, pa_stream_t stream);
+/* The same op with both contractions on fp16 MFMA (fp32 accumulation, fp32 soft-max statistics; csrc/attention_f16.hip) -- the fp16 path of
+ * BASELINE.json configs[4], under its cosine >= 0.999 contract; c in {64, 128, 256}.  split != 0 carries the energy operands as (hi, lo) fp16
+ * pairs (three products: ~21 bits of the logits).  scratch: pa_sa_attention_f16_scratch_halfs(b, n, c, split) fp16 elements, 16-byte aligned. */
+long pa_sa_attention_f16_scratch_halfs(int b, int n, int c, int split);
+int pa_sa_attention_f16(int b, int n, int c, int split, const float *yv, const float *x, void *scratch, float *stats, float *d, pa_stream_t stream);
 
 
 /* out[g][c] = max over s < ns of in[g*ns + s][c]  (rows of c floats) */

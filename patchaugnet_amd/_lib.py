@@ -41,6 +41,7 @@ _SIGS = {
     "pa_chamfer_forward": "iiipppppp",
     "pa_chamfer_backward": "iiipppppppp",
     "pa_knn_generic": "pipiiipp",
+    "pa_knn_candidates": "pipipiip",
     "pa_emd_forward": "iiippppppppppfi",
     "pa_emd_backward": "iippppp",
     "pa_mlp_chain": "iiipppplipippppiiiippppiiiipi",
@@ -54,6 +55,7 @@ _SIGS = {
     "pa_fp_chain_premul": "ippppplppppiiiippppi",
     "pa_mlp_chain_packed": "iiippppplipippppiiiippppiiiipi",
     "pa_sa_attention": "iiipppp",
+    "pa_sa_attention_f16": "iiiippppp",
     "pa_netvlad": "iiiippppppii",
     "pa_furthestsampling_gather": "iiippp",
     "pa_three_nn_weights": "iiipppp",
@@ -133,7 +135,7 @@ def _load(path):
     l.pa_last_error.restype = ctypes.c_char_p
     l.pa_abi_version.restype = _I
     for name, nargs in (("pa_interpolation_backward_scratch_ints", 3), ("pa_netvlad_scratch_floats", 3), ("pa_afa_scratch_floats", 4), ("pa_fc_scratch_floats", 3), ("pa_afa_rows_scratch_floats", 4), ("pa_pack_weights_f16_halfs", 2),
-                        ("pa_afa_fused_scratch_floats", 3), ("pa_attn_train_scratch_floats", 2)):
+                        ("pa_afa_fused_scratch_floats", 3), ("pa_attn_train_scratch_floats", 2), ("pa_sa_attention_f16_scratch_halfs", 4)):
         getattr(l, name).argtypes = [_I] * nargs
         getattr(l, name).restype = ctypes.c_long
     _declare(l, _SIGS)

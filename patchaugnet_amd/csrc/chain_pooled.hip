@@ -8,8 +8,11 @@ int pa_chain_launch_pooled(const PaChain &a, int rt, bool split, int wpw, long n
         // Shared 4-group tiles.  The four-column-tile chunking keeps 170 registers = 3 workgroups per CU; with the last layer in two-tile chunks
         // (NCMAX = 2: 110 registers, same sums in the same order) FOUR fit, and 1024 tiles (the second level at batch 32) run as ONE round on
         // the 256 CUs instead of 768 + 256.  PA_CHAIN_POOLED_NC4 = A/B knob for the former tiling.
+        // A hidden layer is written back in place and must stay ONE chunk per wave: n / 64 <= 2 column tiles for the two-tile chunking.
         static const bool nc4 = getenv("PA_CHAIN_POOLED_NC4") != nullptr;
-        if (nc4) return launch_chain<5, 4, MODE_SA, true, 4>(a, 4, ntiles, st);
+        bool narrow = true;
+        for (int l = 0; l + 1 < a.nlayers; ++l) narrow = narrow && a.L[l].n <= 128;
+        if (nc4 || !narrow) return launch_chain<5, 4, MODE_SA, true, 4>(a, 4, ntiles, st);
         return launch_chain<5, 2, MODE_SA, true, 4>(a, 4, ntiles, st);
     }
     switch (rt) {

@@ -84,7 +84,74 @@ __global__ __launch_bounds__(256) void knn_generic_kernel(const float *__restric
     }
 }
 
+// ---- kNN over a per-query CANDIDATE LIST (the hard-negative refresh of training: datasets/scene_dataset.py:1101-1113 builds a KD-tree over
+// every query's own <= 3000 sampled negatives).  One wavefront per query: the query row sits in LDS, lane l takes candidate positions l, l + 64, ..
+// of the query's list, accumulates the squared distance in dimension order (ssd += tmp * tmp: the arithmetic of row_dist / knn.cu:80-83, so the
+// result equals pa_knn_generic on the gathered rows bit for bit) and the running top-k is the lane-distributed sorted key list with the LIST
+// POSITION as the low word: ties resolve to the earlier position, as a kNN over the gathered rows would.  Rows are row-major (nref, dim):
+// a lane streams its own candidate's row with 16-byte loads.
+__global__ __launch_bounds__(256) void knn_cand_kernel(const float *__restrict__ ref_rows, int dim, const float *__restrict__ q_rows, int nq,
+                                                         const long long *__restrict__ cand, int L, int k, long long *__restrict__ out)
+{
+    extern __shared__ float qcols[];  // [4][dim]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wave;
+    float *qcol = qcols + wave * dim;
+    if (q < nq)
+        for (int d = lane; d < dim; d += 64) qcol[d] = q_rows[(size_t)q * dim + d];
+    __syncthreads();
+    if (q >= nq) return;
+    const long long *cl = cand + (size_t)q * L;
+    u64 list = INF0, thresh = INF0;
+    const bool vec = (dim & 3) == 0 && (reinterpret_cast<uintptr_t>(ref_rows) & 15) == 0;
+    for (int c = 0; c < L; c += 64) {
+        const int pos = c + lane;
+        const long long row = pos < L ? cl[pos] : -1;
+        float ssd = 0.f;
+        if (row >= 0) {
+            const float *r = ref_rows + (size_t)row * dim;
+            if (vec) {
+                for (int d = 0; d < dim; d += 4) {
+                    const float4 v = *reinterpret_cast<const float4 *>(r + d);
+                    float t;
+                    t = v.x - qcol[d]; ssd += t * t;
+                    t = v.y - qcol[d + 1]; ssd += t * t;
+                    t = v.z - qcol[d + 2]; ssd += t * t;
+                    t = v.w - qcol[d + 3]; ssd += t * t;
+                }
+            } else {
+                for (int d = 0; d < dim; ++d) { const float t = r[d] - qcol[d]; ssd += t * t; }
+            }
+        }
+        const u64 key = pa_make_key(ssd, (u32)pos);
+        u64 mask = __ballot(row >= 0 && key < thresh);
+        while (mask) {
+            const int src = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const u64 ck = pa_readlane_u64(key, src);
+            if (ck < thresh) {
+                list = list_insert(list, ck);
+                thresh = pa_readlane_u64(list, k - 1);
+            }
+        }
+    }
+    if (lane < k) out[(size_t)q * k + lane] = list < INF0 ? cl[(u32)list] : -1;      // fewer than k live candidates: -1
+}
+
 }  // namespace
+
+// out (nq, k) int64: for every query the k candidates of ITS list (cand (nq, L) int64 row indices into ref_rows, -1 = padding) nearest to it, nearest
+// first, ties to the earlier list position; -1 where the list has fewer than k live entries.  ref_rows (nref, dim), q_rows (nq, dim) row-major; k <= 64.
+PA_API int pa_knn_candidates(const float *ref_rows, int dim, const float *q_rows, int nq, const int64_t *cand, int L, int k, int64_t *out, pa_stream_t stream)
+{
+    PA_REQUIRE(ref_rows && q_rows && cand && out && dim > 0 && nq > 0 && L > 0, "pa_knn_candidates: bad arguments");
+    PA_REQUIRE(k > 0 && k <= 64, "pa_knn_candidates: k=%d must be 1..64", k);
+    PA_REQUIRE((size_t)dim * 16 <= 64 * 1024, "pa_knn_candidates: dim=%d too large for the LDS query tile", dim);
+    hipLaunchKernelGGL(knn_cand_kernel, dim3(pa_div_up(nq, 4)), dim3(256), (size_t)dim * 16, (hipStream_t)stream, ref_rows, dim, q_rows, nq,
+                       reinterpret_cast<const long long *>(cand), L, k, reinterpret_cast<long long *>(out));
+    PA_CHECK_LAUNCH("pa_knn_candidates");
+    return PA_OK;
+}
 
 PA_API int pa_knn_generic(const float *ref, int nr, const float *query, int nq, int dim, int k, float *dist, int64_t *ind, pa_stream_t stream)
 {

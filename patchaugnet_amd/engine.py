@@ -367,7 +367,7 @@ class _Attn:
     The tied grouped q/k conv is expanded to a dense block-diagonal (C, C) matrix and concatenated with v_conv into one
     K-major (C, 2C) weight; trans_conv + after_norm (eval) fold into one K-major (C, C) weight + bias."""
 
-    def __init__(self, sa, device):
+    def __init__(self, sa, device, f16=False):
         c, gp = sa.v_conv.weight.shape[0], sa.gp
         if c not in (64, 128, 256, 512):
             raise ValueError(f"fused attention is built for 64/128/256/512 channels, got {c}")
@@ -385,17 +385,39 @@ class _Attn:
         self.bt = (sa.trans_conv.bias.detach().double().cpu() * scale.cpu() + shift.cpu()).float().contiguous().to(device)
         self.c = c
         self.wqv_p, self.wt_p = pack_weights(self.wqv_t), pack_weights(self.wt_t)
+        # fp16 path (model.mlp_dtype = "f16", BASELINE configs[4]): the two dense layers on the fp16 chain kernel and both contractions of the
+        # attention on fp16 MFMA (csrc/attention_f16.hip; widths it is built for); PA_ATTN_F16_SPLIT=0 drops the (hi, lo) energy operands (A/B knob)
+        self.f16 = bool(f16) and c in (64, 128, 256)
+        self.split = 0 if os.environ.get("PA_ATTN_F16_SPLIT", "1") == "0" else 1
+        # the q/k/v projection feeds the soft-max logits (a relative 2^-11 there is an ABSOLUTE |e| 2^-11 in the exponent): it stays on
+        # the exact fp32 kernel; PA_ATTN_F16_QV=1 is the A/B knob for the fp16 form
+        self.qv16 = self.f16 and os.environ.get("PA_ATTN_F16_QV", "0") == "1"
+        self.t16 = self.f16 and os.environ.get("PA_ATTN_F16_TRANS", "1") == "1"
+        if self.f16:
+            self.wqv_16, self.wt_16 = pack_weights_f16(self.wqv_t), pack_weights_f16(self.wt_t)
 
     def run(self, x, B, n):
         """x (B*n, C) point-major -> x + relu(BN(trans_conv(x - x_r)))."""
         c, dev = self.c, x.device
         rows = B * n
         yv = torch.empty((rows, 2 * c), dtype=torch.float32, device=dev)
-        call("pa_linear", rows, c, 2 * c, ptr(x), c, ptr(self.wqv_t), ptr(self.wqv_p), ptr(self.bqv), 0, None, 0, ptr(yv), 2 * c)
         stats = torch.empty((rows, 2), dtype=torch.float32, device=dev)
         d = torch.empty((rows, c), dtype=torch.float32, device=dev)
-        call("pa_sa_attention", B, n, c, ptr(yv), ptr(x), ptr(stats), ptr(d))
         out = torch.empty((rows, c), dtype=torch.float32, device=dev)
+        if self.f16:
+            if self.qv16:
+                call("pa_linear_f16", rows, c, 2 * c, ptr(x), c, ptr(self.wqv_t), ptr(self.wqv_16), ptr(self.bqv), 0, None, 0, ptr(yv), 2 * c)
+            else:
+                call("pa_linear", rows, c, 2 * c, ptr(x), c, ptr(self.wqv_t), ptr(self.wqv_p), ptr(self.bqv), 0, None, 0, ptr(yv), 2 * c)
+            scratch = torch.empty(_lib.lib().pa_sa_attention_f16_scratch_halfs(B, n, c, self.split), dtype=torch.float16, device=dev)
+            call("pa_sa_attention_f16", B, n, c, self.split, ptr(yv), ptr(x), ptr(scratch), ptr(stats), ptr(d))
+            if self.t16:
+                call("pa_linear_f16", rows, c, c, ptr(d), c, ptr(self.wt_t), ptr(self.wt_16), ptr(self.bt), 1, ptr(x), c, ptr(out), c)
+            else:
+                call("pa_linear", rows, c, c, ptr(d), c, ptr(self.wt_t), ptr(self.wt_p), ptr(self.bt), 1, ptr(x), c, ptr(out), c)
+            return out
+        call("pa_linear", rows, c, 2 * c, ptr(x), c, ptr(self.wqv_t), ptr(self.wqv_p), ptr(self.bqv), 0, None, 0, ptr(yv), 2 * c)
+        call("pa_sa_attention", B, n, c, ptr(yv), ptr(x), ptr(stats), ptr(d))
         call("pa_linear", rows, c, c, ptr(d), c, ptr(self.wt_t), ptr(self.wt_p), ptr(self.bt), 1, ptr(x), c, ptr(out), c)
         return out
 
@@ -475,7 +497,7 @@ class PatchAugNetEngine:
         with torch.no_grad():
             self.sa = [_Chain(fold_shared_mlp(m.mlps[0], self.device), f16) for m in bb.SA_modules]
             self.fp = [_Chain(fold_shared_mlp(m.mlp, self.device), f16) for m in bb.FP_modules]
-            self.attn = [_Attn(m.sas[0], self.device) if hasattr(m, "sas") else None for m in bb.SA_modules]
+            self.attn = [_Attn(m.sas[0], self.device, f16) if hasattr(m, "sas") else None for m in bb.SA_modules]
         self.agg = model.aggregation
         agg = self.agg
         self.ppt = hasattr(agg, "vlad0")

@@ -344,9 +344,22 @@ labelstat_and_ballquery = LabelStatAndBallQuery.apply
 
 
 def pairwise_distances(x, y=None):
-    """pointops.py:347-363 -- ||x_i - y_j||^2 via the expanded form, clamped at 0 (pure torch, as in the reference)."""
-    x_norm = (x ** 2).sum(1).view(-1, 1)
+    """pointops.py:347-363 -- ||x_i - y_j||^2 via the expanded form, clamped at 0.  x (N, d), y (M, d) -> (N, M).
+    On the MI355X the product runs on the hand-written MFMA GEMM with the norms and the clamp in its epilogue (pa_tgemm_nn, act = 2:
+    csrc/train_gemm.hip -- the kernel the retrieval search uses); CPU tensors take the reference's torch statement."""
     y = x if y is None else y
+    if x.is_cuda:
+        check_device(x, y)
+        x, y = x.float(), y.float()
+        n, d = x.shape
+        m = y.shape[0]
+        yt = y.t().contiguous()                                              # (d, M): the GEMM's B operand
+        xn, yn = (x * x).sum(1), (y * y).sum(1)
+        out = torch.empty((n, m), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            call("pa_tgemm_nn", 1, n, m, d, ptr(x), 0, d, 1, ptr(yt), 0, m, 0, ptr(None), ptr(None), ptr(out), 0, m, 0, ptr(xn), ptr(yn), 2, ptr(None), 0)
+        return out
+    x_norm = (x ** 2).sum(1).view(-1, 1)
     y_norm = (y ** 2).sum(1).view(1, -1)
     return torch.clamp(x_norm + y_norm - 2.0 * torch.mm(x, y.t()), min=0.0)
 

@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from . import knn_cuda
+from ._lib import call, ptr
 
 
 def hip_knn(database, queries, k):
@@ -215,11 +216,10 @@ def get_hard_negatives(query_latent_vector, ref_latent_vectors, negative_indices
 def get_hard_negatives_batch(query_vectors, ref_latent_vectors, negative_index_lists, num_hard_neg=10, knn=hip_knn, chunk=128):
     """The mining refresh of training (train_place_recognition.py:403-406 -> scene_dataset.py:473-492) for a list of queries.
 
-    Candidate sets differ per query.  With the default kNN the whole refresh is batched on the device: the index lists go up once as
-    one padded (nq, L) tensor, and per chunk of queries the candidates' descriptors are gathered, exact squared distances
-    sum((c - q)^2) taken, padding masked to +inf and a stable sort returns the num_hard_neg nearest in (distance, list position) order
-    -- 1400 queries x 3000 negatives: 1.66 s as one launch per query, tens of milliseconds batched.  A custom ``knn`` (tests, CPU
-    stand-ins) keeps the per-query path."""
+    Candidate sets differ per query.  With the default kNN the whole refresh is ONE launch on the device: the index lists go up once as
+    one padded (nq, L) tensor and a wavefront per query selects the num_hard_neg nearest of its own list in (distance, list position)
+    order (pa_knn_candidates) -- 1400 queries x 3000 negatives: 1.66 s as one launch per query.  ``chunk`` is kept for callers that pass
+    it; it no longer has an effect.  A custom ``knn`` (tests, CPU stand-ins) keeps the per-query path."""
     nq = len(negative_index_lists)
     if knn is not hip_knn or nq == 0:
         return [get_hard_negatives(q, ref_latent_vectors, negs, num_hard_neg, knn) for q, negs in zip(query_vectors, negative_index_lists)]
@@ -233,14 +233,12 @@ def get_hard_negatives_batch(query_vectors, ref_latent_vectors, negative_index_l
     dev = ref_latent_vectors.device
     idx_d = torch.from_numpy(idx).to(dev)
     q_all = query_vectors if torch.is_tensor(query_vectors) else torch.stack(list(query_vectors))
-    q_all = q_all.reshape(nq, -1).to(dev)
+    q_all = q_all.reshape(nq, -1).to(dev).float().contiguous()
+    ref = ref_latent_vectors.float().contiguous()
     picked = torch.empty((nq, num_hard_neg), dtype=torch.int64, device=dev)
-    for lo in range(0, nq, chunk):
-        ii = idx_d[lo:lo + chunk]
-        cand = ref_latent_vectors[ii.clamp_min(0)]                                   # (c, L, D)
-        d = ((cand - q_all[lo:lo + chunk, None, :]) ** 2).sum(-1)
-        d = torch.where(ii >= 0, d, torch.full_like(d, float("inf")))
-        order = torch.sort(d, dim=1, stable=True).indices[:, :num_hard_neg]        # ties: earlier list position first, like hip_knn
-        picked[lo:lo + chunk] = torch.gather(ii, 1, order)
+    # one launch: a wavefront per query walks its own candidate list (csrc/knn_generic.hip, pa_knn_candidates) with the direct-sum
+    # arithmetic of the per-query kNN, so the batch returns exactly what the per-query launches return
+    with torch.cuda.device(dev):
+        call("pa_knn_candidates", ptr(ref), ref.shape[1], ptr(q_all), nq, ptr(idx_d), L, num_hard_neg, ptr(picked))
     picked = picked.cpu().numpy()
     return [picked[i].tolist() if lens[i] >= num_hard_neg else [] for i in range(nq)]

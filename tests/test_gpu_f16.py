@@ -89,3 +89,27 @@ def test_pptnet_f16_mlp_path(tag):
     for i in range(4):
         assert np.array_equal(cidx[i].cpu().numpy(), g[f"{tag}_center_idx{i}"])
     assert _cos(d.cpu().numpy(), g[f"{tag}_desc_l2"]).min() >= 0.999
+
+
+@pytest.mark.parametrize("split", [1, 0])
+@pytest.mark.parametrize("b,n,c", [(2, 1024, 64), (3, 256, 128), (2, 64, 256), (1, 20, 64), (2, 100, 128), (1, 333, 64), (2, 37, 256)])
+def test_sa_attention_f16_against_the_fp32_kernel(b, n, c, split):
+    """pa_sa_attention_f16 (csrc/attention_f16.hip: both contractions on fp16 MFMA, fp32 soft-max) against pa_sa_attention on the same
+    [Y | V] rows: ragged n (not a multiple of 16 / 32 / the tile), every width it is built for.  split = 1 carries the energy operands as
+    (hi, lo) fp16 pairs: only V and the soft-max values are rounded to fp16 (2^-11 each); split = 0 also rounds the logits' operands."""
+    from patchaugnet_amd import _lib
+    from patchaugnet_amd._lib import call, ptr
+    g = torch.Generator().manual_seed(n * c + split)
+    yv = (torch.randn(b * n, 2 * c, generator=g) * 0.7).cuda()
+    x = torch.randn(b * n, c, generator=g).cuda()
+    stats = torch.empty(b * n, 2, device="cuda")
+    d32 = torch.empty(b * n, c, device="cuda")
+    call("pa_sa_attention", b, n, c, ptr(yv), ptr(x), ptr(stats), ptr(d32))
+    d16 = torch.full((b * n, c), float("nan"), device="cuda")
+    scratch = torch.empty(_lib.lib().pa_sa_attention_f16_scratch_halfs(b, n, c, split), dtype=torch.float16, device="cuda")
+    call("pa_sa_attention_f16", b, n, c, split, ptr(yv), ptr(x), ptr(scratch), ptr(stats), ptr(d16))
+    xr32, xr16 = (x - d32).double(), (x - d16).double()
+    assert torch.isfinite(d16).all()
+    scale = xr32.abs().max().item()
+    err = (xr16 - xr32).abs().max().item()
+    assert err <= (2e-3 if split else 3e-2) * scale, (err, scale)

@@ -21,21 +21,32 @@ with torch.no_grad():
     for which in (sys.argv[1:] or ["fp0"]):
         kind, lvl = which[:2], int(which[2])
         chain = (eng.sa if kind == "sa" else eng.fp)[lvl]
-        name = "sa" if kind == "sa" else ("fp_premul" if (eng.premul and eng._fold_static[lvl]) else "fp")
-        orig = getattr(chain, name)
+        names = ["sa"] if kind == "sa" else ["fp_premul", "fp"]
         buf = torch.zeros(512 * 8, dtype=torch.int64, device="cuda")
+        used = []
 
-        def wrapped(*a, _o=orig, **k):
-            lib.pa_chain_debug_buffer(ctypes.c_void_p(buf.data_ptr()))
-            r = _o(*a, **k)
-            lib.pa_chain_debug_buffer(None)
-            return r
-        setattr(chain, name, wrapped)
+        def wrap(nm):
+            orig = getattr(chain, nm)
+
+            def wrapped(*a, _o=orig, **k):
+                used.append(nm)
+                lib.pa_chain_debug_buffer(ctypes.c_void_p(buf.data_ptr()))
+                r = _o(*a, **k)
+                lib.pa_chain_debug_buffer(None)
+                return r
+            setattr(chain, nm, wrapped)
+            return orig
+        origs = {nm: wrap(nm) for nm in names}
         model(x, return_feat=False)
         torch.cuda.synchronize()
-        setattr(chain, name, orig)
+        for nm, o_ in origs.items():
+            setattr(chain, nm, o_)
+        name = used[0] if used else names[0]
         t = buf.view(512, 8).cpu().numpy()
         t = t[t[:, 0] > 0]
+        if len(t) == 0:
+            print(which, "no tiles stamped (the level runs a kernel without phase stamps)")
+            continue
         nl = chain.n - (1 if (name == "fp_premul" and lvl == 0) else 0)
         d = t[:, 1:nl + 2] - t[:, 0:nl + 1]
         parts = ["prologue"] + [f"layer{i}" for i in range(nl)]
