@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy rate is ~6300
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32-input MFMA peak (same guide)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 MFMA peak (same guide; AMD's 5 PF headline includes 2:1 sparsity)
 
 
 def parse():
@@ -185,6 +186,78 @@ def measure_traffic(batch, points):
             res[tag] = {"bytes_per_launch": 2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"], "FETCH_SIZE_bytes_raw": v["FETCH_SIZE"], "WRITE_SIZE_bytes": v["WRITE_SIZE"],
                         "launches_sampled": v["launches_sampled"]}
     return (res or None), "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/pmc_target.py in this run; FETCH_SIZE x2 (gfx950, 16-B reads), KiB -> bytes"
+
+
+def step_algorithmic_flops(model, batch, points):
+    """Algorithmic FLOPs of ONE extraction step as the engine runs it (post-fold: the first layer of a feature-propagation level applied to the
+    known points before interpolation, pa_fp_chain_premul), true K (no padding): 2 * rows * K * N per dense layer of every set-abstraction / feature-
+    propagation chain (+ the grouped self-attention of PPT-Net: q/k/v and output projections and the two N x N contractions), the NetVLAD assignment and
+    aggregation GEMMs of every scale, the APFA attention logits and the final FC / gating.  Sampling, neighbour search, interpolation weights and
+    soft-max are not counted (VALU work)."""
+    from patchaugnet_amd.engine import engine_for
+    eng = engine_for(model, "cuda")
+    L, nfp = len(eng.sa), len(eng.fp)
+    npts = [points] + list(eng.sampling[:L])
+    fl = 0.0
+    for i, ch in enumerate(eng.sa):
+        rows = batch * npts[i + 1] * eng.knn[i]
+        fl += 2.0 * rows * sum(l[2] * l[4] for l in ch.layers)
+        if eng.attn[i] is not None:
+            c, n = eng.attn[i].c, npts[i + 1]
+            fl += 2.0 * batch * n * (c * 2 * c + c * c) + 2.0 * batch * n * n * c * 3      # projections; energy twice (statistics pass + apply pass) + V p
+    off = L - nfp
+    for j, ch in enumerate(eng.fp):
+        n_u, m_k = npts[j + off], npts[j + off + 1]
+        c2 = eng.fp[j + 1].n_last if j + 1 < nfp else eng.sa[-1].n_last
+        c1 = (3 if eng.use_origin else 0) if j == 0 else eng.sa[j - 1].n_last
+        folded = eng._fold_static[j] and (c1 <= 4 or n_u >= 512) and n_u >= 2 * m_k
+        l0 = ch.layers[0]
+        rest = sum(l[2] * l[4] for l in ch.layers[1:])
+        if folded:
+            fl += 2.0 * batch * m_k * c2 * l0[4] + 2.0 * batch * n_u * (c1 * l0[4] + rest)
+        else:
+            fl += 2.0 * batch * n_u * (l0[2] * l0[4] + rest)
+    ktot = 0
+    for v in eng.vlads:
+        fl += 2.0 * batch * v.n * v.c * v.k * 2
+        ktot += v.k
+    if eng.head_kind == "afa":
+        fl += 2.0 * batch * ktot * 256 * 256 + 2.0 * batch * ktot * 256 * eng.afa.nout
+    elif eng.head_kind == "fc":
+        fl += 2.0 * batch * ktot * 256 * eng.head.nout
+    if eng.gate is not None:
+        fl += 2.0 * batch * eng.gate.dim * eng.gate.dim
+    return fl
+
+
+def reference_protocol(model, points, batch=100, nbatches=12):
+    """The reference's own (and only) self-reported timing: SceneDataSet.make_descs with stat_time (datasets/scene_dataset.py:666-686, 710-711;
+    place_recognition/evaluate.py:170 runs it at batch 100): per batch, synchronize, start the clock, `model(feed)` on a batch already on the
+    device, descriptors `.detach().cpu().numpy()`, synchronize, stop; the batch time divided by the batch size is every submap's run time; it
+    prints mean +- std in ms.  One stream, one batch at a time, the model API as evaluate.py calls it (model(x) -> (desc, fp_features, centre idx))."""
+    import numpy as np
+    from patchaugnet_amd.weights import synthetic_submaps
+    feeds = [synthetic_submaps(batch, points, seed=900 + i).cuda() for i in range(3)]
+    per = []
+    with torch.no_grad():
+        for i in range(2):
+            out = model(feeds[i % 3])
+            (out[0] if isinstance(out, tuple) else out).detach().cpu().numpy()
+        for i in range(nbatches):
+            feed = feeds[i % 3]
+            torch.cuda.synchronize()
+            t0 = time.time()
+            g = model(feed)
+            if isinstance(g, tuple):
+                g = g[0]
+            g = g.detach().cpu().numpy()
+            g = np.squeeze(g).reshape([-1, g.shape[-1]])
+            torch.cuda.synchronize()
+            per += [(time.time() - t0) * 1000 / batch] * batch
+    return {"run_time_ms_per_submap_mean": float(np.mean(per)), "run_time_ms_per_submap_std": float(np.std(per)), "batch": batch, "batches": nbatches,
+            "submaps_per_s": 1000.0 / float(np.mean(per)),
+            "protocol": "datasets/scene_dataset.py:666-686 (stat_time): synchronize, model(feed) on a device-resident batch + descriptors .cpu().numpy(), "
+                        "synchronize; (batch time / batch size) per submap; mean +- std as the reference prints it; evaluate.py:170 batch size"}
 
 
 def cpu_baseline(cfg, sd, batch, points):
@@ -398,8 +471,30 @@ def extras(a):
                 if rep:
                     rates.append(steps * a.batch / (time.perf_counter() - t0))
         rates.sort()
-        return {"value": rates[1], "unit": "submaps/s", "min": rates[0], "max": rates[-1], "batch": a.batch, "steps": steps,
-                "dtype": "f32" if mlp_dtype == "f32" else "f16 MFMA operands in the shared-MLP chains, fp32 accumulate / everything else fp32"}
+        res = {"value": rates[1], "unit": "submaps/s", "min": rates[0], "max": rates[-1], "batch": a.batch, "steps": steps,
+               "dtype": "f32" if mlp_dtype == "f32" else "f16 MFMA operands in the shared-MLP chains and the self-attention contractions, fp32 accumulate / soft-max / everything else fp32"}
+        try:      # rooflines of the finest feature-propagation chain (the largest dense launch) against BOTH bounds, and the attention's share of the step
+            del gx
+            with torch.no_grad():
+                st = stage_pass(model, x)
+            rows = a.batch * a.points
+            fl = 2.0 * rows * (256 * 256 * 2 + 3 * 256)
+            ms = st.get("fp0.chain")
+            if ms:
+                peak = MFMA_F16_PEAK_TFLOPS if mlp_dtype == "f16" else MFMA_F32_PEAK_TFLOPS
+                byts = rows * 256 * 4.0 + rows * (3 * 4 + 3 * 4 + 3 * 4) + (rows // 4) * 256 * 4.0      # output + (idx3, w3, xyz) + the pre-multiplied known rows once
+                res["roofline"] = {"kernel": ("chain16_kernel<2,16,FPX,0,1>" if mlp_dtype == "f16" else "chain_kernel<1,16,FPX,0,1>") + " (fp0: finest feature-propagation chain)",
+                                   "bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / peak,
+                                   "traffic": None, "algorithmic_flops_per_launch": fl, "ms_per_launch": ms, "timing": "one launch bracketed by HIP events on the launch stream (stage pass)"}
+                res["roofline_hbm"] = {"bound": "hbm", "achieved": byts / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       "algorithmic_bytes_per_launch": byts}
+            res["attention_ms_per_step"] = sum(v for k, v in st.items() if k.endswith(".attn"))
+            res["stages_ms"] = st
+            fls = step_algorithmic_flops(model, a.batch, a.points)
+            res["step_flops"] = fls
+        except Exception as ex:
+            res["roofline"] = {"error": repr(ex)}
+        return res
 
     def emd():
         from patchaugnet_amd import emd_module
@@ -621,6 +716,17 @@ def main():
                     line["roofline"]["timing"] = "HIP events on the launch stream around 9 back-to-back launches of the kernel (average); one bracketed launch: kernels.fp0_chain_single_bracketed_ms"
             except Exception as ex:  # attribution is diagnostics; never lose the bench line over it
                 line["kernels"]["stages_ms"] = {"error": repr(ex)}
+        try:      # the number that describes the whole step (the per-kernel roofline above is its best kernel): algorithmic FLOPs / step time / peak
+            fl = step_algorithmic_flops(model, a.batch, a.points)
+            line["step_mfma_frac"] = {"algorithmic_flops_per_step": fl, "achieved_tflops": fl / (line["ms_per_step"] * 1e-3) / 1e12, "peak_tflops": MFMA_F32_PEAK_TFLOPS,
+                                      "frac": fl / (line["ms_per_step"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                                      "note": "post-fold dense-layer FLOPs of one step (step_algorithmic_flops) / ms_per_step / fp32 MFMA peak; sampling and neighbour search (VALU) not counted"}
+        except Exception as ex:
+            line["step_mfma_frac"] = {"error": repr(ex)}
+        try:
+            line["reference_protocol"] = reference_protocol(model, a.points)
+        except Exception as ex:
+            line["reference_protocol"] = {"error": repr(ex)}
         try:
             line["pcie_inclusive"] = pcie_inclusive(model, a, pipe.gx if use_graphs else pipe)
         except Exception as ex:

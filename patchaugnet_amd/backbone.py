@@ -80,20 +80,52 @@ class SALayer(nn.Module):
         return x + F.relu(self.after_norm(self.trans_conv(x - x_r)))
 
 
-class SAModule(nn.Module):
-    """One set-abstraction level (patch_aug_net.py:195-314 / pptnet.py:137-244)."""
+class SAModuleMSG(nn.Module):
+    """Set abstraction with MULTI-SCALE grouping (``PointNet2SAModuleMSG``, patch_aug_net.py:246-287 with the base class's forward, :203-243):
+    one sampling of ``npoint`` centres, then per scale i its own EdgeConv grouper (``radii[i]`` / ``nsamples[i]``: ball or dilated kNN), shared MLP
+    ``mlps[i]`` and max over the neighbourhood; the scales' features are concatenated along the channels and their neighbour lists along the
+    last axis.  Parameter names (``groupers.{i}``, ``mlps.{i}...``) follow the reference.  The shipped configurations use ONE scale per level
+    (SAModule below, which the fused engine evaluates); a level with several scales runs here, on the HIP op layer + the MFMA training kernels
+    (forward and backward), and the fused engine refuses it."""
+
+    def __init__(self, *, npoint, radii, nsamples, knn_dilation=1, mlps, gp=None, attention=False, use_xyz=True):
+        super().__init__()
+        assert len(radii) == len(nsamples) == len(mlps) and len(mlps) >= 1
+        self.npoint = npoint
+        self.groupers = nn.ModuleList()
+        self.mlps = nn.ModuleList()
+        for radius, nsample, mlp in zip(radii, nsamples, mlps):
+            spec = list(mlp)                                   # (the reference adds the 3 to the caller's own list; a copy here)
+            if use_xyz:
+                spec[0] += 3
+            self.groupers.append(pointops.QueryAndGroup_Edge(radius, nsample, knn_dilation=knn_dilation, use_xyz=use_xyz, ret_sample_idx=True)
+                                 if npoint is not None else pointops.GroupAll(use_xyz))
+            self.mlps.append(SharedMLP(spec, bn=True))
+        if attention:                                          # pptnet.py:137-244: one grouped self-attention per scale, on that scale's output
+            self.sas = nn.ModuleList(SALayer(m.channels[-1], gp) for m in self.mlps)
+
+    def forward(self, xyz, features, geo=None):
+        assert geo is None, "precomputed geometry is built for single-scale levels (SAModule)"
+        center_idx = pointops.furthestsampling(xyz, self.npoint)
+        new_xyz = pointops.gathering(xyz.transpose(1, 2).contiguous(), center_idx).transpose(1, 2).contiguous()
+        center_features = pointops.gathering(features, center_idx)
+        feats, idxs = [], []
+        for i, (grouper, mlp) in enumerate(zip(self.groupers, self.mlps)):
+            grouped, sample_idx = grouper(xyz, new_xyz, features, center_features)         # (B, C, M, K_i)
+            y = mlp.forward_maxpool(grouped)                                              # (B, C'_i, M)
+            if hasattr(self, "sas"):
+                y = self.sas[i](y)
+            feats.append(y)
+            idxs.append(sample_idx)
+        return new_xyz, center_idx, torch.cat(idxs, dim=-1), torch.cat(feats, dim=1)
+
+
+class SAModule(SAModuleMSG):
+    """One set-abstraction level with a single scale (``PointNet2SAModule``, patch_aug_net.py:290-314 / pptnet.py:137-244)."""
 
     def __init__(self, *, mlp, npoint, nsample, knn_dilation=1, gp=None, attention=False, radius=None, use_xyz=True):
-        super().__init__()
-        self.npoint = npoint
-        spec = list(mlp)
-        if use_xyz:
-            spec[0] += 3
-        self.groupers = nn.ModuleList([pointops.QueryAndGroup_Edge(radius, nsample, knn_dilation=knn_dilation,
-                                                                   use_xyz=use_xyz, ret_sample_idx=True)])
-        self.mlps = nn.ModuleList([SharedMLP(spec, bn=True)])
-        if attention:
-            self.sas = nn.ModuleList([SALayer(spec[-1], gp)])
+        super().__init__(npoint=npoint, radii=[radius], nsamples=[nsample], knn_dilation=knn_dilation, mlps=[mlp], gp=gp, attention=attention,
+                         use_xyz=use_xyz)
 
     @torch.no_grad()
     def geometry(self, xyz, coordinate_features=None):
@@ -179,8 +211,11 @@ class PyramidBackbone(nn.Module):
     def __init__(self, *, sampling, knn, sa_mlps, fp_mlps, knn_dilation=1, gp=8, attention=False, use_origin_pc_in_fp=True):
         super().__init__()
         self.use_origin_pc_in_fp = use_origin_pc_in_fp
-        self.SA_modules = nn.ModuleList(SAModule(mlp=m, npoint=s, nsample=k, knn_dilation=knn_dilation, gp=gp, attention=attention)
-                                        for m, s, k in zip(sa_mlps, sampling, knn))
+        # a level whose spec is a LIST of specs (with a list of nsample) is a multi-scale-grouping level (PointNet2SAModuleMSG)
+        self.SA_modules = nn.ModuleList(
+            SAModuleMSG(mlps=m, npoint=s, nsamples=list(k), radii=[None] * len(m), knn_dilation=knn_dilation, gp=gp, attention=attention)
+            if isinstance(m[0], (list, tuple)) else SAModule(mlp=m, npoint=s, nsample=k, knn_dilation=knn_dilation, gp=gp, attention=attention)
+            for m, s, k in zip(sa_mlps, sampling, knn))
         self.FP_modules = nn.ModuleList(FPModule(mlp=m) for m in fp_mlps)
 
     @torch.no_grad()

@@ -494,6 +494,9 @@ class PatchAugNetEngine:
         if self.mlp_dtype not in ("f32", "f16"):
             raise ValueError("mlp_dtype must be 'f32' or 'f16'")
         f16 = self.mlp_dtype == "f16"
+        if any(len(m.mlps) != 1 for m in bb.SA_modules):
+            raise ValueError("fused engine: a multi-scale-grouping level (backbone.SAModuleMSG with several scales) runs on the module path; "
+                             "set model.fused_eval = False")
         with torch.no_grad():
             self.sa = [_Chain(fold_shared_mlp(m.mlps[0], self.device), f16) for m in bb.SA_modules]
             self.fp = [_Chain(fold_shared_mlp(m.mlp, self.device), f16) for m in bb.FP_modules]

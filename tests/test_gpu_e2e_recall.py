@@ -108,15 +108,25 @@ def test_oxford_sized_recall_from_clouds_matches_reference_within_0p1_percent():
     top_k = int(z["top_k"])
     res = retrieval.get_recall_precision(desc, sizes, tuples, top_k=top_k, skip_trip_itself=True)
     assert len(res) == 23 * 22
-    # a trip pair has ~130 queries, so ONE query whose neighbour order flips on a near-tie (descriptors agree to ~1e-5, not bit for bit) moves
-    # that pair by 0.77 points: per pair at most one query's worth; the 0.1-point contract is on the evaluate.py average over 65 561 queries
-    flipped = 0
+    # Descriptors agree with the reference run to ~1e-5, not bit for bit, so a query whose k-th and (k+1)-th neighbours are a near-tie may take
+    # them in the other order.  The check is stated in QUERIES, not in percentage points: per trip pair the largest Recall@N / one-percent-recall
+    # difference is converted back to a number of queries (pairs have ~130 queries: one query = 0.77 points); no pair may differ by more than
+    # ONE query and the whole set (65 561 evaluated queries over 506 pairs) by more than MAX_FLIPPED_QUERIES -- a real regression (a wrong
+    # neighbour list, a dropped query) moves tens of queries and cannot hide inside that allowance.
+    MAX_FLIPPED_QUERIES = 5
+    flipped_queries, flipped_pairs = 0, []
     for i, k in enumerate(map(tuple, z["pairs"])):
-        assert res[k][6] == z["num_eval"][i]
+        ne = int(z["num_eval"][i])
+        assert res[k][6] == ne
         d = max(float(np.abs(np.asarray(res[k][0]) - z["recall"][i]).max()), abs(res[k][2] - float(z["opr"][i])))
-        assert d <= 100.0 / max(int(z["num_eval"][i]), 1) + 1e-3, (k, d)
-        flipped += d > 1e-3
-    assert flipped <= 5, f"{flipped} of 506 trip pairs differ from the reference run"
+        dq = int(round(d * ne / 100.0))
+        assert abs(d * ne / 100.0 - dq) <= 1e-3 * ne, (k, d)              # a difference is a whole number of queries
+        assert dq <= 1, (k, d, dq)
+        if dq:
+            flipped_queries += dq
+            flipped_pairs.append(k)
+    print(f"oxford-sized set: {flipped_queries} flipped queries of {int(z['num_eval'].sum())} in pairs {flipped_pairs}")
+    assert flipped_queries <= MAX_FLIPPED_QUERIES, f"{flipped_queries} queries differ from the reference run (pairs {flipped_pairs})"
     ave = retrieval.average(res, top_k)
     ref = (z["recall"].astype(np.float64).mean(0), float(z["opr"].mean()))
     assert abs(ave[0][0] - ref[0][0]) <= 0.1 and abs(ave[0][4] - ref[0][4]) <= 0.1, (ave[0][:5], ref[0][:5])

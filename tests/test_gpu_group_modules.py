@@ -143,3 +143,49 @@ def test_group_module_feature_gradients(P, mod):
     assert (gc is None) == (rc is None)
     if rc is not None:
         assert torch.allclose(gc, rc, rtol=1e-5, atol=1e-5), (gc - rc).abs().max()
+
+
+@pytest.mark.parametrize("attention", [False, True])
+def test_multi_scale_grouping_level_against_the_oracle(attention):
+    """backbone.SAModuleMSG (PointNet2SAModuleMSG, patch_aug_net.py:246-287 + the base forward :203-243): one sampling, two scales with their own
+    neighbour counts and shared MLPs, features concatenated along the channels and neighbour lists along the last axis -- on the HIP op layer and
+    MFMA dense kernels against the same statement assembled from the CPU oracle's ops and a float64 copy of the same layers."""
+    from patchaugnet_amd.backbone import SAModule, SAModuleMSG
+    from patchaugnet_amd.weights import seeded_state_dict
+    b, n, m, c = 2, 256, 32, 16
+    xyz, _, feats, _ = _inputs(b, n, m, c, seed=77)
+    msg = SAModuleMSG(npoint=m, radii=[None, None], nsamples=[8, 16], knn_dilation=1, mlps=[[c, 16, 32], [c, 32, 64]], gp=4, attention=attention)
+    msg.load_state_dict(seeded_state_dict(msg.state_dict(), seed=5))
+    assert [k for k in msg.state_dict() if k.startswith("mlps.1.")] and (not attention or [k for k in msg.state_dict() if k.startswith("sas.1.")])
+    msg = msg.eval()
+    # oracle composition on the CPU: FPS -> gather -> per scale (EdgeConv group, float64 MLP + max [, attention])
+    cidx = C.furthestsampling(xyz, m)
+    new_xyz = torch.gather(xyz, 1, cidx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    cfeat = torch.gather(feats, 2, cidx.long().unsqueeze(1).expand(-1, c, -1)).contiguous()
+    ref_f, ref_i = [], []
+    cpu = SAModuleMSG(npoint=m, radii=[None, None], nsamples=[8, 16], knn_dilation=1, mlps=[[c, 16, 32], [c, 32, 64]], gp=4, attention=attention)
+    cpu.load_state_dict(msg.state_dict())
+    cpu = cpu.double().eval()
+    with torch.no_grad():
+        for i, ns in enumerate([8, 16]):
+            grouped, sidx = C.QueryAndGroup_Edge(None, ns, knn_dilation=1, use_xyz=True, ret_sample_idx=True)(xyz, new_xyz, feats, cfeat)
+            y = cpu.mlps[i](grouped.double()).max(dim=3)[0]
+            if attention:
+                y = cpu.sas[i](y)
+            ref_f.append(y)
+            ref_i.append(sidx)
+        got = msg.cuda()(xyz.cuda(), feats.cuda())
+    nx, ci, si, f = got
+    assert torch.equal(ci.cpu(), cidx) and torch.equal(nx.cpu(), new_xyz)
+    assert torch.equal(si.cpu(), torch.cat(ref_i, dim=-1))
+    ref = torch.cat(ref_f, dim=1)
+    assert f.shape == (b, 32 + 64, m)
+    assert (f.cpu().double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    # one scale through the MSG class == the single-scale level
+    one = SAModuleMSG(npoint=m, radii=[None], nsamples=[8], knn_dilation=1, mlps=[[c, 16, 32]])
+    single = SAModule(mlp=[c, 16, 32], npoint=m, nsample=8)
+    one.load_state_dict(seeded_state_dict(one.state_dict(), seed=9))
+    single.load_state_dict(one.state_dict())
+    with torch.no_grad():
+        a, bb_ = one.eval().cuda()(xyz.cuda(), feats.cuda()), single.eval().cuda()(xyz.cuda(), feats.cuda())
+    assert all(torch.equal(u, v) for u, v in zip(a, bb_))
