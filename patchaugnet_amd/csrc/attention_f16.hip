@@ -80,26 +80,50 @@ __global__ __launch_bounds__(256) void sa_attn16_kernel(int n, int np, const _Fl
 
     constexpr int YQ = C / 8;                        // 16-byte pieces per Y row
     constexpr int VQ = TJ / 8;                       // 16-byte pieces per V^T row of a tile
-    for (int t0 = 0; t0 < np; t0 += TJ) {
-        // ---- tile t0 .. t0 + TJ - 1: global (L2-resident, 16-byte pieces) -> LDS
-        for (int q = tid; q < TJ * YQ; q += 256) {
-            const int r = q / YQ, part = q - r * YQ;
+    // Tiles are fetched ONE TILE AHEAD into registers (the L2 round trip hides under the previous tile's MFMAs / exps: with fp16 MFMAs a tile is
+    // only a few thousand cycles of work) and dropped into LDS between the two barriers.
+    constexpr int NY = TJ * YQ / 256, NV = C * VQ / 256;
+    static_assert(TJ * YQ % 256 == 0 && C * VQ % 256 == 0, "tile must split evenly over the workgroup");
+    half8 py[NY], pl[SPLIT ? NY : 1], pv[PASS == 2 ? NV : 1];
+    float pm = 0.f;
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto fetch = [&](int t0) {
+#pragma unroll
+        for (int u = 0; u < NY; ++u) {
+            const int q = tid + u * 256, r = q / YQ, part = q - r * YQ;
             const bool ok = t0 + r < np;
-            const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            *reinterpret_cast<half8 *>(Yh + r * YS + part * 8) = ok ? *reinterpret_cast<const half8 *>(yh + (size_t)(t0 + r) * C + part * 8) : z;
-            if (SPLIT) *reinterpret_cast<half8 *>(Yl + r * YS + part * 8) = ok ? *reinterpret_cast<const half8 *>(yl + (size_t)(t0 + r) * C + part * 8) : z;
+            py[u] = ok ? *reinterpret_cast<const half8 *>(yh + (size_t)(t0 + r) * C + part * 8) : zero8;
+            if (SPLIT) pl[u] = ok ? *reinterpret_cast<const half8 *>(yl + (size_t)(t0 + r) * C + part * 8) : zero8;
         }
         if (PASS == 2) {
-            for (int q = tid; q < C * VQ; q += 256) {
-                const int c = q / VQ, part = q - c * VQ;
-                const bool ok = t0 + part * 8 < np;
-                const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-                *reinterpret_cast<half8 *>(Vt + c * VS + part * 8) = ok ? *reinterpret_cast<const half8 *>(vt + (size_t)c * np + t0 + part * 8) : z;
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int q = tid + u * 256, c = q / VQ, part = q - c * VQ;
+                pv[u] = t0 + part * 8 < np ? *reinterpret_cast<const half8 *>(vt + (size_t)c * np + t0 + part * 8) : zero8;
             }
-            for (int r = tid; r < TJ; r += 256)
-                Ms[r] = t0 + r < n ? stats[(size_t)(t0 + r) * 2] : INFINITY;   // log-sum-exp of row i; +inf past the cloud: p = 0
+            if (tid < TJ) pm = t0 + tid < n ? stats[(size_t)(t0 + tid) * 2] : INFINITY;   // log-sum-exp of row i; +inf past the cloud: p = 0
+        }
+    };
+    static_assert(TJ <= 256, "one thread per tile row for the statistics");
+    fetch(0);
+    for (int t0 = 0; t0 < np; t0 += TJ) {
+        // ---- tile t0 .. t0 + TJ - 1: registers -> LDS, then request the next tile
+#pragma unroll
+        for (int u = 0; u < NY; ++u) {
+            const int q = tid + u * 256, r = q / YQ, part = q - r * YQ;
+            *reinterpret_cast<half8 *>(Yh + r * YS + part * 8) = py[u];
+            if (SPLIT) *reinterpret_cast<half8 *>(Yl + r * YS + part * 8) = pl[u];
+        }
+        if (PASS == 2) {
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int q = tid + u * 256, c = q / VQ, part = q - c * VQ;
+                *reinterpret_cast<half8 *>(Vt + c * VS + part * 8) = pv[u];
+            }
+            if (tid < TJ) Ms[tid] = pm;
         }
         __syncthreads();
+        if (t0 + TJ < np) fetch(t0 + TJ);
         if (active) {
             const int nblk = (min(TJ, np - t0)) >> 5;                          // 32-point blocks in this tile (np is a multiple of 32)
             for (int ib = 0; ib < nblk; ++ib) {

@@ -461,7 +461,10 @@ __global__ __launch_bounds__((RT == 1 && WPT == 1 && !POOLED) ? 512 : 256, PA_CH
         const int per = WPT == 1 ? nct : nct / WPT;          // column tiles this wave computes (host: nct % WPT == 0)
         const int cb = WPT == 1 ? 0 : wave * per, ce = cb + per;
         // the four-workgroups-per-CU pooled tiling (NCMAX == 2: <= 128 registers) keeps a 4-deep operand ring; every other tiling up to 8
-        constexpr int PDM = (POOLED && WPT == 4 && NCMAX == 2) ? 4 : 8;
+#ifndef PA_CHAIN_PDMAX          // A/B builds: ring depth of the shared-tile tilings whose k-step is < 16 MFMAs
+#define PA_CHAIN_PDMAX 8
+#endif
+        constexpr int PDM = (POOLED && WPT == 4 && NCMAX == 2) ? 4 : (RT == 1 ? PA_CHAIN_PDMAX : 8);
         if (NCMAX >= 16 && per % 16 == 0) run_layer_chunks<RT, (NCMAX >= 16 ? 16 : NCMAX), MODE, POOLED, WPT, APOOL, PDM>(act, a, L, out, residual, l, tile, lane, cb, ce);
         else if (NCMAX >= 8 && per % 8 == 0) run_layer_chunks<RT, (NCMAX >= 8 ? 8 : NCMAX), MODE, POOLED, WPT, APOOL, PDM>(act, a, L, out, residual, l, tile, lane, cb, ce);
         else if (NCMAX >= 4 && per % 4 == 0) run_layer_chunks<RT, (NCMAX >= 4 ? 4 : NCMAX), MODE, POOLED, WPT, APOOL, PDM>(act, a, L, out, residual, l, tile, lane, cb, ce);
