@@ -50,6 +50,11 @@ int pa_furthestsampling(int b, int n, int m, const float *xyz, float *temp, int 
 /* Engine form: running minima start at 1e10 and never leave registers (no temp tensor) and the sampled coordinates
  * new_xyz (b, m, 3) are written next to idx (fuses the gathering call of patch_aug_net.py:222-225).  n <= 8192. */
 int pa_furthestsampling_gather(int b, int n, int m, const float *xyz, int *idx, float *new_xyz, pa_stream_t stream);
+/* Samples [j_begin, j_end) of the same m-sample sequence (n <= 8192): the running minima live in temp (b, n) between launches -- the launch with
+ * j_begin = 0 initialises them, every launch writes them back, a later one resumes from them and from idx[j_begin - 1].  Launches over ascending
+ * ranges covering [0, m) on one stream produce pa_furthestsampling_gather's idx / new_xyz bit for bit (the reference's order is prefix-stable,
+ * sampling_cuda_kernel.cu:59-168), so consumers of the first samples can start early (the engine's latency mode). */
+int pa_furthestsampling_range(int b, int n, int m, int j_begin, int j_end, const float *xyz, float *temp, int *idx, float *new_xyz, pa_stream_t stream);
 
 /* ---- K2/K3: gathering  (sampling_cuda_kernel.h:15-16, .cu:6-36) -----------------------------
  * forward: out[b,c,j] = points[b,c,idx[b,j]];  backward: grad_points[b,c,idx[b,j]] += grad_out[b,c,j]
@@ -63,6 +68,9 @@ int pa_gathering_backward(int b, int c, int n, int m, const float *grad_out, con
  * +inf like the reference.  Any nsample >= 1 is accepted (the reference silently overflows above
  * 200). */
 int pa_knnquery(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx, float *dist2, pa_stream_t stream);
+/* pa_knnquery for queries q0 .. q0 + mq - 1 of every cloud (buffers keep their m-query stride; same results for those rows).  PA_EUNSUPPORTED when
+ * the level's shape (n, m, nsample) does not run the cell-grid kernel that takes windows: answer the whole level with pa_knnquery then. */
+int pa_knnquery_window(int b, int n, int m, int nsample, int q0, int mq, const float *xyz, const float *new_xyz, int *idx, float *dist2, pa_stream_t stream);
 
 /* ---- K5/K6/K8: grouping  (grouping_cuda_kernel.h:16-19, .cu:28-46, :60-74; grouping_int .cu:33-49)
  * forward: out[b,c,j,s] = points[b,c,idx[b,j,s]]
@@ -204,6 +212,10 @@ int pa_mlp_chain_packed(int mode, int pooled, int nlayers, const float *const *w
                         const float *xyz, const float *feat, const int *center_idx, const int *nbr_idx, int n_src, int m_ctr, int ns, int c_feat,
                         const float *known, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2, int c1,
                         float *out, int ldo, pa_stream_t stream);
+/* The NEXT pa_mlp_chain* call of this thread (mode 1, pooled, the persistent first-level kernel's shape) computes only centres win_off ..
+ * win_off + win_len - 1 of every cloud: rows = clouds * win_len; centre / neighbour / output buffers keep their m_ctr-per-cloud layout.  The window
+ * is consumed by that call.  (First level of the engine's latency mode: its chain runs on the samples of a finished sampling chunk.) */
+int pa_sa_group_window(int win_len, int win_off);
 
 /* ---- PPT-Net grouped self-attention core  (place_recognition/pptnet_origin/models/pptnet.py:261-282; twin GroupSALayer,
  * place_recognition/patch_aug_net/models/loupe.py:69-114).  yv (b, n, 2c) point-major = [Y | V] with Y = q_conv(x) = k_conv(x)

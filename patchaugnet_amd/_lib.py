@@ -23,6 +23,8 @@ _SIGS = {
     "pa_gathering_forward": "iiiippp",
     "pa_gathering_backward": "iiiippp",
     "pa_knnquery": "iiiipppp",
+    "pa_knnquery_window": "iiiiiipppp",
+    "pa_furthestsampling_range": "iiiiipppp",
     "pa_grouping_forward": "iiiiippp",
     "pa_grouping_backward": "iiiiippp",
     "pa_grouping_int_forward": "iiiiippp",
@@ -138,6 +140,7 @@ def _load(path):
                         ("pa_afa_fused_scratch_floats", 3), ("pa_attn_train_scratch_floats", 2), ("pa_sa_attention_f16_scratch_halfs", 4)):
         getattr(l, name).argtypes = [_I] * nargs
         getattr(l, name).restype = ctypes.c_long
+    l.pa_sa_group_window.argtypes, l.pa_sa_group_window.restype = [_I, _I], _I      # thread-local state setter: no stream argument
     _declare(l, _SIGS)
     return l
 

@@ -47,8 +47,14 @@ struct FpsSlot { u64 key; float x, y, z; float pad[3]; };   // 32 bytes
 
 template <int NT, int PPT, bool LDSXYZ>
 __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, FpsOrder ord, const float *__restrict__ xyz_all,
-                                                       float *__restrict__ temp_all, int *__restrict__ idx_all, float *__restrict__ new_xyz_all)
+                                                       float *__restrict__ temp_all, int *__restrict__ idx_all, float *__restrict__ new_xyz_all,
+                                                       int j_begin = 0, int j_end = -1)
 {
+    // [j_begin, j_end): the samples this launch produces (default: all m).  A launch that starts at j_begin > 0 RESUMES: the running minima come
+    // from temp (which the previous launch wrote back) and the last selected point from idx[j_begin - 1] -- the sampling order is prefix-stable
+    // (sampling_cuda_kernel.cu:59-168: round j only needs the minima after round j - 1), so chunked launches give the same samples bit for bit
+    // and whatever consumes the first samples can start while the later ones are still being drawn (engine latency mode).
+    if (j_end < 0) j_end = m;
     constexpr int NW = NT / 64;
     constexpr int LOG_NT = NT == 64 ? 6 : NT == 128 ? 7 : NT == 256 ? 8 : NT == 512 ? 9 : 10;
     static_assert((1 << LOG_NT) == NT, "NT must be a power of two");
@@ -88,17 +94,18 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, FpsOrder ord,
             low[p] = 0u;
         }
     }
-    if (tid == 0) idxs[0] = 0;
+    const int first = j_begin > 0 ? idxs[j_begin - 1] : 0;       // written by the previous launch of the chain (same stream)
+    if (tid == 0 && j_begin == 0) idxs[0] = 0;
     float ox, oy, oz;
     if (LDSXYZ) {
         __syncthreads();
-        ox = sx[0]; oy = sy[0]; oz = sz[0];
+        ox = sx[first]; oy = sy[first]; oz = sz[first];
     } else {
-        ox = xyz[0]; oy = xyz[1]; oz = xyz[2];
+        ox = xyz[first * 3]; oy = xyz[first * 3 + 1]; oz = xyz[first * 3 + 2];
     }
-    if (tid == 0 && nxyz) { nxyz[0] = ox; nxyz[1] = oy; nxyz[2] = oz; }
+    if (tid == 0 && nxyz && j_begin == 0) { nxyz[0] = ox; nxyz[1] = oy; nxyz[2] = oz; }
 
-    for (int j = 1; j < m; ++j) {
+    for (int j = max(j_begin, 1); j < j_end; ++j) {
         u64 best = 0;
 #pragma unroll
         for (int p = 0; p < PPT; ++p) {
@@ -218,11 +225,11 @@ bool fps_lds_xyz()
 #endif
 
 template <int NT, int PPT>
-int launch_reg(int b, int n, int m, FpsOrder ord, const float *xyz, float *temp, int *idx, float *new_xyz, hipStream_t st)
+int launch_reg(int b, int n, int m, FpsOrder ord, const float *xyz, float *temp, int *idx, float *new_xyz, hipStream_t st, int j_begin = 0, int j_end = -1)
 {
 #ifdef PA_EXPERIMENTAL
     if (!fps_lds_xyz()) {
-        hipLaunchKernelGGL((fps_reg_kernel<NT, PPT, false>), dim3(b), dim3(NT), 2 * (NT / 64) * sizeof(FpsSlot), st, n, m, ord, xyz, temp, idx, new_xyz);
+        hipLaunchKernelGGL((fps_reg_kernel<NT, PPT, false>), dim3(b), dim3(NT), 2 * (NT / 64) * sizeof(FpsSlot), st, n, m, ord, xyz, temp, idx, new_xyz, j_begin, j_end);
         return 0;
     }
 #endif
@@ -230,13 +237,13 @@ int launch_reg(int b, int n, int m, FpsOrder ord, const float *xyz, float *temp,
     if (lds > 48 * 1024)  // opt in to the large-LDS carve-out (gfx950: 160 KiB per CU)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_reg_kernel<NT, PPT, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((fps_reg_kernel<NT, PPT, true>), dim3(b), dim3(NT), lds, st, n, m, ord, xyz, temp, idx, new_xyz);
+    hipLaunchKernelGGL((fps_reg_kernel<NT, PPT, true>), dim3(b), dim3(NT), lds, st, n, m, ord, xyz, temp, idx, new_xyz, j_begin, j_end);
     return 0;
 }
 
 }  // namespace
 
-static int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int *idx, float *new_xyz, pa_stream_t stream)
+static int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int *idx, float *new_xyz, pa_stream_t stream, int j_begin = 0, int j_end = -1)
 {
     PA_REQUIRE(b > 0 && n > 0, "pa_furthestsampling: b=%d n=%d must be positive", b, n);
     PA_REQUIRE(xyz && idx, "pa_furthestsampling: null pointer");
@@ -250,15 +257,16 @@ static int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int 
     ord.qbits = 0;
     while ((1 << ord.qbits) < Q) ++ord.qbits;
 
-    if (n <= 64) launch_reg<64, 1>(b, n, m, ord, xyz, temp, idx, new_xyz, st);
-    else if (n <= 128) launch_reg<64, 2>(b, n, m, ord, xyz, temp, idx, new_xyz, st);
-    else if (n <= 256) launch_reg<64, 4>(b, n, m, ord, xyz, temp, idx, new_xyz, st);
-    else if (n <= 512) launch_reg<64, 8>(b, n, m, ord, xyz, temp, idx, new_xyz, st);
-    else if (n <= 1024) launch_reg<256, 4>(b, n, m, ord, xyz, temp, idx, new_xyz, st);
-    else if (n <= 2048) launch_reg<256, 8>(b, n, m, ord, xyz, temp, idx, new_xyz, st);
-    else if (n <= 4096) launch_reg<256, 16>(b, n, m, ord, xyz, temp, idx, new_xyz, st);
-    else if (n <= 8192) launch_reg<256, 32>(b, n, m, ord, xyz, temp, idx, new_xyz, st);
+    if (n <= 64) launch_reg<64, 1>(b, n, m, ord, xyz, temp, idx, new_xyz, st, j_begin, j_end);
+    else if (n <= 128) launch_reg<64, 2>(b, n, m, ord, xyz, temp, idx, new_xyz, st, j_begin, j_end);
+    else if (n <= 256) launch_reg<64, 4>(b, n, m, ord, xyz, temp, idx, new_xyz, st, j_begin, j_end);
+    else if (n <= 512) launch_reg<64, 8>(b, n, m, ord, xyz, temp, idx, new_xyz, st, j_begin, j_end);
+    else if (n <= 1024) launch_reg<256, 4>(b, n, m, ord, xyz, temp, idx, new_xyz, st, j_begin, j_end);
+    else if (n <= 2048) launch_reg<256, 8>(b, n, m, ord, xyz, temp, idx, new_xyz, st, j_begin, j_end);
+    else if (n <= 4096) launch_reg<256, 16>(b, n, m, ord, xyz, temp, idx, new_xyz, st, j_begin, j_end);
+    else if (n <= 8192) launch_reg<256, 32>(b, n, m, ord, xyz, temp, idx, new_xyz, st, j_begin, j_end);
     else {
+        PA_REQUIRE(j_begin == 0 && j_end < 0, "pa_furthestsampling_range: clouds above 8192 points are sampled in one launch");
         PA_REQUIRE(temp && !new_xyz, "pa_furthestsampling: clouds above 8192 points need the caller's temp buffer and no fused gather");
         hipLaunchKernelGGL(fps_stream_kernel, dim3(b), dim3(1024), 0, st, n, m, ord, xyz, temp, idx);
     }
@@ -284,4 +292,18 @@ PA_API int pa_furthestsampling_gather(int b, int n, int m, const float *xyz, int
     PA_REQUIRE(new_xyz, "pa_furthestsampling_gather: null new_xyz");
     PA_REQUIRE(n <= 8192, "pa_furthestsampling_gather: n=%d exceeds the register-resident limit 8192", n);
     return fps_dispatch(b, n, m, xyz, nullptr, idx, new_xyz, stream);
+}
+
+// Samples [j_begin, j_end) of the m-sample sequence (n <= 8192): the first launch of a chain (j_begin = 0) starts the running minima temp (b, n) at
+// 1e10 itself -- the caller need not fill it -- every launch writes them back, a later launch resumes from them and from idx[j_begin - 1].  The
+// chain of launches (same stream, ascending ranges covering [0, m)) produces exactly pa_furthestsampling_gather's idx / new_xyz.
+PA_API int pa_furthestsampling_range(int b, int n, int m, int j_begin, int j_end, const float *xyz, float *temp, int *idx, float *new_xyz, pa_stream_t stream)
+{
+    PA_REQUIRE(temp && n <= 8192, "pa_furthestsampling_range: needs the running-minima buffer and n <= 8192 (n=%d)", n);
+    PA_REQUIRE(j_begin >= 0 && j_begin < j_end && j_end <= m, "pa_furthestsampling_range: bad range [%d, %d) of %d", j_begin, j_end, m);
+    if (j_begin == 0 && hipMemsetD32Async((hipDeviceptr_t)temp, 0x501502f9u /* 1e10f */, (size_t)b * n, (hipStream_t)stream) != hipSuccess) {
+        pa_set_error("pa_furthestsampling_range: could not initialise temp");
+        return PA_EINVAL;
+    }
+    return fps_dispatch(b, n, m, xyz, temp, idx, new_xyz, stream, j_begin, j_end);
 }

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void knn_select_kernel(int n, int m, int k, co
 int pa_knn_lane_try(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx, float *dist2, hipStream_t st, long long *dbg);   // knn_lane.hip (test-only library)
 #endif
 
-int pa_knn_quad_try(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx, float *dist2, hipStream_t st, long long *dbg);   // knn_quad.hip
+int pa_knn_quad_try(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx, float *dist2, hipStream_t st, long long *dbg, int mq = 0);   // knn_quad.hip
 
 static long long *g_knn_dbg = nullptr;
 PA_API void pa_knn_debug_buffer(long long *buf) { g_knn_dbg = buf; }   // profiling hook (6 int64), NULL = off
@@ -298,5 +298,20 @@ PA_API int pa_knnquery(int b, int n, int m, int nsample, const float *xyz, const
         hipLaunchKernelGGL(knn_wave_kernel<false>, dim3(pa_div_up(m, qpb), b), dim3(256), 0, st, n, m, nsample, qpb, xyz, new_xyz, idx, dist2);
     }
     PA_CHECK_LAUNCH("pa_knnquery");
+    return PA_OK;
+}
+
+// pa_knnquery for a WINDOW of every cloud's queries: queries q0 .. q0 + mq - 1 of the m per cloud (rows of new_xyz / idx / dist2 keep their m-query
+// stride).  Same kernels, same results for those rows; returns PA_EUNSUPPORTED when the level's shape does not run the cell-grid kernel that
+// takes windows (the caller then answers the whole level with pa_knnquery).
+PA_API int pa_knnquery_window(int b, int n, int m, int nsample, int q0, int mq, const float *xyz, const float *new_xyz, int *idx, float *dist2, pa_stream_t stream)
+{
+    PA_REQUIRE(b > 0 && n > 0 && m > 0 && nsample > 0 && q0 >= 0 && mq > 0 && q0 + mq <= m, "pa_knnquery_window: bad arguments (m=%d q0=%d mq=%d)", m, q0, mq);
+    PA_REQUIRE(xyz && new_xyz && idx && dist2 && b <= 65535, "pa_knnquery_window: null pointer or b > 65535");
+    if (!pa_knn_quad_try(b, n, m, nsample, xyz, new_xyz + (size_t)q0 * 3, idx + (size_t)q0 * nsample, dist2 + (size_t)q0 * nsample, (hipStream_t)stream, g_knn_dbg, mq)) {
+        pa_set_error("pa_knnquery_window: the level (n=%d, m=%d, nsample=%d) does not run the windowed cell-grid kernel", n, m, nsample);
+        return PA_EUNSUPPORTED;
+    }
+    PA_CHECK_LAUNCH("pa_knnquery_window");
     return PA_OK;
 }

@@ -87,8 +87,10 @@ __device__ __forceinline__ void merge_pair(u32 (&a)[K], int mask)
 // batch).
 template <int K, int KL, int PTS, int NT>
 __global__ __launch_bounds__(NT) void knn_quad_kernel(int n, int m, int q_per_block, const float *__restrict__ xyz_all, const float *__restrict__ new_xyz_all,
-                                                       int *__restrict__ idx_all, float *__restrict__ dist2_all, long long *dbg)
+                                                       int *__restrict__ idx_all, float *__restrict__ dist2_all, long long *dbg, int mq)
 {
+    // m: queries per cloud in the buffers (the stride); mq <= m: queries this launch answers per cloud (a window: the base pointers are offset by
+    // the caller -- pa_knnquery_window, the chunked first level of the engine's latency mode)
 #define KQ_STAMP(i) do { if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
     constexpr int NQ = NT / 4;        // queries per pass
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(NT) void knn_quad_kernel(int n, int m, int q_per_bl
     const float lo0 = grid[0], lo1 = grid[1], lo2 = grid[2], sc0 = grid[3], sc1 = grid[4], sc2 = grid[5];
 
     // this workgroup's queries in cell order
-    const int q_begin = blockIdx.x * q_per_block, q_end = min(q_begin + q_per_block, m);
+    const int q_begin = blockIdx.x * q_per_block, q_end = min(q_begin + q_per_block, mq);
     {
         for (int c = tid; c <= KG_CELLS; c += NT) qcnt[c] = 0;
         __syncthreads();
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(NT) void knn_quad_kernel(int n, int m, int q_per_bl
 #endif
 
 template <int K>
-int launch_quad(int b, int n, int m, const float *xyz, const float *new_xyz, int *idx, float *dist2, hipStream_t st, long long *dbg)
+int launch_quad(int b, int n, int m, const float *xyz, const float *new_xyz, int *idx, float *dist2, hipStream_t st, long long *dbg, int mq)
 {
     constexpr int NT = KQ_NT, PTS = 4096 / KQ_NT;
     const int qpb = KQ_QPB;
@@ -328,7 +330,7 @@ int launch_quad(int b, int n, int m, const float *xyz, const float *new_xyz, int
     constexpr int KL = (K * KQ_KL_NUM + 9) / 10;
     auto kern = knn_quad_kernel<K, KL, PTS, NT>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(pa_div_up(m, qpb), b), dim3(NT), lds, st, n, m, qpb, xyz, new_xyz, idx, dist2, dbg);
+    hipLaunchKernelGGL(kern, dim3(pa_div_up(mq, qpb), b), dim3(NT), lds, st, n, m, qpb, xyz, new_xyz, idx, dist2, dbg, mq);
     return 0;
 }
 
@@ -339,15 +341,16 @@ static int g_quad_on = -1;
 PA_API void pa_knn_quad_enable(int on) { g_quad_on = on ? 1 : 0; }
 
 // 1 when the quad kernel took the call, 0 when it is off or the shape is not one it is built for.
-int pa_knn_quad_try(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx, float *dist2, hipStream_t st, long long *dbg)
+int pa_knn_quad_try(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx, float *dist2, hipStream_t st, long long *dbg, int mq)
 {
+    if (mq <= 0) mq = m;
     if (g_quad_on < 0) g_quad_on = getenv("PA_KNN_NO_QUAD") != nullptr ? 0 : 1;
     static const int nmin = getenv("PA_KNN_QUAD_NMIN") ? atoi(getenv("PA_KNN_QUAD_NMIN")) : 2048, mmin = getenv("PA_KNN_QUAD_MMIN") ? atoi(getenv("PA_KNN_QUAD_MMIN")) : 256;   // tuning knobs
-    if (!g_quad_on || n < nmin || n > 4096 || m < mmin) return 0;
+    if (!g_quad_on || n < nmin || n > 4096 || m < mmin) return 0;      // a function of the level's shape (n, m), never of the window
     switch (nsample) {
-        case 16: launch_quad<16>(b, n, m, xyz, new_xyz, idx, dist2, st, dbg); return 1;
-        case 20: launch_quad<20>(b, n, m, xyz, new_xyz, idx, dist2, st, dbg); return 1;
-        case 32: launch_quad<32>(b, n, m, xyz, new_xyz, idx, dist2, st, dbg); return 1;
+        case 16: launch_quad<16>(b, n, m, xyz, new_xyz, idx, dist2, st, dbg, mq); return 1;
+        case 20: launch_quad<20>(b, n, m, xyz, new_xyz, idx, dist2, st, dbg, mq); return 1;
+        case 32: launch_quad<32>(b, n, m, xyz, new_xyz, idx, dist2, st, dbg, mq); return 1;
         default: return 0;
     }
 }

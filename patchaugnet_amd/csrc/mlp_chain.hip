@@ -52,6 +52,15 @@ static int g_chain_tiny = -1;
 // test / A/B switch for the persistent first-level kernel (sa_tiny.hip): 1 = wherever its shape applies, 0 = never, -1 = the default rule
 PA_API void pa_chain_tiny_enable(int on) { g_chain_tiny = on; }
 
+// pa_sa_group_window: applies to the NEXT pa_mlp_chain* call of this thread (mode 1, pooled), then resets
+static thread_local int g_win_len = 0, g_win_off = 0;
+PA_API int pa_sa_group_window(int win_len, int win_off)
+{
+    PA_REQUIRE(win_len >= 0 && win_off >= 0, "pa_sa_group_window: negative window");
+    g_win_len = win_len; g_win_off = win_off;
+    return PA_OK;
+}
+
 static long long *g_chain_dbg = nullptr;
 // profiling hook (tools/chain_phases.py): device buffer of 512 x 8 int64 receiving s_memtime stamps of the next launches; NULL = off
 PA_API void pa_chain_debug_buffer(long long *buf) { g_chain_dbg = buf; }
@@ -65,6 +74,8 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
                           const float *wskip = nullptr, const float *bias0 = nullptr, const void *const *wp16 = nullptr, int fold0 = 0, int col_slices = 1,
                           float *tap = nullptr, int ldtap = 0)
 {
+    const int win_len = g_win_len, win_off = g_win_off;      // pa_sa_group_window: consumed by this call whatever its outcome
+    g_win_len = g_win_off = 0;
     PA_REQUIRE(nlayers >= 1 && nlayers <= 3, "pa_mlp_chain: nlayers=%d must be 1..3", nlayers);
     PA_REQUIRE(rows > 0 && k0 > 0 && out, "pa_mlp_chain: rows/k0 must be positive and out non-null");
     PaChain a;
@@ -182,8 +193,8 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
     } else if (mode == MODE_SA) {
         PA_REQUIRE(xyz && feat && center_idx && nbr_idx && n_src > 0 && m_ctr > 0 && ns > 0 && c_feat > 0, "pa_mlp_chain: SA mode arguments");
         PA_REQUIRE(k0 == 3 + c_feat, "pa_mlp_chain: SA mode k0=%d must be 3 + c_feat=%d", k0, c_feat);
-        PA_REQUIRE(rows % m_ctr == 0, "pa_mlp_chain: SA rows=%ld must be B*m", rows);
-        PA_REQUIRE((rows / m_ctr) * (long)n_src < 2147483647L, "pa_mlp_chain: B*n_src overflows int32 row ids");
+        PA_REQUIRE(rows % (win_len > 0 ? win_len : m_ctr) == 0, "pa_mlp_chain: SA rows=%ld must be B*m (B * window with pa_sa_group_window)", rows);
+        PA_REQUIRE((rows / (win_len > 0 ? win_len : m_ctr)) * (long)n_src < 2147483647L, "pa_mlp_chain: B*n_src overflows int32 row ids");
         scratch = 2 * R;
     } else if (mode == MODE_FP) {
         PA_REQUIRE(known && idx3 && w3 && n_unknown > 0 && m_known > 0 && c2 > 0 && c1 >= 0 && (c1 == 0 || skip), "pa_mlp_chain: FP mode arguments");
@@ -218,7 +229,12 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
     static const bool no_tiny = getenv("PA_CHAIN_NO_TINY") != nullptr;                                               // A/B knob
     static const long tiny_min = getenv("PA_CHAIN_TINY_MIN_TILES") ? atol(getenv("PA_CHAIN_TINY_MIN_TILES")) : 1024;  // tuning knob
     const bool tiny_on = g_chain_tiny < 0 ? (!no_tiny && ntiles >= tiny_min) : g_chain_tiny > 0;
-    if (is_pooled && !split && tiny_on && pa_sa_tiny_applies(a, RTv)) {
+    if (win_len > 0) {   // rows = clouds * win_len groups; only the persistent first-level kernel takes windows
+        PA_REQUIRE(mode == MODE_SA && is_pooled && !split && pa_sa_tiny_applies(a, RTv) && win_off + win_len <= m_ctr && rows % win_len == 0,
+                   "pa_sa_group_window: the next launch must be the pooled first-level chain with a window inside its %d centres", m_ctr);
+        a.win_len = win_len; a.win_off = win_off;
+        pa_sa_tiny_launch(a, RTv, ntiles, st);
+    } else if (is_pooled && !split && tiny_on && pa_sa_tiny_applies(a, RTv)) {
         pa_sa_tiny_launch(a, RTv, ntiles, st);
     } else if (is_pooled) {
         if (pa_chain_launch_pooled(a, RTv, split, wpw, ntiles, st) != 0) {

@@ -63,6 +63,9 @@ struct PaChain {
     int col_slices, slice_n;
     long wp_slice, wp16_slice;   // packed fp32 floats / fp16 halfs per slice
     int stagger;                 // eight-wave wave-private variant: waves 4..7 (the second wave of every SIMD) start this many x 8128 cycles late
+    // Group window (persistent first-level kernel only, sa_tiny.hip): > 0 = this launch computes centres win_off .. win_off + win_len - 1 of
+    // EVERY cloud (rows = clouds * win_len); the centre / neighbour / output rows keep their m_ctr-per-cloud layout.  pa_sa_group_window.
+    int win_len, win_off;
 };
 
 namespace {

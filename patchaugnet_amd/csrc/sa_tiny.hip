@@ -118,7 +118,8 @@ __global__ __launch_bounds__(ST_WAVES * 64) void sa_tiny_kernel(PaChain a, long 
             rw.src[h] = -1;
             rw.ctr[h] = 0;
             if (r < R && gid < a.rows) {
-                const unsigned g32 = (unsigned)gid;                                 // groups < 2^31 (host-checked): 32-bit division, not the 64-bit loop
+                unsigned g32 = (unsigned)gid;                                       // groups < 2^31 (host-checked): 32-bit division, not the 64-bit loop
+                if (a.win_len > 0) { const unsigned wb = g32 / (unsigned)a.win_len; g32 = wb * (unsigned)a.m_ctr + (unsigned)a.win_off + (g32 - wb * (unsigned)a.win_len); }
                 const unsigned b = g32 / (unsigned)a.m_ctr;
                 rw.src[h] = (int)(b * (unsigned)a.n_src + (unsigned)a.nbr_idx[(size_t)g32 * a.ns + s]);
                 rw.ctr[h] = (int)(b * (unsigned)a.n_src + (unsigned)a.center_idx[g32]);
@@ -264,8 +265,10 @@ __global__ __launch_bounds__(ST_WAVES * 64) void sa_tiny_kernel(PaChain a, long 
                     m[r] = fmaxf(m[r], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m[r]), 0x120 + 4, 0xf, 0xf, true)));   // row_ror:4
                     m[r] = fmaxf(m[r], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m[r]), 0x120 + 8, 0xf, 0xf, true)));   // row_ror:8
                 }
-                const long grp = tile * 4 + li;
-                if (li < 4 && grp < a.rows) {
+                long grp = tile * 4 + li;
+                const bool live = li < 4 && grp < a.rows;
+                if (a.win_len > 0) { const long wb = grp / a.win_len; grp = wb * a.m_ctr + a.win_off + (grp - wb * a.win_len); }
+                if (live) {
                     const int col = ct * 16 + lq * 4;
                     const float4 bias = *reinterpret_cast<const float4 *>(b2 + col);
                     const float4 v = make_float4(fmaxf(m[0] + bias.x, 0.f), fmaxf(m[1] + bias.y, 0.f), fmaxf(m[2] + bias.z, 0.f), fmaxf(m[3] + bias.w, 0.f));

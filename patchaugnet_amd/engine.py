@@ -120,15 +120,22 @@ class _Chain:
         return (self.n, ctypes.cast(self.wt, ctypes.c_void_p), ctypes.cast(self.wpk, ctypes.c_void_p), ctypes.cast(self.bias, ctypes.c_void_p),
                 ctypes.cast(self.kpad, ctypes.c_void_p), ctypes.cast(self.nout, ctypes.c_void_p))
 
-    def sa(self, xyz, feat, center_idx, nbr_idx, c_feat, pooled):
+    def sa(self, xyz, feat, center_idx, nbr_idx, c_feat, pooled, window=None, out=None):
         """pooled: False / 0 = every (group, neighbour) row; True / 1 = max over the neighbourhood in the pooled tiling; 2 = the same result
         from the UNPOOLED shared-tile tiling with an atomic-max epilogue (few groups: the 16-row tiling fills the chip, the pooled one
-        does not; fp32 chains, nsample >= 16)."""
+        does not; fp32 chains, nsample >= 16).  window = (length, offset): only those centres of every cloud, written into `out` (the full
+        (B * m, C) buffer) -- pooled first-level kernel only (pa_sa_group_window)."""
         B, n_src, _ = xyz.shape
         m, ns = nbr_idx.shape[1], nbr_idx.shape[2]
         groups = B * m
         pooled = int(pooled)
-        out = torch.empty((groups if pooled else groups * ns, self.n_last), dtype=torch.float32, device=xyz.device)
+        if out is None:
+            out = torch.empty((groups if pooled else groups * ns, self.n_last), dtype=torch.float32, device=xyz.device)
+        if window is not None:
+            assert pooled == 1 and not self.f16
+            groups = B * window[0]
+            rc = _lib.lib().pa_sa_group_window(int(window[0]), int(window[1]))
+            assert rc == 0
         call(self._fn, 1, pooled, *self._common(), groups, self.k0, None, 0,
              ptr(xyz), ptr(feat), ptr(center_idx), ptr(nbr_idx), n_src, m, ns, c_feat,
              None, None, None, None, 0, 0, 0, 0, ptr(out), self.n_last)
@@ -581,6 +588,25 @@ class PatchAugNetEngine:
                                "build the engine inside `with patchaugnet_amd._lib.experimental():`")
         return on
 
+    def _first_level_chunks(self, npts, ns):
+        """Sample ranges [j0, j1, ..., m] of the first level's sampling in latency mode (None = one launch): the level must run the kernels that take windows --
+        the cell-grid kNN (2048..4096 source points, >= 256 centres, 16 / 20 / 32 neighbours) and the persistent first-level chain
+        (<= 8 -> 32 -> 32 -> 64, fp32, no attention in between) -- rules on the architecture's shapes, never on the batch."""
+        ch = self.sa[0]
+        ok = (len(self.sa) > 1 and 2048 <= npts[0] <= 4096 and npts[1] >= 1024 and npts[1] % 16 == 0 and ns in (16, 20, 32) and 13 <= ns <= 20 and not ch.f16
+              and self.attn[0] is None and [l[4] for l in ch.layers] == [32, 32, 64] and ch.layers[0][3] == 8
+              and os.environ.get("PA_ENGINE_NO_FPS_CHUNKS") is None)
+        # OPT-IN (PA_ENGINE_FPS_CHUNKS = cut points, e.g. "896" or "256,512,768"): measured on MI355X (profiles/r04_latency_mode.txt) every variant
+        # LOSES to the one-launch form of the same latency mode -- batch 1 / 8 / 32: 1.13 / 1.24 / 1.68 ms in one launch, 1.18 / 1.26 / 1.70 ms with
+        # one cut at 896, 1.21 / 1.29 / 1.72 ms with three cuts -- each extra sampling launch and cross-stream hand-over costs ~20 us, about what the
+        # tail it takes off the critical path is worth (the first level's neighbour search + chain are ~35 us at batch 1, ~115 us at batch 32, and
+        # a window's search still pays the whole cloud sort).  The sampling chain itself is what the latency is made of.
+        cuts = os.environ.get("PA_ENGINE_FPS_CHUNKS")
+        if not ok or not cuts:
+            return None
+        inner = [int(v) for v in cuts.split(",")]
+        return [0] + [c for c in inner if 0 < c < npts[1]] + [npts[1]]
+
     def _mark(self, name):
         if self.timer is not None:
             self.timer.mark(name)
@@ -640,7 +666,32 @@ class PatchAugNetEngine:
         overlap = self.geo_overlap and self.timer is None and L > 1 and not torch.cuda.is_current_stream_capturing()
         ev_sa, ev_fp = [None] * L, [None] * nfp
         main = torch.cuda.current_stream(dev)
-        fps(0)
+        # Latency mode, first level in CHUNKS: the sampling order is prefix-stable, so the first quarter of the centres is final when a quarter
+        # of the rounds has run -- its neighbour search and its set-abstraction chain run on a second stream under the NEXT quarter's sampling
+        # (pa_furthestsampling_range / pa_knnquery_window / pa_sa_group_window).  Only when the level runs the kernels that take windows
+        # (the 4096-point configurations of both models); bit-identical to the one-launch form.
+        y0 = None
+        chunks = self._first_level_chunks(npts, self.knn[0]) if overlap else None
+        if chunks:
+            side = self._geo_streams.get(("sa0", main.cuda_stream))
+            if side is None:
+                side = self._geo_streams[("sa0", main.cuda_stream)] = torch.cuda.Stream(device=dev)
+            temp = torch.empty((B, npts[0]), dtype=torch.float32, device=dev)
+            y0 = torch.empty((B * npts[1], self.sa[0].n_last), dtype=torch.float32, device=dev)
+            for j0, j1 in zip(chunks[:-1], chunks[1:]):
+                call("pa_furthestsampling_range", B, npts[0], npts[1], j0, j1, ptr(xyz), ptr(temp), ptr(cidx[0]), ptr(nxyz[0]))
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    call("pa_knnquery_window", B, npts[0], npts[1], self.knn[0], j0, j1 - j0, ptr(xyz), ptr(nxyz[0]), ptr(nbr[0]), ptr(d2[0]))
+                    self.sa[0].sa(xyz, xyz, cidx[0], nbr[0], 3, pooled=True, window=(j1 - j0, j0), out=y0)
+            ev_y0 = torch.cuda.Event()
+            ev_y0.record(side)
+            for t in (temp, y0, cidx[0], nxyz[0], nbr[0], d2[0], xyz):
+                t.record_stream(side)
+        else:
+            fps(0)
         self._mark("sa0.fps")
         if overlap:
             geo = self._geo_streams.get(main.cuda_stream)
@@ -663,6 +714,12 @@ class PatchAugNetEngine:
         for i, chain in enumerate(self.sa):
             src = l_xyz[i]
             m, ns = npts[i + 1], self.knn[i]
+            if i == 0 and y0 is not None:          # chunked first level: neighbour search and chain already ran (side stream)
+                main.wait_event(ev_y0)
+                l_feat.append(y0.view(B, m, chain.n_last))
+                l_c.append(cidx[0])
+                c_feat = chain.n_last
+                continue
             if i == 0:
                 knn(0)
             elif overlap:

@@ -222,3 +222,14 @@ def test_latency_mode_is_bit_identical():
                 d1, fp1, c1 = m(x)
             torch.cuda.synchronize()
         assert torch.equal(d0, d1) and all(torch.equal(a, b) for a, b in zip(fp0, fp1)) and all(torch.equal(a, b) for a, b in zip(c0, c1))
+        # the first level in sampling CHUNKS (prefix-stable order: pa_furthestsampling_range / pa_knnquery_window / pa_sa_group_window), opt-in
+        import os
+        os.environ["PA_ENGINE_FPS_CHUNKS"] = "256,600,896"
+        try:
+            with torch.no_grad():
+                for _ in range(2):
+                    d2, fp2, c2 = m(x)
+                torch.cuda.synchronize()
+        finally:
+            os.environ.pop("PA_ENGINE_FPS_CHUNKS")
+        assert torch.equal(d0, d2) and all(torch.equal(a, b) for a, b in zip(fp0, fp2)) and all(torch.equal(a, b) for a, b in zip(c0, c2))

@@ -435,3 +435,40 @@ def test_knnquery_naive_and_exclude_match_the_reference_definition():
     assert torch.equal(pointops.knnquery_naive(9, x, q).long(), order[:, :, :9])
     assert torch.equal(pointops.knnquery_exclude(9, x, q).long(), order[:, :, 1:10])
     assert torch.equal(pointops.knnquery_exclude(4, x).long()[:, :, 0] != torch.arange(500, device="cuda"), torch.ones(3, 500, dtype=torch.bool, device="cuda"))
+
+
+@pytest.mark.parametrize("b,n,m,parts", [(3, 4096, 1024, 4), (2, 1000, 250, 5), (1, 8192, 64, 2), (2, 300, 300, 3)])
+def test_fps_in_ranges_equals_one_launch(b, n, m, parts):
+    """pa_furthestsampling_range: the sampling order is prefix-stable (sampling_cuda_kernel.cu:59-168), so a chain of launches over ascending
+    ranges -- running minima handed over through temp, last sample through idx -- gives the oracle's samples and coordinates bit for bit."""
+    from patchaugnet_amd import _lib
+    x = cloud(b, n, "uniform")
+    xd = dev(x)
+    ref = o.furthestsampling(x, m)
+    idx = torch.full((b, m), -1, dtype=torch.int32, device="cuda")
+    nx = torch.full((b, m, 3), float("nan"), device="cuda")
+    temp = torch.empty((b, n), device="cuda")
+    cuts = [round(m * i / parts) for i in range(parts + 1)]
+    for j0, j1 in zip(cuts[:-1], cuts[1:]):
+        _lib.call("pa_furthestsampling_range", b, n, m, j0, j1, _lib.ptr(xd), _lib.ptr(temp), _lib.ptr(idx), _lib.ptr(nx))
+    assert np.array_equal(idx.cpu().numpy(), ref)
+    assert np.array_equal(nx.cpu().numpy(), np.take_along_axis(x, ref[..., None].astype(np.int64), 1))
+
+
+def test_knn_window_equals_the_rows_of_the_full_query(P):
+    """pa_knnquery_window answers a window of every cloud's queries in place: same rows as the one-launch query, the rest untouched."""
+    from patchaugnet_amd import _lib
+    b, n, m, k = 3, 4096, 1024, 20
+    x = cloud(b, n, "uniform")
+    q = x[:, RNG.choice(n, m, replace=False)]
+    gi, gd = P.knnquery_with_dist(k, dev(x), dev(q))
+    idx = torch.full((b, m, k), -7, dtype=torch.int32, device="cuda")
+    d2 = torch.full((b, m, k), -1.0, device="cuda")
+    xd, qd = dev(x), dev(q)
+    for q0 in (256, 768):
+        _lib.call("pa_knnquery_window", b, n, m, k, q0, 256, _lib.ptr(xd), _lib.ptr(qd), _lib.ptr(idx), _lib.ptr(d2))
+    for lo, hi, done in ((0, 256, False), (256, 512, True), (512, 768, False), (768, 1024, True)):
+        if done:
+            assert torch.equal(idx[:, lo:hi], gi[:, lo:hi]) and torch.equal(d2[:, lo:hi], gd[:, lo:hi])
+        else:
+            assert (idx[:, lo:hi] == -7).all() and (d2[:, lo:hi] == -1.0).all()
