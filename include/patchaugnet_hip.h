@@ -71,6 +71,13 @@ int pa_knnquery(int b, int n, int m, int nsample, const float *xyz, const float 
 /* pa_knnquery for queries q0 .. q0 + mq - 1 of every cloud (buffers keep their m-query stride; same results for those rows).  PA_EUNSUPPORTED when
  * the level's shape (n, m, nsample) does not run the cell-grid kernel that takes windows: answer the whole level with pa_knnquery then. */
 int pa_knnquery_window(int b, int n, int m, int nsample, int q0, int mq, const float *xyz, const float *new_xyz, int *idx, float *dist2, pa_stream_t stream);
+/* The source cloud's counting sort as a launch of its own: cells = pa_cloud_cellsort_floats(b, n) floats (16-byte aligned), n <= 4096.  A caller
+ * that knows the cloud before the queries (the engine: the input cloud vs the centres its sampling chain is still drawing) sorts early;
+ * pa_knnquery_presorted then answers like pa_knnquery, bit for bit, without every workgroup repeating the sort.  PA_EUNSUPPORTED when the level's
+ * shape does not run the cell-grid kernel (2048..4096 source points, >= 256 queries, nsample 16 / 20 / 32). */
+long pa_cloud_cellsort_floats(int b, int n);
+int pa_cloud_cellsort(int b, int n, const float *xyz, float *cells, pa_stream_t stream);
+int pa_knnquery_presorted(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, const float *cells, int *idx, float *dist2, pa_stream_t stream);
 
 /* ---- K5/K6/K8: grouping  (grouping_cuda_kernel.h:16-19, .cu:28-46, :60-74; grouping_int .cu:33-49)
  * forward: out[b,c,j,s] = points[b,c,idx[b,j,s]]

@@ -24,6 +24,8 @@ _SIGS = {
     "pa_gathering_backward": "iiiippp",
     "pa_knnquery": "iiiipppp",
     "pa_knnquery_window": "iiiiiipppp",
+    "pa_cloud_cellsort": "iipp",
+    "pa_knnquery_presorted": "iiiippppp",
     "pa_furthestsampling_range": "iiiiipppp",
     "pa_grouping_forward": "iiiiippp",
     "pa_grouping_backward": "iiiiippp",
@@ -137,7 +139,7 @@ def _load(path):
     l.pa_last_error.restype = ctypes.c_char_p
     l.pa_abi_version.restype = _I
     for name, nargs in (("pa_interpolation_backward_scratch_ints", 3), ("pa_netvlad_scratch_floats", 3), ("pa_afa_scratch_floats", 4), ("pa_fc_scratch_floats", 3), ("pa_afa_rows_scratch_floats", 4), ("pa_pack_weights_f16_halfs", 2),
-                        ("pa_afa_fused_scratch_floats", 3), ("pa_attn_train_scratch_floats", 2), ("pa_sa_attention_f16_scratch_halfs", 4)):
+                        ("pa_afa_fused_scratch_floats", 3), ("pa_attn_train_scratch_floats", 2), ("pa_sa_attention_f16_scratch_halfs", 4), ("pa_cloud_cellsort_floats", 2)):
         getattr(l, name).argtypes = [_I] * nargs
         getattr(l, name).restype = ctypes.c_long
     l.pa_sa_group_window.argtypes, l.pa_sa_group_window.restype = [_I, _I], _I      # thread-local state setter: no stream argument

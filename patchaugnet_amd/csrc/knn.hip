@@ -242,7 +242,8 @@ __global__ __launch_bounds__(256) void knn_select_kernel(int n, int m, int k, co
 int pa_knn_lane_try(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx, float *dist2, hipStream_t st, long long *dbg);   // knn_lane.hip (test-only library)
 #endif
 
-int pa_knn_quad_try(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx, float *dist2, hipStream_t st, long long *dbg, int mq = 0);   // knn_quad.hip
+int pa_knn_quad_try(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx, float *dist2, hipStream_t st, long long *dbg, int mq = 0,
+                    const float *cells = nullptr);   // knn_quad.hip
 
 static long long *g_knn_dbg = nullptr;
 PA_API void pa_knn_debug_buffer(long long *buf) { g_knn_dbg = buf; }   // profiling hook (6 int64), NULL = off

@@ -85,9 +85,33 @@ __device__ __forceinline__ void merge_pair(u32 (&a)[K], int mask)
 // quad's K-th comes from the union of the four lists (>= the true K-th, so the candidate band and the stop rule only get more conservative), and a
 // lane whose WHOLE list falls inside the band may have dropped a candidate -> that query takes the exact slow path (4 sigma: a few queries per
 // batch).
-template <int K, int KL, int PTS, int NT>
+// Per-cloud record of pa_cloud_cellsort (floats): [0, 4n) the sorted cloud as (x, y, z, index bits); then KG_CELLS + 1 cell END offsets (ints);
+// then lo.xyz, scale.xyz of the cell function.  All workgroups of a cloud used to repeat this counting sort (a quarter of the kernel's time at
+// 128 queries per workgroup); with PRESORT they copy the record -- 16-byte coalesced loads -- instead.
+constexpr int KQ_CNT_PAD = (KG_CELLS + 1 + 3) & ~3;     // cell offsets padded so that every cloud's record stays 16-byte aligned
+__host__ __device__ constexpr long kq_cells_floats(int n) { return 4L * n + KQ_CNT_PAD + 8; }
+
+template <int PTS, int NT>
+__global__ __launch_bounds__(NT) void cellsort_kernel(int n, const float *__restrict__ xyz_all, float *__restrict__ cells_all)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float4 *sorted = reinterpret_cast<float4 *>(smem);
+    float *box = smem + 4 * (size_t)n;
+    int *cnt = reinterpret_cast<int *>(box + 64 * 8);
+    float *red = reinterpret_cast<float *>(cnt + KG_CELLS + 1);
+    float *grid = red + 16 * 6;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int nchunks;
+    cell_sort_cloud<PTS, NT, true>(n, xyz_all + (size_t)b * n * 3, sorted, box, cnt, red, &nchunks, grid);
+    float *rec = cells_all + (size_t)b * kq_cells_floats(n);
+    for (int i = tid; i < n; i += NT) reinterpret_cast<float4 *>(rec)[i] = sorted[i];
+    for (int c = tid; c <= KG_CELLS; c += NT) reinterpret_cast<int *>(rec + 4 * (size_t)n)[c] = cnt[c];
+    if (tid < 6) rec[4 * (size_t)n + KQ_CNT_PAD + tid] = grid[tid];
+}
+
+template <int K, int KL, int PTS, int NT, bool PRESORT = false>
 __global__ __launch_bounds__(NT) void knn_quad_kernel(int n, int m, int q_per_block, const float *__restrict__ xyz_all, const float *__restrict__ new_xyz_all,
-                                                       int *__restrict__ idx_all, float *__restrict__ dist2_all, long long *dbg, int mq)
+                                                       int *__restrict__ idx_all, float *__restrict__ dist2_all, long long *dbg, int mq, const float *__restrict__ cells_all = nullptr)
 {
     // m: queries per cloud in the buffers (the stride); mq <= m: queries this launch answers per cloud (a window: the base pointers are offset by
     // the caller -- pa_knnquery_window, the chunked first level of the engine's latency mode)
@@ -106,7 +130,16 @@ __global__ __launch_bounds__(NT) void knn_quad_kernel(int n, int m, int q_per_bl
     const float *xyz = xyz_all + (size_t)b * n * 3;
     int nchunks;
     KQ_STAMP(0);
-    cell_sort_cloud<PTS, NT, true>(n, xyz, sorted, box, cnt, red, &nchunks, grid);
+    if (PRESORT) {
+        const float *rec = cells_all + (size_t)b * kq_cells_floats(n);
+        for (int i = tid; i < n; i += NT) sorted[i] = reinterpret_cast<const float4 *>(rec)[i];
+        for (int c = tid; c <= KG_CELLS; c += NT) cnt[c] = reinterpret_cast<const int *>(rec + 4 * (size_t)n)[c];
+        if (tid < 6) grid[tid] = rec[4 * (size_t)n + KQ_CNT_PAD + tid];
+        __syncthreads();
+        (void)nchunks; (void)xyz;
+    } else {
+        cell_sort_cloud<PTS, NT, true>(n, xyz, sorted, box, cnt, red, &nchunks, grid);
+    }
     KQ_STAMP(1);
     const float lo0 = grid[0], lo1 = grid[1], lo2 = grid[2], sc0 = grid[3], sc1 = grid[4], sc2 = grid[5];
 
@@ -319,7 +352,7 @@ __global__ __launch_bounds__(NT) void knn_quad_kernel(int n, int m, int q_per_bl
 #endif
 
 template <int K>
-int launch_quad(int b, int n, int m, const float *xyz, const float *new_xyz, int *idx, float *dist2, hipStream_t st, long long *dbg, int mq)
+int launch_quad(int b, int n, int m, const float *xyz, const float *new_xyz, int *idx, float *dist2, hipStream_t st, long long *dbg, int mq, const float *cells)
 {
     constexpr int NT = KQ_NT, PTS = 4096 / KQ_NT;
     const int qpb = KQ_QPB;
@@ -328,9 +361,15 @@ int launch_quad(int b, int n, int m, const float *xyz, const float *new_xyz, int
 #define KQ_KL_NUM 7      // lane list length = ceil(K * KQ_KL_NUM / 10); 10 = the full K
 #endif
     constexpr int KL = (K * KQ_KL_NUM + 9) / 10;
+    if (cells) {
+        auto kern = knn_quad_kernel<K, KL, PTS, NT, true>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(pa_div_up(mq, qpb), b), dim3(NT), lds, st, n, m, qpb, xyz, new_xyz, idx, dist2, dbg, mq, cells);
+        return 0;
+    }
     auto kern = knn_quad_kernel<K, KL, PTS, NT>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(pa_div_up(mq, qpb), b), dim3(NT), lds, st, n, m, qpb, xyz, new_xyz, idx, dist2, dbg, mq);
+    hipLaunchKernelGGL(kern, dim3(pa_div_up(mq, qpb), b), dim3(NT), lds, st, n, m, qpb, xyz, new_xyz, idx, dist2, dbg, mq, (const float *)nullptr);
     return 0;
 }
 
@@ -341,16 +380,48 @@ static int g_quad_on = -1;
 PA_API void pa_knn_quad_enable(int on) { g_quad_on = on ? 1 : 0; }
 
 // 1 when the quad kernel took the call, 0 when it is off or the shape is not one it is built for.
-int pa_knn_quad_try(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx, float *dist2, hipStream_t st, long long *dbg, int mq)
+int pa_knn_quad_try(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx, float *dist2, hipStream_t st, long long *dbg, int mq,
+                    const float *cells)
 {
     if (mq <= 0) mq = m;
     if (g_quad_on < 0) g_quad_on = getenv("PA_KNN_NO_QUAD") != nullptr ? 0 : 1;
     static const int nmin = getenv("PA_KNN_QUAD_NMIN") ? atoi(getenv("PA_KNN_QUAD_NMIN")) : 2048, mmin = getenv("PA_KNN_QUAD_MMIN") ? atoi(getenv("PA_KNN_QUAD_MMIN")) : 256;   // tuning knobs
     if (!g_quad_on || n < nmin || n > 4096 || m < mmin) return 0;      // a function of the level's shape (n, m), never of the window
     switch (nsample) {
-        case 16: launch_quad<16>(b, n, m, xyz, new_xyz, idx, dist2, st, dbg, mq); return 1;
-        case 20: launch_quad<20>(b, n, m, xyz, new_xyz, idx, dist2, st, dbg, mq); return 1;
-        case 32: launch_quad<32>(b, n, m, xyz, new_xyz, idx, dist2, st, dbg, mq); return 1;
+        case 16: launch_quad<16>(b, n, m, xyz, new_xyz, idx, dist2, st, dbg, mq, cells); return 1;
+        case 20: launch_quad<20>(b, n, m, xyz, new_xyz, idx, dist2, st, dbg, mq, cells); return 1;
+        case 32: launch_quad<32>(b, n, m, xyz, new_xyz, idx, dist2, st, dbg, mq, cells); return 1;
         default: return 0;
     }
+}
+
+// ---- the cloud's counting sort as a launch of its own (one workgroup per cloud), for callers that know the cloud before they know the queries:
+// the engine sorts the input cloud while the first level's sampling chain has not even started; the first level's neighbour search then copies
+// the record instead of sorting (pa_knnquery_presorted).  cells: pa_cloud_cellsort_floats(b, n) floats.
+PA_API long pa_cloud_cellsort_floats(int b, int n) { return (long)b * kq_cells_floats(n); }
+
+PA_API int pa_cloud_cellsort(int b, int n, const float *xyz, float *cells, pa_stream_t stream)
+{
+    PA_REQUIRE(b > 0 && n > 0 && n <= 4096 && xyz && cells && ((uintptr_t)cells & 15) == 0, "pa_cloud_cellsort: needs n <= 4096 and a 16-byte aligned record buffer (n=%d)", n);
+    constexpr int NT = KQ_NT, PTS = 4096 / KQ_NT;
+    const size_t lds = (size_t)n * 16 + (size_t)KQ_AUX_FLOATS * 4;
+    auto kern = cellsort_kernel<PTS, NT>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(b), dim3(NT), lds, (hipStream_t)stream, n, xyz, cells);
+    PA_CHECK_LAUNCH("pa_cloud_cellsort");
+    return PA_OK;
+}
+
+// pa_knnquery with the source cloud's record from pa_cloud_cellsort (same results bit for bit); PA_EUNSUPPORTED when the level's shape does not run
+// the cell-grid kernel (2048..4096 source points, >= 256 queries, nsample 16 / 20 / 32): use pa_knnquery then.
+PA_API int pa_knnquery_presorted(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, const float *cells, int *idx, float *dist2, pa_stream_t stream)
+{
+    PA_REQUIRE(b > 0 && n > 0 && m > 0 && nsample > 0 && xyz && new_xyz && cells && idx && dist2 && b <= 65535, "pa_knnquery_presorted: bad arguments");
+    PA_REQUIRE(((uintptr_t)cells & 15) == 0, "pa_knnquery_presorted: the record buffer must be 16-byte aligned");
+    if (!pa_knn_quad_try(b, n, m, nsample, xyz, new_xyz, idx, dist2, (hipStream_t)stream, nullptr, 0, cells)) {
+        pa_set_error("pa_knnquery_presorted: the level (n=%d, m=%d, nsample=%d) does not run the cell-grid kernel", n, m, nsample);
+        return PA_EUNSUPPORTED;
+    }
+    PA_CHECK_LAUNCH("pa_knnquery_presorted");
+    return PA_OK;
 }

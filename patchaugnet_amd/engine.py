@@ -588,6 +588,15 @@ class PatchAugNetEngine:
                                "build the engine inside `with patchaugnet_amd._lib.experimental():`")
         return on
 
+    @staticmethod
+    def _presort_ok(n, m, ns):
+        """The first level's neighbour search takes a pre-sorted cloud (pa_knnquery_presorted: the cell-grid kernel's shapes).  OPT-IN
+        (PA_ENGINE_PRESORT=1): measured on MI355X at batch 32, four streams, it is a wash (36.9 k vs 36.7 k submaps/s, inside the run-to-run
+        spread; profiles/r04_ab_log.txt) -- the sort the eight workgroups of a cloud repeat is hidden under the other streams' work, while the
+        extra launch sits in front of the sampling chain on the step's own stream."""
+        return (2048 <= n <= 4096 and m >= 256 and ns in (16, 20, 32) and os.environ.get("PA_ENGINE_PRESORT") == "1"
+                and os.environ.get("PA_KNN_NO_QUAD") is None)
+
     def _first_level_chunks(self, npts, ns):
         """Sample ranges [j0, j1, ..., m] of the first level's sampling in latency mode (None = one launch): the level must run the kernels that take windows --
         the cell-grid kNN (2048..4096 source points, >= 256 centres, 16 / 20 / 32 neighbours) and the persistent first-level chain
@@ -657,7 +666,17 @@ class PatchAugNetEngine:
         def fps(i):
             call("pa_furthestsampling_gather", B, npts[i], npts[i + 1], ptr(l_xyz[i]), ptr(cidx[i]), ptr(nxyz[i]))
 
+        # first level: the input cloud's cell sort does not depend on the centres, so it is issued BEFORE the sampling chain (one workgroup per
+        # cloud, ~15 us, next to nothing in CU-time); the neighbour search then copies the record instead of sorting in each of its workgroups
+        cells = None
+        if self._presort_ok(npts[0], npts[1], self.knn[0]):
+            cells = torch.empty(_lib.lib().pa_cloud_cellsort_floats(B, npts[0]), dtype=torch.float32, device=dev)
+            call("pa_cloud_cellsort", B, npts[0], ptr(xyz), ptr(cells))
+
         def knn(i):
+            if i == 0 and cells is not None:
+                call("pa_knnquery_presorted", B, npts[0], npts[1], self.knn[0], ptr(xyz), ptr(nxyz[0]), ptr(cells), ptr(nbr[0]), ptr(d2[0]))
+                return
             call("pa_knnquery", B, npts[i], npts[i + 1], self.knn[i], ptr(l_xyz[i]), ptr(nxyz[i]), ptr(nbr[i]), ptr(d2[i]))
 
         def tnn(j):      # patch_aug_net.py:350-353

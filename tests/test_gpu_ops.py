@@ -472,3 +472,46 @@ def test_knn_window_equals_the_rows_of_the_full_query(P):
             assert torch.equal(idx[:, lo:hi], gi[:, lo:hi]) and torch.equal(d2[:, lo:hi], gd[:, lo:hi])
         else:
             assert (idx[:, lo:hi] == -7).all() and (d2[:, lo:hi] == -1.0).all()
+
+
+@pytest.mark.parametrize("kind", LANE_CASES)
+def test_knn_presorted_cloud_equals_the_oracle(kind):
+    """pa_cloud_cellsort + pa_knnquery_presorted (the cloud's counting sort as a launch of its own; the query workgroups copy the record) on the
+    cell-grid stress shapes: exact ties, a degenerate axis, one dense cluster, queries outside the box, non-finite points, ragged n."""
+    import zlib
+    from patchaugnet_amd import _lib
+    rng = np.random.default_rng(zlib.crc32(f"presort-{kind}".encode()))
+    b, n, m, k = 2, 4096, 1024, 20
+    x = (rng.random((b, n, 3), dtype=np.float32) * 2 - 1).astype(np.float32)
+    q = None
+    if kind == "lattice":
+        x = (np.round(x * 4) / 4).astype(np.float32)
+    elif kind == "dup":
+        x[:, rng.choice(n, 400, replace=False)] = x[:, rng.choice(n, 400, replace=False)]
+    elif kind == "planar":
+        x[..., 2] = 0.25
+    elif kind == "line":
+        x[..., 1] = -0.5
+        x[..., 2] = 0.125
+    elif kind == "clustered":
+        x[:, : n - 40] = (x[:, : n - 40] * 0.02 + 0.7).astype(np.float32)
+    elif kind == "outside":
+        q = (rng.random((b, m, 3), dtype=np.float32) * 6 - 3).astype(np.float32)
+    elif kind == "nonfinite":
+        x[0, 7] = np.inf
+        x[1, 100, 1] = np.nan
+        x[1, 2000] = -np.inf
+    elif kind == "ragged":
+        n, m = 3001, 301
+        x = x[:, :n].copy()
+    if q is None:
+        q = x[:, rng.choice(n, m, replace=False)].copy()
+    ri, rd = o.knnquery(k, x, q)
+    xd, qd = dev(x), dev(q)
+    cells = torch.empty(_lib.lib().pa_cloud_cellsort_floats(b, n), device="cuda")
+    idx = torch.empty((b, m, k), dtype=torch.int32, device="cuda")
+    d2 = torch.empty((b, m, k), device="cuda")
+    _lib.call("pa_cloud_cellsort", b, n, _lib.ptr(xd), _lib.ptr(cells))
+    _lib.call("pa_knnquery_presorted", b, n, m, k, _lib.ptr(xd), _lib.ptr(qd), _lib.ptr(cells), _lib.ptr(idx), _lib.ptr(d2))
+    assert np.array_equal(idx.cpu().numpy(), ri)
+    assert np.array_equal(d2.cpu().numpy().view(np.uint32), rd.view(np.uint32))
