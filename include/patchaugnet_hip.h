@@ -230,11 +230,19 @@ int pa_sa_group_window(int win_len, int win_off);
  * Writes d (b, n, c) = x - x_r, x_r = V^T attn, attn = row soft-max of Y Y^T re-normalised by (1e-9 + column sums).
  * stats: scratch of 2*b*n floats (row max and 1/row-sum).  Any n >= 1; c in {64, 128, 256, 512}. */
 int pa_sa_attention(int b, int n, int c, const float *yv, const float *x, float *stats, float *d, pa_stream_t stream);
+/* The same with the layer behind the attention in the second pass's epilogue: out (b, n, c) = x + relu(W (x - x_r) + bias), wt K-major (c x c) fp32 =
+ * trans_conv with after_norm folded (pptnet.py:279-281), bt (c): one launch and one (rows x c) round trip less per level. */
+int pa_sa_attention_trans(int b, int n, int c, const float *yv, const float *x, float *stats, const float *wt, const float *bt, float *out, pa_stream_t stream);
 /* The same op with both contractions on fp16 MFMA (fp32 accumulation, fp32 soft-max statistics; csrc/attention_f16.hip) -- the fp16 path of
  * BASELINE.json configs[4], under its cosine >= 0.999 contract; c in {64, 128, 256}.  split != 0 carries the energy operands as (hi, lo) fp16
  * pairs (three products: ~21 bits of the logits).  scratch: pa_sa_attention_f16_scratch_halfs(b, n, c, split) fp16 elements, 16-byte aligned. */
 long pa_sa_attention_f16_scratch_halfs(int b, int n, int c, int split);
 int pa_sa_attention_f16(int b, int n, int c, int split, const float *yv, const float *x, void *scratch, float *stats, float *d, pa_stream_t stream);
+/* ... and with the layer behind the attention in the same launch: out (b, n, c) = x + relu(W (x - x_r) + bias), W = trans_conv with after_norm folded
+ * (pptnet.py:279-281).  wtp: pa_sa_attention_f16_pack_trans of the K-major (c x c) fp32 weight (c * c fp16 elements); bt (c) fp32. */
+int pa_sa_attention_f16_pack_trans(int c, const float *wt, void *wtp, pa_stream_t stream);
+int pa_sa_attention_trans_f16(int b, int n, int c, int split, const float *yv, const float *x, void *scratch, float *stats, const void *wtp, const float *bt,
+                              float *out, pa_stream_t stream);
 
 
 /* out[g][c] = max over s < ns of in[g*ns + s][c]  (rows of c floats) */

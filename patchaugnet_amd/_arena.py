@@ -1,5 +1,6 @@
 """Zero-filled device buffers of one training step out of ONE filled allocation (used by train_ops.py and pointops.py's backward kernels)."""
 import contextlib
+import threading
 
 import torch
 
@@ -11,6 +12,7 @@ class _ZeroArena:
     off = 0             # bytes handed out
     used = 0            # bytes asked for in this step (the next step's size)
     demand = {}         # device -> bytes
+    owner = None        # (thread id, raw stream) that opened the step: the fill launch is ordered on THAT stream only
 
 
 _arena = _ZeroArena()
@@ -31,6 +33,7 @@ def zero_arena(device):
         yield
         return
     a.active, a.device, a.off, a.used = True, device, 0, 0
+    a.owner = (threading.get_ident(), torch.cuda.current_stream(device).cuda_stream)
     want = a.demand.get(device, 0)
     a.buf = torch.zeros(want, dtype=torch.uint8, device=device) if want else None
     try:
@@ -43,7 +46,10 @@ def zero_arena(device):
 def zeros(shape, dtype, device):
     """torch.zeros(shape, dtype=dtype, device=device), out of the step's zero-filled buffer when one is open (zero_arena)."""
     a = _arena
-    if a.active and torch.device(device) == a.device:
+    # slices only for the thread and stream the step's fill launch was issued on: another stream (a pipeline worker, an autograd node replayed on a
+    # side stream) is not ordered after that launch and gets a buffer of its own
+    if (a.active and torch.device(device) == a.device and a.owner is not None and a.owner[0] == threading.get_ident()
+            and a.owner[1] == torch.cuda.current_stream(a.device).cuda_stream):
         n = dtype.itemsize
         for d in shape:
             n *= d

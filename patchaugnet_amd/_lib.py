@@ -59,7 +59,10 @@ _SIGS = {
     "pa_fp_chain_premul": "ippppplppppiiiippppi",
     "pa_mlp_chain_packed": "iiippppplipippppiiiippppiiiipi",
     "pa_sa_attention": "iiipppp",
+    "pa_sa_attention_trans": "iiipppppp",
     "pa_sa_attention_f16": "iiiippppp",
+    "pa_sa_attention_trans_f16": "iiiippppppp",
+    "pa_sa_attention_f16_pack_trans": "ipp",
     "pa_netvlad": "iiiippppppii",
     "pa_furthestsampling_gather": "iiippp",
     "pa_three_nn_weights": "iiipppp",

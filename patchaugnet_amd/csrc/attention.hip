@@ -39,8 +39,12 @@ struct AttnCfg {
 
 template <int C, int PASS>
 __global__ __launch_bounds__(256) void sa_attn_kernel(int n, const float *__restrict__ yv_all, const float *__restrict__ x_all,
-                                                       float *__restrict__ stats_all, float *__restrict__ d_all)
+                                                       float *__restrict__ stats_all, float *__restrict__ d_all,
+                                                       const float *__restrict__ wt = nullptr, const float *__restrict__ bt = nullptr)
 {
+    // wt != null (pass 2): the layer behind the attention -- trans_conv + BatchNorm (folded) + ReLU + residual, pptnet.py:279-281 -- runs on the wave's 16
+    // points in the epilogue and d_all receives x + relu(W d + b) instead of d (one launch and one (rows x C) round trip less per level).  wt: K-major
+    // (C x C) fp32 with the BatchNorm folded, bt (C).  Exact fp32 MFMA; the contraction visits the channels in the order the registers hold them.
     using Cfg = AttnCfg<C>;
     constexpr int TJ = Cfg::TJ, YS = Cfg::YS, VS = Cfg::VS, KS = C / 4, CT = C / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -177,8 +181,8 @@ __global__ __launch_bounds__(256) void sa_attn_kernel(int n, const float *__rest
         s_run += __shfl_xor(s_run, 16);
         s_run += __shfl_xor(s_run, 32);
         const float den = 1e-9f + s_run;                                       // pptnet.py:277
-        if (j0 + (lane & 15) >= n) return;
-        const size_t row = (size_t)b * n + j0 + (lane & 15);
+        const bool valid = j0 + (lane & 15) < n;   // lanes past the cloud stay in the wave: the fused epilogue's MFMAs take their weight fragments
+        const size_t row = (size_t)b * n + min(j0 + (lane & 15), n - 1);
         const float *xr = x_all + row * C;
         float *dr = d_all + row * C;
 #pragma unroll
@@ -192,39 +196,80 @@ __global__ __launch_bounds__(256) void sa_attn_kernel(int n, const float *__rest
                 d.y = xv.y - o[4 * u + 1][rr] / den;
                 d.z = xv.z - o[4 * u + 2][rr] / den;
                 d.w = xv.w - o[4 * u + 3][rr] / den;
-                *reinterpret_cast<float4 *>(dr + c) = d;
+                if (wt == nullptr) {
+                    if (valid) *reinterpret_cast<float4 *>(dr + c) = d;
+                } else {                                                        // kept in place: the B operands of the fused layer
+                    o[4 * u + 0][rr] = d.x; o[4 * u + 1][rr] = d.y; o[4 * u + 2][rr] = d.z; o[4 * u + 3][rr] = d.w;
+                }
             }
+        }
+        if (wt == nullptr) return;
+        // out[j][co] = x[j][co] + relu(sum_c wt[c][co] d[j][c] + bt[co]): MFMA (u, rr, e) contracts the channels {64 u + 16 g + 4 rr + e : g = 0..3} -- a lane's
+        // own register as the B operand, the weight row of the SAME channel as the A operand (row m = output channel 16 cot + m)
+        const int lg = lane >> 4, lm = lane & 15;
+        for (int cot = 0; cot < CT; ++cot) {
+            floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
+            const float *wp = wt + (size_t)(16 * lg) * C + 16 * cot + lm;
+#pragma unroll
+            for (int u = 0; u < CT / 4; ++u)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(size_t)(64 * u + 4 * rr + e) * C], o[4 * u + e][rr], acc, 0, 0, 0);
+            const int c = cot * 16 + lg * 4;                                    // acc[r]: output channel 16 cot + 4 g + r of point j
+            const float4 bias = *reinterpret_cast<const float4 *>(bt + c);
+            const float4 xv = *reinterpret_cast<const float4 *>(xr + c);
+            float4 y;
+            y.x = xv.x + fmaxf(acc[0] + bias.x, 0.f);
+            y.y = xv.y + fmaxf(acc[1] + bias.y, 0.f);
+            y.z = xv.z + fmaxf(acc[2] + bias.z, 0.f);
+            y.w = xv.w + fmaxf(acc[3] + bias.w, 0.f);
+            if (valid) *reinterpret_cast<float4 *>(dr + c) = y;
         }
     }
 }
 
 template <int C>
-int launch_attn(int b, int n, const float *yv, const float *x, float *stats, float *d, hipStream_t st)
+int launch_attn(int b, int n, const float *yv, const float *x, float *stats, float *d, hipStream_t st, const float *wt = nullptr, const float *bt = nullptr)
 {
     using Cfg = AttnCfg<C>;
     const size_t lds1 = (size_t)Cfg::TJ * Cfg::YS * 4;
     const size_t lds2 = (size_t)(Cfg::TJ * Cfg::YS + Cfg::TJ * Cfg::VS + 2 * Cfg::TJ) * 4;
     const dim3 grid(pa_div_up(n, 64), b);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_attn_kernel<C, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-    hipLaunchKernelGGL((sa_attn_kernel<C, 1>), grid, dim3(256), lds1, st, n, yv, x, stats, d);
-    hipLaunchKernelGGL((sa_attn_kernel<C, 2>), grid, dim3(256), lds2, st, n, yv, x, stats, d);
+    hipLaunchKernelGGL((sa_attn_kernel<C, 1>), grid, dim3(256), lds1, st, n, yv, x, stats, d, (const float *)nullptr, (const float *)nullptr);
+    hipLaunchKernelGGL((sa_attn_kernel<C, 2>), grid, dim3(256), lds2, st, n, yv, x, stats, d, wt, bt);
     return 0;
 }
 
 }  // namespace
 
-PA_API int pa_sa_attention(int b, int n, int c, const float *yv, const float *x, float *stats, float *d, pa_stream_t stream)
+static int attn_dispatch(int b, int n, int c, const float *yv, const float *x, float *stats, float *d, const float *wt, const float *bt, pa_stream_t stream)
 {
     PA_REQUIRE(b > 0 && n > 0 && yv && x && stats && d, "pa_sa_attention: bad arguments");
     PA_REQUIRE(b <= 65535, "pa_sa_attention: b=%d exceeds the grid limit", b);
     hipStream_t st = (hipStream_t)stream;
     switch (c) {
-        case 64: launch_attn<64>(b, n, yv, x, stats, d, st); break;
-        case 128: launch_attn<128>(b, n, yv, x, stats, d, st); break;
-        case 256: launch_attn<256>(b, n, yv, x, stats, d, st); break;
-        case 512: launch_attn<512>(b, n, yv, x, stats, d, st); break;
+        case 64: launch_attn<64>(b, n, yv, x, stats, d, st, wt, bt); break;
+        case 128: launch_attn<128>(b, n, yv, x, stats, d, st, wt, bt); break;
+        case 256: launch_attn<256>(b, n, yv, x, stats, d, st, wt, bt); break;
+        case 512: launch_attn<512>(b, n, yv, x, stats, d, st, wt, bt); break;
         default: pa_set_error("pa_sa_attention: built for 64/128/256/512 channels (PPT-Net widths), got %d", c); return PA_EUNSUPPORTED;
     }
     PA_CHECK_LAUNCH("pa_sa_attention");
     return PA_OK;
+}
+
+PA_API int pa_sa_attention(int b, int n, int c, const float *yv, const float *x, float *stats, float *d, pa_stream_t stream)
+{
+    return attn_dispatch(b, n, c, yv, x, stats, d, nullptr, nullptr, stream);
+}
+
+// The attention AND the layer behind it in one pass-2 launch: out (b, n, c) = x + relu(W (x - x_r) + bias); wt: K-major (c x c) fp32 = trans_conv with
+// after_norm folded (pptnet.py:279-281), bt (c).  Exact fp32 MFMA (the channels are contracted in the order the attention's registers hold them).
+PA_API int pa_sa_attention_trans(int b, int n, int c, const float *yv, const float *x, float *stats, const float *wt, const float *bt, float *out, pa_stream_t stream)
+{
+    PA_REQUIRE(wt && bt && out, "pa_sa_attention_trans: null weights / bias / output");
+    return attn_dispatch(b, n, c, yv, x, stats, out, wt, bt, stream);
 }

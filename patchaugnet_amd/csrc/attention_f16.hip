@@ -44,8 +44,12 @@ struct Attn16Cfg {
 template <int C, int PASS, bool SPLIT>
 __global__ __launch_bounds__(256) void sa_attn16_kernel(int n, int np, const _Float16 *__restrict__ yh_all, const _Float16 *__restrict__ yl_all,
                                                          const _Float16 *__restrict__ vt_all, const float *__restrict__ x_all,
-                                                         float *__restrict__ stats_all, float *__restrict__ d_all)
+                                                         float *__restrict__ stats_all, float *__restrict__ d_all,
+                                                         const _Float16 *__restrict__ wtp = nullptr, const float *__restrict__ bt = nullptr)
 {
+    // wtp != null (pass 2): the layer that follows the attention -- trans_conv + BatchNorm (folded) + ReLU + residual, pptnet.py:279-281 -- is applied to
+    // the wave's 16 points HERE and d_all receives x + relu(W d + b) instead of d: one launch and one (rows x C) round trip less per level.  wtp:
+    // pa_sa_attention_f16_pack_trans of the K-major folded weight (fp16, the k order this epilogue's registers have); bt: folded bias.
     using Cfg = Attn16Cfg<C>;
     constexpr int TJ = Cfg::TJ, YS = Cfg::YS, VS = Cfg::VS, KS = C / 32, CT = C / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -226,22 +230,67 @@ __global__ __launch_bounds__(256) void sa_attn16_kernel(int n, int np, const _Fl
         s_run += __shfl_xor(s_run, 32);
         // pptnet.py:277 in the scaled domain: x_r = o 2^M / (1e-9 + s 2^M) = o / (1e-9 2^-M + s); 2^-M = +inf (a column of mass < 2^-126): x_r = 0
         const float den = 1e-9f * __builtin_amdgcn_exp2f(-m_run) + s_run;
-        if (j0 + li >= n) return;
-        const size_t row = (size_t)b * n + j0 + li;
+        const bool valid = j0 + li < n;            // lanes past the cloud stay in the wave: the fused epilogue's MFMAs take their weight fragments
+        const size_t row = (size_t)b * n + min(j0 + li, n - 1);
         const float *xr = x_all + row * C;
         float *dr = d_all + row * C;
+        if (wtp == nullptr) {
+            if (!valid) return;
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {                                      // o[ct][r]: channel 16 ct + 4 g + r of point j = l % 16
-            const int c = ct * 16 + lg * 4;
+            for (int ct = 0; ct < CT; ++ct) {                                  // o[ct][r]: channel 16 ct + 4 g + r of point j = l % 16
+                const int c = ct * 16 + lg * 4;
+                const float4 xv = *reinterpret_cast<const float4 *>(xr + c);
+                float4 d;
+                d.x = xv.x - o[ct][0] / den;
+                d.y = xv.y - o[ct][1] / den;
+                d.z = xv.z - o[ct][2] / den;
+                d.w = xv.w - o[ct][3] / den;
+                *reinterpret_cast<float4 *>(dr + c) = d;
+            }
+            return;
+        }
+        // fused trans_conv: d (fp16) is the B operand as it sits in the registers -- k-step s takes the channel tiles 2 s and 2 s + 1, k-slot 8 g + e
+        // = channel 32 s + 4 g + e (e < 4) or 32 s + 16 + 4 g + (e - 4); the packed weights enumerate the contraction in the same order.
+        half8 db[C / 32];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const float4 xv = *reinterpret_cast<const float4 *>(xr + ct * 16 + lg * 4);
+            const int sidx = ct >> 1, eo = (ct & 1) * 4;
+            db[sidx][eo + 0] = (_Float16)(xv.x - o[ct][0] / den);
+            db[sidx][eo + 1] = (_Float16)(xv.y - o[ct][1] / den);
+            db[sidx][eo + 2] = (_Float16)(xv.z - o[ct][2] / den);
+            db[sidx][eo + 3] = (_Float16)(xv.w - o[ct][3] / den);
+        }
+        const half8 *wq = reinterpret_cast<const half8 *>(wtp) + lane;          // wtp[((cot * (C / 32) + s) * 64 + lane) * 8 + e]
+#pragma unroll
+        for (int cot = 0; cot < CT; ++cot) {
+            floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sidx = 0; sidx < C / 32; ++sidx)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[(size_t)(cot * (C / 32) + sidx) * 64], db[sidx], acc, 0, 0, 0);
+            const int c = cot * 16 + lg * 4;                                    // acc[r]: output channel 16 cot + 4 g + r of point j
+            const float4 bias = *reinterpret_cast<const float4 *>(bt + c);
             const float4 xv = *reinterpret_cast<const float4 *>(xr + c);
-            float4 d;
-            d.x = xv.x - o[ct][0] / den;
-            d.y = xv.y - o[ct][1] / den;
-            d.z = xv.z - o[ct][2] / den;
-            d.w = xv.w - o[ct][3] / den;
-            *reinterpret_cast<float4 *>(dr + c) = d;
+            float4 y;
+            y.x = xv.x + fmaxf(acc[0] + bias.x, 0.f);
+            y.y = xv.y + fmaxf(acc[1] + bias.y, 0.f);
+            y.z = xv.z + fmaxf(acc[2] + bias.z, 0.f);
+            y.w = xv.w + fmaxf(acc[3] + bias.w, 0.f);
+            if (valid) *reinterpret_cast<float4 *>(dr + c) = y;
         }
     }
+}
+
+// wtp[((cot * (c / 32) + s) * 64 + lane) * 8 + e] = (half) wt[k(s, lane / 16, e) * c + 16 cot + lane % 16],  k(s, g, e) = 32 s + 4 g + e (e < 4) or
+// 32 s + 16 + 4 g + (e - 4): the A-operand fragments of the fused trans_conv epilogue (wt: K-major (c x c) fp32, BatchNorm folded)
+__global__ void attn_pack_trans16_kernel(int c, const float *__restrict__ wt, _Float16 *__restrict__ wtp)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= c * c) return;
+    const int e = t & 7, lane = (t >> 3) & 63, rest = t >> 9, ks = c / 32;
+    const int sidx = rest % ks, cot = rest / ks, g = lane >> 4, m = lane & 15;
+    const int k = e < 4 ? 32 * sidx + 4 * g + e : 32 * sidx + 16 + 4 * g + (e - 4);
+    wtp[t] = (_Float16)wt[(size_t)k * c + 16 * cot + m];
 }
 
 // yv (B, N, 2C) fp32 -> yh / yl (B, Np, C) fp16 rows, vt (B, C, Np) fp16 channel-major with the 32-point block permutation; zero past N.
@@ -281,7 +330,7 @@ __global__ __launch_bounds__(256) void attn_pack16_kernel(int n, int np, const f
 }
 
 template <int C, bool SPLIT>
-int launch_attn16(int b, int n, const float *yv, const float *x, _Float16 *scratch, float *stats, float *d, hipStream_t st)
+int launch_attn16(int b, int n, const float *yv, const float *x, _Float16 *scratch, float *stats, float *d, hipStream_t st, const _Float16 *wtp, const float *bt)
 {
     using Cfg = Attn16Cfg<C>;
     const int np = (n + 31) & ~31;
@@ -294,8 +343,8 @@ int launch_attn16(int b, int n, const float *yv, const float *x, _Float16 *scrat
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_attn16_kernel<C, 2, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     if (lds1 > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_attn16_kernel<C, 1, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-    hipLaunchKernelGGL((sa_attn16_kernel<C, 1, SPLIT>), grid, dim3(256), lds1, st, n, np, yh, yl, vt, x, stats, d);
-    hipLaunchKernelGGL((sa_attn16_kernel<C, 2, SPLIT>), grid, dim3(256), lds2, st, n, np, yh, yl, vt, x, stats, d);
+    hipLaunchKernelGGL((sa_attn16_kernel<C, 1, SPLIT>), grid, dim3(256), lds1, st, n, np, yh, yl, vt, x, stats, d, (const _Float16 *)nullptr, (const float *)nullptr);
+    hipLaunchKernelGGL((sa_attn16_kernel<C, 2, SPLIT>), grid, dim3(256), lds2, st, n, np, yh, yl, vt, x, stats, d, wtp, bt);
     return 0;
 }
 
@@ -306,13 +355,14 @@ PA_API long pa_sa_attention_f16_scratch_halfs(int b, int n, int c, int split) { 
 
 // d (b, n, c) = x - x_r as pa_sa_attention, both contractions on fp16 MFMA (fp32 accumulate, fp32 soft-max).  split != 0: the energy operands
 // as (hi, lo) fp16 pairs (three products).  scratch: pa_sa_attention_f16_scratch_halfs fp16 elements, 16-byte aligned.  c in {64, 128, 256}.
-PA_API int pa_sa_attention_f16(int b, int n, int c, int split, const float *yv, const float *x, void *scratch, float *stats, float *d, pa_stream_t stream)
+static int attn16_dispatch(int b, int n, int c, int split, const float *yv, const float *x, void *scratch, float *stats, float *d, const _Float16 *wtp,
+                           const float *bt, pa_stream_t stream)
 {
     PA_REQUIRE(b > 0 && n > 0 && yv && x && scratch && stats && d, "pa_sa_attention_f16: bad arguments");
     PA_REQUIRE(b <= 65535 && ((uintptr_t)scratch & 15) == 0, "pa_sa_attention_f16: b=%d exceeds the grid limit or scratch is not 16-byte aligned", b);
     hipStream_t st = (hipStream_t)stream;
     _Float16 *sc = reinterpret_cast<_Float16 *>(scratch);
-#define PA_ATTN16(CC) do { if (split) launch_attn16<CC, true>(b, n, yv, x, sc, stats, d, st); else launch_attn16<CC, false>(b, n, yv, x, sc, stats, d, st); } while (0)
+#define PA_ATTN16(CC) do { if (split) launch_attn16<CC, true>(b, n, yv, x, sc, stats, d, st, wtp, bt); else launch_attn16<CC, false>(b, n, yv, x, sc, stats, d, st, wtp, bt); } while (0)
     switch (c) {
         case 64: PA_ATTN16(64); break;
         case 128: PA_ATTN16(128); break;
@@ -321,5 +371,27 @@ PA_API int pa_sa_attention_f16(int b, int n, int c, int split, const float *yv, 
     }
 #undef PA_ATTN16
     PA_CHECK_LAUNCH("pa_sa_attention_f16");
+    return PA_OK;
+}
+
+PA_API int pa_sa_attention_f16(int b, int n, int c, int split, const float *yv, const float *x, void *scratch, float *stats, float *d, pa_stream_t stream)
+{
+    return attn16_dispatch(b, n, c, split, yv, x, scratch, stats, d, nullptr, nullptr, stream);
+}
+
+// The attention AND the layer behind it in one pass-2 launch: out (b, n, c) = x + relu(W (x - x_r) + bias), W = trans_conv with after_norm folded
+// (pptnet.py:279-281), wtp = pa_sa_attention_f16_pack_trans(W K-major) (c * c fp16 elements), bt (c) fp32.
+PA_API int pa_sa_attention_trans_f16(int b, int n, int c, int split, const float *yv, const float *x, void *scratch, float *stats, const void *wtp, const float *bt,
+                                     float *out, pa_stream_t stream)
+{
+    PA_REQUIRE(wtp && bt && out, "pa_sa_attention_trans_f16: null weights / bias / output");
+    return attn16_dispatch(b, n, c, split, yv, x, scratch, stats, out, reinterpret_cast<const _Float16 *>(wtp), bt, stream);
+}
+
+PA_API int pa_sa_attention_f16_pack_trans(int c, const float *wt, void *wtp, pa_stream_t stream)
+{
+    PA_REQUIRE(c > 0 && c % 32 == 0 && wt && wtp, "pa_sa_attention_f16_pack_trans: c=%d must be a multiple of 32", c);
+    hipLaunchKernelGGL(attn_pack_trans16_kernel, dim3(pa_div_up((long)c * c, 256)), dim3(256), 0, (hipStream_t)stream, c, wt, reinterpret_cast<_Float16 *>(wtp));
+    PA_CHECK_LAUNCH("pa_sa_attention_f16_pack_trans");
     return PA_OK;
 }

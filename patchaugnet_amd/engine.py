@@ -402,6 +402,18 @@ class _Attn:
         self.t16 = self.f16 and os.environ.get("PA_ATTN_F16_TRANS", "1") == "1"
         if self.f16:
             self.wqv_16, self.wt_16 = pack_weights_f16(self.wqv_t), pack_weights_f16(self.wt_t)
+            # trans_conv + BatchNorm + ReLU + residual inside the attention's second pass (pa_sa_attention_trans_f16); PA_ATTN_F16_FUSE=0 = A/B knob
+            self.fuse_t = self.t16 and os.environ.get("PA_ATTN_F16_FUSE", "1") == "1"
+            if self.fuse_t:
+                self.wt_fused = torch.empty(c * c, dtype=torch.float16, device=device)
+                call("pa_sa_attention_f16_pack_trans", c, ptr(self.wt_t), ptr(self.wt_fused))
+
+    def _fuse_here(self, n):
+        """The layer behind the attention rides in the second pass's epilogue at the levels with many points and narrow features (PPT-Net's first
+        two: 1024 x 64, 256 x 128; measured 171 -> 163 us and 99 -> 89 us (fp16) at the first).  At the coarse levels (64 x 256, 16 x 512) a wave would
+        stream the whole (C x C) weight for its 16 points with a handful of workgroups on the chip (60 -> 210 us measured at 16 x 512): those keep the
+        column-sliced pa_linear launch.  A rule on the level's shape, never on the batch."""
+        return n >= 256 and self.c <= 128
 
     def run(self, x, B, n):
         """x (B*n, C) point-major -> x + relu(BN(trans_conv(x - x_r)))."""
@@ -417,6 +429,9 @@ class _Attn:
             else:
                 call("pa_linear", rows, c, 2 * c, ptr(x), c, ptr(self.wqv_t), ptr(self.wqv_p), ptr(self.bqv), 0, None, 0, ptr(yv), 2 * c)
             scratch = torch.empty(_lib.lib().pa_sa_attention_f16_scratch_halfs(B, n, c, self.split), dtype=torch.float16, device=dev)
+            if self.fuse_t and self._fuse_here(n):
+                call("pa_sa_attention_trans_f16", B, n, c, self.split, ptr(yv), ptr(x), ptr(scratch), ptr(stats), ptr(self.wt_fused), ptr(self.bt), ptr(out))
+                return out
             call("pa_sa_attention_f16", B, n, c, self.split, ptr(yv), ptr(x), ptr(scratch), ptr(stats), ptr(d))
             if self.t16:
                 call("pa_linear_f16", rows, c, c, ptr(d), c, ptr(self.wt_t), ptr(self.wt_16), ptr(self.bt), 1, ptr(x), c, ptr(out), c)
@@ -424,6 +439,9 @@ class _Attn:
                 call("pa_linear", rows, c, c, ptr(d), c, ptr(self.wt_t), ptr(self.wt_p), ptr(self.bt), 1, ptr(x), c, ptr(out), c)
             return out
         call("pa_linear", rows, c, 2 * c, ptr(x), c, ptr(self.wqv_t), ptr(self.wqv_p), ptr(self.bqv), 0, None, 0, ptr(yv), 2 * c)
+        if os.environ.get("PA_ATTN_FUSE", "1") == "1" and self._fuse_here(n):      # trans_conv + BatchNorm + ReLU + residual in the second pass's epilogue (A/B knob: 0)
+            call("pa_sa_attention_trans", B, n, c, ptr(yv), ptr(x), ptr(stats), ptr(self.wt_t), ptr(self.bt), ptr(out))
+            return out
         call("pa_sa_attention", B, n, c, ptr(yv), ptr(x), ptr(stats), ptr(d))
         call("pa_linear", rows, c, c, ptr(d), c, ptr(self.wt_t), ptr(self.wt_p), ptr(self.bt), 1, ptr(x), c, ptr(out), c)
         return out
@@ -534,7 +552,9 @@ class PatchAugNetEngine:
                         raise ValueError("fused APFA head supports the single-conv attention layer and an output width that is a multiple of 16")
                     self.head_kind = "afa"
                     self.afa = _Afa(agg.afa, self.device)
-                    self._afa_fused = self.afa.nout % 64 == 0 and os.environ.get("PA_ENGINE_AFA_ROWS") is None      # A/B knob: the five-launch head
+                    # pa_afa_fused is built for <= 256 clusters in total and <= 1024 outputs (vlad.hip); anything else takes the five-launch head
+                    self._afa_fused = (self.afa.nout % 64 == 0 and self.afa.nout <= 1024 and sum(ks) <= 256
+                                       and os.environ.get("PA_ENGINE_AFA_ROWS") is None)      # A/B knob: the five-launch head
                 elif agg.aggregation_type == 0:       # loupe.py:298-300: FC over the C-major flattening of (B, C, sum K), BN, L2 normalise
                     self.head_kind = "fc"
                     self.head = _FcHead(agg.hidden_weights, agg.bn, ks, per_scale=False, l2=1, device=self.device)

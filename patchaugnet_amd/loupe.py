@@ -38,7 +38,7 @@ class GatingContext(nn.Module):
 
     def forward(self, x):
         if _hip(x) and x.dim() == 2:
-            return x * torch.sigmoid(train_ops.bn_rows(self.bn1, train_ops.matmul_rows(x, self.gating_weights), self.training))
+            return x * torch.sigmoid(train_ops.bn_rows(self.bn1, train_ops.matmul_rows(x, self.gating_weights), self.bn1.training))
         return x * torch.sigmoid(self.bn1(torch.matmul(x, self.gating_weights)))
 
 
@@ -120,7 +120,7 @@ class AdaptiveFeatureAggregator(nn.Module):
     def forward(self, x):
         x = self.mlpa(x)
         if _hip(x):
-            x = train_ops.bn_rows(self.bn, train_ops.linear_rows(x.flatten(1), self.fc.weight, self.fc.bias), self.training)
+            x = train_ops.bn_rows(self.bn, train_ops.linear_rows(x.flatten(1), self.fc.weight, self.fc.bias), self.bn.training)
         else:
             x = self.bn(self.fc(x.flatten(1)))
         if self.l2_norm:
@@ -153,7 +153,7 @@ class SpatialPyramidNetVLAD(nn.Module):
     def forward(self, features):
         v = torch.cat([vlad(f) for vlad, f in zip(self.vlads, features)], dim=-1)   # (B, C, sum K)
         if self.aggregation_type == 0 and _hip(v):
-            out = train_ops.l2_normalize(train_ops.bn_rows(self.bn, train_ops.matmul_rows(v.flatten(1), self.hidden_weights), self.training))
+            out = train_ops.l2_normalize(train_ops.bn_rows(self.bn, train_ops.matmul_rows(v.flatten(1), self.hidden_weights), self.bn.training))
         elif self.aggregation_type == 0:
             out = F.normalize(self.bn(torch.matmul(v.flatten(1), self.hidden_weights)))
         elif self.aggregation_type == 2:
@@ -180,7 +180,7 @@ class SpatialPyramidNetVLAD4(nn.Module):
     def forward(self, f0, f1, f2, f3):
         v = torch.cat([self.vlad0(f0), self.vlad1(f1), self.vlad2(f2), self.vlad3(f3)], dim=-1)
         if _hip(v):
-            v = train_ops.bn_rows(self.bn2, train_ops.matmul_rows(v, self.hidden_weights), self.training)
+            v = train_ops.bn_rows(self.bn2, train_ops.matmul_rows(v, self.hidden_weights), self.bn2.training)
         else:
             v = self.bn2(torch.matmul(v, self.hidden_weights))
         return self.context_gating(v) if self.gating else v

@@ -79,9 +79,9 @@ def _stn_hip(self, x):
     x = _conv_cm(self.conv3, bn(3), x, tr)
     x = x.max(dim=2)[0]                                               # (B, 1024)
     x = train_ops.linear_rows(x, self.fc1.weight, self.fc1.bias)
-    x = F.relu(train_ops.bn_rows(self.bn4, x, tr) if self.use_bn else x)
+    x = F.relu(train_ops.bn_rows(self.bn4, x, self.bn4.training) if self.use_bn else x)
     x = train_ops.linear_rows(x, self.fc2.weight, self.fc2.bias)
-    x = F.relu(train_ops.bn_rows(self.bn5, x, tr) if self.use_bn else x)
+    x = F.relu(train_ops.bn_rows(self.bn5, x, self.bn5.training) if self.use_bn else x)
     x = train_ops.linear_rows(x, self.fc3.weight, self.fc3.bias) + torch.eye(self.k, dtype=x.dtype, device=x.device).flatten()
     return x.view(-1, self.k, self.k)
 
@@ -191,7 +191,7 @@ def _loupe_hip(self, x):
     pre = train_ops.chain_train(x, [train_ops.BNLayer(self.cluster_weights, self.bn1, relu=False, transposed=True)], training=tr)   # (B, K, N)
     vlad = train_ops.netvlad_tail(pre, x, self.cluster_weights2)                    # soft-max, X . act^T - a_sum * cw2, normalise over C: (B, C, K)
     vlad = train_ops.l2_normalize(vlad.reshape(-1, self.cluster_size * self.feature_size))
-    vlad = train_ops.bn_rows(self.bn2, train_ops.matmul_rows(vlad, self.hidden1_weights), tr)
+    vlad = train_ops.bn_rows(self.bn2, train_ops.matmul_rows(vlad, self.hidden1_weights), self.bn2.training)
     return self.context_gating(vlad) if self.gating else vlad
 
 

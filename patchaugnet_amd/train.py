@@ -101,7 +101,7 @@ def update_global_descs(model, load_batch, n_total, batch_size=36, save_dirs=Non
     scene_dataset.py:494-711) as the training loop uses it (:403-406, batch_size 36): descriptors of all n_total submaps through the fused
     HIP engine (sharded over the ranks when a process group is up: patchaugnet_amd/distributed.py), the model left in the mode it was in.
     save_dirs = (g_desc_dir, l_desc_dir) also writes the reference's per-submap pickle cache (patchaugnet_amd/io.py): ONE pass, every rank
-    writes the files of its own shard only; norm_metas(lo, hi) -> the list of {'scale', 'trans'} dicts of records lo..hi-1 (or a list
+    writes the files of its own shard only (with more than one rank the cache is complete only on a filesystem all ranks share); norm_metas(lo, hi) -> the list of {'scale', 'trans'} dicts of records lo..hi-1 (or a list
     indexed by record; None = un-normalised submaps, identity meta).  Returns the (n_total, 256) matrix on the device: the input of
     retrieval.get_hard_negatives_batch."""
     from .distributed import all_gather_descriptors, dist_info, extract_dataset, shard_bounds
@@ -113,15 +113,17 @@ def update_global_descs(model, load_batch, n_total, batch_size=36, save_dirs=Non
             return extract_dataset(model, load_batch, n_total, batch_size=batch_size, n_streams=n_streams)
         _, rank, world = dist_info()
         lo, hi = shard_bounds(n_total, rank, world)
+        dev = next(model.parameters()).device
         blocks = []
         for b0 in range(lo, hi, batch_size):
             b1 = min(b0 + batch_size, hi)
             x = load_batch(b0, b1)
+            if x.device != dev:                      # pinned / host batches, like extract_dataset's loop
+                x = x.to(dev, non_blocking=True)
             d, fp, ci = model(x)
             metas = None if norm_metas is None else (norm_metas(b0, b1) if callable(norm_metas) else norm_metas[b0:b1])
             save_descriptor_cache(save_dirs[0], save_dirs[1], b0, d, x, fp, ci, norm_metas=metas)
             blocks.append(d)
-        dev = next(model.parameters()).device
         local = torch.cat(blocks, 0) if blocks else torch.empty((0, DEFAULTS["FEATURE_OUTPUT_DIM"]), device=dev)
         return all_gather_descriptors(local, n_total)
     finally:

@@ -205,6 +205,12 @@ class _ChainTrain(Function):
 def chain_train(x, layers, pool=0, groups=False, training=True):
     """x: (B, C0, P) contiguous fp32 on the MI355X; layers: [BNLayer]; returns (B, C_L, P // pool or P).  training=False: BatchNorm with
     the running statistics (eval() mode), same kernels, forward and backward."""
+    # every BatchNorm follows ITS OWN mode flag (a layer frozen with bn.eval() inside a model.train() model keeps its running statistics, as the
+    # torch modules do); one launch chain runs one mode, so the layers of a chain have to agree
+    modes = {bool(L.bn.training) for L in layers}
+    if len(modes) > 1:
+        raise NotImplementedError("chain_train: the BatchNorm layers of one chain are in different modes (train / eval); freeze the whole block")
+    training = modes.pop() if modes else training
     tensors = []
     for L in layers:
         tensors.append(L.weight)
@@ -624,9 +630,16 @@ class _BNRowsTrain(Function):
 
 def bn_rows(bn, x, training):
     """BatchNorm1d over the rows of a small (R, F) matrix in the module's mode (elementwise: no dense kernel either way)."""
-    if training:
+    if training or bn.running_mean is None:          # track_running_stats=False: batch statistics in either mode, like torch
+        if x.shape[0] == 1:
+            raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x.shape),))
         return bn_rows_train(bn, x)
-    return (x - bn.running_mean) * torch.rsqrt(bn.running_var + bn.eps) * bn.weight + bn.bias
+    y = (x - bn.running_mean) * torch.rsqrt(bn.running_var + bn.eps)
+    if bn.weight is not None:
+        y = y * bn.weight
+    if bn.bias is not None:
+        y = y + bn.bias
+    return y
 
 
 def bn_rows_train(bn, x):

@@ -113,3 +113,29 @@ def test_sa_attention_f16_against_the_fp32_kernel(b, n, c, split):
     scale = xr32.abs().max().item()
     err = (xr16 - xr32).abs().max().item()
     assert err <= (2e-3 if split else 3e-2) * scale, (err, scale)
+
+
+@pytest.mark.parametrize("b,n,c", [(2, 1024, 64), (3, 256, 128), (2, 64, 256), (1, 20, 64), (2, 37, 256)])
+def test_sa_attention_f16_fused_trans_layer(b, n, c):
+    """pa_sa_attention_trans_f16: the layer behind the attention (trans_conv + folded BatchNorm + ReLU + residual) in the second pass's epilogue
+    against the two-launch form (pa_sa_attention_f16, then pa_linear_f16 on d with the residual): same fp16 operands, another summation order."""
+    from patchaugnet_amd import _lib
+    from patchaugnet_amd._lib import call, ptr
+    from patchaugnet_amd.engine import pack_weights_f16
+    g = torch.Generator().manual_seed(n + c)
+    yv = (torch.randn(b * n, 2 * c, generator=g) * 0.7).cuda()
+    x = torch.randn(b * n, c, generator=g).cuda()
+    wt = (torch.randn(c, c, generator=g) / c ** 0.5).cuda()          # K-major
+    bt = torch.randn(c, generator=g).cuda()
+    stats = torch.empty(b * n, 2, device="cuda")
+    d = torch.empty(b * n, c, device="cuda")
+    scratch = torch.empty(_lib.lib().pa_sa_attention_f16_scratch_halfs(b, n, c, 1), dtype=torch.float16, device="cuda")
+    call("pa_sa_attention_f16", b, n, c, 1, ptr(yv), ptr(x), ptr(scratch), ptr(stats), ptr(d))
+    two = torch.empty(b * n, c, device="cuda")
+    call("pa_linear_f16", b * n, c, c, ptr(d), c, ptr(wt), ptr(pack_weights_f16(wt)), ptr(bt), 1, ptr(x), c, ptr(two), c)
+    wtp = torch.empty(c * c, dtype=torch.float16, device="cuda")
+    call("pa_sa_attention_f16_pack_trans", c, ptr(wt), ptr(wtp))
+    one = torch.full((b * n, c), float("nan"), device="cuda")
+    call("pa_sa_attention_trans_f16", b, n, c, 1, ptr(yv), ptr(x), ptr(scratch), ptr(stats), ptr(wtp), ptr(bt), ptr(one))
+    assert torch.isfinite(one).all()
+    assert (one - two).abs().max().item() <= 1e-4 * max(1.0, two.abs().max().item())
