@@ -221,6 +221,25 @@ __device__ __forceinline__ void chain_prologue(T *act, float *scratch, const PaC
         const int qpr = C2 >> 2;  // host guarantees c2 % 4 == 0
         const float4 *k4 = reinterpret_cast<const float4 *>(a.known);
         const int items = R * qpr;
+        // PF items per trip with all 3 PF 16-byte gathers issued before the first use: the known features of a whole batch
+        // (33 MB at fp0) live in the Infinity Cache, not in L2, and a wave-private tile has nobody else to hide that latency.  Shared tiles
+        // (four waves per tile): eight items per trip -- the coarser levels' 16- and 32-row tiles are then ONE trip per thread instead of two
+        // dependent ones (phase stamps: the prologue was 14.6 k of a tile's 68.6 k cycles at both of them), and the skip channels (MODE_FP) are
+        // requested in the same flight.
+        constexpr int PF = (WPT == 4 && !POOLED && MODE == MODE_FP) ? 8 : 4;
+        // the skip channels of plain FP mode ride in the same flight when they are 16-byte rows: one float4 per (row, quad)
+        const int C1q = (MODE == MODE_FP && (C1 & 3) == 0 && (reinterpret_cast<uintptr_t>(a.skip) & 15) == 0 && ((k0pad - C2) & 3) == 0 && (C2 & 3) == 0) ? (k0pad - C2) >> 2 : 0;
+        constexpr int SK = 4;                                     // skip quads per thread in flight (R * C1q <= SK * NTH at the model's levels: 16 x 64 and 32 x 16 quads)
+        float4 skv[SK];
+        const bool skip_fast = C1q > 0 && R * C1q <= SK * NTH;
+        if (skip_fast) {
+#pragma unroll
+            for (int u = 0; u < SK; ++u) {
+                const int q = tid + u * NTH, r = q / C1q, part = q - r * C1q;
+                const long p = row0 + r;
+                skv[u] = (q < R * C1q && p < a.rows && part * 4 < C1) ? *reinterpret_cast<const float4 *>(a.skip + p * C1 + part * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
         if (MODE == MODE_FPX && WPT == 1 && C2 == 256) {
             // Common shape (256-wide features, wave-private tile): lane l owns float4 column l of every row, so the bias and the
             // skip weights are loop invariants, row / column indices need no division, and addresses are 32-bit.  This part is
@@ -266,14 +285,12 @@ __device__ __forceinline__ void chain_prologue(T *act, float *scratch, const PaC
                 }
             }
         } else
-        // four items per trip with all twelve 16-byte gathers issued before the first use: the known features of a whole batch
-        // (33 MB at fp0) live in the Infinity Cache, not in L2, and a wave-private tile has nobody else to hide that latency
-        for (int q0 = tid; q0 < items; q0 += NTH * 4) {
-            float4 f[4][3];
-            float w[4][3];
-            int rr[4], pp[4];
+        for (int q0 = tid; q0 < items; q0 += NTH * PF) {
+            float4 f[PF][3];
+            float w[PF][3];
+            int rr[PF], pp[PF];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < PF; ++u) {
                 const int q = min(q0 + u * NTH, items - 1);
                 rr[u] = q / qpr;
                 pp[u] = q - rr[u] * qpr;
@@ -284,7 +301,7 @@ __device__ __forceinline__ void chain_prologue(T *act, float *scratch, const PaC
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < PF; ++u) {
                 if (q0 + u * NTH >= items) break;
                 float v[4];
                 if (MODE == MODE_FPX) {  // bias + skip . Wskip + interpolation, ReLU: this IS the first layer's output (linearity of interpolation)
@@ -311,7 +328,13 @@ __device__ __forceinline__ void chain_prologue(T *act, float *scratch, const PaC
                 pa_store4(act + rr[u] * stride + pp[u] * 4, v[0], v[1], v[2], v[3]);
             }
         }
-        if (MODE == MODE_FP) {
+        if (MODE == MODE_FP && skip_fast) {
+#pragma unroll
+            for (int u = 0; u < SK; ++u) {
+                const int q = tid + u * NTH, r = q / C1q, part = q - r * C1q;
+                if (q < R * C1q) pa_store4(act + r * stride + C2 + part * 4, skv[u].x, skv[u].y, skv[u].z, skv[u].w);
+            }
+        } else if (MODE == MODE_FP) {
             const int tail = k0pad - C2;  // skip channels (patch_aug_net.py:359: cat([interpolated, skip])) + zero padding
             for (int q = tid; q < R * tail; q += NTH) {
                 const int r = q / tail, ch = q - r * tail;
