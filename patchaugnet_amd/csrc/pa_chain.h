@@ -171,16 +171,29 @@ __device__ __forceinline__ void chain_prologue(T *act, float *scratch, const PaC
         if ((C & 3) == 0) {  // centred features -> channels 3..3+C (pointops.py:567-568), 16-byte loads
             const int qpr = C >> 2;
             const float4 *f4 = reinterpret_cast<const float4 *>(a.feat);
-            for (int q = tid; q < R * qpr; q += NTH) {
-                const int r = q / qpr, part = q - r * qpr;
-                const int s = src[r];
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (s >= 0) {
-                    const float4 p = f4[(size_t)s * qpr + part], c = f4[(size_t)ctr[r] * qpr + part];
-                    v = make_float4(p.x - c.x, p.y - c.y, p.z - c.z, p.w - c.w);
+            // four items per trip, all eight 16-byte gathers (neighbour and centre rows) requested before the first use: a 16-row x 256-channel tile is
+            // then one round trip to L2 per thread instead of four dependent ones (padding rows read row 0 and are zeroed)
+            const int items = R * qpr;
+            for (int q0 = tid; q0 < items; q0 += NTH * 4) {
+                float4 pv[4], cv[4];
+                int rr[4], pp[4], ss[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = min(q0 + u * NTH, items - 1);
+                    rr[u] = q / qpr;
+                    pp[u] = q - rr[u] * qpr;
+                    ss[u] = src[rr[u]];
+                    pv[u] = f4[(size_t)max(ss[u], 0) * qpr + pp[u]];
+                    cv[u] = f4[(size_t)ctr[rr[u]] * qpr + pp[u]];
                 }
-                T *d = act + r * stride + 3 + part * 4;
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (q0 + u * NTH >= items) break;
+                    const bool live = ss[u] >= 0;
+                    T *d = act + rr[u] * stride + 3 + pp[u] * 4;
+                    d[0] = live ? pv[u].x - cv[u].x : 0.f; d[1] = live ? pv[u].y - cv[u].y : 0.f;
+                    d[2] = live ? pv[u].z - cv[u].z : 0.f; d[3] = live ? pv[u].w - cv[u].w : 0.f;
+                }
             }
         } else {
             for (int q = tid; q < R * C; q += NTH) {
