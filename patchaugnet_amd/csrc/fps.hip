@@ -14,6 +14,13 @@
 // LDS slot array with ONE barrier per round, and the winner's coordinates come from an LDS copy of the cloud.
 #include "pa_common.h"
 
+#ifndef PA_FPS_CPW_DEFAULT
+#define PA_FPS_CPW_DEFAULT 1
+#endif
+#ifndef PA_FPS_NT_DEFAULT
+#define PA_FPS_NT_DEFAULT 256
+#endif
+
 namespace {
 
 struct FpsOrder {
@@ -45,10 +52,14 @@ __device__ __forceinline__ int fps_decode(u32 lowkey, FpsOrder o)
 //   chain workgroups, the 80 KB NetVLAD ones) off the CUs it runs on; the post-barrier critical path loses one LDS round trip.
 struct FpsSlot { u64 key; float x, y, z; float pad[3]; };   // 32 bytes
 
-template <int NT, int PPT, bool LDSXYZ>
-__global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, FpsOrder ord, const float *__restrict__ xyz_all,
+// CPW: clouds per WORKGROUP (1, 2 or 3): cloud c of a workgroup is the threads [c NT, (c + 1) NT) with their own LDS copy and slot array; the
+// one barrier of a round is shared (every cloud runs the same m - 1 rounds).  Not faster per cloud -- the point is WHERE the launch sits: a
+// batch's sampling chain keeps its CUs for 0.7 ms while other streams' dense kernels run, and a chain workgroup with 132 KB of LDS cannot share
+// a CU with a 48 KB sampling workgroup: with one cloud per workgroup a batch of 32 takes 32 of the 256 CUs away from them, with three 11.
+template <int NT, int PPT, bool LDSXYZ, int CPW = 1>
+__global__ __launch_bounds__(NT * CPW) void fps_reg_kernel(int n, int m, FpsOrder ord, const float *__restrict__ xyz_all,
                                                        float *__restrict__ temp_all, int *__restrict__ idx_all, float *__restrict__ new_xyz_all,
-                                                       int j_begin = 0, int j_end = -1)
+                                                       int j_begin = 0, int j_end = -1, int nclouds = 0)
 {
     // [j_begin, j_end): the samples this launch produces (default: all m).  A launch that starts at j_begin > 0 RESUMES: the running minima come
     // from temp (which the previous launch wrote back) and the last selected point from idx[j_begin - 1] -- the sampling order is prefix-stable
@@ -58,12 +69,18 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, FpsOrder ord,
     constexpr int NW = NT / 64;
     constexpr int LOG_NT = NT == 64 ? 6 : NT == 128 ? 7 : NT == 256 ? 8 : NT == 512 ? 9 : 10;
     static_assert((1 << LOG_NT) == NT, "NT must be a power of two");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    const int sub = CPW > 1 ? (int)threadIdx.x / NT : 0;                  // this thread's cloud inside the workgroup
+    const int per_cloud = 3 * n + ((3 * n) & 1) + 2 * NW * 2;            // floats of LDS per cloud: SoA copy + [2][NW] 64-bit slots
+    float *smem = smem_all + (CPW > 1 ? sub * per_cloud : 0);
     float *sx = smem, *sy = smem + n, *sz = smem + 2 * n;
     u64 *slots = reinterpret_cast<u64 *>(smem + 3 * n + ((3 * n) & 1));  // 8-byte aligned, [2][NW]
     FpsSlot *rslots = reinterpret_cast<FpsSlot *>(smem);                  // LDSXYZ = false: [2][NW]
 
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int tid = CPW > 1 ? (int)threadIdx.x - sub * NT : (int)threadIdx.x;
+    const int b_raw = CPW > 1 ? (int)blockIdx.x * CPW + sub : (int)blockIdx.x;
+    const bool ghost = CPW > 1 && b_raw >= nclouds;                       // padding cloud of the last workgroup: computes on the last real cloud, writes nothing
+    const int b = ghost ? nclouds - 1 : b_raw;
     const float *xyz = xyz_all + (size_t)b * n * 3;
     float *temp = temp_all ? temp_all + (size_t)b * n : nullptr;   // nullptr: start from 1e10 (pointops.py:21), do not write back
     int *idxs = idx_all + (size_t)b * m;
@@ -95,7 +112,7 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, FpsOrder ord,
         }
     }
     const int first = j_begin > 0 ? idxs[j_begin - 1] : 0;       // written by the previous launch of the chain (same stream)
-    if (tid == 0 && j_begin == 0) idxs[0] = 0;
+    if (tid == 0 && j_begin == 0 && !ghost) idxs[0] = 0;
     float ox, oy, oz;
     if (LDSXYZ) {
         __syncthreads();
@@ -103,7 +120,7 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, FpsOrder ord,
     } else {
         ox = xyz[first * 3]; oy = xyz[first * 3 + 1]; oz = xyz[first * 3 + 2];
     }
-    if (tid == 0 && nxyz && j_begin == 0) { nxyz[0] = ox; nxyz[1] = oy; nxyz[2] = oz; }
+    if (tid == 0 && nxyz && j_begin == 0 && !ghost) { nxyz[0] = ox; nxyz[1] = oy; nxyz[2] = oz; }
 
     for (int j = max(j_begin, 1); j < j_end; ++j) {
         u64 best = 0;
@@ -155,12 +172,12 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, FpsOrder ord,
             old = fps_decode((u32)g, ord);
             ox = cx; oy = cy; oz = cz;
         }
-        if (tid == 0) {
+        if (tid == 0 && !ghost) {
             idxs[j] = old;
             if (nxyz) { nxyz[j * 3 + 0] = ox; nxyz[j * 3 + 1] = oy; nxyz[j * 3 + 2] = oz; }
         }
     }
-    if (temp) {
+    if (temp && !ghost) {
 #pragma unroll
         for (int p = 0; p < PPT; ++p) {
             const int k = tid + p * NT;
@@ -234,10 +251,31 @@ int launch_reg(int b, int n, int m, FpsOrder ord, const float *xyz, float *temp,
     }
 #endif
     const size_t lds = (size_t)(3 * n + ((3 * n) & 1)) * 4 + 2 * (NT / 64) * 8;
+    // clouds per workgroup (see the kernel): PA_FPS_CPW = 1 / 2 / 3, default from the A/B in profiles/r04_ab_log.txt; only where a cloud is a
+    // 256-thread group and several clouds' copies fit the 160 KB of a CU
+    // MEASURED AND NOT SHIPPED (test-only library): packing clouds frees CUs for the other streams' dense kernels (a 132 KB chain workgroup cannot share
+    // a CU with a 48 KB sampling workgroup) but the waves of a SIMD slow each other's rounds -- 0.76 / 0.97 / 1.28 ms per launch at 1 / 2 / 3 clouds
+    // per workgroup -- and the four-stream rate falls 37.2 k -> 33.0 k -> 30.3 k submaps/s (eight streams: 36.6 / 32.3 / 29.6 k): the length of the
+    // sampling chain weighs more than the CUs it holds.
+#ifdef PA_EXPERIMENTAL
+    static const int cpw_env = getenv("PA_FPS_CPW") ? atoi(getenv("PA_FPS_CPW")) : PA_FPS_CPW_DEFAULT;
+    int cpw = (NT == 256 && b >= 4) ? cpw_env : 1;
+    while (cpw > 1 && (cpw * lds > 156 * 1024 || cpw * NT > 1024)) --cpw;
+    if (cpw == 3) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_reg_kernel<NT, PPT, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * lds));
+        hipLaunchKernelGGL((fps_reg_kernel<NT, PPT, true, 3>), dim3((b + 2) / 3), dim3(NT * 3), 3 * lds, st, n, m, ord, xyz, temp, idx, new_xyz, j_begin, j_end, b);
+        return 0;
+    }
+    if (cpw == 2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_reg_kernel<NT, PPT, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds));
+        hipLaunchKernelGGL((fps_reg_kernel<NT, PPT, true, 2>), dim3((b + 1) / 2), dim3(NT * 2), 2 * lds, st, n, m, ord, xyz, temp, idx, new_xyz, j_begin, j_end, b);
+        return 0;
+    }
+#endif  // PA_EXPERIMENTAL
     if (lds > 48 * 1024)  // opt in to the large-LDS carve-out (gfx950: 160 KiB per CU)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_reg_kernel<NT, PPT, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((fps_reg_kernel<NT, PPT, true>), dim3(b), dim3(NT), lds, st, n, m, ord, xyz, temp, idx, new_xyz, j_begin, j_end);
+    hipLaunchKernelGGL((fps_reg_kernel<NT, PPT, true>), dim3(b), dim3(NT), lds, st, n, m, ord, xyz, temp, idx, new_xyz, j_begin, j_end, b);
     return 0;
 }
 
@@ -263,7 +301,18 @@ static int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int 
     else if (n <= 512) launch_reg<64, 8>(b, n, m, ord, xyz, temp, idx, new_xyz, st, j_begin, j_end);
     else if (n <= 1024) launch_reg<256, 4>(b, n, m, ord, xyz, temp, idx, new_xyz, st, j_begin, j_end);
     else if (n <= 2048) launch_reg<256, 8>(b, n, m, ord, xyz, temp, idx, new_xyz, st, j_begin, j_end);
-    else if (n <= 4096) launch_reg<256, 16>(b, n, m, ord, xyz, temp, idx, new_xyz, st, j_begin, j_end);
+    else if (n <= 4096) {
+        // threads per cloud: the round is a fixed chain (wave maximum -> slot -> barrier -> decode -> winner's coordinates) plus the per-lane update of
+        // PPT points; more threads shorten the second part and lengthen the slot exchange.  PA_FPS_NT = 256 / 512 / 1024 (A/B knob).
+        // Measured (b = 32, m = 1024): 256 / 512 / 1024 threads per cloud = 0.76 / 0.92 / 1.46 ms per launch (37.3 / 35.7 / 31.9 k submaps/s): the
+        // exchange between more waves costs more than the shorter update saves.  The wider forms are in the test-only library.
+#ifdef PA_EXPERIMENTAL
+        static const int nt = getenv("PA_FPS_NT") ? atoi(getenv("PA_FPS_NT")) : PA_FPS_NT_DEFAULT;
+        if (nt == 1024) { launch_reg<1024, 4>(b, n, m, ord, xyz, temp, idx, new_xyz, st, j_begin, j_end); PA_CHECK_LAUNCH("pa_furthestsampling"); return PA_OK; }
+        if (nt == 512) { launch_reg<512, 8>(b, n, m, ord, xyz, temp, idx, new_xyz, st, j_begin, j_end); PA_CHECK_LAUNCH("pa_furthestsampling"); return PA_OK; }
+#endif
+        launch_reg<256, 16>(b, n, m, ord, xyz, temp, idx, new_xyz, st, j_begin, j_end);
+    }
     else if (n <= 8192) launch_reg<256, 32>(b, n, m, ord, xyz, temp, idx, new_xyz, st, j_begin, j_end);
     else {
         PA_REQUIRE(j_begin == 0 && j_end < 0, "pa_furthestsampling_range: clouds above 8192 points are sampled in one launch");

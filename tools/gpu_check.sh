@@ -78,3 +78,13 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmc_$C
   grep -E "chain_kernel<1, 16, 3|group_lds_kernel<4>|knn_grid|vlad_accum_kernel<4>" $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_$C.txt | cut -c1-60,90-200
 done
+
+# round 4: counters of the fp16 PPT-Net step (configs[4]): MFMA-busy, L2 traffic, L1 accesses of the fp16 chain / attention kernels
+cd $GRAFT_REPO_ROOT
+bash tools/pmc_pass.sh gpurun_out/${TAG}_ppt16_pmc_mfma.txt "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" --model pptnet --mlp-dtype f16 --no-grouping
+bash tools/pmc_pass.sh gpurun_out/${TAG}_ppt16_pmc_FETCH_SIZE.txt "FETCH_SIZE" --model pptnet --mlp-dtype f16 --no-grouping
+bash tools/pmc_pass.sh gpurun_out/${TAG}_ppt16_pmc_WRITE_SIZE.txt "WRITE_SIZE" --model pptnet --mlp-dtype f16 --no-grouping
+bash tools/pmc_pass.sh gpurun_out/${TAG}_ppt16_pmc_tcp.txt "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum" --model pptnet --mlp-dtype f16 --no-grouping
+timeout 300 python tools/emd_time.py > gpurun_out/${TAG}_emd_time.txt 2>&1
+timeout 300 python tools/probes/stage_b2b.py 9 > gpurun_out/${TAG}_stage_b2b.txt 2>&1
+timeout 300 python tools/chain_phases.py fp0 fp1 fp2 sa1 sa2 > gpurun_out/${TAG}_chain_phases.txt 2>&1
