@@ -75,7 +75,9 @@ __device__ __forceinline__ void layer_mfma(const float *__restrict__ wfl, const 
 // of a SIMD in lock-step (measured: layer 2 takes ST_WAVES / 4 x its 5 120 MFMA cycles), so a launch costs about rounds x ST_WAVES / 4 tile
 // times with rounds = ceil(tiles / (CUs x ST_WAVES)): the launcher picks the count that minimises it (B = 32: 8 192 tiles = exactly 4 rounds
 // of 2 048 waves, against 3 rounds of 3 072 of which the last is two-thirds empty).
-template <int RT, int ST_WAVES>
+// WIN: the launch computes a window of every cloud's centres (PaChain::win_len / win_off, pa_sa_group_window) -- an instantiation of its own, so the
+// index arithmetic of the window costs the ordinary launch nothing (compiled into the one kernel it took 14 registers and 6 us of 51)
+template <int RT, int ST_WAVES, bool WIN = false>
 __global__ __launch_bounds__(ST_WAVES * 64) void sa_tiny_kernel(PaChain a, long ntiles)
 {
     constexpr int R = RT * 16;
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(ST_WAVES * 64) void sa_tiny_kernel(PaChain a, long 
             rw.ctr[h] = 0;
             if (r < R && gid < a.rows) {
                 unsigned g32 = (unsigned)gid;                                       // groups < 2^31 (host-checked): 32-bit division, not the 64-bit loop
-                if (a.win_len > 0) { const unsigned wb = g32 / (unsigned)a.win_len; g32 = wb * (unsigned)a.m_ctr + (unsigned)a.win_off + (g32 - wb * (unsigned)a.win_len); }
+                if (WIN) { const unsigned wb = g32 / (unsigned)a.win_len; g32 = wb * (unsigned)a.m_ctr + (unsigned)a.win_off + (g32 - wb * (unsigned)a.win_len); }
                 const unsigned b = g32 / (unsigned)a.m_ctr;
                 rw.src[h] = (int)(b * (unsigned)a.n_src + (unsigned)a.nbr_idx[(size_t)g32 * a.ns + s]);
                 rw.ctr[h] = (int)(b * (unsigned)a.n_src + (unsigned)a.center_idx[g32]);
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(ST_WAVES * 64) void sa_tiny_kernel(PaChain a, long 
                 }
                 long grp = tile * 4 + li;
                 const bool live = li < 4 && grp < a.rows;
-                if (a.win_len > 0) { const long wb = grp / a.win_len; grp = wb * a.m_ctr + a.win_off + (grp - wb * a.win_len); }
+                if (WIN) { const unsigned wb = (unsigned)grp / (unsigned)a.win_len; grp = (long)wb * a.m_ctr + a.win_off + ((unsigned)grp - wb * (unsigned)a.win_len); }
                 if (live) {
                     const int col = ct * 16 + lq * 4;
                     const float4 bias = *reinterpret_cast<const float4 *>(b2 + col);
@@ -304,6 +306,11 @@ static void sa_tiny_launch_t(const PaChain &a_in, long ntiles, int cus, hipStrea
     const size_t lds = (size_t)(ST_WTOT + ST_BTOT + W * RT * 16 * ST_STRIDE) * 4;
     long grid = (ntiles + W - 1) / W;
     if (grid > cus) grid = cus;                              // one persistent workgroup per CU; waves loop over the tiles
+    if (a.win_len > 0) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_tiny_kernel<RT, W, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((sa_tiny_kernel<RT, W, true>), dim3((unsigned)grid), dim3(W * 64), lds, st, a, ntiles);
+        return;
+    }
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_tiny_kernel<RT, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((sa_tiny_kernel<RT, W>), dim3((unsigned)grid), dim3(W * 64), lds, st, a, ntiles);
 }

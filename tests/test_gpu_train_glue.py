@@ -114,8 +114,10 @@ def test_chain_train_counts_batches_inside_the_finalize_kernel():
     assert int(bn.num_batches_tracked) == 1
     train_ops.chain_train(x, [train_ops.BNLayer(W, bn)], groups=True, training=True)
     assert int(bn.num_batches_tracked) == 4
-    train_ops.chain_train(x, [train_ops.BNLayer(W, bn)], training=False)
-    assert int(bn.num_batches_tracked) == 4
+    bn.eval()          # every BatchNorm follows ITS OWN mode flag, like the torch module: a frozen layer inside a train() container keeps its statistics
+    rm = bn.running_mean.clone()
+    train_ops.chain_train(x, [train_ops.BNLayer(W, bn)], training=True)
+    assert int(bn.num_batches_tracked) == 4 and torch.equal(bn.running_mean, rm)
 
 
 def test_zero_arena_hands_out_zero_filled_disjoint_buffers_and_learns_its_size():
