@@ -385,7 +385,10 @@ int pa_knn_quad_try(int b, int n, int m, int nsample, const float *xyz, const fl
 {
     if (mq <= 0) mq = m;
     if (g_quad_on < 0) g_quad_on = getenv("PA_KNN_NO_QUAD") != nullptr ? 0 : 1;
-    static const int nmin = getenv("PA_KNN_QUAD_NMIN") ? atoi(getenv("PA_KNN_QUAD_NMIN")) : 2048, mmin = getenv("PA_KNN_QUAD_MMIN") ? atoi(getenv("PA_KNN_QUAD_MMIN")) : 256;   // tuning knobs
+    // From 1024 source points and 128 queries (round 4; 2048 / 256 before): at the second level of the 4096-point models (1024 -> 128 centres) the
+    // wave-per-query kernel fills the chip with 1024 workgroups for 26 us, this one runs ONE workgroup per cloud for 47 us -- longer on the step's own
+    // stream, but a batch then holds 32 CUs instead of all of them while the other streams' dense kernels run: 37.2 -> 37.5 k submaps/s.
+    static const int nmin = getenv("PA_KNN_QUAD_NMIN") ? atoi(getenv("PA_KNN_QUAD_NMIN")) : 1024, mmin = getenv("PA_KNN_QUAD_MMIN") ? atoi(getenv("PA_KNN_QUAD_MMIN")) : 128;   // tuning knobs
     if (!g_quad_on || n < nmin || n > 4096 || m < mmin) return 0;      // a function of the level's shape (n, m), never of the window
     switch (nsample) {
         case 16: launch_quad<16>(b, n, m, xyz, new_xyz, idx, dist2, st, dbg, mq, cells); return 1;

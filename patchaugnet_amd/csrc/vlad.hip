@@ -117,14 +117,16 @@ __global__ __launch_bounds__(256, KT == 4 ? PA_VLAD_WGS : 1) void vlad_accum_ker
     // addressing kept 16 address pairs alive across the tile, which spilled at two waves per SIMD); rows past row_end read as zero.
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + (size_t)row_begin * VC), 0,
                                                                          (row_end - row_begin) * VC * 4, 0x00020000);
-    auto fetch = [&](int r0) {
+    auto fetch_part = [&](int r0, int u0, int u1) {
         const unsigned base = (unsigned)(r0 - row_begin) * (VC * 4) + (unsigned)tid * 16u;       // the range check covers voffset + imm
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
+            if (u < u0 || u >= u1) continue;
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrs, base + (unsigned)u * 4096u, 0, 0);
             pre[u] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
         }
     };
+    auto fetch = [&](int r0) { fetch_part(r0, 0, PF); };
     VSTAMPK(9);
     fetch(row_begin);
     // A fragments of the assignment GEMM: byte address of X[16 w + i][16 j + 4 q] = arow * 1024 + ((64 j + 16 q) ^ 16 i) = abase ^ (64 j)
@@ -144,7 +146,12 @@ __global__ __launch_bounds__(256, KT == 4 ? PA_VLAD_WGS : 1) void vlad_accum_ker
         VSTAMP(1);
         __syncthreads();
         VSTAMP(2);
-        fetch(r0 + VROWS);
+#ifndef PA_VLAD_FETCH_INTERLEAVE
+#define PA_VLAD_FETCH_INTERLEAVE 1
+#endif
+        // the next tile's 16 loads per thread in TWO halves: back to back they took 3.3 k cycles to issue (phase stamps: every wave of the CU queues on
+        // the one address path) with the matrix pipe idle; the second half goes out at the head of the soft-max, a VALU-only phase
+        fetch_part(r0 + VROWS, 0, PA_VLAD_FETCH_INTERLEAVE ? PF / 2 : PF);
         VSTAMP(3);
         // 2. assignment logits for this wave's 16 rows: X[16 x 256] * Wc[256 x KP]
         floatx4 acc[KT];
@@ -197,6 +204,14 @@ __global__ __launch_bounds__(256, KT == 4 ? PA_VLAD_WGS : 1) void vlad_accum_ker
             }
         }
         VSTAMP(4);
+#ifndef PA_VLAD_SOFTMAX_PRIO
+#define PA_VLAD_SOFTMAX_PRIO 2
+#endif
+        // The soft-max is a few hundred VALU / DPP / exp instructions per wave; the co-resident workgroup's waves are in their GEMM phases meanwhile
+        // and, at equal priority, the older wave's MFMA stream wins the issue slots: the phase stamps put this block at 8.2 k cycles.  Raised priority
+        // for its duration lets it through (the partner loses a few hundred cycles of issue, not eight thousand).
+        if (PA_VLAD_FETCH_INTERLEAVE) fetch_part(r0 + VROWS, PF / 2, PF);
+        if (PA_VLAD_SOFTMAX_PRIO) __builtin_amdgcn_s_setprio(PA_VLAD_SOFTMAX_PRIO);
         // 3. soft-max over the k_true clusters of each row.  C/D layout: column (cluster) = 16*ct + lane%16,
         //    row = 4*(lane/16) + r: a row's clusters live in the 16 lanes of a DPP row and the KT tiles.
 #pragma unroll
@@ -226,6 +241,7 @@ __global__ __launch_bounds__(256, KT == 4 ? PA_VLAD_WGS : 1) void vlad_accum_ker
                 asum[ct] += a;
             }
         }
+        if (PA_VLAD_SOFTMAX_PRIO) __builtin_amdgcn_s_setprio(0);
         VSTAMP(5);
         __syncthreads();
         VSTAMP(6);
