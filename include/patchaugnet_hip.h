@@ -201,6 +201,17 @@ int pa_fp_chain_premul_f16(int nlayers, const float *const *wt, const void *cons
                            int m_known, int c2, int c1, const float *wskip, const void *wskip16, const float *bias0, float *out, int ldo,
                            pa_stream_t stream);   /* wskip16: pa_pack_weights_f16 of wskip, needed when c1 > 4 */
 
+/* The finest level of the fp16 path with the pre-multiplied features as an fp16 table (csrc/fpx_f16.hip: weights shared through LDS by a
+ * workgroup's waves, activations in registers; the interpolation gathers read 512 B instead of 1 KB per neighbour).
+ *   pa_fp_premul_g16        g16[r][:] = fp16(x[r][:256] . W), W the (256 x 256) interpolated-part slice of the first layer, wp16 its
+ *                           pa_pack_weights_f16 packing; x rows 16-byte aligned, ldx >= 256.
+ *   pa_fp_chain_premul_g16  pa_fp_chain_premul_f16 with g16 in place of g.  Only c2 = 256, 1 <= c1 <= 4 and two remaining 256 -> 256 layers
+ *                           (patch_aug_net.py:350-362 / pptnet.py FP level 0); PA_EUNSUPPORTED otherwise. */
+int pa_fp_premul_g16(long rows, const float *x, int ldx, const void *wp16, void *g16, pa_stream_t stream);
+int pa_fp_chain_premul_g16(int nlayers, const void *const *wp16, const float *const *bias, const int *kpad, const int *nout, long rows,
+                           const void *g16, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2, int c1,
+                           const float *wskip, const float *bias0, float *out, int ldo, pa_stream_t stream);
+
 /* One dense layer on point-major rows (the chain kernel's plain mode with a selectable epilogue):
  * out[r][:] = residual[r][:] + act(x[r][:k] . Wt + bias), act = ReLU if relu != 0 else identity; residual may be NULL.
  * wt K-major (kpad x n), kpad = k rounded up to 4 with zero rows, n % 16 == 0; wpk: optional packed copy (below) or NULL. */

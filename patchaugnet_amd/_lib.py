@@ -98,6 +98,8 @@ _SIGS = {
     "pa_knn_mfma_select": "pliiiippppiippp",
     "pa_patch_pairs_count": "ipppppiipppp",
     "pa_patch_pairs_fill": "ipppppiipqpppp",
+    "pa_fp_premul_g16": "lpipp",
+    "pa_fp_chain_premul_g16": "ipppplppppiiiipppi",
 }
 # entry points of the measured-slower variants: exported by the test-only library only (csrc/pa_internal.h section 2)
 _EXP_SIGS = {

@@ -43,6 +43,9 @@ __global__ __launch_bounds__(256) void rowgroup_max_kernel(long groups, int ns, 
 // Generic entry point.  mode: 0 plain rows, 1 set-abstraction gather, 2 feature-propagation interpolate.
 // wt[l] is K-major (kpad[l] x n[l]) with BN folded in and zero rows beyond the true K; bias[l] has n[l] entries.
 int pa_chain16_launch(PaChain &a, int mode, bool is_pooled, bool split, int RTv, int scratch_floats, hipStream_t st);   // mlp_chain_f16.hip
+int pa_fpx16_try(int nlayers, const void *const *wp16, const float *const *bias, const int *kpad, const int *nout, long rows, const float *g, const int *idx3,
+                 const float *w3, const float *skip, int n_unknown, int m_known, int c2, int c1, const float *wskip, const float *bias0, float *out, int ldo,
+                 long long *dbg, hipStream_t st);   // fpx_f16.hip
 bool pa_sa_tiny_applies(const PaChain &a, int rt);                                                                      // sa_tiny.hip
 int pa_sa_tiny_launch(const PaChain &a, int rt, long ntiles, hipStream_t st);
 int pa_linear_lds_try(long rows, int k, int n, const float *x, int ldx, const float *wt, const float *bias, int relu, const float *residual, int ldr,
@@ -64,6 +67,7 @@ PA_API int pa_sa_group_window(int win_len, int win_off)
 static long long *g_chain_dbg = nullptr;
 // profiling hook (tools/chain_phases.py): device buffer of 512 x 8 int64 receiving s_memtime stamps of the next launches; NULL = off
 PA_API void pa_chain_debug_buffer(long long *buf) { g_chain_dbg = buf; }
+long long *pa_chain_dbg_ptr() { return g_chain_dbg; }
 
 static int chain_dispatch(int mode, int pooled, int nlayers, const float *const *wt, const float *const *wpk, const float *const *bias, const int *kpad, const int *nout,
                           long rows, int k0,
@@ -391,6 +395,12 @@ PA_API int pa_fp_chain_premul_f16(int nlayers, const float *const *wt, const voi
 {
     PA_REQUIRE(wp16, "pa_fp_chain_premul_f16: null wp16");
     PA_REQUIRE(c1 <= 4 || wskip16, "pa_fp_chain_premul_f16: c1 > 4 needs the fp16 packing of wskip");
+    PA_REQUIRE(nlayers >= 1 && nlayers <= 3 && wt && bias && kpad && nout && rows > 0 && g && idx3 && w3 && skip && wskip && bias0 && out,
+               "pa_fp_chain_premul_f16: bad arguments");
+    // the finest level's shape (xyz skip, two 256 -> 256 layers left): weights shared through LDS, activations in registers (fpx_f16.hip)
+    const int took = pa_fpx16_try(nlayers, wp16, bias, kpad, nout, rows, g, idx3, w3, skip, n_unknown, m_known, c2, c1, wskip, bias0, out, ldo,
+                                  g_chain_dbg, (hipStream_t)stream);
+    if (took != 0) return took > 0 ? PA_OK : took;
     return fp_premul_dispatch(nlayers, wt, nullptr, wp16, bias, kpad, nout, rows, g, idx3, w3, skip, n_unknown, m_known, c2, c1, wskip, nullptr, wskip16,
                               bias0, out, ldo, stream);
 }

@@ -30,12 +30,16 @@ void pa_knn_debug_buffer(long long *buf);   /* same for the pruned kNN kernel: 6
  *   pa_chain_tiny_enable      the persistent first-set-abstraction kernel (csrc/sa_tiny.hip)
  *   pa_linear_lds_enable      pa_linear at k = 256 on LDS-resident weights (csrc/linear_lds.hip)
  *   pa_emd_persistent_enable  pa_emd_forward as one persistent workgroup per cloud instead of one launch per round (0 / 1)
+ *   pa_fpx16_enable           pa_fp_chain_premul_f16 at the finest level's shape on LDS-shared weights (csrc/fpx_f16.hip): 8 / 4 = waves per
+ *                             workgroup, 0 = the wave-private LDS-tile kernel (fp16 path: both within fp16 rounding of the fp32 kernel, not
+ *                             the same bits)
  * Either setting of every switch gives the same bits (tests/test_gpu_ops.py, test_gpu_chain.py, test_gpu_losses.py). */
 void pa_knn_quad_enable(int on);
 void pa_three_nn_grid_enable(int on);
 void pa_chain_tiny_enable(int on);
 void pa_linear_lds_enable(int on);
 void pa_emd_persistent_enable(int on);
+void pa_fpx16_enable(int mode);
 
 /* ---- 2. measured-slower variants: libpatchaugnet_hip_exp.so only --------------------------------------------------------------------- */
 #ifdef PA_EXPERIMENTAL

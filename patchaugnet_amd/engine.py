@@ -170,6 +170,9 @@ class _Chain:
             "bias": (ctypes.c_void_p * m)(*[l[1].data_ptr() for l in rest]),
             "kpad": (ctypes.c_int * m)(*[l[3] for l in rest]), "nout": (ctypes.c_int * m)(*[l[4] for l in rest]),
         }
+        # fp16 path, finest level's shape: fp16 table + LDS-shared weights (csrc/fpx_f16.hip); a function of the layer shapes only
+        self._premul["g16"] = bool(self.f16 and c2 == 256 and n0 == 256 and 1 <= c1 <= 4 and m == 2 and all(l[3] == 256 and l[4] == 256 for l in rest)
+                                   and os.environ.get("PA_ENGINE_FPX16", "1") != "0")
         if kperm and not self.f16 and m == 2 and all(l[2] == 256 and l[4] == 256 for l in rest):
             self._premul["kperm"] = [pack_weights_kperm(l[0]) for l in rest]
 
@@ -198,6 +201,18 @@ class _Chain:
         if getattr(self, "_premul", None) is None or (self._premul["c2"], self._premul["c1"]) != (c2, c1):
             raise RuntimeError("fp_premul: build_premul(c2, c1) was not run for this level at engine construction")
         pm = self._premul
+        if pm["g16"] and g_pre is None:
+            g16 = torch.empty((B * m_known, 256), dtype=torch.float16, device=dev)
+            call("pa_fp_premul_g16", B * m_known, ptr(known_feat), c2, ptr(pm["w1a_p"]), ptr(g16))
+            if mark is not None:
+                mark()
+            rows = B * n_unknown
+            out = torch.empty((rows, self.n_last), dtype=torch.float32, device=dev)
+            cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
+            for _ in range(getattr(self, "bench_repeat", 1)):
+                call("pa_fp_chain_premul_g16", pm["m"], cast(pm["wpk"]), cast(pm["bias"]), cast(pm["kpad"]), cast(pm["nout"]), rows, ptr(g16), ptr(idx3),
+                     ptr(w3), ptr(skip), n_unknown, m_known, pm["n0"], c1, ptr(pm["wskip"]), ptr(pm["bias0"]), ptr(out), self.n_last)
+            return out
         if g_pre is not None:       # the coarser level's chain already produced known_feat . w1a (attach_tail)
             g = g_pre
         else:

@@ -139,3 +139,50 @@ def test_sa_attention_f16_fused_trans_layer(b, n, c):
     call("pa_sa_attention_trans_f16", b, n, c, 1, ptr(yv), ptr(x), ptr(scratch), ptr(stats), ptr(wtp), ptr(bt), ptr(one))
     assert torch.isfinite(one).all()
     assert (one - two).abs().max().item() <= 1e-4 * max(1.0, two.abs().max().item())
+
+
+@pytest.mark.parametrize("mode,g16", [(8, True), (4, True), (8, False), (4, False), (0, False)])
+@pytest.mark.parametrize("B,n,m,c1", [(3, 4096, 1024, 3), (1, 1000, 256, 3), (2, 77, 19, 1), (1, 300, 64, 4)])
+def test_finest_fp_level_f16_on_lds_shared_weights(mode, g16, B, n, m, c1, monkeypatch):
+    """The finest FP level of the fp16 path (skip = xyz, two 256 -> 256 layers left): fpx_f16.hip shares the weights of a workgroup's waves
+    through LDS and keeps the activations in registers (mode 8 / 4 = waves per workgroup; g16 = the pre-multiplied features as an fp16 table
+    written by pa_fp_premul_g16, the engine's default; otherwise pa_linear_f16 + pa_fp_chain_premul_f16 with an fp32 table); mode 0 = the
+    wave-private LDS-tile kernel.  Reference: the same operand roundings in float64 (fp16 weights, fp16 hidden activations, fp16 table when
+    g16; everything else exact); a hidden value within rounding distance of an fp16 tie may round the other way, hence 2e-3 of the tensor's
+    scale; rows ragged against the 128 / 256-row workgroup tile."""
+    from patchaugnet_amd import _lib
+    from patchaugnet_amd.engine import _Chain
+    from tests.test_gpu_chain import make_layers
+    c2 = 256
+    ref, eng = make_layers([c2 + c1, 256, 256, 256], seed=11 + c1)
+    g = torch.Generator().manual_seed(n)
+    known = torch.randn(B, m, c2, generator=g)
+    skip = torch.randn(B, n, c1, generator=g)
+    idx3 = torch.randint(0, m, (B, n, 3), generator=g).int()
+    w3 = torch.rand(B, n, 3, generator=g)
+    w3 = (w3 / w3.sum(-1, keepdim=True)).contiguous()
+    monkeypatch.setenv("PA_ENGINE_FPX16", "1" if g16 else "0")
+    ch = _Chain(eng, f16=True)
+    ch.build_premul(c2, c1)
+    assert ch._premul["g16"] == g16
+    _lib.lib().pa_fpx16_enable(mode)
+    try:
+        got = ch.fp_premul(known.cuda(), idx3.cuda(), w3.cuda(), skip.cuda(), B, n, m, c2, c1)
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().pa_fpx16_enable(-1)
+    h16 = lambda t: t.half().double()
+    (w1, b1), (w2, b2), (w3_, b3) = [(w.float().double(), b.float().double()) for w, b in ref]
+    gk = (h16(known.double()) @ h16(w1[:, :c2]).t()).float().double()                    # the pre-multiply: fp16 operands, fp32 accumulation
+    if g16:
+        gk = h16(gk)
+    bi = torch.arange(B)[:, None]
+    interp = sum(w3[..., t:t + 1].double() * gk[bi, idx3[:, :, t].long()] for t in range(3))
+    h1 = torch.relu(interp + skip.double() @ w1[:, c2:].t() + b1)
+    h2 = torch.relu(h16(h1) @ h16(w2).t() + b2)
+    exp = torch.relu(h16(h2) @ h16(w3_).t() + b3).reshape(B * n, -1)
+    err = (got.double().cpu() - exp).abs().max().item()
+    assert err <= 2e-3 * exp.abs().max().item(), (err, exp.abs().max().item())
+    full = torch.relu(torch.relu(torch.relu(torch.cat([sum(w3[..., t:t + 1].double() * known.double()[bi, idx3[:, :, t].long()] for t in range(3)),
+                                                       skip.double()], -1) @ w1.t() + b1) @ w2.t() + b2) @ w3_.t() + b3).reshape(B * n, -1)
+    assert (got.double().cpu() - full).abs().max().item() <= 8e-3 * full.abs().max().item()     # and against unrounded operands
