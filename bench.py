@@ -486,8 +486,8 @@ def extras(a):
             ms = st.get("fp0.chain")
             if ms:
                 peak = MFMA_F16_PEAK_TFLOPS if mlp_dtype == "f16" else MFMA_F32_PEAK_TFLOPS
-                byts = rows * 256 * 4.0 + rows * (3 * 4 + 3 * 4 + 3 * 4) + (rows // 4) * 256 * 4.0      # output + (idx3, w3, xyz) + the pre-multiplied known rows once
-                res["roofline"] = {"kernel": ("chain16_kernel<2,16,FPX,0,1>" if mlp_dtype == "f16" else "chain_kernel<1,16,FPX,0,1>") + " (fp0: finest feature-propagation chain)",
+                byts = rows * 256 * 4.0 + rows * (3 * 4 + 3 * 4 + 3 * 4) + (rows // 4) * 256 * (2.0 if mlp_dtype == "f16" else 4.0)      # output + (idx3, w3, xyz) + the pre-multiplied known rows once
+                res["roofline"] = {"kernel": ("fpx16_kernel<4,2,2> (fpx_f16.hip: weights shared through LDS, activations in registers, fp16 pre-multiplied table)" if mlp_dtype == "f16" else "chain_kernel<1,16,FPX,0,1>") + " (fp0: finest feature-propagation chain)",
                                    "bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / peak,
                                    "traffic": None, "algorithmic_flops_per_launch": fl, "ms_per_launch": ms, "timing": "one launch bracketed by HIP events on the launch stream (stage pass)"}
                 res["roofline_hbm"] = {"bound": "hbm", "achieved": byts / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -48,12 +48,17 @@ int pa_fpx16_try(int nlayers, const void *const *wp16, const float *const *bias,
                  long long *dbg, hipStream_t st);   // fpx_f16.hip
 bool pa_sa_tiny_applies(const PaChain &a, int rt);                                                                      // sa_tiny.hip
 int pa_sa_tiny_launch(const PaChain &a, int rt, long ntiles, hipStream_t st);
+bool pa_sa_mid_applies(const PaChain &a, int rt);                                                                       // sa_mid.hip
+int pa_sa_mid_launch(const PaChain &a, int rt, long ntiles, hipStream_t st);
 int pa_linear_lds_try(long rows, int k, int n, const float *x, int ldx, const float *wt, const float *bias, int relu, const float *residual, int ldr,
                       float *out, int ldo, hipStream_t st);                                                                    // linear_lds.hip
 
 static int g_chain_tiny = -1;
 // test / A/B switch for the persistent first-level kernel (sa_tiny.hip): 1 = wherever its shape applies, 0 = never, -1 = the default rule
 PA_API void pa_chain_tiny_enable(int on) { g_chain_tiny = on; }
+static int g_chain_mid = -1;
+// same for the LDS-resident second-level kernel (sa_mid.hip); equal to the generic kernels up to the order of the fp32 additions, not bit for bit
+PA_API void pa_chain_mid_enable(int on) { g_chain_mid = on; }
 
 // pa_sa_group_window: applies to the NEXT pa_mlp_chain* call of this thread (mode 1, pooled), then resets
 static thread_local int g_win_len = 0, g_win_off = 0;
@@ -233,6 +238,14 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
     static const bool no_tiny = getenv("PA_CHAIN_NO_TINY") != nullptr;                                               // A/B knob
     static const long tiny_min = getenv("PA_CHAIN_TINY_MIN_TILES") ? atol(getenv("PA_CHAIN_TINY_MIN_TILES")) : 1024;  // tuning knob
     const bool tiny_on = g_chain_tiny < 0 ? (!no_tiny && ntiles >= tiny_min) : g_chain_tiny > 0;
+    // the second set-abstraction level (67 -> 64 -> 64 -> n2): weights resident in LDS, activations in registers (sa_mid.hip)
+    // Default rule (a function of the layer shapes only, never of the batch size: the kernel contracts in another order than the generic one):
+    // last layer <= 128 wide (PPT-Net's level: 68 KB of LDS, 51 vs 68 us per launch, step + 1.3 %).  At 256 (PatchAugNet's: 100 KB, one workgroup
+    // per CU) the launch alone is 37 vs 48 us, but inside the four-stream pipeline the step gets 0.3-1 % SLOWER (a workgroup that needs most of a
+    // CU's LDS starts only where everything else has drained), so that shape stays on the shared-tile kernel (profiles/r04_ab_log.txt).
+    static const bool no_mid = getenv("PA_CHAIN_NO_MID") != nullptr;                                                 // A/B knob
+    static const int mid_max_n2 = getenv("PA_CHAIN_MID_MAX_N2") ? atoi(getenv("PA_CHAIN_MID_MAX_N2")) : 128;          // A/B knob
+    const bool mid_on = g_chain_mid < 0 ? (!no_mid && nout[nlayers - 1] <= mid_max_n2) : g_chain_mid > 0;
     if (win_len > 0) {   // rows = clouds * win_len groups; only the persistent first-level kernel takes windows
         PA_REQUIRE(mode == MODE_SA && is_pooled && !split && pa_sa_tiny_applies(a, RTv) && win_off + win_len <= m_ctr && rows % win_len == 0,
                    "pa_sa_group_window: the next launch must be the pooled first-level chain with a window inside its %d centres", m_ctr);
@@ -240,6 +253,8 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
         pa_sa_tiny_launch(a, RTv, ntiles, st);
     } else if (is_pooled && !split && tiny_on && pa_sa_tiny_applies(a, RTv)) {
         pa_sa_tiny_launch(a, RTv, ntiles, st);
+    } else if (is_pooled && mid_on && pa_sa_mid_applies(a, RTv)) {
+        if (pa_sa_mid_launch(a, RTv, ntiles, st) != PA_OK) return PA_EINVAL;
     } else if (is_pooled) {
         if (pa_chain_launch_pooled(a, RTv, split, wpw, ntiles, st) != 0) {
             pa_set_error("pa_mlp_chain: pooled tiling is built for nsample in (13..16], (17..20], (29..32]; got %d", ns);

@@ -28,6 +28,8 @@ void pa_knn_debug_buffer(long long *buf);   /* same for the pruned kNN kernel: 6
  *                             wave-per-query kernels
  *   pa_three_nn_grid_enable   pa_nearestneighbor / pa_three_nn_weights on the cell-grid kernel (csrc/three_nn_grid.hip); 0 forces the brute-force scan
  *   pa_chain_tiny_enable      the persistent first-set-abstraction kernel (csrc/sa_tiny.hip)
+ *   pa_chain_mid_enable       the LDS-resident second-set-abstraction kernel (csrc/sa_mid.hip; equal to the generic kernel up to the order of the
+ *                             fp32 additions, not bit for bit)
  *   pa_linear_lds_enable      pa_linear at k = 256 on LDS-resident weights (csrc/linear_lds.hip)
  *   pa_emd_persistent_enable  pa_emd_forward as one persistent workgroup per cloud instead of one launch per round (0 / 1)
  *   pa_fpx16_enable           pa_fp_chain_premul_f16 at the finest level's shape on LDS-shared weights (csrc/fpx_f16.hip): 8 / 4 = waves per
@@ -37,6 +39,7 @@ void pa_knn_debug_buffer(long long *buf);   /* same for the pruned kNN kernel: 6
 void pa_knn_quad_enable(int on);
 void pa_three_nn_grid_enable(int on);
 void pa_chain_tiny_enable(int on);
+void pa_chain_mid_enable(int on);
 void pa_linear_lds_enable(int on);
 void pa_emd_persistent_enable(int on);
 void pa_fpx16_enable(int mode);

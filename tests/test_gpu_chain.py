@@ -216,6 +216,35 @@ def test_sa_first_level_persistent_kernel_is_bit_identical_to_the_generic_one(B,
     close(tiny, exp)
 
 
+@pytest.mark.parametrize("B,n,m,ns,n2", [(32, 1024, 128, 20, 256), (40, 1024, 256, 20, 128), (3, 300, 50, 17, 256), (2, 100, 13, 16, 64), (1, 64, 3, 13, 128)])
+def test_sa_second_level_lds_resident_kernel(B, n, m, ns, n2):
+    """sa_mid.hip (weights of 67 -> 64 -> 64 -> n2 resident in LDS, activations in registers, a wave per 4-group tile): against float64, and
+    against the generic pooled kernel -- equal up to the order of the fp32 additions inside a dot product, not bit for bit.  Cases: the model's
+    shapes (one tile per wave at B = 32; PPT-Net's 256 centres -> the persistent loop runs several tiles per wave), 17 / 16 / 13 neighbours
+    (padding rows, the four-row-tile build), a ragged last tile."""
+    from patchaugnet_amd import _lib
+    from patchaugnet_amd.engine import _Chain
+    dims = [67, 64, 64, n2]
+    ref, eng = make_layers(dims, seed=n + ns)
+    xyz, feat, cidx, nbr = sa_inputs(B, n, m, ns, 64, seed=m)
+    rows = sa_rows_ref(xyz, feat, cidx, nbr).double()
+    exp = mlp_ref(rows, [(w.float().double(), b.float().double()) for w, b in ref]).max(dim=2)[0].reshape(B * m, -1)
+    args = (xyz.cuda(), feat.cuda().contiguous(), cidx.cuda(), nbr.cuda(), 64)
+    lib = _lib.lib()
+    try:
+        lib.pa_chain_mid_enable(1)
+        got = _Chain(eng).sa(*args, pooled=True)
+        lib.pa_chain_mid_enable(0)
+        generic = _Chain(eng).sa(*args, pooled=True)
+        torch.cuda.synchronize()
+    finally:
+        lib.pa_chain_mid_enable(-1)
+    close(got, exp)
+    close(generic, exp)
+    close(got, generic.double(), rtol=2e-5)
+    assert not torch.equal(got, generic) or B * m < 64          # a different kernel did run (different summation order)
+
+
 @pytest.mark.parametrize("rows,n,relu,res,ldx", [(4096, 256, 0, False, 256), (32768, 256, 0, False, 256), (5003, 512, 1, True, 300), (17, 128, 1, False, 256),
                                                   (2048, 256, 1, True, 256)])
 def test_linear_with_lds_resident_weights_is_bit_identical_to_the_chain_kernel(rows, n, relu, res, ldx):
