@@ -12,7 +12,8 @@ class _ZeroArena:
     off = 0             # bytes handed out
     used = 0            # bytes asked for in this step (the next step's size)
     demand = {}         # device -> bytes
-    owner = None        # (thread id, raw stream) that opened the step: the fill launch is ordered on THAT stream only
+    owner = None        # raw stream the step was opened on: the fill launch is ordered on THAT stream only
+    lock = threading.Lock()
 
 
 _arena = _ZeroArena()
@@ -33,7 +34,7 @@ def zero_arena(device):
         yield
         return
     a.active, a.device, a.off, a.used = True, device, 0, 0
-    a.owner = (threading.get_ident(), torch.cuda.current_stream(device).cuda_stream)
+    a.owner = torch.cuda.current_stream(device).cuda_stream
     want = a.demand.get(device, 0)
     a.buf = torch.zeros(want, dtype=torch.uint8, device=device) if want else None
     try:
@@ -46,17 +47,18 @@ def zero_arena(device):
 def zeros(shape, dtype, device):
     """torch.zeros(shape, dtype=dtype, device=device), out of the step's zero-filled buffer when one is open (zero_arena)."""
     a = _arena
-    # slices only for the thread and stream the step's fill launch was issued on: another stream (a pipeline worker, an autograd node replayed on a
-    # side stream) is not ordered after that launch and gets a buffer of its own
-    if (a.active and torch.device(device) == a.device and a.owner is not None and a.owner[0] == threading.get_ident()
-            and a.owner[1] == torch.cuda.current_stream(a.device).cuda_stream):
+    # slices only on the stream the step's fill launch was issued on: another stream (a pipeline worker, an autograd node replayed on a side
+    # stream) is not ordered after that launch and gets a buffer of its own.  The THREAD may differ -- autograd runs a device's backward nodes on
+    # its own worker thread, on the forward's stream -- so the bookkeeping is under a lock and the ordering is the stream's.
+    if a.active and torch.device(device) == a.device and a.owner is not None and a.owner == torch.cuda.current_stream(a.device).cuda_stream:
         n = dtype.itemsize
         for d in shape:
             n *= d
         span = (n + 255) // 256 * 256
-        a.used += span
-        if a.buf is not None and a.off + span <= a.buf.numel() and n > 0:
-            t = a.buf[a.off:a.off + n].view(dtype).view(shape)
-            a.off += span
-            return t
+        with a.lock:
+            a.used += span
+            if a.buf is not None and a.off + span <= a.buf.numel() and n > 0:
+                t = a.buf[a.off:a.off + n].view(dtype).view(shape)
+                a.off += span
+                return t
     return torch.zeros(shape, dtype=dtype, device=device)

@@ -146,6 +146,43 @@ def test_zero_arena_hands_out_zero_filled_disjoint_buffers_and_learns_its_size()
     assert train_ops.zeros((4,), torch.float32, dev).untyped_storage().nbytes() == 16   # outside a step: plain torch.zeros
 
 
+def test_zero_arena_serves_backward_nodes_on_the_steps_stream_and_nobody_on_another_stream():
+    """Autograd runs a device's backward nodes on its own worker thread, on the forward's stream: they are ordered after the step's fill launch
+    and get slices of the step's buffer (the thread-bound rule of an earlier revision sent every backward accumulator to its own fill launch:
+    +28 launches per training step).  A different STREAM is not ordered after the fill and gets a buffer of its own."""
+    import threading
+    from patchaugnet_amd import _arena, train_ops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    _arena._arena.demand.pop(dev, None)
+    seen = []
+
+    class Twice(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            z = train_ops.zeros((64,), torch.float32, g.device)
+            seen.append((threading.get_ident(), z.untyped_storage().data_ptr(), bool(z.any())))
+            return g * 2 + z[0]
+
+    side = torch.cuda.Stream()
+    for step in range(2):
+        with train_ops.zero_arena("cuda"):
+            base = train_ops.zeros((8,), torch.float32, dev)
+            x = torch.ones(4, device=dev, requires_grad=True)
+            Twice.apply(x).sum().backward()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                other = train_ops.zeros((8,), torch.float32, dev)
+            torch.cuda.current_stream().wait_stream(side)
+        assert not seen[-1][2] and not other.any() and (x.grad == 2).all()
+        if step:
+            assert seen[-1][1] == base.untyped_storage().data_ptr(), "a backward node on the step's stream shares the step's buffer"
+            assert other.untyped_storage().data_ptr() != base.untyped_storage().data_ptr(), "another stream gets its own"
+
+
 def test_interpolation_backward_with_prebuilt_lists_is_identical():
     """The inverted (point, neighbour) lists of interpolation's backward built ahead (backbone geometry(), prefetched with the neighbour
     searches) give the gradient the inline build gives (up to the order within a point's list), and the fp64 scatter-add's."""
