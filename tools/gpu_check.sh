@@ -86,5 +86,7 @@ bash tools/pmc_pass.sh gpurun_out/${TAG}_ppt16_pmc_FETCH_SIZE.txt "FETCH_SIZE" -
 bash tools/pmc_pass.sh gpurun_out/${TAG}_ppt16_pmc_WRITE_SIZE.txt "WRITE_SIZE" --model pptnet --mlp-dtype f16 --no-grouping
 bash tools/pmc_pass.sh gpurun_out/${TAG}_ppt16_pmc_tcp.txt "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum" --model pptnet --mlp-dtype f16 --no-grouping
 timeout 300 python tools/emd_time.py > gpurun_out/${TAG}_emd_time.txt 2>&1
+timeout 300 python tools/fpx16_time.py > gpurun_out/${TAG}_fpx16_time.txt 2>&1
+timeout 300 python tools/sa1_time.py > gpurun_out/${TAG}_sa1_time.txt 2>&1
 timeout 300 python tools/probes/stage_b2b.py 9 > gpurun_out/${TAG}_stage_b2b.txt 2>&1
 timeout 300 python tools/chain_phases.py fp0 fp1 fp2 sa1 sa2 > gpurun_out/${TAG}_chain_phases.txt 2>&1
