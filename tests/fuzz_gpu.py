@@ -285,6 +285,102 @@ def f_chain_fp():
         return f"B={B} n={n} m={m} c2={c2} c1={c1} dims={dims} err={err}"
 
 
+def f_sa_mid():
+    """the LDS-resident second-level kernel (sa_mid.hip) forced on: 67 -> 64 -> 64 -> n2, 13..20 neighbours, any group count (ragged tiles, several
+    tiles per wave), against float64 and against the generic pooled kernel"""
+    from tests.test_gpu_chain import make_layers, mlp_ref, sa_inputs, sa_rows_ref
+    from patchaugnet_amd.engine import _Chain
+    B, n, ns = int(rng.integers(1, 6)), logint(2, 3000), int(rng.integers(13, 21))
+    m, n2 = logint(1, min(n, 1500)), 64 * int(rng.integers(1, 5))
+    if B * m * ns > 3e5:
+        return None
+    seed = int(rng.integers(0, 1 << 30))
+    ref, eng = make_layers([67, 64, 64, n2], seed=seed)
+    xyz, feat, cidx, nbr = sa_inputs(B, n, m, ns, 64, seed=seed + 1)
+    rows = sa_rows_ref(xyz, feat, cidx, nbr).double()
+    exp = mlp_ref(rows, [(w.float().double(), b.float().double()) for w, b in ref]).max(dim=2)[0].reshape(B * m, -1)
+    args = (xyz.cuda(), feat.cuda().contiguous(), cidx.cuda(), nbr.cuda(), 64)
+    lib = _lib.lib()
+    try:
+        lib.pa_chain_mid_enable(1)
+        got = _Chain(eng).sa(*args, pooled=True)
+        lib.pa_chain_mid_enable(0)
+        gen = _Chain(eng).sa(*args, pooled=True)
+        torch.cuda.synchronize()
+    finally:
+        lib.pa_chain_mid_enable(-1)
+    scale = exp.abs().max().item() + 1e-12
+    err, errg = (got.double().cpu() - exp).abs().max().item(), (got.double() - gen.double()).abs().max().item()
+    if not (err <= 2e-5 * scale and errg <= 2e-5 * scale):
+        return f"B={B} n={n} m={m} ns={ns} n2={n2} err={err} vs generic={errg}"
+
+
+def f_fpx16():
+    """the fp16 path's finest FP level (fpx_f16.hip): both workgroup shapes, fp16 and fp32 pre-multiplied table, any row count; reference with
+    the same operand roundings in float64 (2e-3 of the scale: a hidden value next to an fp16 tie may round the other way)"""
+    from tests.test_gpu_chain import make_layers
+    from patchaugnet_amd.engine import _Chain
+    B, n, m, c1 = int(rng.integers(1, 4)), logint(1, 6000), logint(1, 1200), int(rng.integers(1, 5))
+    mode, g16 = int(rng.choice([4, 8])), bool(rng.integers(0, 2))
+    seed = int(rng.integers(0, 1 << 30))
+    ref, eng = make_layers([256 + c1, 256, 256, 256], seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    known = torch.randn(B, m, 256, generator=g)
+    skip = torch.randn(B, n, c1, generator=g)
+    idx3 = torch.randint(0, m, (B, n, 3), generator=g).int()
+    w3 = torch.rand(B, n, 3, generator=g)
+    w3 = (w3 / w3.sum(-1, keepdim=True)).contiguous()
+    os.environ["PA_ENGINE_FPX16"] = "1" if g16 else "0"
+    ch = _Chain(eng, f16=True)
+    ch.build_premul(256, c1)
+    os.environ.pop("PA_ENGINE_FPX16")
+    lib = _lib.lib()
+    lib.pa_fpx16_enable(mode)
+    try:
+        got = ch.fp_premul(known.cuda(), idx3.cuda(), w3.cuda(), skip.cuda(), B, n, m, 256, c1)
+        torch.cuda.synchronize()
+    finally:
+        lib.pa_fpx16_enable(-1)
+    h16 = lambda t: t.half().double()
+    (w1, b1), (w2, b2), (w3_, b3) = [(w.float().double(), b.float().double()) for w, b in ref]
+    gk = (h16(known.double()) @ h16(w1[:, :256]).t()).float().double()
+    if g16:
+        gk = h16(gk)
+    bi = torch.arange(B)[:, None]
+    interp = sum(w3[..., t:t + 1].double() * gk[bi, idx3[:, :, t].long()] for t in range(3))
+    h1 = torch.relu(interp + skip.double() @ w1[:, 256:].t() + b1)
+    h2 = torch.relu(h16(h1) @ h16(w2).t() + b2)
+    exp = torch.relu(h16(h2) @ h16(w3_).t() + b3).reshape(B * n, -1)
+    err = (got.double().cpu() - exp).abs().max().item()
+    if not err <= 2e-3 * (exp.abs().max().item() + 1e-12):
+        return f"B={B} n={n} m={m} c1={c1} mode={mode} g16={g16} err={err}"
+
+
+def f_attention_f16():
+    """the fp16 attention (attention_f16.hip: hi / lo logits, column-online scaling, fused layer behind it where the engine fuses) against the
+    fp32 oracle statement: cosine of every point's output row >= 0.999 and max error <= 2e-2 of the scale"""
+    from patchaugnet_amd import backbone
+    from patchaugnet_amd.engine import _Attn
+    from oracle import models_cpu
+    b, n, c = int(rng.integers(1, 4)), logint(1, 1100), int(rng.choice([64, 128, 256]))
+    if n * c > 300000:
+        n = max(1, 300000 // c)
+    torch.manual_seed(int(rng.integers(0, 1 << 30)))
+    sa = backbone.SALayer(c, 8).eval()
+    for p in sa.parameters():
+        p.data.mul_(0.5)
+    x = torch.randn(b, c, n)
+    sd = {"s." + k: v for k, v in sa.state_dict().items()}
+    with torch.no_grad():
+        ref = models_cpu.sa_layer(sd, "s", x, 8)
+        xm = x.transpose(1, 2).contiguous().view(b * n, c).cuda()
+        got = _Attn(sa, xm.device, f16=True).run(xm, b, n).view(b, n, c).transpose(1, 2).cpu()
+    err = (got - ref).abs().max().item()
+    cos = torch.nn.functional.cosine_similarity(got.double(), ref.double(), dim=1).min().item()
+    if not (err <= 2e-2 * max(ref.abs().max().item(), 1.0) and cos >= 0.999):
+        return f"b={b} n={n} c={c} err={err} cos={cos}"
+
+
 def _seed_module(m, seed):
     from patchaugnet_amd.weights import seeded_state_dict
     m.load_state_dict(seeded_state_dict(m.state_dict(), seed=seed))
@@ -417,7 +513,8 @@ def f_train_glue():
 
 
 FAMILIES = (("fps", f_fps), ("knn", f_knn), ("3nn", f_3nn), ("knn_grid", f_knn_grid), ("3nn_grid", f_3nn_grid), ("gather", f_gather), ("backward", f_backward), ("linear", f_linear),
-            ("attention", f_attention), ("chain_sa", f_chain_sa), ("chain_fp", f_chain_fp), ("netvlad", f_netvlad), ("afa", f_afa), ("linear_lds", f_linear_lds), ("train_glue", f_train_glue))
+            ("attention", f_attention), ("chain_sa", f_chain_sa), ("chain_fp", f_chain_fp), ("netvlad", f_netvlad), ("afa", f_afa), ("linear_lds", f_linear_lds), ("train_glue", f_train_glue),
+            ("sa_mid", f_sa_mid), ("fpx16", f_fpx16), ("attention_f16", f_attention_f16))
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:
