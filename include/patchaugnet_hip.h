@@ -297,6 +297,13 @@ int pa_afa_rows(int b, int c, int ktot, int nout, const float *vt, const float *
  * scratch: pa_afa_fused_scratch_floats(b, ktot, nout) floats.  Same function as pa_afa_rows up to fp32 re-association of the FC sum. */
 int pa_netvlad_pyramid(int b, int nscales, const int *n, const int *k, const float *const *x, const float *const *wc_t, const float *const *wc_p,
                        const float *const *bias, const float *const *w2, float *const *scratch, float *out, int phases, pa_stream_t stream);
+/* The same for the model's fp16 path: at the scales with 49..64 clusters (wc16[s] = 32 768 halfs: pa_pack_weights_f16(256, 64) of wc_t[s],
+ * then of wc_t[s] - fp16(wc_t[s]); NULL elsewhere) the assignment GEMM and the aggregation run on the 16-bit MFMAs with fp32 accumulation.  The
+ * soft-max logits keep fp32 accuracy ((hi, lo) fp16 operand pairs, three products); the aggregation takes features and soft-assignments
+ * rounded to bf16 (fp32's exponent range: the masses of clusters nobody is assigned to are below fp16's); logits bias, soft-max, a_sum, residual, normalisation in fp32.  Same scratch layout and finalize as pa_netvlad_pyramid. */
+int pa_netvlad_pyramid_f16(int b, int nscales, const int *n, const int *k, const float *const *x, const float *const *wc_t, const float *const *wc_p,
+                           const void *const *wc16, const float *const *bias, const float *const *w2, float *const *scratch, float *out, int phases,
+                           pa_stream_t stream);
 long pa_afa_fused_scratch_floats(int b, int ktot, int nout);
 int pa_afa_fused(int b, int c, int ktot, int nout, const float *vt, const float *watt_t, const float *fc_wt, const float *fc_bias,
                  const float *scale, const float *shift, int l2norm, float *scratch, float *desc, pa_stream_t stream);

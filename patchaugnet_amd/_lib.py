@@ -72,6 +72,7 @@ _SIGS = {
     "pa_afa_rows": "iiiippppppppipp",
     "pa_fc": "iiipppppippp",
     "pa_netvlad_pyramid": "iipppppppppi",
+    "pa_netvlad_pyramid_f16": "iippppppppppi",
     "pa_afa_fused": "iiiippppppipp",
     "pa_vlad_maxpool": "iiipip",
     "pa_tgemm_nn": "iiiipliipliipppliippipi",

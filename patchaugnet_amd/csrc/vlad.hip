@@ -322,6 +322,187 @@ __global__ __launch_bounds__(256, KT == 4 ? PA_VLAD_WGS : 1) void vlad_accum_ker
     VSTAMPK(12);
 }
 
+// ------------------------------------------------------------------------------------------------ NetVLAD accumulate, fp16 operands
+// The K = 64 scale of the fp16 path (model.mlp_dtype = "f16", BASELINE.json configs[4]): same partials, same finalize, both contractions on
+// the fp16 MFMA with fp32 accumulation; logits bias, soft-max, the a_sum partials and everything after the partials stay fp32.  The fp32 kernel
+// above is bound by its MFMAs (8.6 GFLOP at 60 % of the fp32 matrix rate); here they are a few percent of the launch and it becomes a stream over X.
+//   * the LOGITS keep fp32 accuracy: x = hi + lo and W = Whi + Wlo in fp16 pairs, logits = hi Whi + lo Whi + hi Wlo (three MFMAs, the dropped
+//     term is 2^-22 relative).  A plain fp16 rounding of x is an ABSOLUTE error |x| |W| 2^-11 sqrt(256) in the exponent of the soft-max: with
+//     features of magnitude 50-100 (PPT-Net with seeded random weights: logits of standard deviation 17, nearly one-hot assignments) it flips
+//     assignments -- descriptor cosine 0.52-0.98 in the first build (tools/probes/vlad16_diag.py);
+//   * a lane loads 8 consecutive channels of ITS point per 32-channel k-step (two 16-byte global loads): after the conversion these registers
+//     ARE the A operands (M = point) of the assignment GEMM v_mfma_f32_16x16x32_f16, and one 16-byte LDS store puts the hi part into the
+//     row-major fp16 tile Xh[128][256 + 8];
+//   * the assignment weights (pa_pack_weights_f16(256, 64) of W and of W - fp16(W): lane (k % 16, g) holds W[32 ks + 8 g + e][16 kt + k % 16])
+//     are copied into LDS once per workgroup (global_load_lds) and read lane-linearly;
+//   * the logits come out as D[point 4 g + i][cluster 16 kt + l % 16]: a row's clusters are the 16 lanes of a DPP row x 4 tiles (the soft-max of
+//     the fp32 kernel), and a lane's four values ARE four consecutive points of one cluster = one A operand (M = cluster, K = 16 points) of the
+//     aggregation GEMM v_mfma_f32_16x16x16_f16: they pass through LDS as one 8-byte word per (point quad, cluster) only because the aggregation
+//     splits the CHANNELS over the waves (every wave contracts all 128 points of the tile for its 32 channels);
+//   * the aggregation's B operand (N = channel, K = 16 points) is four 2-byte reads down a column of Xh; the 528-byte row pitch puts the four
+//     k-groups' rows 16 banks apart;
+//   * the AGGREGATION runs in bf16 (v_mfma_f32_16x16x16_bf16), not fp16: a cluster nobody is assigned to still gets a row of the descriptor --
+//     intra-normalisation scales its 1e-8-and-below masses to unit norm -- and those masses are under fp16's range (first build: such rows came
+//     out with cosine ~0 against the fp32 kernel).  bf16 has fp32's exponent; its 8-bit mantissa costs 2^-9 relative per term of sums over
+//     hundreds to thousands of points (measured: every row within cosine 0.999997 of the fp32 kernel, tests/test_gpu_f16.py).
+// One eight-wave workgroup per CU (152 KB of LDS: the tile, both weight halves, the assignment words).
+typedef _Float16 vhalf8 __attribute__((ext_vector_type(8)));
+typedef _Float16 vhalf4 __attribute__((ext_vector_type(4)));
+typedef __bf16 vbf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 vbf4 __attribute__((ext_vector_type(4)));
+typedef short vshort4 __attribute__((ext_vector_type(4)));
+constexpr int V16_ROWS = 128;                                                // rows of X per tile (16 per wave)
+constexpr int V16_PITCH = VC + 8;                                            // halfs per row of Xh
+constexpr int V16_AQ = 66;                                                   // (point quad) pitch of the assignment tile, in clusters
+constexpr size_t V16_LDS = (size_t)V16_ROWS * V16_PITCH * 2 + 2 * 32768 + (V16_ROWS / 4) * V16_AQ * 8 + 8 * 64 * 4;
+
+__global__ __launch_bounds__(512, 1) void vlad_accum16_kernel(int n, int k_true, int rows_per_wg, const float *__restrict__ x_all,
+                                                              const _Float16 *__restrict__ wc16,   // pa_pack_weights_f16(256, 64) of W, then of W - fp16(W)
+                                                              const float *__restrict__ bias, float *__restrict__ part, float *__restrict__ asum_part)
+{
+    constexpr int KT = 4, KP = 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
+    __bf16 *Xh = reinterpret_cast<__bf16 *>(smem16);                          // [128][V16_PITCH] bf16
+    _Float16 *Wh = reinterpret_cast<_Float16 *>(Xh + V16_ROWS * V16_PITCH);   // [hi, lo][4 kt][8 ks][64 lanes][8] fp16
+    __bf16 *Aq = reinterpret_cast<__bf16 *>(Wh + 2 * 16384);                  // [32 point quads][V16_AQ clusters][4 points] bf16
+    float *red = reinterpret_cast<float *>(Aq + (V16_ROWS / 4) * V16_AQ * 4); // [8][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    const int b = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+    const int row_begin = chunk * rows_per_wg;
+    const int row_end = min(row_begin + rows_per_wg, n);
+    const float *x = x_all + (size_t)b * n * VC;
+
+    // assignment weights -> LDS (64 pieces of 1 KB, eight per wave)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int p = u * 8 + wave;
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(wc16 + (size_t)p * 512 + lane * 8),
+                                         (void __attribute__((address_space(3))) *)(reinterpret_cast<unsigned char *>(Wh) + p * 1024), 16, 0, 0);
+    }
+    floatx4 acc2[KT][2];                   // V: [cluster tile kt][channel tile ct]: row m = 4 g + i <-> cluster 16 kt + m, column <-> channel 32 w + 16 ct + li
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc2[kt][ct] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    float asum[KT], bia[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) { asum[kt] = 0.f; bia[kt] = bias[kt * 16 + li]; }
+
+    // a lane's point of the tile at r0: row r0 + 16 w + li (clamped: rows past the end get a = 0 below), channels 32 ks + 8 lq .. + 7
+    float4 pre[16];
+    auto fetch = [&](int r0) {
+        const int row = min(r0 + wave * 16 + li, row_end - 1);
+        const float4 *src = reinterpret_cast<const float4 *>(x + (size_t)row * VC + 8 * lq);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) { pre[2 * ks] = src[8 * ks]; pre[2 * ks + 1] = src[8 * ks + 1]; }
+    };
+    fetch(row_begin);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the weight copies (and the first tile) have landed ...
+    __syncthreads();                                            // ... everybody's
+    const vhalf8 *wf = reinterpret_cast<const vhalf8 *>(Wh) + lane;
+    for (int r0 = row_begin; r0 < row_end; r0 += V16_ROWS) {
+        const int cnt = min(V16_ROWS, row_end - r0);
+        // 1 + 2. convert (hi, lo = x - hi); logits of this wave's 16 points D[point 4 g + i][cluster 16 kt + li] = hi Whi + lo Whi + hi Wlo; the hi
+        //        part into the row-major tile
+        floatx4 acc[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) acc[kt] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const float4 a0 = pre[2 * ks], a1 = pre[2 * ks + 1];
+            const float xv[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            vhalf8 hi, lo;
+            vbf8 xb;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                hi[e] = (_Float16)xv[e];
+                lo[e] = (_Float16)(xv[e] - (float)hi[e]);
+                xb[e] = (__bf16)xv[e];
+            }
+            *reinterpret_cast<vbf8 *>(Xh + (wave * 16 + li) * V16_PITCH + 32 * ks + 8 * lq) = xb;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const vhalf8 wh = wf[(kt * 8 + ks) * 64], wl = wf[(32 + kt * 8 + ks) * 64];
+                acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, wh, acc[kt], 0, 0, 0);
+                acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lo, wh, acc[kt], 0, 0, 0);
+                acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, wl, acc[kt], 0, 0, 0);
+            }
+        }
+        if (r0 + V16_ROWS < row_end) fetch(r0 + V16_ROWS);     // in flight under the soft-max and the aggregation
+        // 3. soft-max over the clusters of each point (fp32), the assignments as (point quad, cluster) words
+        float av[KT][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v[KT], mx = -3.0e38f;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                v[kt] = (kt * 16 + li < k_true) ? acc[kt][r] + bia[kt] : -3.0e38f;
+                mx = fmaxf(mx, v[kt]);
+            }
+            mx = row16_max(mx);
+            float sm = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                v[kt] = (kt * 16 + li < k_true) ? __expf(v[kt] - mx) : 0.f;
+                sm += v[kt];
+            }
+            sm = row16_sum(sm);
+            const float inv = 1.0f / sm;
+            const bool row_live = wave * 16 + lq * 4 + r < cnt;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                av[kt][r] = row_live ? v[kt] * inv : 0.f;
+                asum[kt] += av[kt][r];
+            }
+        }
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+            *reinterpret_cast<vbf4 *>(Aq + ((wave * 4 + lq) * V16_AQ + kt * 16 + li) * 4) =
+                (vbf4){(__bf16)av[kt][0], (__bf16)av[kt][1], (__bf16)av[kt][2], (__bf16)av[kt][3]};
+        __syncthreads();
+        // 4. aggregation over the tile's 128 points for this wave's 32 channels: K = 16 points per MFMA
+#pragma unroll
+        for (int kk = 0; kk < V16_ROWS / 16; ++kk) {
+            vbf4 xf[2], af[KT];
+            const __bf16 *xc = Xh + (16 * kk + 4 * lq) * V16_PITCH + wave * 32 + li;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+                xf[ct] = (vbf4){xc[16 * ct], xc[16 * ct + V16_PITCH], xc[16 * ct + 2 * V16_PITCH], xc[16 * ct + 3 * V16_PITCH]};
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) af[kt] = *reinterpret_cast<const vbf4 *>(Aq + ((4 * kk + lq) * V16_AQ + kt * 16 + li) * 4);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    acc2[kt][ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(vshort4, af[kt]), __builtin_bit_cast(vshort4, xf[ct]), acc2[kt][ct], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // partials in the fp32 kernel's layout: part[b][chunk][cluster][channel]
+    float *po = part + ((size_t)b * nchunks + chunk) * KP * VC;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) po[(size_t)(kt * 16 + 4 * lq + r) * VC + wave * 32 + ct * 16 + li] = acc2[kt][ct][r];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        float sv = asum[kt];
+        sv += __shfl_xor(sv, 16);
+        sv += __shfl_xor(sv, 32);
+        if (lane < 16) red[wave * KP + kt * 16 + lane] = sv;
+    }
+    __syncthreads();
+    if (tid < KP) {
+        float sv = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) sv += red[w * KP + tid];
+        asum_part[((size_t)b * nchunks + chunk) * KP + tid] = sv;
+    }
+}
+
 constexpr int VLAD_MAX_SCALES = 4;
 
 // wc_t [256][64] K-major -> the fragment order of the assignment GEMM above: wc_p[(s * 64 + lane) * 4 + ct] = wc_t[vlad_chan(s, lane / 16)][16 ct + lane % 16]
@@ -1063,8 +1244,9 @@ __global__ __launch_bounds__(1024) void afa_combine_kernel(int ktot, int nout, c
 // bit 2 = the finalize launch (7 = everything).  A caller whose coarse feature maps are ready early (the decoder writes them first) issues
 // phase 1 right behind their producer, while they are still cache-resident, and phases 2 | 4 after the finest level; x[s] of a scale that
 // the requested phases do not read may be NULL.
-PA_API int pa_netvlad_pyramid(int b, int nscales, const int *n, const int *k, const float *const *x, const float *const *wc_t, const float *const *wc_p,
-                              const float *const *bias, const float *const *w2, float *const *scratch, float *out, int phases, pa_stream_t stream)
+static int netvlad_pyramid(int b, int nscales, const int *n, const int *k, const float *const *x, const float *const *wc_t, const float *const *wc_p,
+                           const void *const *wc16, const float *const *bias, const float *const *w2, float *const *scratch, float *out, int phases,
+                           pa_stream_t stream)
 {
     PA_REQUIRE(b > 0 && b <= 65535 && nscales > 0 && nscales <= VLAD_MAX_SCALES && n && k && x && wc_t && bias && w2 && scratch && (out || !(phases & 4)) && (phases & 7),
                "pa_netvlad_pyramid: bad arguments");
@@ -1089,7 +1271,11 @@ PA_API int pa_netvlad_pyramid(int b, int nscales, const int *n, const int *k, co
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vlad_accum_kernel<KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(vlad_accum_kernel<KT>, dim3(chunks, b), dim3(256), lds, st, n[s], k[s], rows, x[s], wc_t[s], wp, bias[s], part, asum);  \
     } while (0)
-        if (kt == 1) PA_VLAD_LAUNCH(1);
+        if (kt == 4 && wc16 && wc16[s]) {   // fp16 path: both contractions on the fp16 MFMA, same partials
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vlad_accum16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)V16_LDS);
+            hipLaunchKernelGGL(vlad_accum16_kernel, dim3(chunks, b), dim3(512), V16_LDS, st, n[s], k[s], rows, x[s], reinterpret_cast<const _Float16 *>(wc16[s]),
+                               bias[s], part, asum);
+        } else if (kt == 1) PA_VLAD_LAUNCH(1);
         else if (kt == 2) PA_VLAD_LAUNCH(2);
         else if (kt == 3) PA_VLAD_LAUNCH(3);
         else PA_VLAD_LAUNCH(4);
@@ -1100,6 +1286,24 @@ PA_API int pa_netvlad_pyramid(int b, int nscales, const int *n, const int *k, co
     if (phases & 4) hipLaunchKernelGGL(vlad_finalize_multi_kernel, dim3(ktot, b), dim3(256), 0, st, fm, out, ktot);
     PA_CHECK_LAUNCH("pa_netvlad_pyramid");
     return PA_OK;
+}
+
+PA_API int pa_netvlad_pyramid(int b, int nscales, const int *n, const int *k, const float *const *x, const float *const *wc_t, const float *const *wc_p,
+                              const float *const *bias, const float *const *w2, float *const *scratch, float *out, int phases, pa_stream_t stream)
+{
+    return netvlad_pyramid(b, nscales, n, k, x, wc_t, wc_p, nullptr, bias, w2, scratch, out, phases, stream);
+}
+
+// The same with fp16 operands at the scales that have 49..64 clusters: wc16[s] = pa_pack_weights_f16(256, 64, wc_t[s]) there (NULL elsewhere: those
+// scales run the fp32 kernel; 32 768 halfs: the packing of W, then of W - fp16(W)).  The logits keep fp32 accuracy ((hi, lo) operand pairs), the
+// aggregation takes features and assignments rounded to fp16, accumulation and everything else fp32:
+// part of the model's fp16 path (descriptors within cosine 0.999 of the fp32 path, not 1e-4).
+PA_API int pa_netvlad_pyramid_f16(int b, int nscales, const int *n, const int *k, const float *const *x, const float *const *wc_t, const float *const *wc_p,
+                                  const void *const *wc16, const float *const *bias, const float *const *w2, float *const *scratch, float *out, int phases,
+                                  pa_stream_t stream)
+{
+    PA_REQUIRE(wc16, "pa_netvlad_pyramid_f16: null wc16");
+    return netvlad_pyramid(b, nscales, n, k, x, wc_t, wc_p, wc16, bias, w2, scratch, out, phases, stream);
 }
 
 PA_API long pa_afa_fused_scratch_floats(int b, int ktot, int nout) { return (long)b * ktot * 4 + (long)b * ktot * nout; }

@@ -297,9 +297,18 @@ class _Pyramid:
     """All scales of the NetVLAD pyramid through pa_netvlad_pyramid: the coarse scales share one accumulate launch and every scale
     shares one finalize launch (per-scale _Vlad.run: two launches each).  Pointer arrays of the weights are built once."""
 
-    def __init__(self, vlads):
+    def __init__(self, vlads, f16=False):
         self.vlads = vlads
         ns = len(vlads)
+        # fp16 path (model.mlp_dtype = "f16"): the 64-cluster scale on the fp16 MFMA (vlad_accum16_kernel); PA_ENGINE_VLAD_F16=0 = A/B knob
+        self.f16 = bool(f16) and os.environ.get("PA_ENGINE_VLAD_F16", "1") != "0" and any(v.k > 48 and v.c == 256 for v in vlads)
+        if self.f16:
+            # (hi, lo) fp16 pairs of the assignment weights: the logits keep fp32 accuracy (vlad.hip)
+            def hilo(w):
+                hi = w.half().float()
+                return torch.cat([pack_weights_f16(w), pack_weights_f16((w - hi).contiguous())])
+            self._wc16 = [hilo(v.wc_t) if (v.k > 48 and v.c == 256) else None for v in vlads]
+            self.wc16 = (ctypes.c_void_p * ns)(*[(t.data_ptr() if t is not None else None) for t in self._wc16])
         self.ns = ns
         self.ktot = sum(v.k for v in vlads)
         arr = lambda ts: (ctypes.c_void_p * ns)(*[(t.data_ptr() if t is not None else None) for t in ts])
@@ -324,6 +333,10 @@ class _Pyramid:
         cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
         xs = (ctypes.c_void_p * self.ns)(*[(f.data_ptr() if f is not None else None) for f in feats])
         state["keep"] = feats                         # the launches read these buffers asynchronously
+        if self.f16:
+            call("pa_netvlad_pyramid_f16", state["b"], self.ns, cast(self.n), cast(self.k), cast(xs), cast(self.wc_t), cast(self.wc_p), cast(self.wc16),
+                 cast(self.bias), cast(self.w2), cast(state["sc"]), ptr(out), phases)
+            return
         call("pa_netvlad_pyramid", state["b"], self.ns, cast(self.n), cast(self.k), cast(xs), cast(self.wc_t), cast(self.wc_p), cast(self.bias),
              cast(self.w2), cast(state["sc"]), ptr(out), phases)
 
@@ -552,7 +565,7 @@ class PatchAugNetEngine:
         ks = [v.cluster_size for v in vl]
         with torch.no_grad():
             self.vlads = [_Vlad(v, self.device) for v in vl]
-            self.pyramid = _Pyramid(self.vlads) if os.environ.get("PA_ENGINE_VLAD_PER_SCALE") is None else None     # A/B knob
+            self.pyramid = _Pyramid(self.vlads, f16=f16) if os.environ.get("PA_ENGINE_VLAD_PER_SCALE") is None else None     # A/B knob
             self._vlad_early = os.environ.get("PA_ENGINE_VLAD_LATE") is None                                       # A/B knob
             self._atomic_pool = os.environ.get("PA_ENGINE_NO_ATOMIC_POOL") is None                                  # A/B knob
             self.afa = self.head = self.gate = None

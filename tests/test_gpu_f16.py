@@ -186,3 +186,45 @@ def test_finest_fp_level_f16_on_lds_shared_weights(mode, g16, B, n, m, c1, monke
     full = torch.relu(torch.relu(torch.relu(torch.cat([sum(w3[..., t:t + 1].double() * known.double()[bi, idx3[:, :, t].long()] for t in range(3)),
                                                        skip.double()], -1) @ w1.t() + b1) @ w2.t() + b2) @ w3_.t() + b3).reshape(B * n, -1)
     assert (got.double().cpu() - full).abs().max().item() <= 8e-3 * full.abs().max().item()     # and against unrounded operands
+
+
+@pytest.mark.parametrize("mag", [0.7, 40.0])
+@pytest.mark.parametrize("b,scales", [(3, [(128, 4), (1024, 16), (4096, 64)]), (2, [(64, 1), (256, 4), (1024, 16), (4096, 64)]), (1, [(2048, 64)]),
+                                      (2, [(1000, 50)]), (5, [(300, 64)])])
+def test_netvlad_pyramid_f16_against_the_fp32_kernel(b, scales, mag):
+    """pa_netvlad_pyramid_f16: the 49..64-cluster scale on the 16-bit MFMAs (vlad.hip vlad_accum16_kernel: logits from (hi, lo) fp16 operand pairs,
+    aggregation with features and soft-assignments in bf16, fp32 accumulation, everything else fp32) against the fp32 pyramid: every
+    intra-normalised cluster row within cosine 0.9999; the other scales run the fp32 kernel in both and are bit-identical.  Ragged point counts
+    (1000, 300: partial tiles and a partial last workgroup), a cluster count below 64, and features of magnitude 40: logits of standard deviation
+    ~15, nearly one-hot assignments.  There a plain fp16 rounding of the logits' operands flips assignments, and fp16 assignments lose the clusters
+    nobody is assigned to -- their masses are 1e-8 and below, under fp16's range, yet intra-normalisation gives their rows the weight of every
+    other row (first builds: descriptor cosine 0.52; row cosines near 0 for those clusters)."""
+    from patchaugnet_amd import loupe
+    from patchaugnet_amd.engine import _Pyramid, _Vlad
+    from tests.test_gpu_head import _seed_module
+    vl, xs = [], []
+    for n, k in scales:
+        v = _seed_module(loupe.NetVLADBase(256, n, k, 256, gating=False), seed=n + k)
+        vl.append(_Vlad(v, torch.device("cuda")))
+        xs.append(torch.relu(torch.randn(b, n, 256, device="cuda")) * mag)       # mag = 40: logits of standard deviation ~15, nearly one-hot assignments
+    ktot = sum(k for _, k in scales)
+    ref = torch.full((b, ktot, 256), 7.0, device="cuda")
+    got = torch.full((b, ktot, 256), -3.0, device="cuda")
+    _Pyramid(vl).run(xs, ref)
+    p16 = _Pyramid(vl, f16=True)
+    assert p16.f16
+    p16.run(xs, got)
+    torch.cuda.synchronize()
+    koff = 0
+    for n, k in scales:
+        r, g = ref[:, koff:koff + k].double(), got[:, koff:koff + k].double()
+        if k > 48:
+            cos = torch.nn.functional.cosine_similarity(r, g, dim=2)
+            whole = torch.nn.functional.cosine_similarity(r.reshape(b, -1), g.reshape(b, -1), dim=1)
+            print(f"n={n} k={k} mag={mag}: row cosine min {cos.min().item():.6f} mean {cos.mean().item():.6f}; whole scale min {whole.min().item():.6f}")
+            assert cos.min().item() >= 0.9999, cos.min().item()
+            assert whole.min().item() >= 0.99999, whole.min().item()
+            assert not torch.equal(r, g)
+        else:
+            assert torch.equal(r, g)
+        koff += k
