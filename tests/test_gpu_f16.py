@@ -206,7 +206,8 @@ def test_netvlad_pyramid_f16_against_the_fp32_kernel(b, scales, mag):
     for n, k in scales:
         v = _seed_module(loupe.NetVLADBase(256, n, k, 256, gating=False), seed=n + k)
         vl.append(_Vlad(v, torch.device("cuda")))
-        xs.append(torch.relu(torch.randn(b, n, 256, device="cuda")) * mag)       # mag = 40: logits of standard deviation ~15, nearly one-hot assignments
+        gen = torch.Generator().manual_seed(1000 * b + n + k)
+        xs.append((torch.relu(torch.randn(b, n, 256, generator=gen)) * mag).cuda())   # mag = 40: logits of standard deviation ~15, nearly one-hot assignments
     ktot = sum(k for _, k in scales)
     ref = torch.full((b, ktot, 256), 7.0, device="cuda")
     got = torch.full((b, ktot, 256), -3.0, device="cuda")
@@ -222,7 +223,11 @@ def test_netvlad_pyramid_f16_against_the_fp32_kernel(b, scales, mag):
             cos = torch.nn.functional.cosine_similarity(r, g, dim=2)
             whole = torch.nn.functional.cosine_similarity(r.reshape(b, -1), g.reshape(b, -1), dim=1)
             print(f"n={n} k={k} mag={mag}: row cosine min {cos.min().item():.6f} mean {cos.mean().item():.6f}; whole scale min {whole.min().item():.6f}")
-            assert cos.min().item() >= 0.9999, cos.min().item()
+            # rows the intra-normalisation left (near) zero -- a cluster whose total mass underflows even fp32: ||v|| < 1e-12 -- have no direction
+            live = r.norm(dim=2) > 0.5
+            assert live.float().mean().item() > 0.9
+            assert cos[live].min().item() >= 0.9999, cos[live].min().item()
+            assert (r - g).abs().max().item() <= 2e-2
             assert whole.min().item() >= 0.99999, whole.min().item()
             assert not torch.equal(r, g)
         else:
