@@ -151,7 +151,7 @@ class _ChainTrain(Function):
         sums_all = zeros((G * 2 * sum(outs),), torch.float64, dev)
         # weight gradients (split-K partial tiles are added with atomics: zero-filled) and dgamma / dbeta, one arena
         nW = [o * c for o, c in zip(outs, ins)]
-        grads = zeros((sum(nW) + 2 * sum(outs),), torch.float32, dev)
+        grads = zeros((sum(nW) + 2 * sum(outs),), torch.float32, dev, keep=True)        # parameter gradients: outlive the step
         wo = [0]
         for n in nW:
             wo.append(wo[-1] + n)
@@ -251,7 +251,7 @@ class _LinearCM(Function):
                 dx = torch.empty_like(x)
                 tgemm_nn(B, C, P, O, W, 0, C, False, g, O * P, P, dx, C * P, P)
             if ctx.needs_input_grad[1]:
-                dW = zeros((O, C), torch.float32, x.device)
+                dW = zeros((O, C), torch.float32, x.device, keep=True)
                 tgemm_kk(B, O, C, P, g, O * P, P, x, C * P, P, dW, 0, C)
                 dW = dW.view_as(W)
         if ctx.has_bias and ctx.needs_input_grad[2]:

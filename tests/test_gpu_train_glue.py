@@ -143,6 +143,14 @@ def test_zero_arena_hands_out_zero_filled_disjoint_buffers_and_learns_its_size()
             assert not big.any()
             kept.append(a)
     assert all((t == 1).all() for t in kept)                                      # an escaped tensor keeps its step's buffer alive
+    for step in range(2):                                                         # keep=True (parameter gradients): a buffer of their own
+        with train_ops.zero_arena("cuda"):
+            big = train_ops.zeros((1 << 18,), torch.float32, dev)
+            g = train_ops.zeros((16,), torch.float32, dev, keep=True)
+            assert not g.any() and not big.any()
+            if step:
+                assert g.untyped_storage().data_ptr() != big.untyped_storage().data_ptr()
+                assert g.untyped_storage().nbytes() < 4096                        # a kept gradient does not pin the step's large buffer
     assert train_ops.zeros((4,), torch.float32, dev).untyped_storage().nbytes() == 16   # outside a step: plain torch.zeros
 
 
