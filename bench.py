@@ -40,7 +40,7 @@ def parse():
     p.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic (it is then null)")
     p.add_argument("--cpu-batch", type=int, default=8)
     p.add_argument("--model", choices=["patch_aug_net", "pptnet"], default="patch_aug_net", help="pptnet = BASELINE.json configs[4]")
-    p.add_argument("--mlp-dtype", choices=["f32", "f16"], default="f32",
+    p.add_argument("--mlp-dtype", choices=["f32", "f16", "f32x3"], default="f32",
                    help="f16: shared-MLP chains on fp16 MFMA (fp32 accumulate; cosine >= 0.999 contract) -- not the headline configuration")
     p.add_argument("--no-graphs", action="store_true", help="issue every step's launches from Python instead of replaying one captured hipGraph per stream")
     p.add_argument("--no-prefetch", action="store_true", help="--config train: no geometry prefetch of the next batch (one graph per step)")
@@ -476,7 +476,21 @@ def extras(a):
                     rates.append(steps * a.batch / (time.perf_counter() - t0))
         rates.sort()
         res = {"value": rates[1], "unit": "submaps/s", "min": rates[0], "max": rates[-1], "batch": a.batch, "steps": steps,
-               "dtype": "f32" if mlp_dtype == "f32" else "f16 MFMA operands in the shared-MLP chains and the self-attention contractions, fp32 accumulate / soft-max / everything else fp32"}
+               "dtype": {"f32": "f32", "f16": "f16 MFMA operands in the shared-MLP chains and the self-attention contractions, fp32 accumulate / soft-max / everything else fp32",
+                         "f32x3": "f32 everywhere except the two 256 -> 256 layers of the finest FP level: every product from (hi, lo) fp16 operand pairs (three fp16 MFMAs, "
+                                  "~2^-21 relative), fp32 accumulate; OPT-IN (model.mlp_dtype = 'f32x3'), not the headline"}[mlp_dtype]}
+        if mlp_dtype == "f32x3":      # the evidence the mode is offered on: its descriptors against the exact-fp32 path's on the same batch
+            with torch.no_grad():
+                d3 = model(x, return_feat=False)
+                d3 = (d3[0] if isinstance(d3, (tuple, list)) else d3).double()
+                model.mlp_dtype = "f32"
+                d1 = model(x, return_feat=False)
+                d1 = (d1[0] if isinstance(d1, (tuple, list)) else d1).double()
+                model.mlp_dtype = mlp_dtype
+            res["parity_vs_exact_fp32_path"] = {"max_abs_diff_of_l2_normalised_descriptors": (d3 - d1).abs().max().item(),
+                                                "min_cosine": torch.nn.functional.cosine_similarity(d3, d1, dim=1).min().item(),
+                                                "note": "tests/test_gpu_chain.py::test_finest_fp_level_from_split_fp16_operands_meets_the_fp32_tolerance: max error against "
+                                                        "float64 6.5e-7 of the scale (the fp32 MFMA kernel on the same data: 6.1e-7)"}
         try:      # rooflines of the finest feature-propagation chain (the largest dense launch) against BOTH bounds, and the attention's share of the step
             del gx
             with torch.no_grad():
@@ -485,9 +499,10 @@ def extras(a):
             fl = 2.0 * rows * (256 * 256 * 2 + 3 * 256)
             ms = st.get("fp0.chain")
             if ms:
-                peak = MFMA_F16_PEAK_TFLOPS if mlp_dtype == "f16" else MFMA_F32_PEAK_TFLOPS
+                peak = MFMA_F16_PEAK_TFLOPS if mlp_dtype == "f16" else MFMA_F32_PEAK_TFLOPS      # f32x3: priced against the fp32 peak it replaces (3x the FLOPs on the fp16 pipe)
                 byts = rows * 256 * 4.0 + rows * (3 * 4 + 3 * 4 + 3 * 4) + (rows // 4) * 256 * (2.0 if mlp_dtype == "f16" else 4.0)      # output + (idx3, w3, xyz) + the pre-multiplied known rows once
-                res["roofline"] = {"kernel": ("fpx16_kernel<4,2,2> (fpx_f16.hip: weights shared through LDS, activations in registers, fp16 pre-multiplied table)" if mlp_dtype == "f16" else "chain_kernel<1,16,FPX,0,1>") + " (fp0: finest feature-propagation chain)",
+                res["roofline"] = {"kernel": {"f16": "fpx16_kernel<4,2,2> (fpx_f16.hip: weights shared through LDS, activations in registers, fp16 pre-multiplied table)", "f32": "chain_kernel<1,16,FPX,0,1>",
+                                              "f32x3": "fpx3_kernel<4> (fpx_f32x3.hip: three fp16 MFMAs per product from (hi, lo) operand pairs)"}[mlp_dtype] + " (fp0: finest feature-propagation chain)",
                                    "bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / peak,
                                    "traffic": None, "algorithmic_flops_per_launch": fl, "ms_per_launch": ms, "timing": "one launch bracketed by HIP events on the launch stream (stage pass)"}
                 res["roofline_hbm"] = {"bound": "hbm", "achieved": byts / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -515,6 +530,7 @@ def extras(a):
     guarded("configs3_training_step", train)
     guarded("configs4_pptnet_f32", lambda: extract_rate("pptnet", "f32"))
     guarded("configs4_pptnet_f16", lambda: extract_rate("pptnet", "f16"))
+    guarded("configs1_f32x3_opt_in", lambda: extract_rate("patch_aug_net", "f32x3"))
     guarded("emd_16x4096", emd)
     return out
 
@@ -679,7 +695,8 @@ def main():
         "metric": f"4096-pt submaps/sec descriptor extraction ({'PatchAugNet' if a.model == 'patch_aug_net' else 'PPT-Net'}, inputs resident in HBM)",
         "value": submaps / dt, "unit": "submaps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if a.mlp_dtype == "f32" else "f16 MFMA operands in the shared-MLP chains, fp32 accumulate / everything else fp32", "data": "synthetic",
+        "dtype": {"f32": "f32", "f16": "f16 MFMA operands in the shared-MLP chains, fp32 accumulate / everything else fp32",
+                  "f32x3": "f32 everywhere except the two 256 -> 256 layers of the finest FP level: products from (hi, lo) fp16 operand pairs (three fp16 MFMAs, ~2^-21 relative), fp32 accumulate -- OPT-IN, not the headline"}[a.mlp_dtype], "data": "synthetic",
         "config": {"workload": (f"PatchAugNet inference, {a.points}-pt synthetic submaps, batch={a.batch}, 1xMI355X per rank (BASELINE.json configs[1])"
                                 if a.model == "patch_aug_net" else
                                 f"PPT-Net inference, {a.points}-pt synthetic submaps, batch={a.batch} per MI355X (BASELINE.json configs[4])"),

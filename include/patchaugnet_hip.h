@@ -212,6 +212,16 @@ int pa_fp_chain_premul_g16(int nlayers, const void *const *wp16, const float *co
                            const void *g16, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2, int c1,
                            const float *wskip, const float *bias0, float *out, int ldo, pa_stream_t stream);
 
+/* OPT-IN (model.mlp_dtype = "f32x3"; never the default path): pa_fp_chain_premul at the finest level's shape (c2 = 256, 1 <= c1 <= 4, two remaining
+ * 256 -> 256 layers) with every product of the two dense layers evaluated from (hi, lo) fp16 operand pairs -- hi(a) hi(w) + lo(a) hi(w) +
+ * hi(a) lo(w) on the fp16 MFMA with fp32 accumulation: ~2^-21 relative per product (fp32 MFMA: 2^-24; TF32: 2^-11) at 3/16 of the fp32 MFMA's
+ * issue time (csrc/fpx_f32x3.hip).  g fp32 as for pa_fp_chain_premul.  wp16x3[l]: 131 072 halfs = pa_pack_weights_f16(256, 256) of
+ * hi(W_l 2^s_l), then of lo(W_l 2^s_l), s_l a per-layer power-of-two scale that keeps lo(W) out of fp16's subnormal range; inv_scale[l] = 2^-s_l
+ * (host array).  PA_EUNSUPPORTED for any other shape. */
+int pa_fp_chain_premul_x3(int nlayers, const void *const *wp16x3, const float *inv_scale, const float *const *bias, long rows, const float *g,
+                          const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2, int c1, const float *wskip,
+                          const float *bias0, float *out, int ldo, pa_stream_t stream);
+
 /* One dense layer on point-major rows (the chain kernel's plain mode with a selectable epilogue):
  * out[r][:] = residual[r][:] + act(x[r][:k] . Wt + bias), act = ReLU if relu != 0 else identity; residual may be NULL.
  * wt K-major (kpad x n), kpad = k rounded up to 4 with zero rows, n % 16 == 0; wpk: optional packed copy (below) or NULL. */

@@ -149,7 +149,7 @@ class _Chain:
              ptr(known_feat), ptr(idx3), ptr(w3), ptr(skip), n_unknown, m_known, c2, c1, ptr(out), self.n_last)
         return out
 
-    def build_premul(self, c2, c1, kperm=False):
+    def build_premul(self, c2, c1, kperm=False, x3=False):
         """Split and pack the first layer for pa_fp_chain_premul ONCE, at engine construction (on the constructing stream): nothing is
         packed lazily in the hot path, so pipeline streams never race a pack kernel issued on another stream."""
         wt0, b0, _, _, n0 = self.layers[0]
@@ -173,6 +173,19 @@ class _Chain:
         # fp16 path, finest level's shape: fp16 table + LDS-shared weights (csrc/fpx_f16.hip); a function of the layer shapes only
         self._premul["g16"] = bool(self.f16 and c2 == 256 and n0 == 256 and 1 <= c1 <= 4 and m == 2 and all(l[3] == 256 and l[4] == 256 for l in rest)
                                    and os.environ.get("PA_ENGINE_FPX16", "1") != "0")
+        # opt-in "f32x3" (model.mlp_dtype): the two 256 -> 256 layers of the finest level from (hi, lo) fp16 operand pairs (csrc/fpx_f32x3.hip)
+        self._premul["x3"] = None
+        if x3 and not self.f16 and c2 == 256 and n0 == 256 and 1 <= c1 <= 4 and m == 2 and all(l[3] == 256 and l[4] == 256 for l in rest):
+            bufs, inv = [], []
+            for l in rest:
+                w = l[0]
+                s = int(torch.floor(torch.log2(1024.0 / w.abs().max().clamp_min(1e-30))).item())
+                s = max(min(s, 24), -24)
+                ws = w * (2.0 ** s)                                   # exact
+                hi = ws.half().float()
+                bufs.append(torch.cat([pack_weights_f16(hi.contiguous()), pack_weights_f16((ws - hi).contiguous())]))
+                inv.append(2.0 ** -s)
+            self._premul["x3"] = {"bufs": bufs, "wq": (ctypes.c_void_p * 2)(*[b.data_ptr() for b in bufs]), "inv": (ctypes.c_float * 2)(*inv)}
         if kperm and not self.f16 and m == 2 and all(l[2] == 256 and l[4] == 256 for l in rest):
             self._premul["kperm"] = [pack_weights_kperm(l[0]) for l in rest]
 
@@ -232,6 +245,13 @@ class _Chain:
                  ptr(g), ptr(idx3), ptr(w3), ptr(skip), n_unknown, m_known, pm["n0"], c1, ptr(pm["wskip"]), ptr(pm["wskip_p"]), ptr(pm["bias0"]),
                  ptr(g_next), tl["n_tail"], ptr(out), self.n_last, 0)
             return out, g_next
+        if pm.get("x3") is not None and not tail:
+            x3 = pm["x3"]
+            cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
+            for _ in range(getattr(self, "bench_repeat", 1)):
+                call("pa_fp_chain_premul_x3", pm["m"], cast(x3["wq"]), cast(x3["inv"]), cast(pm["bias"]), rows, ptr(g), ptr(idx3), ptr(w3), ptr(skip),
+                     n_unknown, m_known, pm["n0"], c1, ptr(pm["wskip"]), ptr(pm["bias0"]), ptr(out), self.n_last)
+            return out
         if (not self.f16 and c1 <= 4 and pm["n0"] == 256 and len(rest) == 2 and all(l[2] == 256 and l[4] == 256 for l in rest)
                 and "kperm" in pm):
             # experimental register-resident variant (fpx_reg.hip, opt-in: slower than the LDS-tiled kernel so far); a function of the
@@ -544,8 +564,10 @@ class PatchAugNetEngine:
         # "f32" (default): exact fp32 MFMA.  "f16": the shared-MLP chains run on fp16 MFMA with fp32 accumulation (model.mlp_dtype or
         # PA_ENGINE_MLP_DTYPE); sampling, grouping indices, attention, NetVLAD and the heads stay fp32.
         self.mlp_dtype = getattr(model, "mlp_dtype", None) or os.environ.get("PA_ENGINE_MLP_DTYPE", "f32")
-        if self.mlp_dtype not in ("f32", "f16"):
-            raise ValueError("mlp_dtype must be 'f32' or 'f16'")
+        # "f32x3" (opt-in, never a default): everything as "f32" except the two 256 -> 256 layers of the finest FP level, whose products are
+        # evaluated from (hi, lo) fp16 operand pairs on the fp16 MFMA (~2^-21 relative per product; csrc/fpx_f32x3.hip).
+        if self.mlp_dtype not in ("f32", "f16", "f32x3"):
+            raise ValueError("mlp_dtype must be 'f32', 'f16' or 'f32x3'")
         f16 = self.mlp_dtype == "f16"
         if any(len(m.mlps) != 1 for m in bb.SA_modules):
             raise ValueError("fused engine: a multi-scale-grouping level (backbone.SAModuleMSG with several scales) runs on the module path; "
@@ -605,7 +627,7 @@ class PatchAugNetEngine:
                 if ok:
                     # PA_ENGINE_FPX_REG / PA_ENGINE_TAIL select measured-slower variants that only the test-only library exports
                     # (`with _lib.experimental():`, csrc/pa_internal.h section 2); with the product library they are refused, not ignored
-                    chain.build_premul(c2, c1, kperm=self._exp_knob("PA_ENGINE_FPX_REG", "pa_fpx256"))
+                    chain.build_premul(c2, c1, kperm=self._exp_knob("PA_ENGINE_FPX_REG", "pa_fpx256"), x3=self.mlp_dtype == "f32x3")
             # a level whose chain runs as [skip layer | one 256-wide layer] can carry the next finer level's pre-multiply as a third layer
             # (pa_fp_chain_premul_tap).  Measured at B = 32 and NOT the default: the pre-multiply launch goes 0.050 -> 0.005 ms but the
             # shared-tile chain that now carries it 0.072 -> 0.112 ms (the stand-alone launch runs the faster eight-wave tiling) -- net zero.

@@ -216,6 +216,40 @@ def test_sa_first_level_persistent_kernel_is_bit_identical_to_the_generic_one(B,
     close(tiny, exp)
 
 
+@pytest.mark.parametrize("B,n,m,c1", [(3, 4096, 1024, 3), (1, 1000, 256, 3), (2, 77, 19, 1), (1, 300, 64, 4)])
+def test_finest_fp_level_from_split_fp16_operands_meets_the_fp32_tolerance(B, n, m, c1):
+    """Opt-in "f32x3" (fpx_f32x3.hip): every product of the two 256 -> 256 layers as hi(a) hi(w) + lo(a) hi(w) + hi(a) lo(w) on the fp16 MFMA
+    (weights scaled by a power of two per layer).  It has to pass the SAME test as the fp32 kernels -- 2e-5 of the tensor's scale against
+    float64 -- and is reported next to the exact-fp32 kernel's error on the same data."""
+    from patchaugnet_amd.engine import _Chain
+    c2 = 256
+    ref, eng = make_layers([c2 + c1, 256, 256, 256], seed=21 + c1)
+    g = torch.Generator().manual_seed(n)
+    known = torch.randn(B, m, c2, generator=g)
+    skip = torch.randn(B, n, c1, generator=g)
+    idx3 = torch.randint(0, m, (B, n, 3), generator=g).int()
+    w3 = torch.rand(B, n, 3, generator=g)
+    w3 = (w3 / w3.sum(-1, keepdim=True)).contiguous()
+    bi = torch.arange(B)[:, None]
+    interp = sum(w3[..., t:t + 1].double() * known.double()[bi, idx3[:, :, t].long()] for t in range(3))
+    exp = mlp_ref(torch.cat([interp, skip.double()], -1), [(w.float().double(), b.float().double()) for w, b in ref]).reshape(B * n, -1)
+    args = (known.cuda(), idx3.cuda(), w3.cuda(), skip.cuda(), B, n, m, c2, c1)
+    ch3 = _Chain(eng)
+    ch3.build_premul(c2, c1, x3=True)
+    assert ch3._premul["x3"] is not None
+    got = ch3.fp_premul(*args)
+    ch = _Chain(eng)
+    ch.build_premul(c2, c1)
+    exact = ch.fp_premul(*args)
+    torch.cuda.synchronize()
+    scale = exp.abs().max().item()
+    e3, e1 = (got.double().cpu() - exp).abs().max().item() / scale, (exact.double().cpu() - exp).abs().max().item() / scale
+    print(f"relative max error against float64: split fp16 operands {e3:.2e}, fp32 MFMA {e1:.2e}")
+    close(got, exp)
+    close(exact, exp)
+    assert e3 <= 4e-6
+
+
 @pytest.mark.parametrize("B,n,m,ns,n2", [(32, 1024, 128, 20, 256), (40, 1024, 256, 20, 128), (3, 300, 50, 17, 256), (2, 100, 13, 16, 64), (1, 64, 3, 13, 128)])
 def test_sa_second_level_lds_resident_kernel(B, n, m, ns, n2):
     """sa_mid.hip (weights of 67 -> 64 -> 64 -> n2 resident in LDS, activations in registers, a wave per 4-group tile): against float64, and
