@@ -218,6 +218,7 @@ int pa_fp_chain_premul_g16(int nlayers, const void *const *wp16, const float *co
  * issue time (csrc/fpx_f32x3.hip).  g fp32 as for pa_fp_chain_premul.  wp16x3[l]: 131 072 halfs = pa_pack_weights_f16(256, 256) of
  * hi(W_l 2^s_l), then of lo(W_l 2^s_l), s_l a per-layer power-of-two scale that keeps lo(W) out of fp16's subnormal range; inv_scale[l] = 2^-s_l
  * (host array).  PA_EUNSUPPORTED for any other shape. */
+int pa_linear_x3(long rows, const float *x, int ldx, const void *wp16x3, float inv_scale, float *out, int ldo, pa_stream_t stream);   /* the level's pre-multiply: out = x[:, :256] . W, one layer, same arithmetic */
 int pa_fp_chain_premul_x3(int nlayers, const void *const *wp16x3, const float *inv_scale, const float *const *bias, long rows, const float *g,
                           const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2, int c1, const float *wskip,
                           const float *bias0, float *out, int ldo, pa_stream_t stream);

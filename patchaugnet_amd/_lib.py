@@ -101,6 +101,7 @@ _SIGS = {
     "pa_patch_pairs_fill": "ipppppiipqpppp",
     "pa_fp_premul_g16": "lpipp",
     "pa_fp_chain_premul_x3": "ippplppppiiiipppi",
+    "pa_linear_x3": "lpipfpi",
     "pa_fp_chain_premul_g16": "ipppplppppiiiipppi",
 }
 # entry points of the measured-slower variants: exported by the test-only library only (csrc/pa_internal.h section 2)

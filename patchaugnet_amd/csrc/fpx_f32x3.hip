@@ -32,11 +32,13 @@ struct Fpx3Args {
     const float *b[2];
     float *out;
     int ldo, n_unknown, m_known, c1, xcd_remap;
+    const float *x;       // PREMUL form: out[r][:] = x[r][:256] . W (one layer, no bias / ReLU), rows = rows of x
+    int ldx;
 };
 
 __device__ __forceinline__ int r_ofs3(int ct, int g) { return 32 * (ct >> 1) + 8 * g + 4 * (ct & 1); }
 
-template <int WAVES>
+template <int WAVES, bool PREMUL>
 __global__ __launch_bounds__(WAVES * 64, 2) void fpx3_kernel(Fpx3Args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fpx3_lds[];
@@ -64,8 +66,32 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fpx3_kernel(Fpx3Args a)
         }
     };
 
-    // ---- h1 (hi, lo) in registers: interpolation + skip term + bias, ReLU ------------------------------------------------------------------
     const long row = (blk * WAVES + wave) * 16 + mq, rowc = row < a.rows ? row : a.rows - 1;
+    half8 hhi[8], hlo[8];
+    auto split = [&](int p, const float (&v)[8]) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const _Float16 hi = (_Float16)v[e];
+            hhi[p][e] = hi;
+            hlo[p][e] = (_Float16)(v[e] - (float)hi);
+        }
+    };
+    if constexpr (PREMUL) {
+        // ---- operand = the rows themselves: lane (mq, g) holds x[row][32 ks + 8 g .. + 7] ---------------------------------------------------
+        const float4 *xp = reinterpret_cast<const float4 *>(a.x + (size_t)rowc * a.ldx + 8 * g);
+        float4 f[8][2];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) { f[ks][0] = xp[8 * ks]; f[ks][1] = xp[8 * ks + 1]; }
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(0);
+        fetch(1);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const float v[8] = {f[ks][0].x, f[ks][0].y, f[ks][0].z, f[ks][0].w, f[ks][1].x, f[ks][1].y, f[ks][1].z, f[ks][1].w};
+            split(ks, v);
+        }
+    } else {
+    // ---- h1 (hi, lo) in registers: interpolation + skip term + bias, ReLU ------------------------------------------------------------------
     const long cloud = rowc / a.n_unknown;
     int nb[3];
     float wj[3], sv[4];
@@ -94,15 +120,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fpx3_kernel(Fpx3Args a)
     const float *gp[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) gp[t] = a.g + (size_t)(cloud * a.m_known + nb[t]) * 256 + 8 * g;
-    half8 hhi[8], hlo[8];
-    auto split = [&](int p, const float (&v)[8]) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const _Float16 hi = (_Float16)v[e];
-            hhi[p][e] = hi;
-            hlo[p][e] = (_Float16)(v[e] - (float)hi);
-        }
-    };
     __syncthreads();   // cst visible
 #pragma unroll
     for (int q = 0; q < 8; q += 4) {   // 24 16-byte gathers in flight
@@ -142,16 +159,19 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fpx3_kernel(Fpx3Args a)
         }
     }
 
+    }
+
     // ---- the two layers: one barrier per k-step slab ---------------------------------------------------------------------------------------
     floatx4 acc[16];
     unsigned off0 = lane * 16u, off1 = SLAB + lane * 16u;
     asm volatile("" : "+v"(off0), "+v"(off1));
     const half8 *buf0 = reinterpret_cast<const half8 *>(fpx3_lds + off0), *buf1 = reinterpret_cast<const half8 *>(fpx3_lds + off1);
+    constexpr int NSLAB = PREMUL ? 8 : 16;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
+    for (int s = 0; s < NSLAB; ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (s >= 1 && s + 1 < 16) fetch(s + 1);
+        if (s >= 1 && s + 1 < NSLAB) fetch(s + 1);
         if ((s & 7) == 0) {
 #pragma unroll
             for (int ct = 0; ct < 16; ++ct) acc[ct] = (floatx4){0.f, 0.f, 0.f, 0.f};
@@ -174,7 +194,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fpx3_kernel(Fpx3Args a)
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-        if (s == 7) {   // h2 = relu(acc 2^-s + b2), split again, straight from the accumulators
+        if (!PREMUL && s == 7) {   // h2 = relu(acc 2^-s + b2), split again, straight from the accumulators
             const float is = a.inv_scale[0];
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
@@ -187,16 +207,20 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fpx3_kernel(Fpx3Args a)
         }
     }
 
-    // ---- out = relu(acc 2^-s + b3) ------------------------------------------------------------------------------------------------------------
+    // ---- out = relu(acc 2^-s + b3)  (PREMUL: out = acc 2^-s) ------------------------------------------------------------------------------
     if (row < a.rows) {
-        const float is = a.inv_scale[1];
+        const float is = a.inv_scale[PREMUL ? 0 : 1];
         float *o = a.out + (size_t)row * a.ldo;
 #pragma unroll
         for (int ct = 0; ct < 16; ++ct) {
             const int c = r_ofs3(ct, g);
-            const float4 bz = *reinterpret_cast<const float4 *>(cst + 1536 + c);
-            *reinterpret_cast<float4 *>(o + c) = make_float4(fmaxf(fmaf(acc[ct][0], is, bz.x), 0.f), fmaxf(fmaf(acc[ct][1], is, bz.y), 0.f),
-                                                             fmaxf(fmaf(acc[ct][2], is, bz.z), 0.f), fmaxf(fmaf(acc[ct][3], is, bz.w), 0.f));
+            if (PREMUL) {
+                *reinterpret_cast<float4 *>(o + c) = make_float4(acc[ct][0] * is, acc[ct][1] * is, acc[ct][2] * is, acc[ct][3] * is);
+            } else {
+                const float4 bz = *reinterpret_cast<const float4 *>(cst + 1536 + c);
+                *reinterpret_cast<float4 *>(o + c) = make_float4(fmaxf(fmaf(acc[ct][0], is, bz.x), 0.f), fmaxf(fmaf(acc[ct][1], is, bz.y), 0.f),
+                                                                 fmaxf(fmaf(acc[ct][2], is, bz.z), 0.f), fmaxf(fmaf(acc[ct][3], is, bz.w), 0.f));
+            }
         }
     }
 }
@@ -223,8 +247,24 @@ PA_API int pa_fp_chain_premul_x3(int nlayers, const void *const *wp16x3, const f
     static const bool no_xcd = getenv("PA_CHAIN_NO_XCD_REMAP") != nullptr;
     a.xcd_remap = no_xcd ? 0 : 1;
     const size_t lds = 2 * 32 * 1024 + 7 * 1024;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fpx3_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(fpx3_kernel<4>, dim3(pa_div_up(rows, 64)), dim3(256), lds, (hipStream_t)stream, a);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fpx3_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((fpx3_kernel<4, false>), dim3(pa_div_up(rows, 64)), dim3(256), lds, (hipStream_t)stream, a);
     PA_CHECK_LAUNCH("pa_fp_chain_premul_x3");
+    return PA_OK;
+}
+
+// The pre-multiply of that level in the same arithmetic: out[r][:] = x[r][:256] . W for the (256 x 256) interpolated-part slice W of the first
+// layer; wp16x3 / inv_scale as above (one layer).  fp32 output (the table pa_fp_chain_premul_x3 gathers from).
+PA_API int pa_linear_x3(long rows, const float *x, int ldx, const void *wp16x3, float inv_scale, float *out, int ldo, pa_stream_t stream)
+{
+    PA_REQUIRE(rows > 0 && x && wp16x3 && out && ldx >= 256 && ldx % 4 == 0 && ldo >= 256 && ldo % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0,
+               "pa_linear_x3: needs 256-wide 16-byte aligned rows");
+    Fpx3Args a = {};
+    a.rows = rows; a.x = x; a.ldx = ldx; a.wq[0] = reinterpret_cast<const half8 *>(wp16x3); a.inv_scale[0] = inv_scale; a.out = out; a.ldo = ldo;
+    a.xcd_remap = 0;
+    const size_t lds = 2 * 32 * 1024 + 7 * 1024;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fpx3_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((fpx3_kernel<4, true>), dim3(pa_div_up(rows, 64)), dim3(256), lds, (hipStream_t)stream, a);
+    PA_CHECK_LAUNCH("pa_linear_x3");
     return PA_OK;
 }

@@ -176,16 +176,17 @@ class _Chain:
         # opt-in "f32x3" (model.mlp_dtype): the two 256 -> 256 layers of the finest level from (hi, lo) fp16 operand pairs (csrc/fpx_f32x3.hip)
         self._premul["x3"] = None
         if x3 and not self.f16 and c2 == 256 and n0 == 256 and 1 <= c1 <= 4 and m == 2 and all(l[3] == 256 and l[4] == 256 for l in rest):
-            bufs, inv = [], []
-            for l in rest:
-                w = l[0]
+            def hilo(w):
                 s = int(torch.floor(torch.log2(1024.0 / w.abs().max().clamp_min(1e-30))).item())
                 s = max(min(s, 24), -24)
                 ws = w * (2.0 ** s)                                   # exact
                 hi = ws.half().float()
-                bufs.append(torch.cat([pack_weights_f16(hi.contiguous()), pack_weights_f16((ws - hi).contiguous())]))
-                inv.append(2.0 ** -s)
-            self._premul["x3"] = {"bufs": bufs, "wq": (ctypes.c_void_p * 2)(*[b.data_ptr() for b in bufs]), "inv": (ctypes.c_float * 2)(*inv)}
+                return torch.cat([pack_weights_f16(hi.contiguous()), pack_weights_f16((ws - hi).contiguous())]), 2.0 ** -s
+            packed = [hilo(l[0]) for l in rest]
+            bufs, inv = [b for b, _ in packed], [i for _, i in packed]
+            w1a3, inv1a = hilo(w1a)
+            self._premul["x3"] = {"bufs": bufs, "wq": (ctypes.c_void_p * 2)(*[b.data_ptr() for b in bufs]), "inv": (ctypes.c_float * 2)(*inv),
+                                  "w1a": w1a3, "inv1a": inv1a}
         if kperm and not self.f16 and m == 2 and all(l[2] == 256 and l[4] == 256 for l in rest):
             self._premul["kperm"] = [pack_weights_kperm(l[0]) for l in rest]
 
@@ -228,6 +229,9 @@ class _Chain:
             return out
         if g_pre is not None:       # the coarser level's chain already produced known_feat . w1a (attach_tail)
             g = g_pre
+        elif pm.get("x3") is not None and not tail:      # opt-in f32x3: the pre-multiply in the same split-operand arithmetic
+            g = torch.empty((B * m_known, pm["n0"]), dtype=torch.float32, device=dev)
+            call("pa_linear_x3", B * m_known, ptr(known_feat), c2, ptr(pm["x3"]["w1a"]), ctypes.c_float(pm["x3"]["inv1a"]), ptr(g), pm["n0"])
         else:
             g = torch.empty((B * m_known, pm["n0"]), dtype=torch.float32, device=dev)
             call("pa_linear_f16" if self.f16 else "pa_linear", B * m_known, c2, pm["n0"], ptr(known_feat), c2, ptr(pm["w1a"]), ptr(pm["w1a_p"]),
