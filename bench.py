@@ -499,7 +499,9 @@ def extras(a):
             fl = 2.0 * rows * (256 * 256 * 2 + 3 * 256)
             ms = st.get("fp0.chain")
             if ms:
-                peak = MFMA_F16_PEAK_TFLOPS if mlp_dtype == "f16" else MFMA_F32_PEAK_TFLOPS      # f32x3: priced against the fp32 peak it replaces (3x the FLOPs on the fp16 pipe)
+                peak = MFMA_F32_PEAK_TFLOPS if mlp_dtype == "f32" else MFMA_F16_PEAK_TFLOPS
+                if mlp_dtype == "f32x3":
+                    fl = 3.0 * 2.0 * rows * (256 * 256 * 2) + 2.0 * rows * 3 * 256      # ISSUED on the fp16 pipe: three MFMAs per product of the two dense layers
                 byts = rows * 256 * 4.0 + rows * (3 * 4 + 3 * 4 + 3 * 4) + (rows // 4) * 256 * (2.0 if mlp_dtype == "f16" else 4.0)      # output + (idx3, w3, xyz) + the pre-multiplied known rows once
                 res["roofline"] = {"kernel": {"f16": "fpx16_kernel<4,2,2> (fpx_f16.hip: weights shared through LDS, activations in registers, fp16 pre-multiplied table)", "f32": "chain_kernel<1,16,FPX,0,1>",
                                               "f32x3": "fpx3_kernel<4> (fpx_f32x3.hip: three fp16 MFMAs per product from (hi, lo) operand pairs)"}[mlp_dtype] + " (fp0: finest feature-propagation chain)",

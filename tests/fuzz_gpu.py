@@ -356,6 +356,34 @@ def f_fpx16():
         return f"B={B} n={n} m={m} c1={c1} mode={mode} g16={g16} err={err}"
 
 
+def f_fpx3():
+    """opt-in "f32x3" (fpx_f32x3.hip: the finest FP level and its pre-multiply from (hi, lo) fp16 operand pairs) against float64 at the FP32 families'
+    tolerance, 2e-5 of the scale; any row count, weights of random magnitude (the per-layer power-of-two scale)"""
+    from tests.test_gpu_chain import make_layers, mlp_ref
+    from patchaugnet_amd.engine import _Chain
+    B, n, m, c1 = int(rng.integers(1, 4)), logint(1, 6000), logint(1, 1200), int(rng.integers(1, 5))
+    seed = int(rng.integers(0, 1 << 30))
+    ref, eng = make_layers([256 + c1, 256, 256, 256], seed=seed)
+    mag = float(2.0 ** rng.integers(-6, 7))                       # layer weights from 2^-6 to 2^6 times the usual
+    ref = [(w * (mag if i == 1 else 1.0), b) for i, (w, b) in enumerate(ref)]
+    eng = [((wt * (mag if i == 1 else 1.0)).contiguous(), b, k, kp, nn) for i, (wt, b, k, kp, nn) in enumerate(eng)]
+    g = torch.Generator().manual_seed(seed + 1)
+    known = torch.randn(B, m, 256, generator=g) * float(2.0 ** rng.integers(-3, 6))
+    skip = torch.randn(B, n, c1, generator=g)
+    idx3 = torch.randint(0, m, (B, n, 3), generator=g).int()
+    w3 = torch.rand(B, n, 3, generator=g)
+    w3 = (w3 / w3.sum(-1, keepdim=True)).contiguous()
+    ch = _Chain(eng)
+    ch.build_premul(256, c1, x3=True)
+    got = ch.fp_premul(known.cuda(), idx3.cuda(), w3.cuda(), skip.cuda(), B, n, m, 256, c1)
+    bi = torch.arange(B)[:, None]
+    interp = sum(w3[..., t:t + 1].double() * known.double()[bi, idx3[:, :, t].long()] for t in range(3))
+    exp = mlp_ref(torch.cat([interp, skip.double()], -1), [(w.float().double(), b.float().double()) for w, b in ref]).reshape(B * n, -1)
+    err = (got.double().cpu() - exp).abs().max().item()
+    if not err <= 2e-5 * (exp.abs().max().item() + 1e-12):
+        return f"B={B} n={n} m={m} c1={c1} mag={mag} err={err} scale={exp.abs().max().item()}"
+
+
 def f_attention_f16():
     """the fp16 attention (attention_f16.hip: hi / lo logits, column-online scaling, fused layer behind it where the engine fuses) against the
     fp32 oracle statement: cosine of every point's output row >= 0.999 and max error <= 2e-2 of the scale"""
@@ -514,7 +542,7 @@ def f_train_glue():
 
 FAMILIES = (("fps", f_fps), ("knn", f_knn), ("3nn", f_3nn), ("knn_grid", f_knn_grid), ("3nn_grid", f_3nn_grid), ("gather", f_gather), ("backward", f_backward), ("linear", f_linear),
             ("attention", f_attention), ("chain_sa", f_chain_sa), ("chain_fp", f_chain_fp), ("netvlad", f_netvlad), ("afa", f_afa), ("linear_lds", f_linear_lds), ("train_glue", f_train_glue),
-            ("sa_mid", f_sa_mid), ("fpx16", f_fpx16), ("attention_f16", f_attention_f16))
+            ("sa_mid", f_sa_mid), ("fpx16", f_fpx16), ("attention_f16", f_attention_f16), ("fpx3", f_fpx3))
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:
