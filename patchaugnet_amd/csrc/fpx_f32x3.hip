@@ -32,13 +32,14 @@ struct Fpx3Args {
     const float *b[2];
     float *out;
     int ldo, n_unknown, m_known, c1, xcd_remap;
+    long long *dbg;       // profiling only (pa_chain_debug_buffer): cycle stamps of the first 512 wave tiles
     const float *x;       // PREMUL form: out[r][:] = x[r][:256] . W (one layer, no bias / ReLU), rows = rows of x
     int ldx;
 };
 
 __device__ __forceinline__ int r_ofs3(int ct, int g) { return 32 * (ct >> 1) + 8 * g + 4 * (ct & 1); }
 
-template <int WAVES, bool PREMUL>
+template <int WAVES, bool PREMUL, bool DBG = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void fpx3_kernel(Fpx3Args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fpx3_lds[];
@@ -49,6 +50,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fpx3_kernel(Fpx3Args a)
     float *cst = reinterpret_cast<float *>(fpx3_lds + 2 * SLAB);   // wskip[4][256], bias0[256], b2[256], b3[256]
     const long nblk = gridDim.x;
     const long blk = (a.xcd_remap && (nblk & 7) == 0) ? (long)(blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3) : (long)blockIdx.x;
+    unsigned *stamps = reinterpret_cast<unsigned *>(fpx3_lds + 2 * SLAB + 7 * 1024);   // profiling build only: branch-free LDS stamps
+#define FPX3_STAMP(i) do { if (DBG) stamps[wave * 8 + (i)] = (unsigned)__builtin_readcyclecounter(); } while (0)
+    FPX3_STAMP(0);
 
     // slab s = (layer s / 8, k-step s % 8) into buffer s & 1; piece p = (part p / 16: hi, lo; column tile p % 16), source lanes permuted so that
     // the fragment's columns come out in r-order (fpx_f16.hip)
@@ -121,6 +125,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fpx3_kernel(Fpx3Args a)
 #pragma unroll
     for (int t = 0; t < 3; ++t) gp[t] = a.g + (size_t)(cloud * a.m_known + nb[t]) * 256 + 8 * g;
     __syncthreads();   // cst visible
+    FPX3_STAMP(1);
 #pragma unroll
     for (int q = 0; q < 8; q += 4) {   // 24 16-byte gathers in flight
         __builtin_amdgcn_sched_barrier(0);
@@ -161,6 +166,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fpx3_kernel(Fpx3Args a)
 
     }
 
+    FPX3_STAMP(2);
     // ---- the two layers: one barrier per k-step slab ---------------------------------------------------------------------------------------
     floatx4 acc[16];
     unsigned off0 = lane * 16u, off1 = SLAB + lane * 16u;
@@ -171,6 +177,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fpx3_kernel(Fpx3Args a)
     for (int s = 0; s < NSLAB; ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (s == 0) FPX3_STAMP(3);
         if (s >= 1 && s + 1 < NSLAB) fetch(s + 1);
         if ((s & 7) == 0) {
 #pragma unroll
@@ -194,6 +201,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fpx3_kernel(Fpx3Args a)
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        if (s == 7) FPX3_STAMP(4);
         if (!PREMUL && s == 7) {   // h2 = relu(acc 2^-s + b2), split again, straight from the accumulators
             const float is = a.inv_scale[0];
 #pragma unroll
@@ -207,6 +215,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fpx3_kernel(Fpx3Args a)
         }
     }
 
+    FPX3_STAMP(5);
     // ---- out = relu(acc 2^-s + b3)  (PREMUL: out = acc 2^-s) ------------------------------------------------------------------------------
     if (row < a.rows) {
         const float is = a.inv_scale[PREMUL ? 0 : 1];
@@ -223,9 +232,24 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fpx3_kernel(Fpx3Args a)
             }
         }
     }
+    if (DBG) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        FPX3_STAMP(6);
+        if (blk * WAVES + wave < 512 && lane < 7) a.dbg[(blk * WAVES + wave) * 8 + lane] = (long long)stamps[wave * 8 + lane];
+    }
+#undef FPX3_STAMP
 }
 
+// Measured limit of this form (tools/fpx3_time.py, phase stamps): of 61.8 k cycles per 64-row workgroup 35.7 k are the layers, and those are bound by
+// the LDS fragment reads -- a 16-row wave tile reads 32 KB of (hi, lo) fragments per k-step for 48 MFMAs; with two co-resident workgroups that is
+// 256 KB per k-step and CU = 2 k cycles at the LDS's 128 B/clk.  Twice the rows per fragment read needs the (hi, lo) operands of 32 rows + 128
+// accumulators = 256 registers before anything else, i.e. one wave per SIMD and the memory phases hidden in software; a persistent build of that
+// shape (next tile's gathers consumed into a second operand set under the current tile's layers) needs ~650 registers as written (144 spilled) and
+// was dropped.  Open: the second operand set in LDS, or 32x32x16 MFMAs (half the fragment bytes per MAC).
+
 }  // namespace
+
+long long *pa_chain_dbg_ptr();   // mlp_chain.hip
 
 // pa_fp_chain_premul for the finest level's shape (c2 = 256, 1 <= c1 <= 4, two remaining 256 -> 256 layers) with every dense-layer product
 // evaluated from (hi, lo) fp16 operand pairs (three fp16 MFMAs, ~2^-21 relative).  wp16x3[l]: 131072 halfs = pa_pack_weights_f16(256, 256) of
@@ -246,9 +270,11 @@ PA_API int pa_fp_chain_premul_x3(int nlayers, const void *const *wp16x3, const f
     a.out = out; a.ldo = ldo; a.n_unknown = n_unknown; a.m_known = m_known; a.c1 = c1;
     static const bool no_xcd = getenv("PA_CHAIN_NO_XCD_REMAP") != nullptr;
     a.xcd_remap = no_xcd ? 0 : 1;
-    const size_t lds = 2 * 32 * 1024 + 7 * 1024;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fpx3_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((fpx3_kernel<4, false>), dim3(pa_div_up(rows, 64)), dim3(256), lds, (hipStream_t)stream, a);
+    a.dbg = pa_chain_dbg_ptr();
+    const size_t lds = 2 * 32 * 1024 + 7 * 1024 + (a.dbg ? 256 : 0);
+    auto kern = a.dbg ? fpx3_kernel<4, false, true> : fpx3_kernel<4, false, false>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(pa_div_up(rows, 64)), dim3(256), lds, (hipStream_t)stream, a);
     PA_CHECK_LAUNCH("pa_fp_chain_premul_x3");
     return PA_OK;
 }

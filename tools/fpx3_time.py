@@ -30,3 +30,20 @@ for name, x3 in (("fp32 MFMA (chain_kernel<1,16,FPX>)", False), ("split fp16 ope
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 50 * 1e3)
     print(f"{name}: {best:.1f} us per launch", flush=True)
+# phase stamps of the split kernel (profiling build: same code + seven LDS stamp stores per wave)
+import ctypes
+import numpy as np
+from patchaugnet_amd import _lib
+lib = _lib.lib()
+lib.pa_chain_debug_buffer.argtypes = [ctypes.c_void_p]
+lib.pa_chain_debug_buffer.restype = None
+buf = torch.zeros(512 * 8, dtype=torch.int64, device="cuda")
+lib.pa_chain_debug_buffer(ctypes.c_void_p(buf.data_ptr()))
+ch.fp_premul(known, idx3, w3, skip, B, n, m, c2, c1, g_pre=gk)
+torch.cuda.synchronize()
+lib.pa_chain_debug_buffer(None)
+t = buf.view(512, 8).cpu().numpy()[:, :7]
+t = t[t[:, 6] != 0]
+d = (t[:, 1:] - t[:, :-1]) & 0xffffffff
+names = ["setup+idx", "gather", "wait W", "layer2", "layer3", "store"]
+print(f"fpx3 ({len(t)} wave tiles, cycles): " + "  ".join(f"{nm} {np.median(d[:, i]):.0f}" for i, nm in enumerate(names)), " total", np.median((t[:, 6] - t[:, 0]) & 0xffffffff), flush=True)
