@@ -1256,7 +1256,12 @@ static int netvlad_pyramid(int b, int nscales, const int *n, const int *k, const
     fm.nscales = nscales;
     int ktot = 0;
     for (int s = 0; s < nscales; ++s) {
-        const int kp = (k[s] + 15) & ~15, kt = kp / 16, chunks = vlad_chunks(n[s]), rows = vlad_rows_per_wg(n[s]);
+        const int kp = (k[s] + 15) & ~15, kt = kp / 16;
+        int chunks = vlad_chunks(n[s]), rows = vlad_rows_per_wg(n[s]);
+        // the 16-bit kernel is one eight-wave workgroup per CU: 512 rows each = one round of 256 workgroups at B = 32 and half the partial volume
+        // (16.7 instead of 33 MB; the scratch is sized for the smaller chunks).  PA_VLAD16_ROWS = A/B knob
+        static const int rows16 = getenv("PA_VLAD16_ROWS") ? atoi(getenv("PA_VLAD16_ROWS")) : 512;
+        if (kt == 4 && wc16 && wc16[s] && n[s] >= 2048 && rows16 >= rows && rows16 % V16_ROWS == 0) { rows = rows16; chunks = (n[s] + rows - 1) / rows; }
         const bool run = kp == 16 ? (phases & 1) : (phases & 2);
         PA_REQUIRE(n[s] > 0 && k[s] > 0 && k[s] <= 64 && (x[s] || !run) && wc_t[s] && bias[s] && w2[s] && scratch[s],
                    "pa_netvlad_pyramid: scale %d: bad arguments (<= 64 clusters)", s);
