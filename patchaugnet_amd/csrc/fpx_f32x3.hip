@@ -244,8 +244,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fpx3_kernel(Fpx3Args a)
 // the LDS fragment reads -- a 16-row wave tile reads 32 KB of (hi, lo) fragments per k-step for 48 MFMAs; with two co-resident workgroups that is
 // 256 KB per k-step and CU = 2 k cycles at the LDS's 128 B/clk.  Twice the rows per fragment read needs the (hi, lo) operands of 32 rows + 128
 // accumulators = 256 registers before anything else, i.e. one wave per SIMD and the memory phases hidden in software; a persistent build of that
-// shape (next tile's gathers consumed into a second operand set under the current tile's layers) needs ~650 registers as written (144 spilled) and
-// was dropped.  Open: the second operand set in LDS, or 32x32x16 MFMAs (half the fragment bytes per MAC).
+// shape (next tile's gathers consumed into a second operand set under the current tile's layers) was built three ways and dropped: both operand sets
+// in registers spills 144; sixteen unrolled slab steps are 200 KB of code (instruction-cache bound: 428 us); half of the second set in a wave-private
+// LDS stage with the layer loop rolled still spills 73 and runs in 214 us (all three bit-correct).  Open: 32x32x16 MFMAs do not change the count
+// (the tile's operands and accumulators are the same registers); the operand set of row tile 1 read from LDS per k-step instead of held.
 
 }  // namespace
 
