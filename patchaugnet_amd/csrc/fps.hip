@@ -44,6 +44,16 @@ __device__ __forceinline__ int fps_decode(u32 lowkey, FpsOrder o)
     return (int)((q << o.log2bs) | r);
 }
 
+// fminf(d, t) for a d that comes out of arithmetic and a running minimum t: v_min_f32 returns the other operand for a quiet NaN exactly as fminf does; the
+// compiler's form first quiets a possible SIGNALLING NaN in t (v_max_f32 t, t -- one more instruction per point and round), which only a caller-supplied
+// temp buffer could hold: the launcher's load canonicalises those once instead.
+__device__ __forceinline__ float fps_min(float d, float t)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(d), "v"(t));
+    return r;
+}
+
 // Register-resident path: NT threads, PPT points per lane, n <= NT*PPT.
 // LDSXYZ = true: cloud copy in LDS (SoA, 12 B/point: 48 KB at n = 4096), the winner's coordinates are read from it after the barrier.
 // LDSXYZ = false (opt-in, see fps_lds_xyz below): no cloud copy.  Each wave fetches ITS winner's coordinates from the owning lane's registers (uniform register index
@@ -98,7 +108,7 @@ __global__ __launch_bounds__(NT * CPW) void fps_reg_kernel(int n, int m, FpsOrde
             px[p] = xyz[k * 3 + 0];
             py[p] = xyz[k * 3 + 1];
             pz[p] = xyz[k * 3 + 2];
-            t[p] = temp ? temp[k] : 1e10f;
+            t[p] = temp ? __builtin_canonicalizef(temp[k]) : 1e10f;     // quiets a signalling NaN once (see fps_min)
             low[p] = fps_lowkey(k, ord);
             if (LDSXYZ) {
                 sx[k] = px[p];
@@ -122,17 +132,46 @@ __global__ __launch_bounds__(NT * CPW) void fps_reg_kernel(int n, int m, FpsOrde
     }
     if (tid == 0 && nxyz && j_begin == 0 && !ghost) { nxyz[0] = ox; nxyz[1] = oy; nxyz[2] = oz; }
 
+    // The round's arithmetic on PAIRS of points (PAIRED): the packed fp32 instructions of gfx950 (v_pk_add_f32 / v_pk_mul_f32: two IEEE operations per lane and
+    // issue slot, each rounded exactly like its scalar form, so d is the same bits) take two points' dx, dy, dz, their squares and the two sums in eight
+    // instructions; the compiler's own packing of the scalar loop pairs (z, x) of ONE point and leaves y scalar: six per point, plus a v_max t, t in front
+    // of every fminf (quieting a signalling NaN the running minimum can never be).  Ten instructions per pair against sixteen: the round is ~60 % VALU
+    // issue at one wave per SIMD (the rest is the DPP maximum and three LDS round trips).
+    constexpr bool PAIRED = LDSXYZ && PPT % 2 == 0 && PPT >= 2;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 qx[PAIRED ? PPT / 2 : 1], qy[PAIRED ? PPT / 2 : 1], qz[PAIRED ? PPT / 2 : 1];
+    if (PAIRED) {
+#pragma unroll
+        for (int h = 0; h < PPT / 2; ++h) {
+            qx[h] = (f2){px[2 * h], px[2 * h + 1]};
+            qy[h] = (f2){py[2 * h], py[2 * h + 1]};
+            qz[h] = (f2){pz[2 * h], pz[2 * h + 1]};
+        }
+    }
     for (int j = max(j_begin, 1); j < j_end; ++j) {
         // (a two-pass form -- the largest minimum with three-operand maxima, then the largest low key among the points that have it: 48 instead of
         // ~110 instructions -- was measured SLOWER, 0.755 vs 0.69 us per round: the second pass cannot start before the first ends, while the running
         // 64-bit maximum overlaps the distance arithmetic)
         u64 best = 0;
+        if (PAIRED) {
+            const f2 o2x = (f2){ox, ox}, o2y = (f2){oy, oy}, o2z = (f2){oz, oz};
 #pragma unroll
-        for (int p = 0; p < PPT; ++p) {
-            const float dx = px[p] - ox, dy = py[p] - oy, dz = pz[p] - oz;
-            const float d = dx * dx + dy * dy + dz * dz;  // sampling_cuda_kernel.cu:93
-            t[p] = fminf(d, t[p]);                        // :94
-            best = pa_max_u64(best, pa_make_key(t[p], low[p]));
+            for (int h = 0; h < PPT / 2; ++h) {
+                const f2 dx = qx[h] - o2x, dy = qy[h] - o2y, dz = qz[h] - o2z;
+                const f2 d = dx * dx + dy * dy + dz * dz;     // sampling_cuda_kernel.cu:93, two points
+                t[2 * h] = fps_min(d.x, t[2 * h]);            // :94
+                t[2 * h + 1] = fps_min(d.y, t[2 * h + 1]);
+                best = pa_max_u64(best, pa_make_key(t[2 * h], low[2 * h]));
+                best = pa_max_u64(best, pa_make_key(t[2 * h + 1], low[2 * h + 1]));
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < PPT; ++p) {
+                const float dx = px[p] - ox, dy = py[p] - oy, dz = pz[p] - oz;
+                const float d = dx * dx + dy * dy + dz * dz;  // sampling_cuda_kernel.cu:93
+                t[p] = fminf(d, t[p]);                        // :94
+                best = pa_max_u64(best, pa_make_key(t[p], low[p]));
+            }
         }
         u64 g = pa_wave_max_key2(best);   // two 32-bit DPP reductions: -1 % per round against the 64-bit form (the round is bound by the LDS / barrier round trips)
         int old;

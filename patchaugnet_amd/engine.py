@@ -714,7 +714,12 @@ class PatchAugNetEngine:
     def stale(self, model):
         return self._key != self._params_key(model)
 
-    def backbone(self, xyz, early=None):
+    def sample_first_level(self, xyz, cidx0, nxyz0):
+        """The first level's farthest-point sampling alone, into caller-owned buffers ((B, m) int32 indices, (B, m, 3) centres): the
+        launch extract.GraphedExtractor puts on its sampling streams; hand the buffers to forward(..., s0=(cidx0, nxyz0))."""
+        call("pa_furthestsampling_gather", xyz.shape[0], xyz.shape[1], self.sampling[0], ptr(xyz), ptr(cidx0), ptr(nxyz0))
+
+    def backbone(self, xyz, early=None, s0=None):
         """xyz (B, N, 3) -> point-major features per level + level-0 centre indices.  early(l_feat): called once the decoder has written every
         level but the finest (the engine issues the coarse NetVLAD scales there).
 
@@ -735,6 +740,8 @@ class PatchAugNetEngine:
         off = L - nfp                              # FP level j interpolates level j + off + 1's features onto level j + off's points
         w3 = [torch.empty((B, npts[j + off], 3), dtype=torch.float32, device=dev) for j in range(nfp)]
         idx3 = [torch.empty((B, npts[j + off], 3), dtype=torch.int32, device=dev) for j in range(nfp)]
+        if s0 is not None:                         # first level already sampled (sample_first_level on another stream)
+            cidx[0], nxyz[0] = s0
         l_xyz = [xyz] + nxyz
 
         def fps(i):
@@ -764,7 +771,7 @@ class PatchAugNetEngine:
         # (pa_furthestsampling_range / pa_knnquery_window / pa_sa_group_window).  Only when the level runs the kernels that take windows
         # (the 4096-point configurations of both models); bit-identical to the one-launch form.
         y0 = None
-        chunks = self._first_level_chunks(npts, self.knn[0]) if overlap else None
+        chunks = self._first_level_chunks(npts, self.knn[0]) if overlap and s0 is None else None
         if chunks:
             side = self._geo_streams.get(("sa0", main.cuda_stream))
             if side is None:
@@ -783,7 +790,7 @@ class PatchAugNetEngine:
             ev_y0.record(side)
             for t in (temp, y0, cidx[0], nxyz[0], nbr[0], d2[0], xyz):
                 t.record_stream(side)
-        else:
+        elif s0 is None:
             fps(0)
         self._mark("sa0.fps")
         if overlap:
@@ -878,14 +885,15 @@ class PatchAugNetEngine:
                 early(l_feat)        # every decoder level but the finest exists: the coarse NetVLAD scales read them while they are cache-resident
         return l_feat, l_c
 
-    def forward(self, x, views=True):
-        """-> desc (B, 256), (fp_features views, level-0 centre indices); views=False skips the index mapping (descriptor-only callers)."""
+    def forward(self, x, views=True, s0=None):
+        """-> desc (B, 256), (fp_features views, level-0 centre indices); views=False skips the index mapping (descriptor-only callers).
+        s0: (indices, centres) of the first level when sample_first_level already ran for this x."""
         if x.device.index is not None and x.device.index != torch.cuda.current_device():
             with torch.cuda.device(x.device):        # the C ABI launches on the CURRENT device's stream: follow the tensor
-                return self._forward(x, views)
-        return self._forward(x, views)
+                return self._forward(x, views, s0)
+        return self._forward(x, views, s0)
 
-    def _forward(self, x, views):
+    def _forward(self, x, views, s0=None):
         xyz = x.squeeze(1).contiguous()
         self._mark("start")
         nfp = len(self.fp)
@@ -900,7 +908,7 @@ class PatchAugNetEngine:
         def early(l_feat):
             coarse = [l_feat[j].contiguous() for j in range(nfp - 1, 0, -1)]
             pyr.launch(st, coarse + [None], v, 1)
-        l_feat, l_c = self.backbone(xyz, early if split else None)
+        l_feat, l_c = self.backbone(xyz, early if split else None, s0)
         feats = [l_feat[j] for j in range(nfp - 1, -1, -1)]                                   # coarse -> fine, (B, N_i, 256)
         if pyr is not None:
             fc = [f.contiguous() for f in feats]

@@ -23,14 +23,20 @@ def _as_tensor(a):
 
 
 def run_model(model, queries, positives, negatives, other_neg, nn_dict=None, num_points=4096, require_grad=True, device=None, args=DEFAULTS,
-              geometry=None):
+              geometry=None, input_grad=False):
     """train_place_recognition.py:142-164.  queries (bs,1,N,3), positives (bs,P,N,3), negatives (bs,Nn,N,3), other_neg (bs,1,N,3);
-    returns {'global_desc': (q, pos, neg, other) split along dim 1, 'patch_recon': dict or None}."""
+    returns {'global_desc': (q, pos, neg, other) split along dim 1, 'patch_recon': dict or None}.
+
+    input_grad: the reference marks the FEED as requiring a gradient (:155 ``feed_tensor.requires_grad_(require_grad)``), which makes autograd carry a
+    gradient with respect to the input coordinates through every level -- the first layers' dX contractions, the grouping / interpolation scatters of
+    the coordinate channels, the 3-NN weight arithmetic -- into a tensor the training loop drops (nothing reads feed.grad; losses and every PARAMETER
+    gradient are the same without it: tests/test_gpu_train_full.py holds them against the reference run).  Default off; True restores the
+    reference's graph for callers that want d loss / d coordinates."""
     device = device or next(model.parameters()).device
     q = _as_tensor(queries)
     # the four groups go to the device first and are concatenated there (a host-side cat spins the ATen thread pool, hostcpu.py)
     feed = torch.cat([_as_tensor(t).to(device, non_blocking=True) for t in (q, positives, negatives, other_neg)], 1)
-    feed = feed.view((-1, 1, num_points, 3)).requires_grad_(require_grad)
+    feed = feed.view((-1, 1, num_points, 3)).requires_grad_(bool(require_grad and input_grad))
     kw = {} if geometry is None else {"geometry": geometry}      # coordinate-only launches done ahead of time (GraphedTrainer(prefetch=True))
     with torch.set_grad_enabled(require_grad):
         out = model(feed, nn_dict, return_feat=False, **kw) if nn_dict is not None else model(feed, return_feat=False, **kw)
