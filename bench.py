@@ -143,7 +143,7 @@ DOMINANT_KERNEL_RE = r"chain_kernel<[12], 16, 3, false, 1[,>]"     # fp0 feature
 GROUPING_KERNEL_RE = r"group_lds_kernel<4>"
 
 
-def measure_traffic(batch, points):
+def measure_traffic(batch, points, target=None, patterns=None):
     """HBM bytes per launch of the dominant kernel and of the graded gather, measured NOW: two rocprofv3 passes (FETCH_SIZE and
     WRITE_SIZE cannot share a pass on gfx950: MI355X_MICROARCH.md, PMC slots) over tools/pmc_target.py, which runs the same engine
     steps at the same shape in a child process.  Correction per the guide's HBM section: the counters are KiB; FETCH_SIZE reports
@@ -164,15 +164,15 @@ def measure_traffic(batch, points):
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
-            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable, os.path.join(ROOT, "tools", "pmc_target.py"),
-                   "--batch", str(batch), "--points", str(points)]
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable] + (
+                target or [os.path.join(ROOT, "tools", "pmc_target.py"), "--batch", str(batch), "--points", str(points)])
             res = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
             dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith("results.db")]
             if res.returncode != 0 or not dbs:
                 return None, f"rocprofv3 --pmc {counter} failed (rc {res.returncode}): {res.stdout[-300:]}"
             c = sqlite3.connect(dbs[0])
             for name, avg, n in c.execute("select kernel_name, avg(value), count(*) from counters_collection where counter_name = ? group by kernel_name", (counter,)):
-                for tag, rx in (("dominant", DOMINANT_KERNEL_RE), ("grouping", GROUPING_KERNEL_RE)):
+                for tag, rx in (patterns or (("dominant", DOMINANT_KERNEL_RE), ("grouping", GROUPING_KERNEL_RE))):
                     if re.search(rx, name):
                         out.setdefault(tag, {})[counter] = avg * 1024.0
                         out[tag]["launches_sampled"] = n
@@ -185,7 +185,8 @@ def measure_traffic(batch, points):
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             res[tag] = {"bytes_per_launch": 2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"], "FETCH_SIZE_bytes_raw": v["FETCH_SIZE"], "WRITE_SIZE_bytes": v["WRITE_SIZE"],
                         "launches_sampled": v["launches_sampled"]}
-    return (res or None), "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/pmc_target.py in this run; FETCH_SIZE x2 (gfx950, 16-B reads), KiB -> bytes"
+    return (res or None), ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/%s in this run; FETCH_SIZE x2 (gfx950, 16-B reads), "
+                           "KiB -> bytes" % (os.path.basename(target[0]) if target else "pmc_target.py"))
 
 
 def step_algorithmic_flops(model, batch, points):
@@ -328,7 +329,7 @@ def pcie_inclusive(model, a, pipe):
                     "the K steps after one warm-up repetition (never the headline value)"}
 
 
-def train_bench(a, emit=True):
+def train_bench(a, emit=True, pmc=None):
     """BASELINE.json configs[3]: one training step per bench step -- the reference's native tuple of 18 clouds (1 query + 2 positives +
     14 negatives + 1 other negative, configs/patch_aug_net.yaml:60-62; BASELINE.json says batch=16, the reference's loader only makes
     18), nn_dict with 2 (query, positive) pairs => 3 related clouds through the decoder and the patch Chamfer loss, quadruplet loss,
@@ -384,6 +385,11 @@ def train_bench(a, emit=True):
     ms = ev_time_ms(lambda: train_ops.tgemm_nn(B, M, N, K, W, 0, K, True, X, K * N, N, Y, M * N, N, bmode=1, bp=pblk, stats=stats), iters=20)
     flops = 2.0 * B * M * N * K
     tf = flops / (ms * 1e-3) / 1e12
+    traffic = tnote = None
+    if (emit if pmc is None else pmc) and not a.no_pmc:      # HBM bytes of that launch: FETCH_SIZE / WRITE_SIZE passes over the same call in a child process (tools/tgemm_target.py)
+        pm, tnote = measure_traffic(0, 0, target=[os.path.join(ROOT, "tools", "tgemm_target.py"), "6", str(clouds)],
+                                    patterns=(("dominant", r"tgemm_nn_kernel<64, 16, true, 1, true, true>"),))
+        traffic = pm["dominant"]["bytes_per_launch"] if pm and "dominant" in pm else None
     line = {
         "metric": "training steps/sec (PatchAugNet quadruplet step, patch Chamfer reconstruction loss)", "value": a.steps / dt, "unit": "steps/s",
         "clouds_per_s": clouds * a.steps / dt, "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -399,7 +405,8 @@ def train_bench(a, emit=True):
                        "unrelated clouds); the captured graph replays every kernel of the step regardless, so the timing is representative",
         "roofline": {"kernel": "tgemm_nn_kernel<64,16,true,1> (pa_tgemm_nn: 256 -> 256 layer of the finest FP level, forward: BatchNorm + ReLU of the "
                                "previous layer in the loader, statistics in the epilogue)", "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None, "algorithmic_flops_per_launch": flops, "ms_per_launch": ms},
+                     "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": tnote,
+                     "algorithmic_bytes_per_launch": 4.0 * B * N * (M + K) + 4.0 * M * K, "algorithmic_flops_per_launch": flops, "ms_per_launch": ms},
     }
     if emit:
         print(json.dumps(line))
@@ -447,7 +454,7 @@ def extras(a):
     def train():
         b = copy.copy(a)
         b.steps, b.warmup, b.no_graphs, b.no_prefetch = 20, 3, False, False
-        line = train_bench(b, emit=False)
+        line = train_bench(b, emit=False, pmc=True)
         return {k: line[k] for k in ("ms_per_step", "value", "unit", "clouds_per_s", "roofline", "losses_last_step", "losses_note")} | {"workload": line["config"]["workload"]}
 
     def extract_rate(model_name, mlp_dtype):

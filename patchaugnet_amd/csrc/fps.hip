@@ -54,6 +54,14 @@ __device__ __forceinline__ float fps_min(float d, float t)
     return r;
 }
 
+// value pinned to vector registers (an empty asm with a "+v" operand is opaque to the uniformity analysis)
+__device__ __forceinline__ u64 fps_in_vgpr(u64 v)
+{
+    u32 lo = (u32)v, hi = (u32)(v >> 32);
+    asm("" : "+v"(lo), "+v"(hi));          // not volatile: the four slot reads stay one batch of loads
+    return ((u64)hi << 32) | lo;
+}
+
 // Register-resident path: NT threads, PPT points per lane, n <= NT*PPT.
 // LDSXYZ = true: cloud copy in LDS (SoA, 12 B/point: 48 KB at n = 4096), the winner's coordinates are read from it after the barrier.
 // LDSXYZ = false (opt-in, see fps_lds_xyz below): no cloud copy.  Each wave fetches ITS winner's coordinates from the owning lane's registers (uniform register index
@@ -180,8 +188,17 @@ __global__ __launch_bounds__(NT * CPW) void fps_reg_kernel(int n, int m, FpsOrde
                 u64 *s = slots + (j & 1) * NW;
                 if ((tid & 63) == 0) s[tid >> 6] = g;
                 __syncthreads();
+                // The slots are wave-uniform and the compiler would take the maximum on the SCALAR unit: a v_readfirstlane per half, a vector compare
+                // against a scalar pair, s_cselect, then the decode on scalars and three v_mov for the LDS addresses -- ~35 instructions with a
+                // vector -> scalar -> vector hand-over at every step of a chain every wave waits on.  Kept in vector registers it is 9 + 8 plain VALU
+                // instructions and the addresses are already where ds_read wants them.
+                u64 sv[NW];
 #pragma unroll
-                for (int w = 0; w < NW; ++w) g = pa_max_u64(g, s[w]);
+                for (int w = 0; w < NW; ++w) sv[w] = s[w];
+                u64 gv = fps_in_vgpr(sv[0]);
+#pragma unroll
+                for (int w = 1; w < NW; ++w) gv = pa_max_u64(gv, fps_in_vgpr(sv[w]));
+                g = gv;
             }
             old = fps_decode((u32)g, ord);
             ox = sx[old];
