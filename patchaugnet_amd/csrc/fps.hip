@@ -63,7 +63,7 @@ __device__ __forceinline__ u64 fps_in_vgpr(u64 v)
 }
 
 // Register-resident path: NT threads, PPT points per lane, n <= NT*PPT.
-// LDSXYZ = true: cloud copy in LDS (SoA, 12 B/point: 48 KB at n = 4096), the winner's coordinates are read from it after the barrier.
+// LDSXYZ = true: cloud copy in LDS ((x, y, z, -) by rank, 16 B/point: 64 KB at n = 4096), the winner's coordinates are read from it after the barrier.
 // LDSXYZ = false (opt-in, see fps_lds_xyz below): no cloud copy.  Each wave fetches ITS winner's coordinates from the owning lane's registers (uniform register index
 //   + v_readlane) and publishes (key, x, y, z) in its slot before the round's single barrier; after it every thread takes the slot
 //   with the largest key.  LDS: 256 bytes, so the 0.7 ms launch no longer keeps LDS-heavy kernels of other streams (the 132 KB
@@ -89,10 +89,14 @@ __global__ __launch_bounds__(NT * CPW) void fps_reg_kernel(int n, int m, FpsOrde
     static_assert((1 << LOG_NT) == NT, "NT must be a power of two");
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
     const int sub = CPW > 1 ? (int)threadIdx.x / NT : 0;                  // this thread's cloud inside the workgroup
-    const int per_cloud = 3 * n + ((3 * n) & 1) + 2 * NW * 2;            // floats of LDS per cloud: SoA copy + [2][NW] 64-bit slots
+    // The LDS copy of the cloud is indexed by RANK (the key's low half is ~rank): the winner's coordinates are one 16-byte read at (~low) * 16 straight
+    // from the selected key -- the decode of the point index (not, shift, bit reverse, shift, mask, shift, or) leaves the round's serial chain and only
+    // thread 0 runs it, for the index it stores.  Ranks without a point (n below a multiple of the reference's block size) are never read.
+    const int nrank = 1 << (ord.log2bs + ord.qbits);
+    const int per_cloud = 4 * nrank + 2 * NW * 2;                         // floats of LDS per cloud: (x, y, z, -) by rank + [2][NW] 64-bit slots
     float *smem = smem_all + (CPW > 1 ? sub * per_cloud : 0);
-    float *sx = smem, *sy = smem + n, *sz = smem + 2 * n;
-    u64 *slots = reinterpret_cast<u64 *>(smem + 3 * n + ((3 * n) & 1));  // 8-byte aligned, [2][NW]
+    float4 *sp = reinterpret_cast<float4 *>(smem);
+    u64 *slots = reinterpret_cast<u64 *>(smem + 4 * nrank);              // [2][NW]
     FpsSlot *rslots = reinterpret_cast<FpsSlot *>(smem);                  // LDSXYZ = false: [2][NW]
 
     const int tid = CPW > 1 ? (int)threadIdx.x - sub * NT : (int)threadIdx.x;
@@ -118,11 +122,7 @@ __global__ __launch_bounds__(NT * CPW) void fps_reg_kernel(int n, int m, FpsOrde
             pz[p] = xyz[k * 3 + 2];
             t[p] = temp ? __builtin_canonicalizef(temp[k]) : 1e10f;     // quiets a signalling NaN once (see fps_min)
             low[p] = fps_lowkey(k, ord);
-            if (LDSXYZ) {
-                sx[k] = px[p];
-                sy[k] = py[p];
-                sz[k] = pz[p];
-            }
+            if (LDSXYZ) sp[~low[p]] = make_float4(px[p], py[p], pz[p], 0.f);
         } else {  // padding: key 0 never beats a real point (real low keys are >= 1)
             px[p] = py[p] = pz[p] = 0.f;
             t[p] = 0.f;
@@ -133,8 +133,10 @@ __global__ __launch_bounds__(NT * CPW) void fps_reg_kernel(int n, int m, FpsOrde
     if (tid == 0 && j_begin == 0 && !ghost) idxs[0] = 0;
     float ox, oy, oz;
     if (LDSXYZ) {
+        if (NW > 1 && tid < 3) slots[tid] = 0;
         __syncthreads();
-        ox = sx[first]; oy = sy[first]; oz = sz[first];
+        const float4 o4 = sp[~fps_lowkey(first, ord)];
+        ox = o4.x; oy = o4.y; oz = o4.z;
     } else {
         ox = xyz[first * 3]; oy = xyz[first * 3 + 1]; oz = xyz[first * 3 + 2];
     }
@@ -156,6 +158,7 @@ __global__ __launch_bounds__(NT * CPW) void fps_reg_kernel(int n, int m, FpsOrde
             qz[h] = (f2){pz[2 * h], pz[2 * h + 1]};
         }
     }
+    int slot_i = 0;                                            // this round's selection slot (three rotate, see below)
     for (int j = max(j_begin, 1); j < j_end; ++j) {
         // (a two-pass form -- the largest minimum with three-operand maxima, then the largest low key among the points that have it: 48 instead of
         // ~110 instructions -- was measured SLOWER, 0.755 vs 0.69 us per round: the second pass cannot start before the first ends, while the running
@@ -181,31 +184,38 @@ __global__ __launch_bounds__(NT * CPW) void fps_reg_kernel(int n, int m, FpsOrde
                 best = pa_max_u64(best, pa_make_key(t[p], low[p]));
             }
         }
-        u64 g = pa_wave_max_key2(best);   // two 32-bit DPP reductions: -1 % per round against the 64-bit form (the round is bound by the LDS / barrier round trips)
+        u64 g;
         int old;
         if (LDSXYZ) {
             if (NW > 1) {
-                u64 *s = slots + (j & 1) * NW;
-                if ((tid & 63) == 0) s[tid >> 6] = g;
+                // Selection across the workgroup by the LDS atomic unit: ONE wave-level reduction (the largest minimum, six DPP steps), then the lanes
+                // that hold it -- one per wave unless minima tie exactly -- send their whole key to ds_max_u64 on this round's slot; the unit orders equal
+                // minima by the low half and the four waves against each other, and after the barrier the slot IS the selected key.  Against the form it
+                // replaces (second DPP reduction for the low half, a slot per wave, four slot reads and three 64-bit compare / select steps in every
+                // wave) the round loses ~30 dependent instructions: 0.58 -> see profiles/r04_ab_log.txt.  Three slots rotate: round j's is cleared
+                // during round j - 1 (thread 0, before that round's barrier; its last readers passed the barrier of round j - 2 ... j - 1 before).
+                const u32 hi = (u32)(best >> 32);
+                const u32 H = pa_wave_max_u32(hi);
+                u64 *cur = slots + slot_i;
+                slot_i = slot_i == 2 ? 0 : slot_i + 1;
+                if (tid == 0) slots[slot_i] = 0;
+                // (as inline assembly: hipcc's atomic optimizer rewrites __hip_atomic_fetch_max into a scalar loop over the active lanes -- fourteen
+                // instructions and two branches to save an LDS operation that one lane issues anyway; the wait belongs to the assembly too, the
+                // compiler's counter bookkeeping does not see the operation)
+                if (hi == H) asm volatile("ds_max_u64 %0, %1" : : "v"((u32)(uintptr_t)cur), "v"(best) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
                 __syncthreads();
-                // The slots are wave-uniform and the compiler would take the maximum on the SCALAR unit: a v_readfirstlane per half, a vector compare
-                // against a scalar pair, s_cselect, then the decode on scalars and three v_mov for the LDS addresses -- ~35 instructions with a
-                // vector -> scalar -> vector hand-over at every step of a chain every wave waits on.  Kept in vector registers it is 9 + 8 plain VALU
-                // instructions and the addresses are already where ds_read wants them.
-                u64 sv[NW];
-#pragma unroll
-                for (int w = 0; w < NW; ++w) sv[w] = s[w];
-                u64 gv = fps_in_vgpr(sv[0]);
-#pragma unroll
-                for (int w = 1; w < NW; ++w) gv = pa_max_u64(gv, fps_in_vgpr(sv[w]));
-                g = gv;
+                g = fps_in_vgpr(*cur);
+            } else {
+                g = pa_wave_max_key2(best);
             }
-            old = fps_decode((u32)g, ord);
-            ox = sx[old];
-            oy = sy[old];
-            oz = sz[old];
+            const float4 o4 = sp[~(u32)g];
+            ox = o4.x; oy = o4.y; oz = o4.z;
+            old = 0;
+            if (tid == 0) old = fps_decode((u32)g, ord);
         } else {
             // this wave's winner: point kw = owner thread + p * NT lives in register set p of lane kw % 64 of THIS wave (g is wave-uniform)
+            g = pa_wave_max_key2(best);
             const int kw = fps_decode((u32)g, ord);
             const int pw = __builtin_amdgcn_readfirstlane(kw >> LOG_NT), lw = __builtin_amdgcn_readfirstlane(kw & 63);
             const int pi = pw < PPT ? pw : 0;                             // a wave of padding lanes only decodes garbage (its key never wins)
@@ -309,7 +319,7 @@ int launch_reg(int b, int n, int m, FpsOrder ord, const float *xyz, float *temp,
         return 0;
     }
 #endif
-    const size_t lds = (size_t)(3 * n + ((3 * n) & 1)) * 4 + 2 * (NT / 64) * 8;
+    const size_t lds = ((size_t)16 << (ord.log2bs + ord.qbits)) + 2 * (NT / 64) * 8;      // the cloud by rank (see the kernel) + the slot pairs
     // clouds per workgroup (see the kernel): PA_FPS_CPW = 1 / 2 / 3, default from the A/B in profiles/r04_ab_log.txt; only where a cloud is a
     // 256-thread group and several clouds' copies fit the 160 KB of a CU
     // MEASURED AND NOT SHIPPED (test-only library): packing clouds frees CUs for the other streams' dense kernels (a 132 KB chain workgroup cannot share
