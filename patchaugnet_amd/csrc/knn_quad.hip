@@ -287,12 +287,18 @@ __global__ __launch_bounds__(NT) void knn_quad_kernel(int n, int m, int q_per_bl
             // ---- pass 3: exact keys to LDS, output slot = rank among the quad's keys
             const int off = (part > 0 ? c0 : 0) + (part > 1 ? c1 : 0) + (part > 2 ? c2 : 0);
             u64 *kq = keys + ql * (KQ_TCAP + 4);
+            // Every list entry's point is fetched in ONE batch of LDS reads (an entry that is no candidate reads position 0 or its own point: harmless)
+            // and its exact key built; the stores are predicated.  (One entry at a time behind a wave vote, each LDS read waited for, this block and
+            // the rank loop below were 18.5 k of the workgroup's 90 k cycles.)
+            u64 mine[KL];
+            {
+                float4 pj[KL];
 #pragma unroll
-            for (int j = 0; j < KL; ++j) {
-                if (!__any(j < qn)) break;
-                if (j < qn) {
-                    const float4 p = sorted[L[j] & ((1u << KQ_TAG) - 1u)];
-                    kq[off + j] = pa_make_key(dist(p), (u32)__float_as_int(p.w));
+                for (int j = 0; j < KL; ++j) pj[j] = sorted[L[j] & ((1u << KQ_TAG) - 1u)];
+#pragma unroll
+                for (int j = 0; j < KL; ++j) {
+                    mine[j] = pa_make_key(dist(pj[j]), (u32)__float_as_int(pj[j].w));
+                    if (j < qn) kq[off + j] = mine[j];
                 }
             }
             if (part == 0) { kq[total] = ~0ull; kq[total + 1] = ~0ull; kq[total + 2] = ~0ull; }      // the rank loop reads four keys per trip
@@ -301,16 +307,27 @@ __global__ __launch_bounds__(NT) void knn_quad_kernel(int n, int m, int q_per_bl
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (int e = 0; e < qn; ++e) {
-                const u64 mine = kq[off + e];
-                int rank = 0;
-                for (int t = 0; t < total; t += 4) {
-                    const u64 a0 = kq[t], a1 = kq[t + 1], a2 = kq[t + 2], a3 = kq[t + 3];
-                    rank += (a0 < mine ? 1 : 0) + (a1 < mine ? 1 : 0) + (a2 < mine ? 1 : 0) + (a3 < mine ? 1 : 0);
+            // ranks: every block of four keys is read once (the next block is in flight meanwhile) and compared with ALL of this lane's candidates --
+            // the loop over a lane's candidates with an LDS round trip per block inside it paid that latency qn times over
+            int rank[KL];
+#pragma unroll
+            for (int j = 0; j < KL; ++j) rank[j] = 0;
+            const int qmax = max(max(c0, c1), max(c2, c3));
+            u64 a0 = kq[0], a1 = kq[1], a2 = kq[2], a3 = kq[3];
+            for (int t = 0; t < total; t += 4) {
+                const u64 n0 = kq[t + 4], n1 = kq[t + 5], n2 = kq[t + 6], n3 = kq[t + 7];       // past the quad's keys: the next quad's (or the query order behind the last): never compared
+#pragma unroll
+                for (int j = 0; j < KL; ++j) {
+                    if (!__any(j < qmax)) break;
+                    rank[j] += (a0 < mine[j] ? 1 : 0) + (a1 < mine[j] ? 1 : 0) + (a2 < mine[j] ? 1 : 0) + (a3 < mine[j] ? 1 : 0);
                 }
-                if (rank < K) {
-                    idx_all[o + rank] = (int)(u32)mine;
-                    dist2_all[o + rank] = __uint_as_float((u32)(mine >> 32));
+                a0 = n0; a1 = n1; a2 = n2; a3 = n3;
+            }
+#pragma unroll
+            for (int j = 0; j < KL; ++j) {
+                if (j < qn && rank[j] < K) {
+                    idx_all[o + rank[j]] = (int)(u32)mine[j];
+                    dist2_all[o + rank[j]] = __uint_as_float((u32)(mine[j] >> 32));
                 }
             }
             for (int j = total + part; j < K; j += 4) {          // fewer than K admissible points: (0, +inf) like the reference
@@ -397,6 +414,10 @@ int pa_knn_quad_try(int b, int n, int m, int nsample, const float *xyz, const fl
         default: return 0;
     }
 }
+
+#ifdef KG_STAMPS
+PA_API int pa_kg_stamps_read(long long *host16) { return hipMemcpyFromSymbol(host16, HIP_SYMBOL(kg_stamps), 16 * sizeof(long long)) == hipSuccess ? 0 : -1; }
+#endif
 
 // ---- the cloud's counting sort as a launch of its own (one workgroup per cloud), for callers that know the cloud before they know the queries:
 // the engine sorts the input cloud while the first level's sampling chain has not even started; the first level's neighbour search then copies

@@ -7,6 +7,13 @@ namespace {
 
 constexpr int KG_CELLS = 512;
 
+#ifdef KG_STAMPS     // phase stamps of the sort (variant builds only: tools/build_variant.sh NAME -DKG_STAMPS knn_quad.hip; read with pa_kg_stamps_read)
+__device__ long long kg_stamps[16];
+#define KG_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) kg_stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define KG_STAMP(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ u32 kg_spread3(u32 v)  // 3 bits -> every third bit
 {
     return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4);
@@ -20,17 +27,33 @@ __device__ __forceinline__ u64 kg_shfl_xor_u64(u64 v, int m)
 
 __device__ __forceinline__ u64 kg_wave_min_u64(u64 v) { return ~pa_wave_max_u64(~v); }
 
+// min / max of a float over the wavefront, returned broadcast.  DPP row shifts and row broadcasts (one VALU instruction per step; the xor-shuffle
+// butterfly this replaces is an LDS crossbar round trip per step -- six reductions of six steps were 3.8 k of the sort's 23 k cycles).  Lanes a
+// step has no source for keep `ident` (bound_ctrl off), so the identity never has to be a bit pattern of zeros.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float kg_dpp_f(float v, float ident)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ident), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float kg_wave_min_f(float v)
 {
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) v = fminf(v, __shfl_xor(v, s));
-    return v;
+    v = fminf(v, kg_dpp_f<PA_DPP_ROW_SHR(1), 0xf>(v, INFINITY));
+    v = fminf(v, kg_dpp_f<PA_DPP_ROW_SHR(2), 0xf>(v, INFINITY));
+    v = fminf(v, kg_dpp_f<PA_DPP_ROW_SHR(4), 0xf>(v, INFINITY));
+    v = fminf(v, kg_dpp_f<PA_DPP_ROW_SHR(8), 0xf>(v, INFINITY));
+    v = fminf(v, kg_dpp_f<PA_DPP_ROW_BCAST15, 0xa>(v, INFINITY));
+    v = fminf(v, kg_dpp_f<PA_DPP_ROW_BCAST31, 0xc>(v, INFINITY));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float kg_wave_max_f(float v)
 {
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) v = fmaxf(v, __shfl_xor(v, s));
-    return v;
+    v = fmaxf(v, kg_dpp_f<PA_DPP_ROW_SHR(1), 0xf>(v, -INFINITY));
+    v = fmaxf(v, kg_dpp_f<PA_DPP_ROW_SHR(2), 0xf>(v, -INFINITY));
+    v = fmaxf(v, kg_dpp_f<PA_DPP_ROW_SHR(4), 0xf>(v, -INFINITY));
+    v = fmaxf(v, kg_dpp_f<PA_DPP_ROW_SHR(8), 0xf>(v, -INFINITY));
+    v = fmaxf(v, kg_dpp_f<PA_DPP_ROW_BCAST15, 0xa>(v, -INFINITY));
+    v = fmaxf(v, kg_dpp_f<PA_DPP_ROW_BCAST31, 0xc>(v, -INFINITY));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // LDS floats needed behind the sorted points (16 n bytes): boxes [64][8], cell counters [KG_CELLS + 1], cross-wave scratch [16][6]
@@ -49,13 +72,20 @@ __device__ __forceinline__ int cell_sort_cloud(int n, const float *__restrict__ 
     constexpr int NW = NT / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // ---- 1. cloud bounding box over the finite points
+    KG_STAMP(0);
     float px[PTS], py[PTS], pz[PTS];
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    // (16-byte loads of the cloud into LDS and a pick-up from there -- a third of the cache-line requests -- measured no different: the phase is the
+    // latency of the first touch at launch, not the address path)
+#pragma unroll
+    for (int u = 0; u < PTS; ++u) {
+        const int i = tid + u * NT;
+        if (i < n) { px[u] = xyz[i * 3 + 0]; py[u] = xyz[i * 3 + 1]; pz[u] = xyz[i * 3 + 2]; }
+    }
 #pragma unroll
     for (int u = 0; u < PTS; ++u) {
         const int i = tid + u * NT;
         if (i < n) {
-            px[u] = xyz[i * 3 + 0]; py[u] = xyz[i * 3 + 1]; pz[u] = xyz[i * 3 + 2];
             if (isfinite(px[u]) && isfinite(py[u]) && isfinite(pz[u])) {
                 lo[0] = fminf(lo[0], px[u]); hi[0] = fmaxf(hi[0], px[u]);
                 lo[1] = fminf(lo[1], py[u]); hi[1] = fmaxf(hi[1], py[u]);
@@ -63,6 +93,7 @@ __device__ __forceinline__ int cell_sort_cloud(int n, const float *__restrict__ 
             }
         }
     }
+    KG_STAMP(1);
     for (int c = tid; c <= KG_CELLS; c += NT) cnt[c] = 0;
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
@@ -86,6 +117,7 @@ __device__ __forceinline__ int cell_sort_cloud(int n, const float *__restrict__ 
         for (int t = 0; t < 3; ++t) { grid_out[t] = lo[t]; grid_out[3 + t] = scale[t]; }
     }
     // ---- 2. Morton cell of every point, histogram
+    KG_STAMP(2);
     int cell[PTS];
 #pragma unroll
     for (int u = 0; u < PTS; ++u) {
@@ -104,6 +136,7 @@ __device__ __forceinline__ int cell_sort_cloud(int n, const float *__restrict__ 
     }
     __syncthreads();
     // ---- 3. exclusive scan of the 513 bins (wave 0, 9 bins per lane), scatter
+    KG_STAMP(3);
     if (wave == 0) {
         int v[9], sum = 0;
 #pragma unroll
@@ -129,6 +162,7 @@ __device__ __forceinline__ int cell_sort_cloud(int n, const float *__restrict__ 
     __syncthreads();
     const int n_valid = cnt[KG_CELLS];                                           // start of the non-finite bin == number of finite points
     __syncthreads();
+    KG_STAMP(4);
 #pragma unroll
     for (int u = 0; u < PTS; ++u) {
         const int i = tid + u * NT;
@@ -139,9 +173,10 @@ __device__ __forceinline__ int cell_sort_cloud(int n, const float *__restrict__ 
     }
     __syncthreads();
     // ---- 4. chunk bounding boxes: four threads per chunk, 16 points each, combined inside the quad
+    KG_STAMP(5);
     const int nchunks = (n_valid + 63) >> 6;
     *nchunks_out = nchunks;
-    {
+    if (!ROWMAJOR) {            // only the chunk-pruned kernel (knn.hip) reads the boxes; the cell-grid kernels walk cells (5.5 k of the sort's 23 k cycles)
         const int c = tid >> 2, part = tid & 3;
         float bl[3] = {INFINITY, INFINITY, INFINITY}, bh[3] = {-INFINITY, -INFINITY, -INFINITY};
         if (c < nchunks) {
@@ -165,8 +200,9 @@ __device__ __forceinline__ int cell_sort_cloud(int n, const float *__restrict__ 
             float *bx = box + c * 8;
             bx[0] = bl[0]; bx[1] = bl[1]; bx[2] = bl[2]; bx[3] = bh[0]; bx[4] = bh[1]; bx[5] = bh[2];
         }
+        __syncthreads();
     }
-    __syncthreads();
+    KG_STAMP(6);
 
     return n_valid;
 }

@@ -27,3 +27,7 @@ for kind in ("uniform", "street"):
         print(f"   quad kernel, block 0 thread 0: cloud sort {t[1]-t[0]} cyc, query sort {t[2]-t[1]}, pass1 {t[3]-t[2]}, pass2 {t[4]-t[3]}, pass3 {t[5]-t[4]}; R = {t[8]}, keys {t[9]}, overflow {t[10]}")
     if os.environ.get("PA_KNN_LANE"):
         print(f"   block 0, thread 0: sort {t[1]-t[0]} cyc, pass1 {t[2]-t[1]}, pass2 {t[3]-t[2]}, pass3 {t[4]-t[3]}, store {t[5]-t[4]}; R = {t[6]}, queued {t[7]}; pass-1 candidates per lane: max {t[8]}, mean {t[9] / 64:.0f}")
+    if _lib.has("pa_kg_stamps_read"):      # variant build with -DKG_STAMPS (tools/build_variant.sh): phases of the cloud sort
+        h = (ctypes.c_longlong * 16)(); lib.pa_kg_stamps_read.argtypes = [ctypes.c_void_p]; lib.pa_kg_stamps_read(h)
+        t = list(h)
+        print("   cloud sort phases (cycles): load+box %d, reduce %d, cells+histogram %d, scan %d, scatter %d, chunk boxes %d" % tuple(t[i + 1] - t[i] for i in range(6)))
