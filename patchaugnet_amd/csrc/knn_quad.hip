@@ -182,6 +182,24 @@ __global__ __launch_bounds__(NT) void knn_quad_kernel(int n, int m, int q_per_bl
 
         // every `step`-th point (from `first`) of the cells at Chebyshev distance r_from .. r_to from the query's cell
         auto scan = [&](int r_from, int r_to, int first, int step, auto &&fn) {
+            // one contiguous range of the sorted cloud (the cells c0 .. c1 of a row), two candidates per trip with the NEXT trip's two LDS reads issued
+            // before this trip's candidates are processed (a trip is ~55 VALU instructions behind a ~130-cycle read; with two waves per SIMD the
+            // read of a trip was exposed about half of the time).  The look-ahead reads up to 3 steps + 1 past `end`: other cells' points or the
+            // first bytes behind the array (the box / counter area of the same LDS allocation) -- never used.
+            auto seg = [&](int c0, int c1) {
+                const int beg = c0 ? cnt[c0 - 1] : 0, end = cnt[c1];
+                int pos = beg + first;
+                if (pos >= end) return;
+                float4 pa = sorted[pos], pb = sorted[pos + step];
+                while (pos + step < end) {
+                    const float4 na = sorted[pos + 2 * step], nb = sorted[pos + 3 * step];
+                    fn(pos, pa);
+                    fn(pos + step, pb);
+                    pa = na; pb = nb;
+                    pos += 2 * step;
+                }
+                if (pos < end) fn(pos, pa);
+            };
             for (int dz = -r_to; dz <= r_to; ++dz) {
                 const int z = cz + dz;
                 if (z < 0 || z > 7) continue;
@@ -193,34 +211,25 @@ __global__ __launch_bounds__(NT) void knn_quad_kernel(int n, int m, int q_per_bl
                     const bool interior = r_from > 0 && abs(dz) < r_from && abs(dy) < r_from;   // the middle of the row was scanned before
                     {
                         const int c0 = rowbase + xl, c1 = rowbase + (interior ? min(cx - r_from, xh) : xh);
-                        if (c1 >= c0) {
-                            const int beg = c0 ? cnt[c0 - 1] : 0, end = cnt[c1];
-                            int pos = beg + first;
-                            for (; pos + step < end; pos += 2 * step) {      // two candidates per trip: both LDS reads in flight together
-                                const float4 pa = sorted[pos], pb = sorted[pos + step];
-                                fn(pos, pa);
-                                fn(pos + step, pb);
-                            }
-                            if (pos < end) fn(pos, sorted[pos]);
-                        }
+                        if (c1 >= c0) seg(c0, c1);
                     }
                     if (interior) {
                         const int c0 = rowbase + max(cx + r_from, xl), c1 = rowbase + xh;
-                        if (c1 >= c0) {
-                            const int beg = c0 ? cnt[c0 - 1] : 0, end = cnt[c1];
-                            int pos = beg + first;
-                            for (; pos + step < end; pos += 2 * step) {      // two candidates per trip: both LDS reads in flight together
-                                const float4 pa = sorted[pos], pb = sorted[pos + step];
-                                fn(pos, pa);
-                                fn(pos + step, pb);
-                            }
-                            if (pos < end) fn(pos, sorted[pos]);
-                        }
+                        if (c1 >= c0) seg(c0, c1);
                     }
                 }
             }
         };
-        auto dist = [&](const float4 &p) { return (qx - p.x) * (qx - p.x) + (qy - p.y) * (qy - p.y) + (qz - p.z) * (qz - p.z); };   // :31
+        // (x, y) as one packed subtract / multiply on the register pair the LDS read delivers, z scalar: the same IEEE operations in the same order
+        // (dx*dx + dy*dy) + dz*dz; left to itself the compiler pairs components of TWO candidates and spends nine v_mov per trip assembling them
+        typedef float kq_f2 __attribute__((ext_vector_type(2)));
+        const kq_f2 qxy = (kq_f2){qx, qy};
+        auto dist = [&](const float4 &p) {                                                                                       // :31
+            kq_f2 d = qxy - (kq_f2){p.x, p.y};
+            d = d * d;
+            const float dz = qz - p.z;
+            return (d.x + d.y) + dz * dz;
+        };
         auto outside_bound = [&](int R) {
             float best = INFINITY;
             auto face = [&](float f, int c, float sc) {
