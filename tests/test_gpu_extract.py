@@ -233,3 +233,24 @@ def test_latency_mode_is_bit_identical():
         finally:
             os.environ.pop("PA_ENGINE_FPS_CHUNKS")
         assert torch.equal(d0, d2) and all(torch.equal(a, b) for a, b in zip(fp0, fp2)) and all(torch.equal(a, b) for a, b in zip(c0, c2))
+
+
+@pytest.mark.parametrize("name", ["patch_aug_net", "pptnet"])
+def test_first_level_sampled_ahead_is_bit_identical(name):
+    """PatchAugNetEngine.sample_first_level on another stream + forward(s0=...) (the hook tools/probes/cumask.py measures): the same descriptors,
+    feature maps and centre indices as the forward that samples for itself."""
+    m = _model(name)
+    x = synthetic_submaps(4, 4096, seed=33).cuda()
+    with torch.no_grad():
+        d0, fp0, c0 = m(x)
+        eng = m._engine
+        cidx = torch.empty(4, eng.sampling[0], dtype=torch.int32, device="cuda")
+        nxyz = torch.empty(4, eng.sampling[0], 3, device="cuda")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            eng.sample_first_level(x.squeeze(1).contiguous(), cidx, nxyz)
+        torch.cuda.current_stream().wait_stream(side)
+        d1, (fp1, c1) = eng.forward(x, views=True, s0=(cidx, nxyz))
+        torch.cuda.synchronize()
+    assert torch.equal(d0, d1) and all(torch.equal(a, b) for a, b in zip(fp0, fp1)) and all(torch.equal(a, b) for a, b in zip(c0, c1))

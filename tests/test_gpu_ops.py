@@ -23,6 +23,10 @@ def cloud(b, n, kind="uniform"):
     elif kind == "dup":        # 10 % exact duplicates
         k = max(n // 10, 1)
         x[:, RNG.choice(n, k, replace=False)] = x[:, RNG.choice(n, k, replace=False)]
+    elif kind == "same":       # every point the same: every running minimum ties in every round (the selection's LDS atomic takes all 256 lanes' keys)
+        x[:] = x[:, :1]
+    elif kind == "padded":     # a quarter real points, the rest zero padding: the late rounds tie on a minimum of exactly 0
+        x[:, n // 4:] = 0.0
     return x
 
 
@@ -33,7 +37,8 @@ def dev(a):
 FPS_CASES = [(2, 4096, 1024, "uniform"), (3, 1024, 128, "uniform"), (2, 128, 16, "uniform"), (2, 256, 64, "lattice"),
              (2, 64, 16, "uniform"), (1, 1000, 100, "dup"), (2, 100, 37, "uniform"), (1, 600, 600, "lattice"),
              (2, 2048, 64, "uniform"), (1, 5000, 50, "uniform"), (1, 8192, 33, "lattice"), (1, 9000, 20, "uniform"),
-             (1, 1, 1, "uniform"), (2, 3, 3, "uniform"), (1, 4096, 1024, "lattice"), (1, 512, 300, "dup")]
+             (1, 1, 1, "uniform"), (2, 3, 3, "uniform"), (1, 4096, 1024, "lattice"), (1, 512, 300, "dup"),
+             (2, 4096, 64, "same"), (1, 1024, 32, "same"), (2, 4096, 1100, "padded"), (1, 2048, 600, "padded"), (1, 6000, 1600, "padded")]
 
 
 @pytest.mark.parametrize("b,n,m,kind", FPS_CASES)

@@ -90,3 +90,6 @@ timeout 300 python tools/fpx16_time.py > gpurun_out/${TAG}_fpx16_time.txt 2>&1
 timeout 300 python tools/sa1_time.py > gpurun_out/${TAG}_sa1_time.txt 2>&1
 timeout 300 python tools/probes/stage_b2b.py 9 > gpurun_out/${TAG}_stage_b2b.txt 2>&1
 timeout 300 python tools/chain_phases.py fp0 fp1 fp2 sa1 sa2 > gpurun_out/${TAG}_chain_phases.txt 2>&1
+timeout 300 python tools/fps_time.py > gpurun_out/${TAG}_fps_time.txt 2>&1
+timeout 300 python tools/knn_time.py > gpurun_out/${TAG}_knn_time.txt 2>&1
+timeout 300 python tools/tnn_time.py > gpurun_out/${TAG}_tnn_time.txt 2>&1
