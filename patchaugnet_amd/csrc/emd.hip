@@ -830,8 +830,15 @@ PA_API int pa_emd_forward(int b, int n, int m, const float *xyz1, const float *x
         PA_CHECK_LAUNCH("pa_emd_forward");
         return PA_OK;
     }
-    // chip-wide: G workgroups per cloud (about two workgroups per CU in total)
-    int G = 512 / b;
+    // chip-wide: G workgroups per cloud, ONE workgroup per CU in total.  (Two per CU -- 512 workgroups of 1024 threads and 73 KB of LDS at the reference's
+    // call shape -- was the first tuning; the long tail of the auction has a handful of bidders per round and a round then costs what the launch costs:
+    // 21 us with 512 workgroups, 15.8 us with 256, and the early rounds do not lose either: (16, 4096, 3) 64 / 1024 rounds 3.11 / 23.3 -> 2.49 / 17.6 ms.)
+    int cus_emd = 256;
+    {
+        int dev_emd = 0;
+        if (hipGetDevice(&dev_emd) == hipSuccess) (void)hipDeviceGetAttribute(&cus_emd, hipDeviceAttributeMultiprocessorCount, dev_emd);
+    }
+    int G = cus_emd / b;
     if (G > 32) G = 32;
     if (G < 1) G = 1;
     while (G > 1 && n / G < 64) G >>= 1;
@@ -870,9 +877,35 @@ PA_API int pa_emd_forward(int b, int n, int m, const float *xyz1, const float *x
     const int tail_from = getenv("PA_EMD_TAIL_FROM") ? atoi(getenv("PA_EMD_TAIL_FROM")) : (1 << 30);      // read per call: a test knob
     if (n <= 4096 && g_emd_persistent != 0 && tail_from < iters) r1 = tail_from < 0 ? 0 : tail_from;
 #endif
-    for (int it = 0; it < r1; ++it)
-        hipLaunchKernelGGL(emd_round_kernel, dim3(G, b), dim3(EMD_THREADS), lds_bytes, (hipStream_t)stream, n, xyz1, xyz2, dist, assignment, price,
+    // The workgroups per cloud may follow a schedule over the round index (A/B knob PA_EMD_SCHED="from:G,from:G,...", default none: measured, one
+    // workgroup per CU from the first round on is the best of them, profiles/r04_ab_log.txt) -- a function of the round only, so results cannot depend on
+    // it: the slices are recomputed from the launch's own grid; the bidder list, the counters and the arrival count are per cloud and per launch.
+    struct Step { int from, g; };
+    static Step sched[8];
+    static int nsched = -1;
+    if (nsched < 0) {
+        const char *e = getenv("PA_EMD_SCHED");
+        const char *txt = e ? e : "";
+        int k = 0;
+        while (*txt && k < 8) {
+            char *end = nullptr;
+            const long f = strtol(txt, &end, 10);
+            if (end == txt || *end != ':') break;
+            txt = end + 1;
+            const long gg = strtol(txt, &end, 10);
+            if (end == txt) break;
+            sched[k].from = (int)f; sched[k].g = (int)gg; ++k;
+            txt = (*end == ',') ? end + 1 : end;
+        }
+        nsched = k;
+    }
+    for (int it = 0; it < r1; ++it) {
+        int Gi = G;
+        for (int k = 0; k < nsched; ++k)
+            if (it >= sched[k].from && sched[k].g > 0 && sched[k].g < G) Gi = sched[k].g;
+        hipLaunchKernelGGL(emd_round_kernel, dim3(Gi, b), dim3(EMD_THREADS), lds_bytes, (hipStream_t)stream, n, xyz1, xyz2, dist, assignment, price,
                            assignment_inv, bid, bid_increments, max_increments, max_idx, eps, it == iters - 1 ? 1 : 0);
+    }
 #ifdef PA_EXPERIMENTAL
     if (r1 < iters) {
         const size_t tail_lds = (size_t)n * 32 + (size_t)n * 4;       // eight float arrays + two 16-bit lists
