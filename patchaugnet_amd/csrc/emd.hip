@@ -28,6 +28,9 @@ namespace {
 
 constexpr int EMD_THREADS = 1024;
 constexpr int EMD_WAVES = EMD_THREADS / 64;
+#ifndef EMD_DIRECT_MAX
+#define EMD_DIRECT_MAX 8     // bidders of a workgroup up to which its scan reads global memory instead of staging the objects in LDS (0 = never)
+#endif
 
 struct Bid3 {
     float best, better;
@@ -79,6 +82,46 @@ __device__ __forceinline__ float ld_agent_f(const float *p) { return __hip_atomi
 __device__ __forceinline__ int ld_agent_i(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent_f(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent_i(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// bid_scan straight from global memory (objects (n, 3) as the caller passes them, this round's prices with agent-scope loads): for the workgroups of
+// the auction's long tail, which have one or two bidders -- staging all n objects and prices in LDS first (64 KB, sixteen loads a thread and a barrier)
+// costs more than the few objects a lane then looks at.  Same operations in the same order on the same values: bit-identical bids.
+__device__ __forceinline__ Bid3 bid_scan_direct(const float *xyz2, const float *price, float x1, float y1, float z1, int k0, int k1, int lane)
+{
+    Bid3 b = {-1e9f, -1e9f, -1};
+    auto take = [&](float d, int k) {
+        if (d > b.best) {
+            b.better = b.best;
+            b.best = d;
+            b.best_i = k;
+        } else if (d > b.better) {
+            b.better = d;
+        }
+    };
+    int k = k0 + lane;
+    for (; k + 192 < k1; k += 256) {
+        float ox[4], oy[4], oz[4], op[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int kk = k + 64 * t;
+            ox[t] = xyz2[kk * 3 + 0]; oy[t] = xyz2[kk * 3 + 1]; oz[t] = xyz2[kk * 3 + 2];
+            op[t] = ld_agent_f(price + kk);
+        }
+        float d[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float dx = ox[t] - x1, dy = oy[t] - y1, dz = oz[t] - z1;
+            d[t] = (float)(3.0 - (double)sqrtf(dx * dx + dy * dy + dz * dz) - (double)op[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) take(d[t], k + 64 * t);
+    }
+    for (; k < k1; k += 64) {
+        const float dx = xyz2[k * 3 + 0] - x1, dy = xyz2[k * 3 + 1] - y1, dz = xyz2[k * 3 + 2] - z1;
+        take((float)(3.0 - (double)sqrtf(dx * dx + dy * dy + dz * dz) - (double)ld_agent_f(price + k)), k);
+    }
+    return b;
+}
 
 // emd_cuda.cu:10-20 -- float atomicMax by compare-and-swap (replace only when val > stored)
 __device__ __forceinline__ void atomic_max_f(float *addr, float val)
@@ -264,13 +307,16 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_round_kernel(int n, const flo
         __syncthreads();
     }
     if (U > 0) {
-        // the objects and this round's prices: only workgroups that have a bidder pay for the 16 n bytes
-        for (int k = tid; k < n; k += EMD_THREADS) {
-            x2[k] = xyz2[k * 3 + 0];
-            y2[k] = xyz2[k * 3 + 1];
-            z2[k] = xyz2[k * 3 + 2];
-            pr[k] = ld_agent_f(price + k);
-        }
+        // the objects and this round's prices: only workgroups that have a bidder pay for the 16 n bytes -- and with one or two bidders (EMD_DIRECT_MAX)
+        // not even those: the scan reads its few objects per lane straight from global memory (bid_scan_direct)
+        const bool direct = U <= EMD_DIRECT_MAX;                  // workgroup-uniform
+        if (!direct)
+            for (int k = tid; k < n; k += EMD_THREADS) {
+                x2[k] = xyz2[k * 3 + 0];
+                y2[k] = xyz2[k * 3 + 1];
+                z2[k] = xyz2[k * 3 + 2];
+                pr[k] = ld_agent_f(price + k);
+            }
         if (tid == 0) list_base = atomicAdd(gcount, U);          // this workgroup's segment of the cloud's bidder list
         __syncthreads();
         for (int u = tid; u < U; u += EMD_THREADS) __hip_atomic_store(glist + list_base + u, unass[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -286,7 +332,8 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_round_kernel(int n, const flo
             if (u < U) {
                 j = unass[u];
                 const float x1 = xyz1[j * 3 + 0], y1 = xyz1[j * 3 + 1], z1 = xyz1[j * 3 + 2];
-                b = bid_scan(x2, y2, z2, pr, x1, y1, z1, part * slice, (part + 1) * slice, lane);
+                b = direct ? bid_scan_direct(xyz2, price, x1, y1, z1, part * slice, (part + 1) * slice, lane)
+                           : bid_scan(x2, y2, z2, pr, x1, y1, z1, part * slice, (part + 1) * slice, lane);
 #pragma unroll
                 for (int s = 1; s < 64; s <<= 1) {
                     const float ob = __shfl_xor(b.best, s), obt = __shfl_xor(b.better, s);
