@@ -652,6 +652,10 @@ class PatchAugNetEngine:
         # a forked branch serialises against the other streams' graphs at replay (34.5 k -> 18.7 k submaps/s measured), so it is never
         # applied while a stream is capturing.
         self.geo_overlap = os.environ.get("PA_ENGINE_GEO_OVERLAP") is not None
+        # keep_geometry = True: backbone() leaves its level-local centre / neighbour indices and the set-abstraction features in
+        # self.last_geometry (parity tests read the reference's sample_idx_origin / sa_features from it, patch_aug_net.py:169-177)
+        self.keep_geometry = False
+        self.last_geometry = None
         self._geo_streams = {}
 
     @staticmethod
@@ -846,6 +850,7 @@ class PatchAugNetEngine:
             l_feat.append(y.view(B, m, chain.n_last))
             l_c.append(cidx[i])
             c_feat = chain.n_last
+        sa_feat = l_feat[1:]                       # the list entries are replaced (not written) by the decoder levels below
         g_pre = None
         for i in range(-1, -(nfp + 1), -1):
             chain = self.fp[nfp + i]
@@ -883,6 +888,8 @@ class PatchAugNetEngine:
             l_feat[i - 1] = y.view(B, n_u, chain.n_last)
             if early is not None and nfp + i == 1:
                 early(l_feat)        # every decoder level but the finest exists: the coarse NetVLAD scales read them while they are cache-resident
+        if self.keep_geometry:
+            self.last_geometry = {"center_idx": list(cidx), "sample_idx": list(nbr), "sa_features": list(sa_feat)}
         return l_feat, l_c
 
     def forward(self, x, views=True, s0=None):

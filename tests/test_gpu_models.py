@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from patchaugnet_amd import configs
-from tests._util import golden, seeded_sd_from_table, samples
+from tests._util import golden, seeded_sd_from_table, samples, summarize
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -44,7 +44,54 @@ def test_patch_aug_net_vs_reference_vectors(tag, fused):
         assert np.array_equal(cidx[i].cpu().numpy(), g[f"{tag}_center_idx{i}"])
         assert fp[i].shape[1] == 256 and fp[i].shape[3] == 1
         assert np.allclose(samples(fp[i].contiguous()), g[f"{tag}_fp{i}_samples"], atol=2e-4, rtol=1e-4)
+        assert np.allclose(summarize(fp[i].contiguous()), g[f"{tag}_fp{i}_summary"], rtol=2e-5, atol=2e-6)
     _check_desc(desc, g[f"{tag}_desc"])
+
+
+@pytest.mark.parametrize("tag", ["small", "full"])
+@pytest.mark.parametrize("fused", [False, True])
+def test_patch_aug_net_backbone_indices_and_sa_features_vs_reference_vectors(tag, fused):
+    """The backbone outputs the descriptor test above does not see, against the vectors of the reference's own ``backbone()``
+    (patch_aug_net.py:155-192): ``sample_idx_origin`` (:169-177) at every level and the last set-abstraction level's features.
+    Module path: bit-equal including the reference's ``randperm`` column order (same CPU generator, same seed).  Engine: it keeps each
+    group's nsample nearest in ascending order and never draws the permutation (max-pool is order-invariant), so rows are compared
+    as sorted lists -- duplicates included."""
+    from patchaugnet_amd import backbone as bb
+    from patchaugnet_amd.engine import engine_for
+    g = golden("patch_aug_net")
+    cfg = configs.patch_aug_net_config()
+    if tag == "small":
+        cfg = configs.scaled_config(cfg, 512)
+    m = _pan(cfg)
+    x = torch.from_numpy(g[f"{tag}_x"]).cuda()
+    with torch.no_grad():
+        if fused:
+            if not m.fused_eval:
+                pytest.skip("fused engine not enabled yet")
+            eng = engine_for(m, x.device)
+            eng.keep_geometry = True
+            try:
+                eng.forward(x)
+            finally:
+                eng.keep_geometry = False
+            geo, eng.last_geometry = eng.last_geometry, None
+            c_o, s_o = bb.origin_indices(geo["center_idx"], geo["sample_idx"])
+            sa2 = geo["sa_features"][2].transpose(1, 2).contiguous()                 # (B, m2, C) -> the reference's (B, C, m2)
+        else:
+            torch.manual_seed(int(g["seed_fwd"]))
+            res = m.backbone(x.squeeze(1))
+            c_o, s_o, sa2 = res["center_idx_origin"], res["sample_idx_origin"], res["sa_features"][2]
+    for i in range(3):
+        ref = g[f"{tag}_sample_idx{i}"]
+        got = s_o[i].cpu().numpy()
+        assert got.shape == ref.shape and got.dtype == ref.dtype
+        assert np.array_equal(c_o[i].cpu().numpy(), g[f"{tag}_center_idx{i}"])
+        if fused:
+            assert np.array_equal(np.sort(got, axis=-1), np.sort(ref, axis=-1)), f"level {i}"
+        else:
+            assert np.array_equal(got, ref), f"level {i}"
+    assert np.allclose(samples(sa2), g[f"{tag}_sa2_samples"], atol=2e-4, rtol=1e-4)
+    assert np.allclose(summarize(sa2), g[f"{tag}_sa2_summary"], rtol=2e-5, atol=2e-6)
 
 
 @pytest.mark.parametrize("model_name", ["patch_aug_net", "pptnet"])
