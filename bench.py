@@ -85,6 +85,39 @@ def grouping_roofline():
     return out
 
 
+# The sampling round's latency model (latency-bound kernels report achieved time against a stated model).
+# fps_reg_kernel<256,16> is one workgroup (4 wavefronts, one per SIMD) per cloud running m - 1 strictly serial rounds; a round of the shipped ISA
+# (hipcc --cuda-device-only -S csrc/fps.hip) is 128 VALU instructions for the 16 points of a lane (8 pair blocks: 3 v_pk_add + 3 v_pk_mul + 2 v_pk_add,
+# 2 v_min, 2 x (v_cmp_gt_u64 + 2 v_cndmask)), the wave maximum (6 DPP steps + v_readlane), and the selection tail (ds_max_u64 -> s_waitcnt ->
+# s_barrier -> ds_read_b64 -> ds_read_b96 of the winner's coordinates).  tools/probes/fps_model.hip times each of those instruction blocks ALONE on
+# the same occupancy (one wave per SIMD, s_memtime) and the three blocks chained as one dependent stream; profiles/r05_fps_model.txt is its output
+# on the MI355X: pair block 88.2 cycles (x 8), wave maximum 136.0, tail 331.8; chained 1037 cycles per round (the tail's LDS round trips overlap the
+# head of the next round's VALU block; the blocks' plain sum is 1173).  Model = the chained figure at the clock the launch holds.
+FPS_MODEL = {"pair_block_cycles": 88.2, "pair_blocks_per_round": 8, "wave_max_cycles": 136.0, "tail_cycles": 331.8, "chained_round_cycles": 1037.0,
+             "clock_ghz": 2.36, "source": "tools/probes/fps_model.hip -> profiles/r05_fps_model.txt (s_memtime, one wave per SIMD, 32 workgroups)"}
+
+
+def fps_latency_roofline(batch, points, m):
+    """roofline_latency of the longest kernel of a step: measured us per sampling round (HIP events on the launch stream around 10 launches)
+    against the model above."""
+    from patchaugnet_amd import _lib
+    from patchaugnet_amd.weights import synthetic_submaps
+    xyz = synthetic_submaps(batch, points, seed=5).squeeze(1).cuda().contiguous()
+    idx = torch.empty(batch, m, dtype=torch.int32, device="cuda")
+    q = torch.empty(batch, m, 3, device="cuda")
+    ms = ev_time_ms(lambda: _lib.call("pa_furthestsampling_gather", batch, points, m, _lib.ptr(xyz), _lib.ptr(idx), _lib.ptr(q)), iters=10)
+    rounds = m - 1
+    us_round = ms * 1e3 / rounds
+    model_us = FPS_MODEL["chained_round_cycles"] / (FPS_MODEL["clock_ghz"] * 1e3)
+    return {"kernel": "fps_reg_kernel<256,16> (pa_furthestsampling_gather: first level, one workgroup of 4 wavefronts per cloud, %d CUs of 256 busy)" % min(batch, 256),
+            "bound": "latency (serial rounds; neither HBM nor MFMA)", "rounds": rounds, "ms_per_launch": ms, "us_per_round": us_round,
+            "model_us_per_round": model_us, "frac": model_us / us_round,
+            "model": "cycles of the round's three instruction blocks measured alone at the kernel's occupancy and chained as one dependent stream "
+                     "(8 x 16-instruction pair block + 6-step DPP wave maximum + ds_max_u64 / barrier / two LDS reads), / the clock the launch holds",
+            "model_terms": FPS_MODEL,
+            "counters": "profiles/r05_fps_pmc_sq.txt (SQ_WAVE_CYCLES / SQ_BUSY_CYCLES / SQ_INSTS_VALU / SQ_INSTS_LDS of the same kernel)"}
+
+
 def stage_pass(model, x, iters=5):
     """Per-stage device time of one step (HIP events between stages) for the roofline attribution."""
     from patchaugnet_amd import profiling
@@ -535,7 +568,41 @@ def extras(a):
             res[f"ms_{iters}_iters"] = ms
         return res
 
+    def config2_sweep():
+        """SURVEY.md section 8(d), config 2 beside the headline point: the street-like input (3-5 planes + 5 % exact duplicates: ties in sampling and
+        neighbour search) at batch 32, and uniform clouds at batch 1 / 8 / 256 -- same engine, one hipGraph per stream, inputs resident in HBM."""
+        from patchaugnet_amd import configs, patch_aug_net
+        from patchaugnet_amd.extract import GraphedExtractor
+        from patchaugnet_amd.weights import seeded_state_dict, synthetic_submaps
+        model = patch_aug_net.Network(param=configs.patch_aug_net_config(), use_a2a_recon=True, use_l2_norm=True)
+        model.load_state_dict(seeded_state_dict(model.state_dict()))
+        model = model.cuda().eval()
+        res = []
+        for batch, kind, steps in ((32, "street", 40), (1, "uniform", 200), (8, "uniform", 100), (256, "uniform", 12)):
+            x = synthetic_submaps(batch, a.points, seed=1234, kind=kind).cuda()
+            with torch.no_grad():
+                gx = GraphedExtractor(model, tuple(x.shape), a.streams, resident_inputs=[x])
+                rates = []
+                for rep in range(4):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    gx.begin()
+                    for _ in range(steps):
+                        gx.run(x)
+                    gx.end()
+                    torch.cuda.synchronize()
+                    if rep:
+                        rates.append(steps * batch / (time.perf_counter() - t0))
+            rates.sort()
+            res.append({"batch": batch, "input": kind, "steps": steps, "streams": a.streams, "submaps_per_s": rates[1], "min": rates[0], "max": rates[-1],
+                        "ms_per_step": batch / rates[1] * 1e3})
+            del gx, x
+            gc.collect()
+            torch.cuda.empty_cache()
+        return {"workload": "PatchAugNet inference, 4096-pt synthetic submaps, 1xMI355X (BASELINE.json configs[1] at other batch sizes / input distribution)", "points": res}
+
     guarded("configs0_pointnetvlad_cpu", pointnetvlad_cpu)
+    guarded("configs1_sweep", config2_sweep)
     guarded("configs3_training_step", train)
     guarded("configs4_pptnet_f32", lambda: extract_rate("pptnet", "f32"))
     guarded("configs4_pptnet_f16", lambda: extract_rate("pptnet", "f16"))
@@ -744,6 +811,10 @@ def main():
                 line.update(dominant_kernel_roofline(st, cfg, a.batch, a.points, g, pmc, note))
                 if "roofline" in line and b2b:
                     line["roofline"]["timing"] = "HIP events on the launch stream around 9 back-to-back launches of the kernel (average); one bracketed launch: kernels.fp0_chain_single_bracketed_ms"
+                try:
+                    line["roofline_latency"] = fps_latency_roofline(a.batch, a.points, cfg["SAMPLING"][0])
+                except Exception as ex:
+                    line["roofline_latency"] = {"error": repr(ex)}
             except Exception as ex:  # attribution is diagnostics; never lose the bench line over it
                 line["kernels"]["stages_ms"] = {"error": repr(ex)}
         try:      # the number that describes the whole step (the per-kernel roofline above is its best kernel): algorithmic FLOPs / step time / peak

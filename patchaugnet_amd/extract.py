@@ -79,8 +79,10 @@ class GraphedExtractor:
     def __init__(self, model, batch_shape, n_streams=4, device=None, warmup=2, resident_inputs=None):
         """resident_inputs: optional list of device tensors of ``batch_shape`` that ALREADY hold the batches (one per slot, reused round-robin;
         a single tensor serves every slot): slot i's graph is captured reading resident_inputs[i % len] IN PLACE, so ``run(that_tensor)``
-        replays with no staging copy.  Any other tensor handed to run() is copied into the slot's bound buffer first (which overwrites a
-        resident tensor: pass resident_inputs only for data the caller does not need preserved, or always run() the bound tensors)."""
+        replays with no staging copy.  A slot whose bound tensor is its own (len(resident_inputs) >= n_streams, distinct storages) also
+        accepts any other tensor: it is copied into the bound buffer first, on the slot's stream (which overwrites the resident tensor).
+        Slots that SHARE a bound tensor accept only that tensor: a staging copy into it on one slot's stream would race with the other
+        slots' replays reading it on theirs, so run() refuses instead of giving silently wrong descriptors."""
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         assert not model.training, "hipGraph capture is for evaluation (fused engine, no autograd)"
         _prime_stream_queues(self.device)
@@ -105,6 +107,8 @@ class GraphedExtractor:
                     y = model(x, return_feat=False)
                 self.slots.append((g, x, y, st))
         torch.cuda.synchronize(self.device)
+        ptrs = [sl[1].data_ptr() for sl in self.slots]
+        self._shared_input = [ptrs.count(p) > 1 for p in ptrs]       # slot's bound input is read by another slot's graph too
         self._i = 0
         self._model = model
         self._engine = getattr(model, "_engine", None)      # the graphs point at THIS engine's folded / packed weight buffers
@@ -120,10 +124,16 @@ class GraphedExtractor:
 
     def run(self, x, out=None):
         """x: (B,1,N,3) device or pinned-host tensor of the captured shape.  Returns the slot's output buffer (or ``out``)."""
-        g, xs, ys, st = self.slots[self._i % len(self.slots)]
+        k = self._i % len(self.slots)
+        g, xs, ys, st = self.slots[k]
+        foreign = x is not xs and not (x.is_cuda and x.data_ptr() == xs.data_ptr())
+        if foreign and self._shared_input[k]:
+            raise RuntimeError("GraphedExtractor.run: this slot's graph reads a resident input that other slots read too; copying another "
+                               "tensor into it would race with their replays.  Pass the resident tensor itself, or build the extractor with "
+                               "one distinct resident tensor per stream (or none: every slot then owns a staging buffer)")
         self._i += 1
         with torch.cuda.stream(st):
-            if x is not xs and not (x.is_cuda and x.data_ptr() == xs.data_ptr()):
+            if foreign:
                 xs.copy_(x, non_blocking=True)
             g.replay()
             if out is not None:

@@ -345,12 +345,15 @@ labelstat_and_ballquery = LabelStatAndBallQuery.apply
 
 def pairwise_distances(x, y=None):
     """pointops.py:347-363 -- ||x_i - y_j||^2 via the expanded form, clamped at 0.  x (N, d), y (M, d) -> (N, M).
-    On the MI355X the product runs on the hand-written MFMA GEMM with the norms and the clamp in its epilogue (pa_tgemm_nn, act = 2:
-    csrc/train_gemm.hip -- the kernel the retrieval search uses); CPU tensors take the reference's torch statement."""
+    The reference's statement is plain differentiable torch; it stays the form whenever a gradient could flow (an input requires grad while
+    grad mode is on), for mixed devices and for non-fp32 inputs.  Two fp32 device tensors outside autograd run on the hand-written MFMA GEMM
+    with the norms and the clamp in its epilogue (pa_tgemm_nn, act = 2: csrc/train_gemm.hip -- the kernel the retrieval search uses);
+    strided views are made contiguous first."""
     y = x if y is None else y
-    if x.is_cuda:
-        check_device(x, y)
-        x, y = x.float(), y.float()
+    needs_grad = torch.is_grad_enabled() and (x.requires_grad or y.requires_grad)
+    if x.is_cuda and y.is_cuda and x.device == y.device and x.dtype == torch.float32 and y.dtype == torch.float32 and not needs_grad \
+            and x.dim() == 2 and y.dim() == 2:
+        x, y = x.detach().contiguous(), y.detach().contiguous()
         n, d = x.shape
         m = y.shape[0]
         yt = y.t().contiguous()                                              # (d, M): the GEMM's B operand

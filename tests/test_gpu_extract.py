@@ -254,3 +254,31 @@ def test_first_level_sampled_ahead_is_bit_identical(name):
         d1, (fp1, c1) = eng.forward(x, views=True, s0=(cidx, nxyz))
         torch.cuda.synchronize()
     assert torch.equal(d0, d1) and all(torch.equal(a, b) for a, b in zip(fp0, fp1)) and all(torch.equal(a, b) for a, b in zip(c0, c1))
+
+
+def test_graphed_extractor_with_shared_resident_input_refuses_foreign_tensors():
+    """Slots captured on ONE resident tensor read it in place from several streams: a staging copy into it on one slot's stream would race
+    with the other slots' replays (wrong descriptors, silently).  run() takes the bound tensor and refuses any other; with one distinct
+    resident tensor per stream a foreign tensor is copied into the slot's own buffer and gives the plain forward's descriptors."""
+    from patchaugnet_amd.extract import GraphedExtractor
+    m = _model("patch_aug_net")
+    x = synthetic_submaps(4, 4096, 41).cuda()
+    other = synthetic_submaps(4, 4096, 42).cuda()
+    with torch.no_grad():
+        ref_x, ref_o = m(x, return_feat=False).clone(), m(other, return_feat=False).clone()
+        gx = GraphedExtractor(m, tuple(x.shape), n_streams=3, resident_inputs=[x])
+        gx.begin()
+        outs = [gx.run(x, out=torch.empty(4, 256, device="cuda")) for _ in range(5)]
+        with pytest.raises(RuntimeError, match="resident input"):
+            gx.run(other)
+        gx.end()
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, ref_x) for o in outs)
+        res = [x.clone() for _ in range(3)]
+        gy = GraphedExtractor(m, tuple(x.shape), n_streams=3, resident_inputs=res)
+        gy.begin()
+        outs = [gy.run(t, out=torch.empty(4, 256, device="cuda")) for t in (res[0], other, res[2], other, other)]
+        gy.end()
+        torch.cuda.synchronize()
+        for o, r in zip(outs, (ref_x, ref_o, ref_x, ref_o, ref_o)):
+            assert torch.equal(o, r)

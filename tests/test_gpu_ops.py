@@ -520,3 +520,28 @@ def test_knn_presorted_cloud_equals_the_oracle(kind):
     _lib.call("pa_knnquery_presorted", b, n, m, k, _lib.ptr(xd), _lib.ptr(qd), _lib.ptr(cells), _lib.ptr(idx), _lib.ptr(d2))
     assert np.array_equal(idx.cpu().numpy(), ri)
     assert np.array_equal(d2.cpu().numpy().view(np.uint32), rd.view(np.uint32))
+
+
+def test_pairwise_distances_device_path_and_autograd():
+    """pointops.py:347-363.  Outside autograd two fp32 device tensors run on the MFMA GEMM (norms + clamp in the epilogue); strided views are
+    accepted; with a gradient required the reference's differentiable torch statement runs and the gradient flows."""
+    from patchaugnet_amd import pointops
+    g = torch.Generator().manual_seed(3)
+    x, y = torch.randn(300, 256, generator=g).cuda(), torch.randn(170, 256, generator=g).cuda()
+    ref = torch.clamp((x.double() ** 2).sum(1)[:, None] + (y.double() ** 2).sum(1)[None, :] - 2.0 * x.double() @ y.double().t(), min=0.0)
+    with torch.no_grad():
+        d = pointops.pairwise_distances(x, y)
+        assert d.shape == (300, 170) and d.grad_fn is None
+        assert torch.allclose(d.double(), ref, rtol=1e-5, atol=1e-3)
+        ds = pointops.pairwise_distances(x.t().contiguous().t(), y[::2])          # a transposed (strided) view and a strided slice
+        assert torch.allclose(ds.double(), ref[:, ::2], rtol=1e-5, atol=1e-3)
+        dself = pointops.pairwise_distances(x)
+        assert dself.shape == (300, 300) and float(dself.diagonal().abs().max()) < 1e-2
+    xg = x.clone().requires_grad_(True)
+    dg = pointops.pairwise_distances(xg, y)
+    assert dg.grad_fn is not None
+    dg.sum().backward()
+    gref = 2.0 * (x.double()[:, None, :] - y.double()[None, :, :]).sum(1)
+    assert torch.allclose(xg.grad.double(), gref, rtol=1e-4, atol=1e-2)
+    d2 = pointops.pairwise_distances(x.detach(), y.detach())                       # no gradient required: the GEMM path, same values
+    assert d2.grad_fn is None and torch.allclose(d2, dg.detach(), rtol=1e-5, atol=1e-3)
