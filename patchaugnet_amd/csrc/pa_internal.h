@@ -35,7 +35,11 @@ void pa_knn_debug_buffer(long long *buf);   /* same for the pruned kNN kernel: 6
  *   pa_fpx16_enable           pa_fp_chain_premul_f16 at the finest level's shape on LDS-shared weights (csrc/fpx_f16.hip): 8 / 4 = waves per
  *                             workgroup, 0 = the wave-private LDS-tile kernel (fp16 path: both within fp16 rounding of the fp32 kernel, not
  *                             the same bits)
- * Either setting of every switch gives the same bits (tests/test_gpu_ops.py, test_gpu_chain.py, test_gpu_losses.py). */
+ *   pa_tgemm_cm_enable        pa_tgemm_nn's aligned shapes on LDS-resident weights (csrc/train_gemm_cm.hip): 1 = wherever the shape rules hold
+ *                             (also below the default's minimum tile count), 0 = never (the LDS-tiled kernel)
+ * Either setting of the index / gather / inference switches gives the same bits (tests/test_gpu_ops.py, test_gpu_chain.py, test_gpu_losses.py);
+ * pa_chain_mid_enable, pa_fpx16_enable and pa_tgemm_cm_enable select kernels that agree to fp32 / fp16 rounding (a different summation
+ * order of the statistics or the contraction), as their lines above say. */
 void pa_knn_quad_enable(int on);
 void pa_three_nn_grid_enable(int on);
 void pa_chain_tiny_enable(int on);
@@ -43,6 +47,7 @@ void pa_chain_mid_enable(int on);
 void pa_linear_lds_enable(int on);
 void pa_emd_persistent_enable(int on);
 void pa_fpx16_enable(int mode);
+void pa_tgemm_cm_enable(int on);
 
 /* ---- 2. measured-slower variants: libpatchaugnet_hip_exp.so only --------------------------------------------------------------------- */
 #ifdef PA_EXPERIMENTAL

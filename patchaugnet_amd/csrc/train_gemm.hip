@@ -993,6 +993,10 @@ TOp make_top(int mode, const float *aux, const float *p, int nch)
 
 }  // namespace
 
+int pa_tgemm_cm_try(int batch, int M, int N, int K, const float *A, long sAb, int lda, int a_kcontig, const float *B, long sBb, int ldb, int bmode,
+                    const float *baux, const float *bp, float *C, long sCb, int ldc, int beta, const float *bias, const float *colv, int act,
+                    double *stats, int per_batch_stats, hipStream_t st);      // train_gemm_cm.hip
+
 #ifdef PA_EXPERIMENTAL
 static int g_tgemm_wave = -1;
 // test / A/B switch: 1 = the wave-private kernel wherever its shape rules hold, 0 = never, -1 = the environment (PA_TGEMM_WAVE, default off)
@@ -1035,6 +1039,14 @@ PA_API int pa_tgemm_nn(int batch, int M, int N, int K, const float *A, long sAb,
     const long t64 = (long)((M + 63) / 64) * ((N + NN_BN - 1) / NN_BN) * batch;
     const bool deep = K > 16 && !big && t64 < 1024;     // few workgroups: latency-bound rounds, halve their number (measured: hurts the chip-filling launches)
     hipStream_t st = (hipStream_t)stream;
+    // the chip-filling aligned shapes (K = 64 / 128 / 256, M and N multiples of 64, A shared by the batch) run on LDS-resident weights with the B
+    // operand straight from 16-byte global loads (csrc/train_gemm_cm.hip); everything else stays here
+    {
+        const int took = pa_tgemm_cm_try(batch, M, N, K, A, sAb, lda, a_kcontig, B, sBb, ldb, bmode, baux, bp, C, sCb, ldc, beta, bias, colv, act, stats,
+                                         per_batch_stats, st);
+        if (took < 0) { pa_set_error("pa_tgemm_nn (LDS-resident weights): launch failed"); return PA_EINVAL; }
+        if (took) return PA_OK;
+    }
 #ifdef PA_EXPERIMENTAL
     // the wave-private kernel for the aligned shapes (tgemm_nnw_kernel): OPT-IN (PA_TGEMM_WAVE=1 or pa_tgemm_wave_enable).  Measured against the
     // LDS-tiled kernel on MI355X (tools/probes/tgemm_scale.py, 18 x (M x 4096 x 256)): M = 64: 54 vs 60 us, M = 256: 125 vs 123 us, M = 512: 211 vs

@@ -484,3 +484,57 @@ def test_wave_private_gemm_matches_the_lds_tiled_kernel(a_kcontig, bmode, B, M, 
     scale = outs[0].abs().max().item()
     assert (outs[0] - outs[1]).abs().max().item() <= 2e-5 * scale
     assert torch.allclose(stats[0], stats[1], rtol=1e-5, atol=1e-4 * scale * N)
+
+
+def _cm_switch(on):
+    import ctypes
+    from patchaugnet_amd import _lib
+    lib = _lib.lib()
+    lib.pa_tgemm_cm_enable.argtypes, lib.pa_tgemm_cm_enable.restype = [ctypes.c_int], None
+    lib.pa_tgemm_cm_enable(on)
+
+
+@pytest.mark.parametrize("a_kcontig,bmode,use_stats", [(True, 0, True), (True, 1, True), (False, 0, False), (False, 2, False), (False, 3, False), (True, 2, False),
+                                                       (False, 1, True)])
+@pytest.mark.parametrize("B,M,N,K,bias", [(3, 64, 128, 64, False), (2, 256, 320, 256, True), (1, 128, 64, 128, False), (5, 192, 192, 256, False),
+                                          (18, 256, 1024, 256, False), (2, 512, 64, 64, True), (3, 64, 96, 64, False), (7, 128, 416, 128, True)])
+def test_lds_resident_weights_gemm_against_float64_and_the_lds_tiled_kernel(a_kcontig, bmode, use_stats, B, M, N, K, bias):
+    """pa_tgemm_nn on LDS-resident weights (csrc/train_gemm_cm.hip: a workgroup pinned to a 128-row block of A, the B operand as 16-byte global loads
+    that are the fragments of four interleaved column tiles, statistics in wave-private fp64 LDS blocks) against (a) the float64 statement of
+    include/patchaugnet_hip.h's definition and (b) the LDS-tiled kernel on the same operands: every operand transform, both layouts of A,
+    one- and two-half row blocks (M = 64 / 192 / 512), ragged tile counts per workgroup, bias, statistics."""
+    from patchaugnet_amd import train_ops as T
+    g = torch.Generator().manual_seed(M + 3 * N + K + bmode)
+    A = (torch.randn(M, K, generator=g) if a_kcontig else torch.randn(K, M, generator=g)) / K ** 0.5
+    X = torch.randn(B, K, N, generator=g)
+    aux = torch.randn(B, K, N, generator=g)
+    p = _p_block(K, g)
+    bvec = torch.randn(M, generator=g)
+    Ad, Xd, auxd, pd, bd = A.cuda(), X.cuda(), aux.cuda(), p.cuda().contiguous(), bvec.cuda()
+    outs, sts = [], []
+    try:
+        for on in (0, 1):
+            _cm_switch(on)
+            C = torch.full((B, M, N), 0.5, device="cuda")
+            st = torch.zeros(T.STAT_SLOTS, 2, M, dtype=torch.float64, device="cuda")
+            T.tgemm_nn(B, M, N, K, Ad, 0, K if a_kcontig else M, a_kcontig, Xd, K * N, N, C, M * N, N, bmode=bmode, baux=auxd if bmode >= 2 else None,
+                       bp=pd if bmode else None, bias=bd if bias else None, stats=st if use_stats else None)
+            outs.append(C)
+            sts.append(st.sum(0))
+        torch.cuda.synchronize()
+    finally:
+        _cm_switch(-1)
+    A64 = A.double() if a_kcontig else A.double().t()
+    ref = torch.matmul(A64, torch.stack([_tf(bmode, X[b].double(), aux[b].double(), p.double()) for b in range(B)]))
+    if bias:
+        ref = ref + bvec.double()[None, :, None]
+    scale = max(ref.abs().max().item(), 1.0)
+    for name, C in zip(("lds-tiled", "lds-resident weights"), outs):
+        err = (C.cpu().double() - ref).abs().max().item()
+        assert err <= 2e-5 * scale + 1e-6 * K, (name, err, scale)
+    assert (outs[0] - outs[1]).abs().max().item() <= 2e-5 * scale
+    if use_stats:
+        v = outs[1].cpu().double()
+        s = torch.stack([v.sum((0, 2)), (v * v).sum((0, 2))])
+        assert torch.allclose(sts[1].cpu(), s, rtol=1e-5, atol=1e-4 * scale), (sts[1].cpu() - s).abs().max()
+        assert torch.allclose(sts[0], sts[1], rtol=1e-5, atol=1e-4 * scale * N)
