@@ -104,6 +104,18 @@ int pa_interpolation_backward_gather(int b, int c, int n, int m, const float *gr
  * pa_interpolation_backward_gather calls with idx = weight = NULL for the same (b, n, m). */
 int pa_interpolation_backward_lists(int b, int n, int m, const int *idx, const float *weight, int *scratch, pa_stream_t stream);
 
+/* Training-mode feature propagation with the first 1x1 convolution folded through the interpolation (csrc/fp_fold_train.hip; the module of
+ * patch_aug_net.py:350-362 in train() mode).  W [interp(F); S] = interp(W_a F) + W_b S:
+ *   forward   Y1 (b,O,n) = interpolation(Z (b,O,m) = W_a F; idx, weight) + Wb (O x C1, row stride ldw) . S (b,C1,n), 0 <= C1 <= 8; stats:
+ *             PA_BN_STAT_SLOTS x 2*O doubles receiving (accumulating) the per-channel sum and sum of squares of Y1, or NULL;
+ *   backward  g (b,O,n) gradient of the layer's activation, yraw its raw output, p the layer's 7*O BatchNorm block after pa_bn_bwd_finalize,
+ *             relu its activation mask, lists = pa_interpolation_backward_lists(idx, weight): writes G (b,O,m) = interpolation^T(dY1) and ADDS
+ *             dY1 . S^T to dWb (O x C1, row stride ldw). */
+int pa_fp_fold_forward(int b, int O, int m, int n, int C1, const float *Z, const int *idx, const float *weight, const float *S, const float *Wb, int ldw,
+                       float *out, double *stats, pa_stream_t stream);
+int pa_fp_fold_backward(int b, int O, int n, int m, int C1, const float *g, const float *yraw, const float *p, int relu, const float *S,
+                        const int *lists, float *G, float *dWb, int ldw, pa_stream_t stream);
+
 /* K9 with the FP module's inverse-distance weights fused in (patch_aug_net.py:350-353): weight (b,n,3), idx (b,n,3). */
 int pa_three_nn_weights(int b, int n, int m, const float *unknown, const float *known, float *weight, int *idx, pa_stream_t stream);
 

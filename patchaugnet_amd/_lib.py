@@ -100,6 +100,8 @@ _SIGS = {
     "pa_patch_pairs_count": "ipppppiipppp",
     "pa_patch_pairs_fill": "ipppppiipqpppp",
     "pa_fp_premul_g16": "lpipp",
+    "pa_fp_fold_forward": "iiiiipppppipp",
+    "pa_fp_fold_backward": "iiiiipppippppi",
     "pa_fp_chain_premul_x3": "ippplppppiiiipppi",
     "pa_linear_x3": "lpipfpi",
     "pa_fp_chain_premul_g16": "ipppplppppiiiipppi",

@@ -9,11 +9,13 @@ Module trees / parameter names follow ``place_recognition/patch_aug_net/models/p
 autograd-capable path (training, and the reference-shaped intermediate tensors); evaluation runs the fused HIP
 engine instead (patchaugnet_amd/engine.py), which reads the very same parameters.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import pointops
+from . import pointops, train_ops
 from .pt_util import SharedMLP
 
 
@@ -164,6 +166,8 @@ class SAModule(SAModuleMSG):
 class FPModule(nn.Module):
     """Feature propagation (patch_aug_net.py:317-363)."""
 
+    fold_first_layer = os.environ.get("PA_FP_NO_FOLD") is None      # A/B and test switch: False = interpolation -> cat -> SharedMLP as written in the reference
+
     def __init__(self, *, mlp):
         super().__init__()
         self.mlp = SharedMLP(mlp, bn=True)
@@ -189,6 +193,10 @@ class FPModule(nn.Module):
             lists = None
         else:
             idx, weight, lists = geo
+        if self.fold_first_layer and train_ops.fp_fold_applies(known_feats, unknown_feats, idx, len(self.mlp)) and self.mlp[0].conv.weight.shape[0] % 8 == 0:
+            # the first 1x1 convolution folded through the interpolation: its contractions run on the known points (csrc/fp_fold_train.hip)
+            layers = [train_ops.BNLayer(l.conv.weight, l.bn.bn) for l in self.mlp]
+            return train_ops.fp_chain_train_folded(known_feats, unknown_feats, idx, weight, lists, layers, training=self.mlp.training)
         x = pointops.interpolation(known_feats, idx, weight, lists)
         if unknown_feats is not None:
             x = torch.cat([x, unknown_feats], dim=1)

@@ -68,14 +68,14 @@ __device__ __forceinline__ float cm_tf(float g, float y, const float4 &c0, const
     return (gm - c1.x - xhat * c1.y) * c1.z;
 }
 
-// NG = K / 32 register groups of eight k-steps (2, 4 or 8: K = 64, 128, 256); MH = 64-row halves of the workgroup's row block (1 or 2);
+// NG = K / 32 (1, 2, 4 or 8: K = 32, 64, 128, 256); MH = 64-row halves of the workgroup's row block (1 or 2);
 // CT = columns per lane = column tiles per wave tile (4: 64-column tiles, 16-byte accesses; 2: 32-column tiles, 8-byte accesses -- twice the tiles
 // for launches whose 64-column tile count leaves SIMDs idle in the last round, and half the accumulators: twelve wavefronts per workgroup)
 template <int NG, int MODE, int MH, bool STATS, int CT, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void tgemm_cm_kernel(CMArgs a)
 {
     constexpr int KS = NG * 8;                          // k-steps of four channels
-    constexpr int GS = MODE >= 2 ? 4 : 8;               // k-steps per register group (the backward transforms carry a second operand: half the group)
+    constexpr int GS = (MODE >= 2 || NG == 1) ? 4 : 8;  // k-steps per register group (the backward transforms carry a second operand: half the group; K = 32: two groups of four)
     constexpr int NGR = KS / GS;                        // register groups per tile (even)
     constexpr int TW = 16 * CT;                         // columns of a wave tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -140,14 +140,16 @@ __global__ __launch_bounds__(WAVES * 64) void tgemm_cm_kernel(CMArgs a)
         if (a.a_kcontig) {                              // 16-byte reads along k: element e of the read is k = 4 s + e, i.e. k-step s, lane row kq = e
             for (int q = tid; q < rows * KS; q += NT) {
                 const int m = q % rows, s = q / rows;
-                const float4 v = *reinterpret_cast<const float4 *>(a.A + (size_t)(mbase + m) * a.lda + 4 * s);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);          // rows past M (M not a multiple of 64): zero fragments, never stored
+                if (mbase + m < a.M) v = *reinterpret_cast<const float4 *>(a.A + (size_t)(mbase + m) * a.lda + 4 * s);
                 float *dst = smem + ((size_t)(s * MH + (m >> 6)) * 64 + (m & 15)) * 4 + ((m & 63) >> 4);
                 dst[0] = v.x; dst[64] = v.y; dst[128] = v.z; dst[192] = v.w;       // kq = 0..3: lane + 16 -> + 64 floats
             }
         } else {                                        // 16-byte reads along m: four consecutive rows of one k
             for (int q = tid; q < (rows / 4) * K; q += NT) {
                 const int k = q / (rows / 4), m = (q - k * (rows / 4)) * 4;
-                const float4 v = *reinterpret_cast<const float4 *>(a.A + (size_t)k * a.lda + mbase + m);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (mbase + m < a.M) v = *reinterpret_cast<const float4 *>(a.A + (size_t)k * a.lda + mbase + m);      // M % 4 == 0 (host)
                 float *dst = smem + ((size_t)((k >> 2) * MH + (m >> 6)) * 64 + (k & 3) * 16 + (m & 15)) * 4 + ((m & 63) >> 4);
                 dst[0] = v.x; dst[4] = v.y; dst[8] = v.z; dst[12] = v.w;           // m % 16 + 1 -> next lane -> + 4 floats
             }
@@ -239,6 +241,7 @@ __global__ __launch_bounds__(WAVES * 64) void tgemm_cm_kernel(CMArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = mrow0 + 16 * i + r;
+                if (m >= a.M) continue;                 // padding rows of the last row block
                 const float bs = a.bias ? a.bias[m] : 0.f;
                 float v[CT];
 #pragma unroll
@@ -279,8 +282,10 @@ __global__ __launch_bounds__(WAVES * 64) void tgemm_cm_kernel(CMArgs a)
             }
             const unsigned sl = (blockIdx.x + blockIdx.y * gridDim.x) % PA_BN_STAT_SLOTS;
             double *st = a.stats + (size_t)sl * 2 * a.M;
-            atomicAdd(st + mbase + 64 * hh + row, s1);
-            atomicAdd(st + a.M + mbase + 64 * hh + row, s2);
+            if (mbase + 64 * hh + row < a.M) {
+                atomicAdd(st + mbase + 64 * hh + row, s1);
+                atomicAdd(st + a.M + mbase + 64 * hh + row, s2);
+            }
         }
     }
 }
@@ -318,11 +323,13 @@ int pa_tgemm_cm_try(int batch, int M, int N, int K, const float *A, long sAb, in
     static const long min_tiles = getenv("PA_TGEMM_CM_MIN_TILES") ? atol(getenv("PA_TGEMM_CM_MIN_TILES")) : 1024;
     if (g_tgemm_cm == 0 || (g_tgemm_cm < 0 && off)) return 0;
     if (act != 0 || beta || colv || sAb != 0 || (per_batch_stats && (bmode || stats)) || (stats && bmode >= 2)) return 0;
-    if (M % 64 || N % 32 || (K != 64 && K != 128 && K != 256)) return 0;
+    // rows: whole 64-row blocks, or a last block at least half full (its padding rows are zero fragments: wasted MFMAs, which the narrow layers
+    // that need this -- 32 output channels over 20 480 grouped points -- do not miss: they are bound by their HBM traffic)
+    if (M % 4 || M < 32 || (M % 64 != 0 && M % 64 < 32) || N % 32 || (K != 32 && K != 64 && K != 128 && K != 256)) return 0;
     if (!aligned16(A) || lda % 4 || !aligned16(B) || ldb % 4 || sBb % 4 || !aligned16(C) || ldc % 4 || sCb % 4 || (bmode >= 2 && !aligned16(baux))) return 0;
     if ((double)batch * (double)sBb * 4.0 >= 2147483647.0 || (double)batch * (double)sCb * 4.0 >= 2147483647.0) return 0;      // 32-bit buffer offsets
-    const int MH = M % 128 == 0 ? 2 : 1;
-    const int chunks = M / (64 * MH);
+    const int MH = (M + 63) / 64 % 2 == 0 ? 2 : 1;
+    const int chunks = (M + 64 * MH - 1) / (64 * MH);
     if (g_tgemm_cm < 0 && (long)batch * (N / 32) * MH * chunks < 2 * min_tiles) return 0;      // few tiles: the LDS-tiled kernel's finer tiles fill the chip better
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -358,7 +365,7 @@ int pa_tgemm_cm_try(int batch, int M, int N, int K, const float *A, long sAb, in
 #define CM_CT(NGv, MODEv, MHv) { if (CT == 4) launch_cm<NGv, MODEv, MHv, 4>(a, grid, s, st); else launch_cm<NGv, MODEv, MHv, 2>(a, grid, s, st); }
 #define CM_MH(NGv, MODEv) { if (MH == 2) CM_CT(NGv, MODEv, 2) else CM_CT(NGv, MODEv, 1) }
 #define CM_MODE(NGv) switch (bmode) { case 0: CM_MH(NGv, 0) break; case 1: CM_MH(NGv, 1) break; case 2: CM_MH(NGv, 2) break; default: CM_MH(NGv, 3) break; }
-    if (K == 256) { CM_MODE(8) } else if (K == 128) { CM_MODE(4) } else { CM_MODE(2) }
+    if (K == 256) { CM_MODE(8) } else if (K == 128) { CM_MODE(4) } else if (K == 64) { CM_MODE(2) } else { CM_MODE(1) }
 #undef CM_MODE
 #undef CM_MH
 #undef CM_CT

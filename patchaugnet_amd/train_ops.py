@@ -22,6 +22,7 @@ import torch
 from torch.autograd import Function
 
 from ._arena import zero_arena, zeros              # noqa: F401  (zero_arena is part of this module's interface)
+from . import _lib as _lib_mod
 from ._lib import call, check_device, ptr
 
 STAT_SLOTS = 32          # PA_BN_STAT_SLOTS (include/patchaugnet_hip.h): replicas of a layer's statistics block
@@ -218,6 +219,166 @@ def chain_train(x, layers, pool=0, groups=False, training=True):
             tensors.append(L.bias)
         tensors += [L.bn.weight, L.bn.bias]
     return _ChainTrain.apply(x.contiguous(), layers, int(pool), bool(groups), bool(training), *tensors)
+
+
+class _FoldedFPChain(Function):
+    """Feature-propagation level under autograd with its FIRST layer folded through the interpolation (csrc/fp_fold_train.hip):
+    ``SharedMLP(cat([interpolation(F, idx, weight), S], 1))`` of patch_aug_net.py:350-362 without the (B, C2 + C1, n) tensor and with the first
+    layer's three contractions on the m known points instead of the n >= 2 m unknown ones:
+
+        W [interp(F); S] = interp(W_a F) + W_b S          (interpolation acts on the point axis, the 1x1 convolution on the channel axis)
+
+    forward: Z = W_a F (pa_tgemm_nn on m columns) -> pa_fp_fold_forward (interpolation + skip term + the layer's BatchNorm statistics) -> the remaining
+    layers as in _ChainTrain.  backward: the remaining layers as in _ChainTrain down to the gradient of the first layer's activation, then
+    pa_bn_bwd_reduce / _finalize of that layer, pa_fp_fold_backward (G = interp^T(dY1), dW_b += dY1 S^T in one pass) and dW_a = G F^T,
+    dF = W_a^T G on m columns.  S (the raw coordinates at the finest level) takes no gradient.  Same values as the unfolded form up to fp32
+    summation order."""
+
+    @staticmethod
+    def forward(ctx, F, S, idx, weight, lists, layers, training, *tensors):
+        check_device(F, S, idx, weight)
+        _f32(F, S, *tensors)
+        B, C2, m = F.shape
+        C1, n = S.shape[1], S.shape[2]
+        dev = F.device
+        it = iter(tensors)
+        Ws, gammas, betas = [], [], []
+        for L in layers:
+            assert L.bias is None and not L.transposed, "the folded feature-propagation chain takes SharedMLP layers (no bias, (O, C) weights)"
+            Ws.append(next(it)); gammas.append(next(it)); betas.append(next(it))
+        outs = [L.out_channels for L in layers]
+        O = outs[0]
+        W1 = Ws[0].reshape(O, C2 + C1)
+        stats_all = zeros((STAT_SLOTS * 2 * sum(outs),), torch.float64, dev) if training else None
+        p_all = torch.empty(7 * sum(outs), dtype=torch.float32, device=dev)
+        ys, ps = [], []
+        so = po = 0
+
+        def bn_params(i, y_count):
+            nonlocal so, po
+            Oi = outs[i]
+            stats = stats_all[so:so + STAT_SLOTS * 2 * Oi] if training else None
+            p = p_all[po:po + 7 * Oi]
+            so += STAT_SLOTS * 2 * Oi
+            po += 7 * Oi
+            return stats, p
+
+        def finalize(i, stats, p):
+            L = layers[i]
+            if training:
+                rm, rv, mom = _bn_buffers(L.bn)
+                nbt = L.bn.num_batches_tracked if rm is not None else None
+                call("pa_bn_finalize", outs[i], 1, float(B * n), ptr(stats), ptr(gammas[i]), ptr(betas[i]), float(L.bn.eps), mom, ptr(rm), ptr(rv), ptr(p), ptr(nbt))
+            else:
+                assert L.bn.running_mean is not None, "eval-mode BatchNorm without running statistics uses batch statistics: call with training=True"
+                call("pa_bn_eval_params", outs[i], 1, ptr(gammas[i]), ptr(betas[i]), ptr(L.bn.running_mean), ptr(L.bn.running_var), float(L.bn.eps), ptr(p))
+
+        with _guard(F):
+            Wa = W1[:, :C2].contiguous()                                   # (O, C2): the interpolated channels' columns
+            Z = torch.empty((B, O, m), dtype=torch.float32, device=dev)
+            tgemm_nn(B, O, m, C2, Wa, 0, C2, True, F, C2 * m, m, Z, O * m, m)
+            y = torch.empty((B, O, n), dtype=torch.float32, device=dev)
+            stats, p = bn_params(0, n)
+            Wb = W1[:, C2:]                                                # (O, C1) view, row stride C2 + C1: read in place
+            call("pa_fp_fold_forward", B, O, m, n, C1, ptr(Z), ptr(idx), ptr(weight), ptr(S), ptr(Wb), C2 + C1, ptr(y), ptr(stats))
+            finalize(0, stats, p)
+            ys.append(y); ps.append(p)
+            prev, prevp, cin = y, p, O
+            for i in range(1, len(layers)):
+                L, W, Oi = layers[i], Ws[i], outs[i]
+                assert W.numel() // Oi == cin and (L.relu or i == len(layers) - 1)
+                y = torch.empty((B, Oi, n), dtype=torch.float32, device=dev)
+                stats, p = bn_params(i, n)
+                tgemm_nn(B, Oi, n, cin, W, 0, cin, True, prev, cin * n, n, y, Oi * n, n, bmode=1, bp=prevp, stats=stats)
+                finalize(i, stats, p)
+                ys.append(y); ps.append(p)
+                prev, prevp, cin = y, p, Oi
+            out = torch.empty((B, cin, n), dtype=torch.float32, device=dev)
+            call("pa_bn_apply", B, cin, n, 0, int(layers[-1].relu), ptr(prev), ptr(prevp), ptr(out), ptr(None), 0)
+        ctx.save_for_backward(F, S, idx, weight, Wa, *Ws)
+        ctx.layers, ctx.ys, ctx.ps, ctx.lists, ctx.training = layers, ys, ps, lists, training
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        F, S, idx, weight, Wa, *Ws = ctx.saved_tensors
+        layers, ys, ps, lists = ctx.layers, ctx.ys, ctx.ps, ctx.lists
+        B, C2, m = F.shape
+        C1, n = S.shape[1], S.shape[2]
+        dev = F.device
+        outs = [y.shape[1] for y in ys]
+        ins = [C2 + C1] + outs[:-1]
+        O = outs[0]
+        g = gout.contiguous()
+        sums_all = zeros((2 * sum(outs),), torch.float64, dev)
+        nW = [o * c for o, c in zip(outs, ins)]
+        grads = zeros((sum(nW) + 2 * sum(outs),), torch.float32, dev, keep=True)        # parameter gradients: outlive the step
+        wo = [0]
+        for k in nW:
+            wo.append(wo[-1] + k)
+        go = wo[-1]
+        so = [0]
+        for o in outs:
+            so.append(so[-1] + 2 * o)
+        per_layer = [None] * len(layers)
+        count = float(B * n) if ctx.training else float("inf")
+        with _guard(F):
+            for i in range(len(layers) - 1, -1, -1):
+                L, y, p = layers[i], ys[i], ps[i]
+                Oi, Ci = outs[i], ins[i]
+                sums = sums_all[so[i]:so[i + 1]]
+                call("pa_bn_bwd_reduce", B, Oi, n, ptr(g), ptr(y), ptr(p), int(L.relu), ptr(sums), 0)
+                dgamma = grads[go + 2 * sum(outs[:i]):go + 2 * sum(outs[:i]) + Oi]
+                dbeta = grads[go + 2 * sum(outs[:i]) + Oi:go + 2 * sum(outs[:i]) + 2 * Oi]
+                call("pa_bn_bwd_finalize", Oi, 1, count, ptr(sums), ptr(p), ptr(dgamma), ptr(dbeta))
+                mode = 2 if L.relu else 3
+                dW = grads[wo[i]:wo[i + 1]].view(Oi, Ci)
+                if i > 0:
+                    tgemm_kk(B, Oi, Ci, n, g, Oi * n, n, ys[i - 1], Ci * n, n, dW, 0, Ci, amode=mode, aaux=y, ap=p, bmode=1, bp=ps[i - 1])
+                    gp = torch.empty((B, Ci, n), dtype=torch.float32, device=dev)
+                    tgemm_nn(B, Ci, n, Oi, Ws[i], 0, Ci, False, g, Oi * n, n, gp, Ci * n, n, bmode=mode, baux=y, bp=p)
+                    g = gp
+                else:
+                    if lists is None:
+                        lists = torch.empty(_lib_mod.lib().pa_interpolation_backward_scratch_ints(B, n, m), dtype=torch.int32, device=dev)
+                        call("pa_interpolation_backward_lists", B, n, m, ptr(idx), ptr(weight), ptr(lists))
+                    G = torch.empty((B, O, m), dtype=torch.float32, device=dev)
+                    # dW[:, C2:] += dY1 S^T (the kernel's atomics, row stride C2 + C1); G = interp^T(dY1)
+                    call("pa_fp_fold_backward", B, O, n, m, C1, ptr(g), ptr(y), ptr(p), int(L.relu), ptr(S), ptr(lists), ptr(G), ptr(dW[:, C2:]), C2 + C1)
+                    # dW[:, :C2] += sum_b G_b F_b^T (contraction over the m known points); dF_b = W_a^T G_b
+                    tgemm_kk(B, O, C2, m, G, O * m, m, F, C2 * m, m, dW, 0, C2 + C1)
+                    dF = None
+                    if ctx.needs_input_grad[0]:
+                        dF = torch.empty((B, C2, m), dtype=torch.float32, device=dev)
+                        tgemm_nn(B, C2, m, O, Wa, 0, C2, False, G, O * m, m, dF, C2 * m, m)
+                per_layer[i] = [dW.view_as(Ws[i]), dgamma, dbeta]
+        ctx.ys = ctx.ps = None
+        flat = [t for pl in per_layer for t in pl]
+        return (dF, None, None, None, None, None, None, *flat)
+
+
+def fp_chain_train_folded(known_feats, skip, idx, weight, lists, layers, training=True):
+    """The decoder level ``SharedMLP(cat([interpolation(known_feats, idx, weight), skip], 1))`` with its first layer folded through the
+    interpolation (see _FoldedFPChain).  known_feats (B, C2, m), skip (B, C1 <= 8, n) without gradient, idx / weight (B, n, 3)."""
+    modes = {bool(L.bn.training) for L in layers}
+    if len(modes) > 1:
+        raise NotImplementedError("fp_chain_train_folded: the BatchNorm layers of one chain are in different modes (train / eval); freeze the whole block")
+    training = modes.pop() if modes else training
+    tensors = []
+    for L in layers:
+        tensors += [L.weight, L.bn.weight, L.bn.bias]
+    return _FoldedFPChain.apply(known_feats.contiguous(), skip.contiguous(), idx, weight, lists, layers, bool(training), *tensors)
+
+
+def fp_fold_applies(known_feats, skip, idx, n_layers):
+    """Shape rule of the fold (a function of the level's architecture, never of the batch): a skip of at most eight channels that takes no
+    gradient (the raw coordinates of the finest level), at least twice as many unknown as known points, shapes the kernels are built for."""
+    if skip is None or known_feats.dim() != 3 or skip.dim() != 3 or not known_feats.is_cuda:
+        return False
+    B, C2, m = known_feats.shape
+    C1, n = skip.shape[1], skip.shape[2]
+    return (n_layers >= 2 and 1 <= C1 <= 8 and not skip.requires_grad and n >= 2 * m and 1024 <= n <= 4096 and n % 4 == 0 and m % 4 == 0 and m <= 4096
+            and C2 % 4 == 0 and known_feats.dtype == torch.float32 and skip.dtype == torch.float32)
 
 
 class _LinearCM(Function):

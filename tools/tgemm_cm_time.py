@@ -10,7 +10,8 @@ lib.pa_tgemm_cm_enable.argtypes, lib.pa_tgemm_cm_enable.restype = [ctypes.c_int]
 shapes = [("fp0 fwd", 18, 256, 4096, 256, True, 1, True), ("fp0 dX", 18, 256, 4096, 256, False, 2, False), ("fp1 fwd", 18, 256, 1024, 256, True, 1, True),
           ("fp1 dX", 18, 256, 1024, 256, False, 2, False), ("vlad assign", 18, 64, 4096, 256, False, 0, True), ("vlad dX", 18, 256, 4096, 64, True, 3, False),
           ("sa1 L3 fwd", 18, 256, 2560, 64, True, 1, True), ("sa1 dX", 18, 64, 2560, 256, False, 2, False), ("sa2 L3", 18, 512, 320, 256, True, 1, True),
-          ("fp2 L2", 18, 256, 128, 256, True, 1, True)]
+          ("fp2 L2", 18, 256, 128, 256, True, 1, True), ("sa0 L3 fwd", 18, 64, 20480, 32, True, 1, True), ("sa0 L2 fwd", 18, 32, 20480, 32, True, 1, True),
+          ("sa0 L3 dX", 18, 32, 20480, 64, False, 2, False), ("sa0 L2 dX", 18, 32, 20480, 32, False, 2, False)]
 only = os.environ.get('PA_TGEMM_CM_ONLY')
 for name, B, M, N, K, kc, bmode, stats in shapes:
     if only and not name.startswith(only):
