@@ -384,6 +384,12 @@ int pa_bn_eval_params(int nch, int groups, const float *gamma, const float *beta
                       float *p, pa_stream_t stream);
 /* sums (2*C doubles, zero-filled) += per-channel sum of mask(g) and of mask(g)*xhat over g, y (B, C, P); relu != 0: mask = BN(y) > 0. */
 int pa_bn_bwd_reduce(int B, int C, long P, const float *g, const float *y, const float *p, int relu, double *sums, int per_batch_stats, pa_stream_t stream);
+/* pa_tgemm_nn for an input-gradient contraction (bmode 2 / 3, A shared by the batch, C contiguous (batch, M, N)) fused with the NEXT (earlier)
+ * layer's pa_bn_bwd_reduce(batch, M, N, C, ynext, pnext, relu_next, sums_next): where the LDS-resident-weights kernel takes the shape the
+ * sums ride on the contraction's epilogue, otherwise the two launches run one after the other.  Same results either way (fp32 summation order). */
+int pa_tgemm_nn_bnred(int batch, int M, int N, int K, const float *A, int lda, int a_kcontig, const float *B, long sBb, int ldb, int bmode,
+                      const float *baux, const float *bp, float *C, long sCb, int ldc, const float *ynext, const float *pnext, int relu_next,
+                      double *sums_next, pa_stream_t stream);
 /* rows 4..6 of p from the sums; dgamma / dbeta (nch floats) written when given. */
 int pa_bn_bwd_finalize(int nch, int groups, double count, const double *sums, float *p, float *dgamma, float *dbeta, pa_stream_t stream);
 /* out = [relu](y*scale + shift) over (B, C, P); pool > 0: max over groups of `pool` consecutive points (patch_aug_net.py:236) ->

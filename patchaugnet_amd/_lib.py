@@ -79,6 +79,7 @@ _SIGS = {
     "pa_tgemm_kk": "iiilpliipppliippliii",
     "pa_bn_finalize": "iidpppffpppp",
     "pa_bn_bwd_reduce": "iilpppipi",
+    "pa_tgemm_nn_bnred": "iiiipiipliippplippip",
     "pa_bn_eval_params": "iippppfp",
     "pa_quadruplet_loss": "iiiipffiiiipp",
     "pa_softmax_cols": "iiippp",

@@ -98,7 +98,8 @@ __global__ __launch_bounds__(FF_NT) void fp_fold_fwd_kernel(int O, int m, int n,
 
 // grid (O / 4, b), NT threads; LDS 4 n floats + reduction scratch.  The four channel rows of dY1 are built in LDS from (g, raw Y1, BatchNorm
 // parameters), then (a) contracted with the skip rows for dW_b and (b) gathered over the inverted neighbour lists into G.
-template <int NT>
+// CP: skip channels padded to 4 or 8 (compile time: the accumulators and their reduction cost CP, not 8)
+template <int NT, int CP>
 __global__ __launch_bounds__(NT) void fp_fold_bwd_kernel(int O, int n, int m, int C1, const float *__restrict__ g, const float *__restrict__ yraw,
                                                          const float *__restrict__ p, int relu, const float *__restrict__ S, const int *__restrict__ off_all,
                                                          const int2 *__restrict__ ent_all, float *__restrict__ G, float *__restrict__ dWb, int ldw)
@@ -128,31 +129,31 @@ __global__ __launch_bounds__(NT) void fp_fold_bwd_kernel(int O, int n, int m, in
     __syncthreads();
     // (a) dW_b[c0 + r][c] += sum_j dY1[r][j] S[b][c][j]
     if (C1 > 0) {
-        float acc[4][8];
+        float acc[4][CP];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) acc[r][c] = 0.f;
+            for (int c = 0; c < CP; ++c) acc[r][c] = 0.f;
         for (int j = tid; j < n; j += NT) {
-            float sv[8];
+            float sv[CP];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) sv[c] = c < C1 ? S[((size_t)b * C1 + c) * n + j] : 0.f;
+            for (int c = 0; c < CP; ++c) sv[c] = c < C1 ? S[((size_t)b * C1 + c) * n + j] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float d = rows[(size_t)r * n + j];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) acc[r][c] += d * sv[c];
+                for (int c = 0; c < CP; ++c) acc[r][c] += d * sv[c];
             }
         }
         const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
+            for (int c = 0; c < CP; ++c) {
                 float v = acc[r][c];
 #pragma unroll
                 for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-                if (lane == 0) red[wave * 32 + r * 8 + c] = v;
+                if (lane == 0) red[wave * 32 + r * 8 + c] = v;      // (columns c >= CP of the scratch are never read: the adder below stops at C1 <= CP)
             }
         __syncthreads();
         if (tid < 32 && (tid & 7) < C1) {
@@ -227,17 +228,24 @@ PA_API int pa_fp_fold_backward(int b, int O, int n, int m, int C1, const float *
     const int *off = lists;
     const int2 *ent = reinterpret_cast<const int2 *>(lists + (((size_t)b * (m + 1) + 1) & ~(size_t)1));
     hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_BWD                                                                                                                                              \
+    if (C1 <= 4) {                                                                                                                                              \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fp_fold_bwd_kernel<NT, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((fp_fold_bwd_kernel<NT, 4>), dim3(O / 4, b), dim3(NT), lds, st, O, n, m, C1, g, yraw, p, relu, S, off, ent, G, dWb, ldw);             \
+    } else {                                                                                                                                                    \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fp_fold_bwd_kernel<NT, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((fp_fold_bwd_kernel<NT, 8>), dim3(O / 4, b), dim3(NT), lds, st, O, n, m, C1, g, yraw, p, relu, S, off, ent, G, dWb, ldw);             \
+    }
     if (m >= 1024) {
         constexpr int NT = 1024;
         const size_t lds = ((size_t)4 * n + (NT / 64) * 32) * sizeof(float);
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fp_fold_bwd_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(fp_fold_bwd_kernel<NT>, dim3(O / 4, b), dim3(NT), lds, st, O, n, m, C1, g, yraw, p, relu, S, off, ent, G, dWb, ldw);
+        LAUNCH_BWD
     } else {
         constexpr int NT = 256;
         const size_t lds = ((size_t)4 * n + (NT / 64) * 32) * sizeof(float);
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fp_fold_bwd_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(fp_fold_bwd_kernel<NT>, dim3(O / 4, b), dim3(NT), lds, st, O, n, m, C1, g, yraw, p, relu, S, off, ent, G, dWb, ldw);
+        LAUNCH_BWD
     }
+#undef LAUNCH_BWD
     PA_CHECK_LAUNCH("pa_fp_fold_backward");
     return PA_OK;
 }

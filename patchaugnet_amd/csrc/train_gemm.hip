@@ -995,7 +995,8 @@ TOp make_top(int mode, const float *aux, const float *p, int nch)
 
 int pa_tgemm_cm_try(int batch, int M, int N, int K, const float *A, long sAb, int lda, int a_kcontig, const float *B, long sBb, int ldb, int bmode,
                     const float *baux, const float *bp, float *C, long sCb, int ldc, int beta, const float *bias, const float *colv, int act,
-                    double *stats, int per_batch_stats, hipStream_t st);      // train_gemm_cm.hip
+                    double *stats, int per_batch_stats, hipStream_t st, const float *ynext = nullptr, const float *pnext = nullptr, int relu_next = 0,
+                    double *sums_next = nullptr);      // train_gemm_cm.hip
 
 #ifdef PA_EXPERIMENTAL
 static int g_tgemm_wave = -1;
@@ -1186,6 +1187,25 @@ PA_API int pa_bn_bwd_reduce(int B, int C, long P, const float *g, const float *y
     else hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, C, P, g, y, p, sums, vec, sPb, sSumb);
     PA_CHECK_LAUNCH("pa_bn_bwd_reduce");
     return PA_OK;
+}
+
+// pa_tgemm_nn for an input-gradient contraction (bmode 2 / 3) whose result C (batch, M, N) is the gradient of the NEXT (earlier) layer's activation,
+// together with that layer's pa_bn_bwd_reduce(batch, M, N, C, ynext, pnext, relu_next, sums_next): on the LDS-resident-weights kernel the sums ride on
+// the contraction's epilogue (C is not read back); shapes that kernel does not take run the two launches.  A shared by the batch (sAb = 0).
+PA_API int pa_tgemm_nn_bnred(int batch, int M, int N, int K, const float *A, int lda, int a_kcontig, const float *B, long sBb, int ldb, int bmode,
+                             const float *baux, const float *bp, float *C, long sCb, int ldc, const float *ynext, const float *pnext, int relu_next,
+                             double *sums_next, pa_stream_t stream)
+{
+    PA_REQUIRE(batch > 0 && M > 0 && N > 0 && K > 0 && A && B && C && ynext && pnext && sums_next, "pa_tgemm_nn_bnred: bad arguments");
+    PA_REQUIRE(bmode >= 2 && bmode <= 3 && baux && bp, "pa_tgemm_nn_bnred: an input-gradient contraction (bmode 2 / 3)");
+    PA_REQUIRE(sCb == (long)M * N && ldc == N, "pa_tgemm_nn_bnred: C contiguous (batch, M, N) like ynext");
+    const int took = pa_tgemm_cm_try(batch, M, N, K, A, 0, lda, a_kcontig, B, sBb, ldb, bmode, baux, bp, C, sCb, ldc, 0, nullptr, nullptr, 0, nullptr, 0,
+                                     (hipStream_t)stream, ynext, pnext, relu_next, sums_next);
+    if (took < 0) { pa_set_error("pa_tgemm_nn_bnred: launch failed"); return PA_EINVAL; }
+    if (took) return PA_OK;
+    const int rc = pa_tgemm_nn(batch, M, N, K, A, 0, lda, a_kcontig, B, sBb, ldb, bmode, baux, bp, C, sCb, ldc, 0, nullptr, nullptr, 0, nullptr, 0, stream);
+    if (rc != PA_OK) return rc;
+    return pa_bn_bwd_reduce(batch, M, N, C, ynext, pnext, relu_next, sums_next, 0, stream);
 }
 
 PA_API int pa_bn_bwd_finalize(int nch, int groups, double count, const double *sums, float *p, float *dgamma, float *dbeta, pa_stream_t stream)

@@ -38,7 +38,9 @@ struct CMArgs {
     const float *p;                                    // per-channel parameters, SoA p[j*K + ch] (mode 1: j < 2; modes 2/3: j < 7)
     float *C; long sCb; int ldc;
     const float *bias;                                 // per m or null
-    double *stats;                                     // [PA_BN_STAT_SLOTS][2*M] or null
+    int beta;                                          // 1: C += (the result is added to what C holds: a second gradient contribution)
+    double *stats;                                     // STATS 1: [PA_BN_STAT_SLOTS][2*M] sum / sum of squares of C; STATS 2: [2*M] BatchNorm-backward sums; or null
+    const float *ynext, *pnext; int relu_next;         // STATS 2: raw output (layout of C) and 7*M parameter block of the layer whose activation gradient C is
     int coltiles_per_cloud;                            // N / (16 CT)
     long coltiles;                                     // batch * N / (16 CT)
     long tiles_per_group;                              // wave tiles (column tile x 64-row half) per workgroup
@@ -71,7 +73,7 @@ __device__ __forceinline__ float cm_tf(float g, float y, const float4 &c0, const
 // NG = K / 32 (1, 2, 4 or 8: K = 32, 64, 128, 256); MH = 64-row halves of the workgroup's row block (1 or 2);
 // CT = columns per lane = column tiles per wave tile (4: 64-column tiles, 16-byte accesses; 2: 32-column tiles, 8-byte accesses -- twice the tiles
 // for launches whose 64-column tile count leaves SIMDs idle in the last round, and half the accumulators: twelve wavefronts per workgroup)
-template <int NG, int MODE, int MH, bool STATS, int CT, int WAVES>
+template <int NG, int MODE, int MH, int STATS, int CT, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void tgemm_cm_kernel(CMArgs a)
 {
     constexpr int KS = NG * 8;                          // k-steps of four channels
@@ -82,6 +84,7 @@ __global__ __launch_bounds__(WAVES * 64) void tgemm_cm_kernel(CMArgs a)
     float4 *wf = reinterpret_cast<float4 *>(smem);                               // [KS][MH][64 lanes] float4: lane's A fragments of m-tiles 0..3 of half h, k-step s
     float4 *ptab = wf + KS * MH * 64;                                           // [K][2] float4 (modes >= 1)
     double *sst = reinterpret_cast<double *>(ptab + (MODE ? 2 * KS * 4 : 0));   // [WAVES][64][2] (STATS)
+    float4 *qtab = reinterpret_cast<float4 *>(sst + (STATS ? WAVES * 128 : 0));  // [64 MH] (scale, shift, mean, rstd) of the NEXT layer's rows (STATS 2)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, slot = lane & 15, kq = lane >> 4;
     const int mbase = blockIdx.y * 64 * MH;
 
@@ -96,6 +99,7 @@ __global__ __launch_bounds__(WAVES * 64) void tgemm_cm_kernel(CMArgs a)
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.B), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(MODE >= 2 ? a.aux : a.B), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t nrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(STATS == 2 ? a.ynext : a.B), 0, 0x7fffffff, 0x00020000);
     const unsigned krow = 16u * (unsigned)a.ldb;        // bytes from one k-step's rows to the next (four channels)
     auto tile_offs = [&](long t, unsigned &bo, unsigned &co) {
         const long ct = MH == 2 ? (t >> 1) : t;
@@ -164,6 +168,11 @@ __global__ __launch_bounds__(WAVES * 64) void tgemm_cm_kernel(CMArgs a)
         }
         if (STATS)
             for (int q = tid; q < WAVES * 64 * 2; q += NT) sst[q] = 0.0;
+        if (STATS == 2)
+            for (int q = tid; q < rows; q += NT) {
+                const int m = min(mbase + q, a.M - 1);
+                qtab[q] = make_float4(a.pnext[m], a.pnext[(size_t)a.M + m], a.pnext[(size_t)2 * a.M + m], a.pnext[(size_t)3 * a.M + m]);
+            }
     }
     __syncthreads();
 
@@ -247,6 +256,11 @@ __global__ __launch_bounds__(WAVES * 64) void tgemm_cm_kernel(CMArgs a)
 #pragma unroll
                 for (int t = 0; t < CT; ++t) v[t] = acc[i][t][r] + bs;
                 const unsigned so = (unsigned)(16 * i + r) * 4u * (unsigned)a.ldc;
+                if (a.beta) {
+                    const Vec old = ldv(crs, co, so);
+#pragma unroll
+                    for (int t = 0; t < CT; ++t) v[t] += old.v[t];
+                }
                 if constexpr (CT == 4) {
                     const u32x4 uv = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
                     __builtin_amdgcn_raw_buffer_store_b128(uv, crs, co, so, 0);
@@ -254,10 +268,29 @@ __global__ __launch_bounds__(WAVES * 64) void tgemm_cm_kernel(CMArgs a)
                     const u32x2 uv = {__float_as_uint(v[0]), __float_as_uint(v[1])};
                     __builtin_amdgcn_raw_buffer_store_b64(uv, crs, co, so, 0);
                 }
-                if (STATS) {
+                if (STATS == 1) {
                     float p1, p2;
                     if constexpr (CT == 4) { p1 = (v[0] + v[1]) + (v[2] + v[3]); p2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]); }
                     else { p1 = v[0] + v[1]; p2 = v[0] * v[0] + v[1] * v[1]; }
+                    const float t1 = dpp_row_sum16(p1), t2 = dpp_row_sum16(p2);
+                    if (slot == 15) {
+                        double *d = myst + (16 * i + 4 * kq + r) * 2;
+                        d[0] += (double)t1;
+                        d[1] += (double)t2;
+                    }
+                }
+                if (STATS == 2) {
+                    // C is the gradient of the NEXT (earlier) layer's activation: that layer's BatchNorm-backward sums ride on this epilogue
+                    // (sum mask(g), sum mask(g) xhat per row; train_gemm.hip: bn_bwd_reduce_kernel) instead of a pass of their own over (g, y)
+                    const Vec yv = ldv(nrs, co, so);
+                    const float4 q = qtab[64 * h + 16 * i + 4 * kq + r];
+                    float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+                    for (int t = 0; t < CT; ++t) {
+                        const float gm = (!a.relu_next || fmaf(yv.v[t], q.x, q.y) > 0.f) ? v[t] : 0.f;
+                        p1 += gm;
+                        p2 += gm * ((yv.v[t] - q.z) * q.w);
+                    }
                     const float t1 = dpp_row_sum16(p1), t2 = dpp_row_sum16(p2);
                     if (slot == 15) {
                         double *d = myst + (16 * i + 4 * kq + r) * 2;
@@ -280,7 +313,7 @@ __global__ __launch_bounds__(WAVES * 64) void tgemm_cm_kernel(CMArgs a)
                 const int wh = MH == 2 ? (int)(wt0 & 1) : 0;
                 if (wh == hh && wt0 < t_end) { s1 += sst[(size_t)w * 128 + row * 2]; s2 += sst[(size_t)w * 128 + row * 2 + 1]; }
             }
-            const unsigned sl = (blockIdx.x + blockIdx.y * gridDim.x) % PA_BN_STAT_SLOTS;
+            const unsigned sl = STATS == 1 ? (blockIdx.x + blockIdx.y * gridDim.x) % PA_BN_STAT_SLOTS : 0u;
             double *st = a.stats + (size_t)sl * 2 * a.M;
             if (mbase + 64 * hh + row < a.M) {
                 atomicAdd(st + mbase + 64 * hh + row, s1);
@@ -293,18 +326,23 @@ __global__ __launch_bounds__(WAVES * 64) void tgemm_cm_kernel(CMArgs a)
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <int NG, int MODE, int MH, int CT>
-void launch_cm(const CMArgs &a, dim3 grid, bool stats, hipStream_t st)
+void launch_cm(const CMArgs &a, dim3 grid, int stats, hipStream_t st)
 {
     constexpr int WAVES = CT == 4 ? 8 : 12;
-    const size_t lds = (size_t)NG * 8 * MH * 64 * 16 + (MODE ? (size_t)NG * 32 * 32 : 0) + (stats ? (size_t)WAVES * 128 * 8 : 0);
-    if (stats) {
-        if constexpr (MODE < 2) {                       // statistics ride on forward contractions only
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tgemm_cm_kernel<NG, MODE, MH, true, CT, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((tgemm_cm_kernel<NG, MODE, MH, true, CT, WAVES>), grid, dim3(WAVES * 64), lds, st, a);
+    const size_t lds = (size_t)NG * 8 * MH * 64 * 16 + (MODE ? (size_t)NG * 32 * 32 : 0) + (stats ? (size_t)WAVES * 128 * 8 : 0) + (stats == 2 ? (size_t)64 * MH * 16 : 0);
+    if (stats == 1) {
+        if constexpr (MODE < 2) {                       // output statistics ride on forward contractions only
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tgemm_cm_kernel<NG, MODE, MH, 1, CT, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((tgemm_cm_kernel<NG, MODE, MH, 1, CT, WAVES>), grid, dim3(WAVES * 64), lds, st, a);
+        }
+    } else if (stats == 2) {
+        if constexpr (MODE >= 2) {                      // the next layer's BatchNorm-backward sums ride on input-gradient contractions only
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tgemm_cm_kernel<NG, MODE, MH, 2, CT, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((tgemm_cm_kernel<NG, MODE, MH, 2, CT, WAVES>), grid, dim3(WAVES * 64), lds, st, a);
         }
     } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tgemm_cm_kernel<NG, MODE, MH, false, CT, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((tgemm_cm_kernel<NG, MODE, MH, false, CT, WAVES>), grid, dim3(WAVES * 64), lds, st, a);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tgemm_cm_kernel<NG, MODE, MH, 0, CT, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((tgemm_cm_kernel<NG, MODE, MH, 0, CT, WAVES>), grid, dim3(WAVES * 64), lds, st, a);
     }
 }
 
@@ -317,12 +355,13 @@ PA_API void pa_tgemm_cm_enable(int on) { g_tgemm_cm = on; }
 // 1 when the LDS-resident-weights kernel took the call (pa_tgemm_nn asks first), 0 when the shape is not one it is built for.
 int pa_tgemm_cm_try(int batch, int M, int N, int K, const float *A, long sAb, int lda, int a_kcontig, const float *B, long sBb, int ldb, int bmode,
                     const float *baux, const float *bp, float *C, long sCb, int ldc, int beta, const float *bias, const float *colv, int act,
-                    double *stats, int per_batch_stats, hipStream_t st)
+                    double *stats, int per_batch_stats, hipStream_t st, const float *ynext, const float *pnext, int relu_next, double *sums_next)
 {
     static const bool off = getenv("PA_TGEMM_NO_CM") != nullptr;
     static const long min_tiles = getenv("PA_TGEMM_CM_MIN_TILES") ? atol(getenv("PA_TGEMM_CM_MIN_TILES")) : 1024;
     if (g_tgemm_cm == 0 || (g_tgemm_cm < 0 && off)) return 0;
-    if (act != 0 || beta || colv || sAb != 0 || (per_batch_stats && (bmode || stats)) || (stats && bmode >= 2)) return 0;
+    if (act != 0 || (beta && (stats || sums_next)) || colv || sAb != 0 || (per_batch_stats && (bmode || stats)) || (stats && bmode >= 2)) return 0;
+    if (sums_next && (bmode < 2 || stats || per_batch_stats || !ynext || !pnext || !aligned16(ynext))) return 0;
     // rows: whole 64-row blocks, or a last block at least half full (its padding rows are zero fragments: wasted MFMAs, which the narrow layers
     // that need this -- 32 output channels over 20 480 grouped points -- do not miss: they are bound by their HBM traffic)
     if (M % 4 || M < 32 || (M % 64 != 0 && M % 64 < 32) || N % 32 || (K != 32 && K != 64 && K != 128 && K != 256)) return 0;
@@ -356,12 +395,13 @@ int pa_tgemm_cm_try(int batch, int M, int N, int K, const float *A, long sAb, in
     a.M = M; a.N = N; a.K = K; a.batch = batch;
     a.A = A; a.lda = lda; a.a_kcontig = a_kcontig;
     a.B = B; a.sBb = sBb; a.ldb = ldb; a.aux = baux; a.p = bp;
-    a.C = C; a.sCb = sCb; a.ldc = ldc; a.bias = bias; a.stats = stats;
+    a.C = C; a.sCb = sCb; a.ldc = ldc; a.bias = bias; a.beta = beta ? 1 : 0; a.stats = sums_next ? sums_next : stats;
+    a.ynext = ynext; a.pnext = pnext; a.relu_next = relu_next;
     a.coltiles_per_cloud = N / (16 * CT); a.coltiles = coltiles; a.tiles_per_group = tpg;
     static const int dbg = getenv("PA_TGEMM_CM_DBG") ? atoi(getenv("PA_TGEMM_CM_DBG")) : 0;
     a.dbg = dbg;
     const dim3 grid((unsigned)groups, (unsigned)chunks);
-    const bool s = stats != nullptr;
+    const int s = sums_next ? 2 : (stats != nullptr ? 1 : 0);
 #define CM_CT(NGv, MODEv, MHv) { if (CT == 4) launch_cm<NGv, MODEv, MHv, 4>(a, grid, s, st); else launch_cm<NGv, MODEv, MHv, 2>(a, grid, s, st); }
 #define CM_MH(NGv, MODEv) { if (MH == 2) CM_CT(NGv, MODEv, 2) else CM_CT(NGv, MODEv, 1) }
 #define CM_MODE(NGv) switch (bmode) { case 0: CM_MH(NGv, 0) break; case 1: CM_MH(NGv, 1) break; case 2: CM_MH(NGv, 2) break; default: CM_MH(NGv, 3) break; }

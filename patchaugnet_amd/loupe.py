@@ -80,8 +80,8 @@ def _netvlad_hip(self, x):
     """Channel-major statement of NetVLADBase.forward on the MI355X: x (B, C, N).  The assignment GEMM + BatchNorm is a one-layer chain
     (cluster-major (B, K, N) output, statistics fused into the GEMM epilogue), the aggregation X . act^T a batched k-contiguous GEMM."""
     layer = train_ops.BNLayer(self.cluster_weights, self.bn1, relu=False, transposed=True)
-    pre = train_ops.chain_train(x, [layer], training=self.training)                                # (B, K, N) logits
-    vlad = train_ops.netvlad_tail(pre, x, self.cluster_weights2)          # soft-max, X . act^T - a_sum * cw2, intra-normalisation: (B, C, K)
+    # assignment GEMM + BatchNorm -> (B, K, N) logits; soft-max, X . act^T - a_sum * cw2, intra-normalisation -> (B, C, K); one autograd node
+    vlad = train_ops.netvlad_fused(x, layer, self.cluster_weights2, training=self.training)
     return vlad.view(-1, self.cluster_size * self.feature_size) if self.flatten else vlad
 
 

@@ -166,12 +166,15 @@ class _ChainTrain(Function):
                 full = torch.empty((B, O, P), dtype=torch.float32, device=dev)
                 call("pa_maxpool_bwd", B * O, P // pool, int(pool), ptr(g), ptr(arg), ptr(full))
                 g = full
+            reduced = False          # this layer's BatchNorm-backward sums already rode on the contraction that produced its activation gradient
             for i in range(len(layers) - 1, -1, -1):
                 L, W, y, p = layers[i], Ws[i], ys[i], ps[i]
                 O, C = outs[i], ins[i]
                 prev = x if i == 0 else ys[i - 1]
                 sums = sums_all[so[i]:so[i + 1]]
-                call("pa_bn_bwd_reduce", B, O, P, ptr(g), ptr(y), ptr(p), int(L.relu), ptr(sums), int(groups))
+                if not reduced:
+                    call("pa_bn_bwd_reduce", B, O, P, ptr(g), ptr(y), ptr(p), int(L.relu), ptr(sums), int(groups))
+                reduced = False
                 dgamma = grads[go + 2 * sum(outs[:i]):go + 2 * sum(outs[:i]) + O]
                 dbeta = grads[go + 2 * sum(outs[:i]) + O:go + 2 * sum(outs[:i]) + 2 * O]
                 # eval(): no batch-statistics terms in the input gradient -- count = +inf leaves rows 4, 5 of p at zero
@@ -183,8 +186,17 @@ class _ChainTrain(Function):
                 if i > 0 or ctx.needs_input_grad[0]:
                     gp = torch.empty((B, C, P), dtype=torch.float32, device=dev)
                     # dX (C x P) = W^T (C x O) . dY (O x P): A(m = c, k = o) = W[o*C + c] (or W[c*O + o] for a transposed weight)
-                    tgemm_nn(B, C, P, O, W, 0, O if L.transposed else C, L.transposed, g, O * P, P, gp, C * P, P, bmode=mode, baux=y, bp=p,
-                             per_batch_stats=groups)
+                    if i > 0 and not groups:
+                        # ... together with layer i - 1's BatchNorm-backward sums over (gp, its raw output): one launch where the shape allows
+                        call("pa_tgemm_nn_bnred", B, C, P, O, ptr(W), O if L.transposed else C, int(L.transposed), ptr(g), O * P, P, mode, ptr(y), ptr(p),
+                             ptr(gp), C * P, P, ptr(ys[i - 1]), ptr(ps[i - 1]), int(layers[i - 1].relu), ptr(sums_all[so[i - 1]:so[i]]))
+                        reduced = True
+                    else:
+                        acc = getattr(ctx, "accumulate_into", None) if i == 0 else None      # a second consumer's gradient of x already sits there
+                        if acc is not None:
+                            gp = acc
+                        tgemm_nn(B, C, P, O, W, 0, O if L.transposed else C, L.transposed, g, O * P, P, gp, C * P, P, bmode=mode, baux=y, bp=p,
+                                 beta=1 if acc is not None else 0, per_batch_stats=groups)
                     g = gp
                 else:
                     g = None
@@ -323,11 +335,13 @@ class _FoldedFPChain(Function):
         per_layer = [None] * len(layers)
         count = float(B * n) if ctx.training else float("inf")
         with _guard(F):
+            reduced = False
             for i in range(len(layers) - 1, -1, -1):
                 L, y, p = layers[i], ys[i], ps[i]
                 Oi, Ci = outs[i], ins[i]
                 sums = sums_all[so[i]:so[i + 1]]
-                call("pa_bn_bwd_reduce", B, Oi, n, ptr(g), ptr(y), ptr(p), int(L.relu), ptr(sums), 0)
+                if not reduced:
+                    call("pa_bn_bwd_reduce", B, Oi, n, ptr(g), ptr(y), ptr(p), int(L.relu), ptr(sums), 0)
                 dgamma = grads[go + 2 * sum(outs[:i]):go + 2 * sum(outs[:i]) + Oi]
                 dbeta = grads[go + 2 * sum(outs[:i]) + Oi:go + 2 * sum(outs[:i]) + 2 * Oi]
                 call("pa_bn_bwd_finalize", Oi, 1, count, ptr(sums), ptr(p), ptr(dgamma), ptr(dbeta))
@@ -336,7 +350,9 @@ class _FoldedFPChain(Function):
                 if i > 0:
                     tgemm_kk(B, Oi, Ci, n, g, Oi * n, n, ys[i - 1], Ci * n, n, dW, 0, Ci, amode=mode, aaux=y, ap=p, bmode=1, bp=ps[i - 1])
                     gp = torch.empty((B, Ci, n), dtype=torch.float32, device=dev)
-                    tgemm_nn(B, Ci, n, Oi, Ws[i], 0, Ci, False, g, Oi * n, n, gp, Ci * n, n, bmode=mode, baux=y, bp=p)
+                    call("pa_tgemm_nn_bnred", B, Ci, n, Oi, ptr(Ws[i]), Ci, 0, ptr(g), Oi * n, n, mode, ptr(y), ptr(p), ptr(gp), Ci * n, n,
+                         ptr(ys[i - 1]), ptr(ps[i - 1]), int(layers[i - 1].relu), ptr(sums_all[so[i - 1]:so[i]]))
+                    reduced = True
                     g = gp
                 else:
                     if lists is None:
@@ -687,6 +703,46 @@ class _NetVladTail(Function):
                 tgemm_nn(B, K, N, C, dv, C * K, K, False, x, C * N, N, dpre, K * N, N)
                 call("pa_softmax_cols_backward", B, K, N, ptr(act), ptr(dpre), ptr(dasum), ptr(dpre))
         return dpre, dx, dcw2
+
+
+class _Bag:
+    """Stand-in for an autograd ctx when one Function drives another Function's static forward / backward."""
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+class _NetVladFused(Function):
+    """NetVLADBase.forward (loupe.py:196-222) as ONE autograd node: the assignment layer (_ChainTrain, one BatchNorm layer without ReLU) and the
+    tail (_NetVladTail) both consume x; as two nodes autograd adds their two (B, C, N) gradients with a pass of its own (75 MB read twice and
+    written once at the finest scale).  Here the tail's backward writes dx and the assignment layer's input-gradient contraction ADDS to it
+    (pa_tgemm_nn beta = 1)."""
+
+    @staticmethod
+    def forward(ctx, x, layer, training, cw2, W, gamma, beta):
+        c1, c2 = _Bag(), _Bag()
+        pre = _ChainTrain.forward(c1, x, [layer], 0, False, training, W, gamma, beta)
+        out = _NetVladTail.forward(c2, pre, x, cw2)
+        ctx.c1, ctx.c2 = c1, c2
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        c1, c2 = ctx.c1, ctx.c2
+        need_x = ctx.needs_input_grad[0]
+        c2.needs_input_grad = (True, need_x, ctx.needs_input_grad[3])
+        dpre, dx, dcw2 = _NetVladTail.backward(c2, gout)
+        c1.needs_input_grad = (need_x,)
+        c1.accumulate_into = dx
+        res = _ChainTrain.backward(c1, dpre)
+        ctx.c1 = ctx.c2 = None
+        return res[0], None, None, dcw2, res[5], res[6], res[7]
+
+
+def netvlad_fused(x, layer, cw2, training=True):
+    """x (B, C, N) -> intra-normalised VLAD (B, C, K): assignment layer + tail as one autograd node (see _NetVladFused)."""
+    training = bool(layer.bn.training)
+    return _NetVladFused.apply(x.contiguous(), layer, training, cw2, layer.weight, layer.bn.weight, layer.bn.bias)
 
 
 def netvlad_tail(pre, x, cw2):
