@@ -223,6 +223,10 @@ int pa_fp_premul_g16(long rows, const float *x, int ldx, const void *wp16, void 
 int pa_fp_chain_premul_g16(int nlayers, const void *const *wp16, const float *const *bias, const int *kpad, const int *nout, long rows,
                            const void *g16, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2, int c1,
                            const float *wskip, const float *bias0, float *out, int ldo, pa_stream_t stream);
+/* pa_fp_chain_premul_g16 with the level's output in fp16: out16 (rows, 256) halfs, 16-byte aligned (for pa_netvlad_pyramid_f16h). */
+int pa_fp_chain_premul_g16h(int nlayers, const void *const *wp16, const float *const *bias, const int *kpad, const int *nout, long rows,
+                            const void *g16, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2, int c1,
+                            const float *wskip, const float *bias0, void *out16, pa_stream_t stream);
 
 /* OPT-IN (model.mlp_dtype = "f32x3"; never the default path): pa_fp_chain_premul at the finest level's shape (c2 = 256, 1 <= c1 <= 4, two remaining
  * 256 -> 256 layers) with every product of the two dense layers evaluated from (hi, lo) fp16 operand pairs -- hi(a) hi(w) + lo(a) hi(w) +
@@ -327,6 +331,12 @@ int pa_netvlad_pyramid(int b, int nscales, const int *n, const int *k, const flo
 int pa_netvlad_pyramid_f16(int b, int nscales, const int *n, const int *k, const float *const *x, const float *const *wc_t, const float *const *wc_p,
                            const void *const *wc16, const float *const *bias, const float *const *w2, float *const *scratch, float *out, int phases,
                            pa_stream_t stream);
+/* The same where the feature maps of the scales flagged in x16_mask (bit s) arrive as fp16 rows of 256 halfs (x[s] points at halfs; only scales
+ * that run the fp16 kernel).  Producer: pa_fp_chain_premul_g16h.  For descriptor-only extraction on the fp16 path: the finest map is written
+ * and read once in half the bytes. */
+int pa_netvlad_pyramid_f16h(int b, int nscales, const int *n, const int *k, const float *const *x, const float *const *wc_t, const float *const *wc_p,
+                            const void *const *wc16, const float *const *bias, const float *const *w2, float *const *scratch, float *out, int phases,
+                            int x16_mask, pa_stream_t stream);
 long pa_afa_fused_scratch_floats(int b, int ktot, int nout);
 int pa_afa_fused(int b, int c, int ktot, int nout, const float *vt, const float *watt_t, const float *fc_wt, const float *fc_bias,
                  const float *scale, const float *shift, int l2norm, float *scratch, float *desc, pa_stream_t stream);

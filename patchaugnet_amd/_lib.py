@@ -73,6 +73,7 @@ _SIGS = {
     "pa_fc": "iiipppppippp",
     "pa_netvlad_pyramid": "iipppppppppi",
     "pa_netvlad_pyramid_f16": "iippppppppppi",
+    "pa_netvlad_pyramid_f16h": "iippppppppppii",
     "pa_afa_fused": "iiiippppppipp",
     "pa_vlad_maxpool": "iiipip",
     "pa_tgemm_nn": "iiiipliipliipppliippipi",
@@ -106,6 +107,7 @@ _SIGS = {
     "pa_fp_chain_premul_x3": "ippplppppiiiipppi",
     "pa_linear_x3": "lpipfpi",
     "pa_fp_chain_premul_g16": "ipppplppppiiiipppi",
+    "pa_fp_chain_premul_g16h": "ipppplppppiiiippp",
 }
 # entry points of the measured-slower variants: exported by the test-only library only (csrc/pa_internal.h section 2)
 _EXP_SIGS = {

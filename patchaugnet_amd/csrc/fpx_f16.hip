@@ -48,6 +48,7 @@ struct Fpx16Args {
     const half8 *wq[2];   // pa_pack_weights_f16(256, 256) of the layers
     const float *b[2];
     float *out;
+    _Float16 *out16;      // OUT16: the result as fp16 rows of 256 (descriptor-only callers: the map is only read by the fp16 NetVLAD kernel)
     int ldo, n_unknown, m_known, c1, xcd_remap;
     // PREMUL form: g16out[r][:] = fp16(x[r][:256] . W): rows = rows of x
     const float *x;
@@ -59,7 +60,7 @@ struct Fpx16Args {
 __device__ __forceinline__ int r_ofs(int ct, int g) { return 32 * (ct >> 1) + 8 * g + 4 * (ct & 1); }
 
 // NL layers of 256 -> 256 on 32-row wave tiles.  PREMUL: operand = rows of x, one layer, fp16 output without bias / ReLU.
-template <int WAVES, int KSB, int NL, bool PREMUL, bool G16, bool DBG>
+template <int WAVES, int KSB, int NL, bool PREMUL, bool G16, bool DBG, bool OUT16 = false>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 1 : 2) void fpx16_kernel(Fpx16Args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fpx16_lds[];
@@ -335,6 +336,23 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 1 : 2) void fpx16_kernel(F
                 }
             }
         }
+    } else if constexpr (OUT16) {
+        // ---- out16 = fp16(relu(acc + b3)): a column-tile pair = eight consecutive channels = ONE 16-byte store (half the store volume) ----------
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const long row = row0 + rt * 16;
+            if (row < a.rows) {
+                _Float16 *o = a.out16 + (size_t)row * 256 + 8 * g;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const float4 b0 = *reinterpret_cast<const float4 *>(cst + 1536 + r_ofs(2 * p, g)), b1 = *reinterpret_cast<const float4 *>(cst + 1536 + r_ofs(2 * p + 1, g));
+                    const floatx4 lo = acc[rt][2 * p], hi = acc[rt][2 * p + 1];
+                    *reinterpret_cast<half8 *>(o + 32 * p) =
+                        (half8){(_Float16)fmaxf(lo[0] + b0.x, 0.f), (_Float16)fmaxf(lo[1] + b0.y, 0.f), (_Float16)fmaxf(lo[2] + b0.z, 0.f), (_Float16)fmaxf(lo[3] + b0.w, 0.f),
+                                (_Float16)fmaxf(hi[0] + b1.x, 0.f), (_Float16)fmaxf(hi[1] + b1.y, 0.f), (_Float16)fmaxf(hi[2] + b1.z, 0.f), (_Float16)fmaxf(hi[3] + b1.w, 0.f)};
+                }
+            }
+        }
     } else {
         // ---- out = relu(acc + b3): 16 bytes per lane, a column-tile pair = 32 contiguous bytes ------------------------------------------
 #pragma unroll
@@ -360,11 +378,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 1 : 2) void fpx16_kernel(F
 #undef FPX16_STAMP
 }
 
-template <int WAVES, int KSB, int NL, bool PREMUL, bool G16>
+template <int WAVES, int KSB, int NL, bool PREMUL, bool G16, bool OUT16 = false>
 void launch_fpx16(const Fpx16Args &a, hipStream_t st)
 {
     const size_t lds = (size_t)2 * KSB * 16 * 1024 + 7 * 1024 + (a.dbg ? 256 : 0);
-    auto kern = a.dbg ? fpx16_kernel<WAVES, KSB, NL, PREMUL, G16, true> : fpx16_kernel<WAVES, KSB, NL, PREMUL, G16, false>;
+    auto kern = (a.dbg && !OUT16) ? fpx16_kernel<WAVES, KSB, NL, PREMUL, G16, true, false> : fpx16_kernel<WAVES, KSB, NL, PREMUL, G16, false, OUT16>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(pa_div_up(a.rows, WAVES * 32)), dim3(WAVES * 64), lds, st, a);
 }
@@ -386,7 +404,8 @@ bool fpx16_shape(int nlayers, const void *const *wp16, const int *kpad, const in
 }
 
 int fpx16_chain(bool g16, const void *const *wp16, const float *const *bias, long rows, const void *g, const int *idx3, const float *w3, const float *skip,
-                int n_unknown, int m_known, int c1, const float *wskip, const float *bias0, float *out, int ldo, long long *dbg, hipStream_t st)
+                int n_unknown, int m_known, int c1, const float *wskip, const float *bias0, float *out, int ldo, long long *dbg, hipStream_t st,
+                _Float16 *out16 = nullptr)
 {
     Fpx16Args a = {};
     a.rows = rows; a.g = g; a.idx3 = idx3; a.w3 = w3; a.skip = skip; a.wskip = wskip; a.bias0 = bias0;
@@ -395,6 +414,12 @@ int fpx16_chain(bool g16, const void *const *wp16, const float *const *bias, lon
     static const bool no_xcd = getenv("PA_CHAIN_NO_XCD_REMAP") != nullptr;
     a.xcd_remap = no_xcd ? 0 : 1;
     const bool w8 = fpx16_mode() == 8;
+    if (out16) {               // fp16 table in, fp16 map out (four-wave workgroups: the shipped form)
+        a.out16 = out16; a.dbg = nullptr;
+        launch_fpx16<4, 2, 2, false, true, true>(a, st);
+        PA_CHECK_LAUNCH("pa_fp_chain_premul_g16h");
+        return PA_OK;
+    }
     if (g16) { if (w8) launch_fpx16<8, 4, 2, false, true>(a, st); else launch_fpx16<4, 2, 2, false, true>(a, st); }
     else     { if (w8) launch_fpx16<8, 4, 2, false, false>(a, st); else launch_fpx16<4, 2, 2, false, false>(a, st); }
     PA_CHECK_LAUNCH("pa_fp_chain_premul_f16(lds)");
@@ -444,4 +469,20 @@ PA_API int pa_fp_chain_premul_g16(int nlayers, const void *const *wp16, const fl
         return PA_EUNSUPPORTED;
     }
     return fpx16_chain(true, wp16, bias, rows, g16, idx3, w3, skip, n_unknown, m_known, c1, wskip, bias0, out, ldo, pa_chain_dbg_ptr(), (hipStream_t)stream);
+}
+
+// pa_fp_chain_premul_g16 with the level's output ALSO in fp16: out16 (rows, 256) halfs.  For callers that hand the map to the fp16 NetVLAD kernel
+// only (descriptor extraction without feature maps: pa_netvlad_pyramid_f16h): the 134 MB fp32 store and its re-read become 67 MB each.
+PA_API int pa_fp_chain_premul_g16h(int nlayers, const void *const *wp16, const float *const *bias, const int *kpad, const int *nout, long rows,
+                                   const void *g16, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2, int c1,
+                                   const float *wskip, const float *bias0, void *out16, pa_stream_t stream)
+{
+    PA_REQUIRE(wp16 && bias && kpad && nout && rows > 0 && g16 && idx3 && w3 && skip && wskip && bias0 && out16, "pa_fp_chain_premul_g16h: null argument");
+    PA_REQUIRE(((uintptr_t)out16 & 15) == 0, "pa_fp_chain_premul_g16h: out16 must be 16-byte aligned");
+    if (!fpx16_shape(nlayers, wp16, kpad, nout, c2, c1, reinterpret_cast<const float *>(out16), 256, rows, n_unknown) || ((uintptr_t)g16 & 15) != 0) {
+        pa_set_error("pa_fp_chain_premul_g16h: only c2 = 256, 1 <= c1 <= 4 and two 256 -> 256 layers (got nlayers=%d c2=%d c1=%d)", nlayers, c2, c1);
+        return PA_EUNSUPPORTED;
+    }
+    return fpx16_chain(true, wp16, bias, rows, g16, idx3, w3, skip, n_unknown, m_known, c1, wskip, bias0, nullptr, 256, nullptr, (hipStream_t)stream,
+                       reinterpret_cast<_Float16 *>(out16));
 }

@@ -356,6 +356,9 @@ constexpr int V16_PITCH = VC + 8;                                            // 
 constexpr int V16_AQ = 66;                                                   // (point quad) pitch of the assignment tile, in clusters
 constexpr size_t V16_LDS = (size_t)V16_ROWS * V16_PITCH * 2 + 2 * 32768 + (V16_ROWS / 4) * V16_AQ * 8 + 8 * 64 * 4;
 
+// X16: the feature map arrives as fp16 rows (pa_fp_chain_premul_g16h wrote it for this kernel alone): half the read, no (hi, lo) split of x
+// (the map IS its hi part; its own rounding, 2^-11 relative per feature, is that of every other operand of the fp16 path)
+template <bool X16>
 __global__ __launch_bounds__(512, 1) void vlad_accum16_kernel(int n, int k_true, int rows_per_wg, const float *__restrict__ x_all,
                                                               const _Float16 *__restrict__ wc16,   // pa_pack_weights_f16(256, 64) of W, then of W - fp16(W)
                                                               const float *__restrict__ bias, float *__restrict__ part, float *__restrict__ asum_part)
@@ -372,6 +375,7 @@ __global__ __launch_bounds__(512, 1) void vlad_accum16_kernel(int n, int k_true,
     const int row_begin = chunk * rows_per_wg;
     const int row_end = min(row_begin + rows_per_wg, n);
     const float *x = x_all + (size_t)b * n * VC;
+    const _Float16 *xh16 = reinterpret_cast<const _Float16 *>(x_all) + (size_t)b * n * VC;      // X16
 
     // assignment weights -> LDS (64 pieces of 1 KB, eight per wave)
 #pragma unroll
@@ -390,12 +394,18 @@ __global__ __launch_bounds__(512, 1) void vlad_accum16_kernel(int n, int k_true,
     for (int kt = 0; kt < KT; ++kt) { asum[kt] = 0.f; bia[kt] = bias[kt * 16 + li]; }
 
     // a lane's point of the tile at r0: row r0 + 16 w + li (clamped: rows past the end get a = 0 below), channels 32 ks + 8 lq .. + 7
-    float4 pre[16];
+    float4 pre[X16 ? 8 : 16];
     auto fetch = [&](int r0) {
         const int row = min(r0 + wave * 16 + li, row_end - 1);
-        const float4 *src = reinterpret_cast<const float4 *>(x + (size_t)row * VC + 8 * lq);
+        if constexpr (X16) {
+            const float4 *src = reinterpret_cast<const float4 *>(xh16 + (size_t)row * VC + 8 * lq);      // eight halfs = 16 bytes per k-step
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) { pre[2 * ks] = src[8 * ks]; pre[2 * ks + 1] = src[8 * ks + 1]; }
+            for (int ks = 0; ks < 8; ++ks) pre[ks] = src[4 * ks];
+        } else {
+            const float4 *src = reinterpret_cast<const float4 *>(x + (size_t)row * VC + 8 * lq);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) { pre[2 * ks] = src[8 * ks]; pre[2 * ks + 1] = src[8 * ks + 1]; }
+        }
     };
     fetch(row_begin);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the weight copies (and the first tile) have landed ...
@@ -410,22 +420,28 @@ __global__ __launch_bounds__(512, 1) void vlad_accum16_kernel(int n, int k_true,
         for (int kt = 0; kt < KT; ++kt) acc[kt] = (floatx4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            const float4 a0 = pre[2 * ks], a1 = pre[2 * ks + 1];
-            const float xv[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
             vhalf8 hi, lo;
             vbf8 xb;
+            if constexpr (X16) {
+                hi = __builtin_bit_cast(vhalf8, pre[ks]);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                hi[e] = (_Float16)xv[e];
-                lo[e] = (_Float16)(xv[e] - (float)hi[e]);
-                xb[e] = (__bf16)xv[e];
+                for (int e = 0; e < 8; ++e) xb[e] = (__bf16)(float)hi[e];
+            } else {
+                const float4 a0 = pre[2 * ks], a1 = pre[2 * ks + 1];
+                const float xv[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    hi[e] = (_Float16)xv[e];
+                    lo[e] = (_Float16)(xv[e] - (float)hi[e]);
+                    xb[e] = (__bf16)xv[e];
+                }
             }
             *reinterpret_cast<vbf8 *>(Xh + (wave * 16 + li) * V16_PITCH + 32 * ks + 8 * lq) = xb;
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
                 const vhalf8 wh = wf[(kt * 8 + ks) * 64], wl = wf[(32 + kt * 8 + ks) * 64];
                 acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, wh, acc[kt], 0, 0, 0);
-                acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lo, wh, acc[kt], 0, 0, 0);
+                if constexpr (!X16) acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lo, wh, acc[kt], 0, 0, 0);
                 acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, wl, acc[kt], 0, 0, 0);
             }
         }
@@ -1246,7 +1262,7 @@ __global__ __launch_bounds__(1024) void afa_combine_kernel(int ktot, int nout, c
 // the requested phases do not read may be NULL.
 static int netvlad_pyramid(int b, int nscales, const int *n, const int *k, const float *const *x, const float *const *wc_t, const float *const *wc_p,
                            const void *const *wc16, const float *const *bias, const float *const *w2, float *const *scratch, float *out, int phases,
-                           pa_stream_t stream)
+                           pa_stream_t stream, int x16_mask = 0)
 {
     PA_REQUIRE(b > 0 && b <= 65535 && nscales > 0 && nscales <= VLAD_MAX_SCALES && n && k && x && wc_t && bias && w2 && scratch && (out || !(phases & 4)) && (phases & 7),
                "pa_netvlad_pyramid: bad arguments");
@@ -1276,9 +1292,13 @@ static int netvlad_pyramid(int b, int nscales, const int *n, const int *k, const
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vlad_accum_kernel<KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(vlad_accum_kernel<KT>, dim3(chunks, b), dim3(256), lds, st, n[s], k[s], rows, x[s], wc_t[s], wp, bias[s], part, asum);  \
     } while (0)
-        if (kt == 4 && wc16 && wc16[s]) {   // fp16 path: both contractions on the fp16 MFMA, same partials
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vlad_accum16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)V16_LDS);
-            hipLaunchKernelGGL(vlad_accum16_kernel, dim3(chunks, b), dim3(512), V16_LDS, st, n[s], k[s], rows, x[s], reinterpret_cast<const _Float16 *>(wc16[s]),
+        if (kt == 4 && wc16 && wc16[s] && ((x16_mask >> s) & 1)) {   // fp16 path, fp16 feature map
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vlad_accum16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)V16_LDS);
+            hipLaunchKernelGGL(vlad_accum16_kernel<true>, dim3(chunks, b), dim3(512), V16_LDS, st, n[s], k[s], rows, x[s], reinterpret_cast<const _Float16 *>(wc16[s]),
+                               bias[s], part, asum);
+        } else if (kt == 4 && wc16 && wc16[s]) {   // fp16 path: both contractions on the fp16 MFMA, same partials
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vlad_accum16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)V16_LDS);
+            hipLaunchKernelGGL(vlad_accum16_kernel<false>, dim3(chunks, b), dim3(512), V16_LDS, st, n[s], k[s], rows, x[s], reinterpret_cast<const _Float16 *>(wc16[s]),
                                bias[s], part, asum);
         } else if (kt == 1) PA_VLAD_LAUNCH(1);
         else if (kt == 2) PA_VLAD_LAUNCH(2);
@@ -1309,6 +1329,18 @@ PA_API int pa_netvlad_pyramid_f16(int b, int nscales, const int *n, const int *k
 {
     PA_REQUIRE(wc16, "pa_netvlad_pyramid_f16: null wc16");
     return netvlad_pyramid(b, nscales, n, k, x, wc_t, wc_p, wc16, bias, w2, scratch, out, phases, stream);
+}
+
+// pa_netvlad_pyramid_f16 where the feature maps of the scales in x16_mask (bit s) are fp16 rows of 256 halfs (x[s] then points at halfs): only
+// scales that run the fp16 kernel (wc16[s] != NULL, 49..64 clusters, >= 2048 points) may be flagged.  The producer is pa_fp_chain_premul_g16h.
+PA_API int pa_netvlad_pyramid_f16h(int b, int nscales, const int *n, const int *k, const float *const *x, const float *const *wc_t, const float *const *wc_p,
+                                   const void *const *wc16, const float *const *bias, const float *const *w2, float *const *scratch, float *out, int phases,
+                                   int x16_mask, pa_stream_t stream)
+{
+    PA_REQUIRE(wc16, "pa_netvlad_pyramid_f16h: null wc16");
+    for (int s = 0; s < nscales && s < VLAD_MAX_SCALES; ++s)
+        PA_REQUIRE(!((x16_mask >> s) & 1) || (wc16[s] && ((k[s] + 15) & ~15) == 64), "pa_netvlad_pyramid_f16h: scale %d is not an fp16-kernel scale", s);
+    return netvlad_pyramid(b, nscales, n, k, x, wc_t, wc_p, wc16, bias, w2, scratch, out, phases, stream, x16_mask);
 }
 
 PA_API long pa_afa_fused_scratch_floats(int b, int ktot, int nout) { return (long)b * ktot * 4 + (long)b * ktot * nout; }

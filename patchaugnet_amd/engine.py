@@ -208,7 +208,7 @@ class _Chain:
             "nout": (ctypes.c_int * m)(*([l[4] for l in rest] + [fm["n0"]])),
         }
 
-    def fp_premul(self, known_feat, idx3, w3, skip, B, n_unknown, m_known, c2, c1, mark=None, g_pre=None, tail=False):
+    def fp_premul(self, known_feat, idx3, w3, skip, B, n_unknown, m_known, c2, c1, mark=None, g_pre=None, tail=False, out16=False):
         """Finest feature-propagation level: the first layer is applied to the m_known coarse points BEFORE interpolation
         (pa_fp_chain_premul; interpolation is linear), the skip (xyz) term is added in the kernel's prologue."""
         dev = known_feat.device
@@ -221,8 +221,14 @@ class _Chain:
             if mark is not None:
                 mark()
             rows = B * n_unknown
-            out = torch.empty((rows, self.n_last), dtype=torch.float32, device=dev)
             cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
+            if out16:       # descriptor-only extraction: the map goes to the fp16 NetVLAD kernel and nowhere else -> fp16 rows, half the bytes both ways
+                out = torch.empty((rows, self.n_last), dtype=torch.float16, device=dev)
+                for _ in range(getattr(self, "bench_repeat", 1)):
+                    call("pa_fp_chain_premul_g16h", pm["m"], cast(pm["wpk"]), cast(pm["bias"]), cast(pm["kpad"]), cast(pm["nout"]), rows, ptr(g16), ptr(idx3),
+                         ptr(w3), ptr(skip), n_unknown, m_known, pm["n0"], c1, ptr(pm["wskip"]), ptr(pm["bias0"]), ptr(out))
+                return out
+            out = torch.empty((rows, self.n_last), dtype=torch.float32, device=dev)
             for _ in range(getattr(self, "bench_repeat", 1)):
                 call("pa_fp_chain_premul_g16", pm["m"], cast(pm["wpk"]), cast(pm["bias"]), cast(pm["kpad"]), cast(pm["nout"]), rows, ptr(g16), ptr(idx3),
                      ptr(w3), ptr(skip), n_unknown, m_known, pm["n0"], c1, ptr(pm["wskip"]), ptr(pm["bias0"]), ptr(out), self.n_last)
@@ -349,7 +355,7 @@ class _Pyramid:
         scr = [torch.empty(lib.pa_netvlad_scratch_floats(b, v.n, v.k), dtype=torch.float32, device=dev) for v in self.vlads]
         return {"b": b, "scr": scr, "sc": (ctypes.c_void_p * self.ns)(*[t.data_ptr() for t in scr])}
 
-    def launch(self, state, feats, out, phases):
+    def launch(self, state, feats, out, phases, x16_mask=0):
         """feats: per scale (B, n_s, 256) point-major, coarse -> fine (None where `phases` does not read the scale); phases as pa_netvlad_pyramid."""
         for v, f in zip(self.vlads, feats):
             if f is not None and (f.shape[1] != v.n or f.shape[2] != v.c):
@@ -357,6 +363,10 @@ class _Pyramid:
         cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
         xs = (ctypes.c_void_p * self.ns)(*[(f.data_ptr() if f is not None else None) for f in feats])
         state["keep"] = feats                         # the launches read these buffers asynchronously
+        if self.f16 and x16_mask:        # the flagged scales' maps are fp16 rows (fp_premul(out16=True))
+            call("pa_netvlad_pyramid_f16h", state["b"], self.ns, cast(self.n), cast(self.k), cast(xs), cast(self.wc_t), cast(self.wc_p), cast(self.wc16),
+                 cast(self.bias), cast(self.w2), cast(state["sc"]), ptr(out), phases, x16_mask)
+            return
         if self.f16:
             call("pa_netvlad_pyramid_f16", state["b"], self.ns, cast(self.n), cast(self.k), cast(xs), cast(self.wc_t), cast(self.wc_p), cast(self.wc16),
                  cast(self.bias), cast(self.w2), cast(state["sc"]), ptr(out), phases)
@@ -656,6 +666,9 @@ class PatchAugNetEngine:
         # self.last_geometry (parity tests read the reference's sample_idx_origin / sa_features from it, patch_aug_net.py:169-177)
         self.keep_geometry = False
         self.last_geometry = None
+        # fp16 path: forward(views=False) keeps the finest feature map in fp16 between its producer and the NetVLAD kernel (PA_ENGINE_FP0_F16=0: A/B knob)
+        self._fp0_half_ok = os.environ.get("PA_ENGINE_FP0_F16", "1") != "0"
+        self._fp0_half = False
         self._geo_streams = {}
 
     @staticmethod
@@ -879,7 +892,8 @@ class PatchAugNetEngine:
                     nc1 = (3 if self.use_origin else 0) if nfp + i - 1 == 0 else self.sa[nfp + i - 2].n_last
                     fuse = (nc1 <= 4 or nn_u >= 512) and nn_u >= 2 * nm_k
                 res = chain.fp_premul(known_feat.contiguous(), idx3_l, w3_l, skip.contiguous(), B, n_u, m_k, c2, c1,
-                                      mark=lambda k=nfp + i: self._mark(f"fp{k}.premul"), g_pre=g_pre, tail=fuse)
+                                      mark=lambda k=nfp + i: self._mark(f"fp{k}.premul"), g_pre=g_pre, tail=fuse,
+                                      out16=bool(self._fp0_half and nfp + i == 0 and not fuse and g_pre is None and chain._premul["g16"]))
                 y, g_pre = res if fuse else (res, None)
             else:
                 g_pre = None
@@ -915,11 +929,17 @@ class PatchAugNetEngine:
         def early(l_feat):
             coarse = [l_feat[j].contiguous() for j in range(nfp - 1, 0, -1)]
             pyr.launch(st, coarse + [None], v, 1)
+        # fp16 path, descriptor-only call: the finest map is read by the fp16 NetVLAD kernel alone -> written (and read) as fp16 rows
+        fine = self.vlads[-1] if self.vlads else None
+        self._fp0_half = bool(not views and pyr is not None and pyr.f16 and self._fp0_half_ok and fine is not None and fine.k > 48 and fine.c == 256
+                              and xyz.shape[1] >= 2048 and (getattr(self.fp[0], "_premul", None) or {}).get("g16"))
         l_feat, l_c = self.backbone(xyz, early if split else None, s0)
+        half_map = self._fp0_half and l_feat[0].dtype == torch.float16
+        self._fp0_half = False
         feats = [l_feat[j] for j in range(nfp - 1, -1, -1)]                                   # coarse -> fine, (B, N_i, 256)
         if pyr is not None:
             fc = [f.contiguous() for f in feats]
-            pyr.launch(st, ([None] * (nfp - 1) + fc[-1:]) if split else fc, v, 6 if split else 7)
+            pyr.launch(st, ([None] * (nfp - 1) + fc[-1:]) if split else fc, v, 6 if split else 7, x16_mask=(1 << (nfp - 1)) if half_map else 0)
         else:
             koff = 0
             for vl, f in zip(self.vlads, feats):

@@ -233,3 +233,41 @@ def test_netvlad_pyramid_f16_against_the_fp32_kernel(b, scales, mag):
         else:
             assert torch.equal(r, g)
         koff += k
+
+
+@pytest.mark.parametrize("name", ["patch_aug_net", "pptnet"])
+def test_descriptor_only_call_keeps_the_finest_map_in_fp16(name):
+    """fp16 path, ``model(x, return_feat=False)`` at full size: the finest feature-propagation level writes its (B x 4096, 256) map as fp16 rows
+    (pa_fp_chain_premul_g16h) and the 64-cluster NetVLAD kernel reads those (pa_netvlad_pyramid_f16h) -- half the bytes of the step's largest
+    store and of its re-read.  Held to the fp16 path's own bar against the vectors of the reference's classes (cosine >= 0.999), and to the
+    return_feat=True form of the same path (fp32 map between the two kernels) at cosine >= 0.9999."""
+    from patchaugnet_amd import patch_aug_net, pptnet
+    g = golden(name)
+    if name == "patch_aug_net":
+        m = patch_aug_net.Network(param=configs.patch_aug_net_config(), use_a2a_recon=True, use_l2_norm=True)
+        ref = g["full_desc"]
+    else:
+        m = pptnet.Network(param=configs.pptnet_config(), use_normalize=True)
+        ref = g["full_desc_l2"]
+    m.load_state_dict(seeded_sd_from_table(name), strict=True)
+    m = m.cuda().eval()
+    m.mlp_dtype = "f16"
+    x = torch.from_numpy(g["full_x"]).cuda()
+    with torch.no_grad():
+        d_feat, fp, _ = m(x)                                   # fp32 map (the caller gets it)
+        eng = m._engine
+        seen = []
+        orig = eng.pyramid.launch
+        eng.pyramid.launch = lambda st, feats, out, phases, x16_mask=0: (seen.append((x16_mask, [None if f is None else f.dtype for f in feats])),
+                                                                        orig(st, feats, out, phases, x16_mask=x16_mask))[1]
+        try:
+            d_only = m(x, return_feat=False)
+        finally:
+            eng.pyramid.launch = orig
+    d_only = d_only[0] if isinstance(d_only, (tuple, list)) else d_only
+    assert fp[-1].dtype == torch.float32
+    assert any(mask and dts[-1] == torch.float16 for mask, dts in seen), seen      # the fp16 map really was what the NetVLAD kernel read
+    a, b = d_only.cpu().numpy(), d_feat.cpu().numpy()
+    assert np.isfinite(a).all()
+    assert _cos(a, ref).min() >= 0.999, _cos(a, ref).min()
+    assert _cos(a, b).min() >= 0.9999, _cos(a, b).min()
