@@ -172,6 +172,7 @@ def dominant_kernel_roofline(st, cfg, batch, points, grouping, pmc=None, pmc_not
     }
 
 
+TRAIN_DOMINANT_KERNEL_RE = r"tgemm_cm_kernel<8, 1, 2, 1, 2, 12>"     # pa_tgemm_nn at 18 x (256 x 4096 x 256), forward form (csrc/train_gemm_cm.hip)
 DOMINANT_KERNEL_RE = r"chain_kernel<[12], 16, 3, false, 1[,>]"     # fp0 feature-propagation chain (pa_fp_chain_premul): 16-row tiles (32 with PA_CHAIN_FPX_RT2)
 GROUPING_KERNEL_RE = r"group_lds_kernel<4>"
 
@@ -421,7 +422,7 @@ def train_bench(a, emit=True, pmc=None):
     traffic = tnote = None
     if (emit if pmc is None else pmc) and not a.no_pmc:      # HBM bytes of that launch: FETCH_SIZE / WRITE_SIZE passes over the same call in a child process (tools/tgemm_target.py)
         pm, tnote = measure_traffic(0, 0, target=[os.path.join(ROOT, "tools", "tgemm_target.py"), "6", str(clouds)],
-                                    patterns=(("dominant", r"tgemm_nn_kernel<64, 16, true, 1, true, true>"),))
+                                    patterns=(("dominant", TRAIN_DOMINANT_KERNEL_RE),))
         traffic = pm["dominant"]["bytes_per_launch"] if pm and "dominant" in pm else None
     line = {
         "metric": "training steps/sec (PatchAugNet quadruplet step, patch Chamfer reconstruction loss)", "value": a.steps / dt, "unit": "steps/s",
@@ -429,15 +430,15 @@ def train_bench(a, emit=True, pmc=None):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"PatchAugNet training step, quadruplet tuple of {clouds} x {n}-pt synthetic submaps (1+2+14+1), 3 related clouds "
                                "through the decoder, patch Chamfer + quadruplet loss, backward, Adam (BASELINE.json configs[3]), 1xMI355X",
-                   "clouds_per_step": clouds, "points": n, "path": "HIP point ops + HIP training GEMMs (csrc/train_gemm.hip), autograd graph in torch",
+                   "clouds_per_step": clouds, "points": n, "path": "HIP point ops + HIP training GEMMs (csrc/train_gemm_cm.hip, train_gemm.hip, fp_fold_train.hip), autograd graph in torch",
                    "weights": "key-seeded random init", "parallelism": "dp1",
                    "launch": ("one hipGraph replay per step (forward + losses + backward + Adam)" + ("" if a.no_prefetch else
                               "; sampling / neighbour search / 3-NN of the next batch replayed on a side stream under it")) if graphed else "python launches"},
         "losses_last_step": losses,
         "losses_note": "place_recognition = 0.0 means the hinge of the quadruplet loss is inactive on this synthetic tuple (random-init descriptors of "
                        "unrelated clouds); the captured graph replays every kernel of the step regardless, so the timing is representative",
-        "roofline": {"kernel": "tgemm_nn_kernel<64,16,true,1> (pa_tgemm_nn: 256 -> 256 layer of the finest FP level, forward: BatchNorm + ReLU of the "
-                               "previous layer in the loader, statistics in the epilogue)", "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS,
+        "roofline": {"kernel": "tgemm_cm_kernel<8,1,2,1,2,12> (pa_tgemm_nn on LDS-resident weights, csrc/train_gemm_cm.hip: 256 -> 256 layer of the finest FP "
+                               "level, forward: BatchNorm + ReLU of the previous layer on the loaded operand registers, statistics in the epilogue)", "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": tnote,
                      "algorithmic_bytes_per_launch": 4.0 * B * N * (M + K) + 4.0 * M * K, "algorithmic_flops_per_launch": flops, "ms_per_launch": ms},
     }

@@ -11,9 +11,7 @@ import torch
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.environ.get("PA_LIB_PATH", os.path.join(_CSRC, "libpatchaugnet_hip.so"))   # override: A/B of two builds in one session
-EXP_LIB_PATH = os.path.join(_CSRC, "libpatchaugnet_hip_exp.so")   # test-only superset with the measured-slower variants (csrc/Makefile)
 _lib = None
-_exp = None
 
 _I, _F, _P = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
@@ -109,12 +107,6 @@ _SIGS = {
     "pa_fp_chain_premul_g16": "ipppplppppiiiipppi",
     "pa_fp_chain_premul_g16h": "ipppplppppiiiippp",
 }
-# entry points of the measured-slower variants: exported by the test-only library only (csrc/pa_internal.h section 2)
-_EXP_SIGS = {
-    "pa_fp_chain_premul_tap": "ippppplppppiiiippppipii",
-    "pa_fpx256": "lppppiiipppppppi",
-}
-_EXP_SWITCHES = ("pa_knn_lane_enable", "pa_fps_reg_xyz_enable", "pa_tgemm_wave_enable")
 _T = {"i": _I, "f": _F, "p": _P, "l": ctypes.c_long, "d": ctypes.c_double, "q": ctypes.c_ulonglong}
 
 
@@ -167,30 +159,8 @@ def lib():
     return _lib
 
 
-class experimental:
-    """Context manager (tests / probes only): inside it every call() goes to libpatchaugnet_hip_exp.so, the superset library that also
-    carries the measured-slower kernel variants and their switches (csrc/pa_internal.h section 2).  The product library never contains
-    them; nothing in the package enters this context on its own."""
-
-    def __enter__(self):
-        global _lib, _exp
-        if _exp is None:
-            _exp = _load(EXP_LIB_PATH)
-            _declare(_exp, _EXP_SIGS)
-            for name in _EXP_SWITCHES:
-                getattr(_exp, name).argtypes, getattr(_exp, name).restype = [_I], None
-        self._saved = _lib
-        _lib = _exp
-        return _exp
-
-    def __exit__(self, *exc):
-        global _lib
-        _lib = self._saved
-        return False
-
-
 def has(name):
-    """Does the active library export `name`?  (The experimental entry points exist only inside `with experimental():`.)"""
+    """Does the library export `name`?"""
     return hasattr(_lib or lib(), name)
 
 

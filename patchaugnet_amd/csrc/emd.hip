@@ -442,393 +442,6 @@ __global__ __launch_bounds__(EMD_THREADS) void emd_round_kernel(int n, const flo
     }
 }
 
-#ifdef PA_EXPERIMENTAL   // two measured-slower forms of the long auction: test-only library
-// ---- resident form: the chip-wide kernel above with EVERY round inside ONE launch ---------------------------------------------------------------
-// The rounds of different clouds are independent, and within a cloud a round only has to order its G workgroups: bids -> the last arriver's
-// GetMax / Assign -> everybody's next round.  The kernel boundary did that at ~21 us per round in the auction's long tail (a launch of 512
-// sixteen-wave workgroups, each re-loading the objects it might bid on, for a handful of bidders per cloud).  Here the G workgroups of a cloud stay
-// resident for the whole call: the objects are loaded into LDS ONCE, and a round ends with a per-cloud generation word the last arriver publishes
-// (release) and the other G - 1 workgroups poll (one lane, agent-scope loads, s_sleep between polls; acquire when it moves).  No grid-wide barrier:
-// clouds never wait for each other.  Needs all G * b workgroups co-resident (G * b <= 512 = two per CU, the launcher's rule); every poll loop is
-// bounded and raises an abort word the whole cloud honours, so a co-residency failure ends in a wrong answer the host can detect, never in a hang.
-// State words live in the cloud's `dist` row like the round kernel's: int index n/2 + {0: arrivals, 1: bidders, 2: generation, 3: abort, 4: departures}.
-constexpr int EMD_SPIN_LIMIT = 1 << 21;
-
-__global__ __launch_bounds__(EMD_THREADS) void emd_resident_kernel(int n, const float *__restrict__ xyz1_all, const float *__restrict__ xyz2_all,
-                                                                    float *dist_all, int *assignment_all, float *price_all, int *assignment_inv_all,
-                                                                    int *bid_all, float *bid_inc_all, float *max_inc_all, int *max_idx_all, float eps,
-                                                                    int iters)
-{
-    extern __shared__ float lds[];
-    float *x2 = lds, *y2 = lds + n, *z2 = lds + 2 * n, *pr = lds + 3 * n;
-    unsigned short *unass = (unsigned short *)(lds + 4 * n);
-    __shared__ int wcnt[EMD_WAVES];
-    __shared__ int is_last, list_base, go;
-    __shared__ Bid3 part_bid[EMD_WAVES];
-
-    const int i = blockIdx.y, g = blockIdx.x, G = gridDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const size_t off = (size_t)i * n;
-    const float *xyz1 = xyz1_all + off * 3, *xyz2 = xyz2_all + off * 3;
-    int *ass = assignment_all + off, *ass_inv = assignment_inv_all + off, *bid = bid_all + off, *max_idx = max_idx_all + off;
-    float *price = price_all + off, *binc = bid_inc_all + off, *minc = max_inc_all + off, *dist = dist_all + off;
-    unsigned short *glist = reinterpret_cast<unsigned short *>(dist);
-    int *arrive = reinterpret_cast<int *>(dist) + n / 2, *gcount = arrive + 1, *gen = arrive + 2, *abortw = arrive + 3, *depart = arrive + 4;
-
-    for (int k = tid; k < n; k += EMD_THREADS) {              // the objects never change: once per launch
-        x2[k] = xyz2[k * 3 + 0];
-        y2[k] = xyz2[k * 3 + 1];
-        z2[k] = xyz2[k * 3 + 2];
-    }
-    __syncthreads();
-    const int per = (n + G - 1) / G, s0 = g * per, s1 = min(s0 + per, n);
-
-    for (int it = 0; it < iters; ++it) {
-        const bool last = it == iters - 1;
-        // ---- this workgroup's bidders: the unassigned points of its slice
-        int U = 0;
-        for (int c = s0; c < s1; c += EMD_THREADS) {
-            const int j = c + tid;
-            const bool un = j < s1 && ld_agent_i(ass + j) == -1;
-            const u64 mask = __ballot(un);
-            if (lane == 0) wcnt[wave] = __popcll(mask);
-            __syncthreads();
-            int before = 0, total = 0;
-            for (int w = 0; w < EMD_WAVES; ++w) {
-                const int cw = wcnt[w];
-                before += (w < wave) ? cw : 0;
-                total += cw;
-            }
-            if (un) unass[U + before + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)j;
-            U += total;
-            __syncthreads();
-        }
-        if (U > 0) {
-            for (int k = tid; k < n; k += EMD_THREADS) pr[k] = ld_agent_f(price + k);      // this round's prices
-            if (tid == 0) list_base = atomicAdd(gcount, U);
-            __syncthreads();
-            for (int u = tid; u < U; u += EMD_THREADS) __hip_atomic_store(glist + list_base + u, unass[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int W = 1;
-            while (W < EMD_WAVES && U * W * 2 <= EMD_WAVES) W *= 2;
-            const int slice = n / W;
-            for (int u0 = 0; u0 < U; u0 += EMD_WAVES / W) {
-                const int u = u0 + wave / W, part = wave % W;
-                Bid3 b = {-1e9f, -1e9f, -1};
-                int j = -1;
-                if (u < U) {
-                    j = unass[u];
-                    const float x1 = xyz1[j * 3 + 0], y1 = xyz1[j * 3 + 1], z1 = xyz1[j * 3 + 2];
-                    b = bid_scan(x2, y2, z2, pr, x1, y1, z1, part * slice, (part + 1) * slice, lane);
-#pragma unroll
-                    for (int sft = 1; sft < 64; sft <<= 1) {
-                        const float ob = __shfl_xor(b.best, sft), obt = __shfl_xor(b.better, sft);
-                        const int oi = __shfl_xor(b.best_i, sft);
-                        b = bid_merge(b, ob, obt, oi);
-                    }
-                }
-                if (W > 1) {
-                    if (lane == 0) part_bid[wave] = b;
-                    __syncthreads();
-                    if (part == 0 && u < U)
-                        for (int q = 1; q < W; ++q) { const Bid3 o = part_bid[wave + q]; b = bid_merge(b, o.best, o.better, o.best_i); }
-                    __syncthreads();
-                }
-                if (lane == 0 && part == 0 && u < U) {
-                    const float inc = b.best - b.better + eps;
-                    st_agent_i(bid + j, b.best_i);
-                    st_agent_f(binc + j, inc);
-                    if (b.best_i >= 0) atomic_max_f(minc + b.best_i, inc);
-                }
-            }
-        }
-        // ---- arrival (as in the round kernel): every wave's stores retired, one lane's release, the counter
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int last_one = (atomicAdd(arrive, 1) == G - 1) ? 1 : 0;
-            if (last_one) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            is_last = last_one;
-        }
-        __syncthreads();
-        if (!is_last) {
-            if (last) break;                                  // nothing left to read: the last arriver finishes the call
-            // ---- wait for the cloud's generation word: the round is resolved (or the auction is over / aborted)
-            if (tid == 0) {
-                int seen = 0, spins = 0;
-                while (true) {
-                    seen = ld_agent_i(gen);
-                    if (seen > it || ld_agent_i(abortw) != 0) break;
-                    if (++spins > EMD_SPIN_LIMIT) { st_agent_i(abortw, 1); break; }
-                    __builtin_amdgcn_s_sleep(8);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                go = (seen > it && seen <= iters && ld_agent_i(abortw) == 0) ? seen : -1;
-            }
-            __syncthreads();
-            const int nx = go;
-            __syncthreads();
-            if (nx < 0 || nx >= iters) break;                 // aborted, or every point is assigned (generation jumped to iters)
-            continue;
-        }
-        // ---- the last arriver resolves the round for the whole cloud
-        U = ld_agent_i(gcount);
-        __syncthreads();
-        if (tid == 0) { st_agent_i(gcount, 0); st_agent_i(arrive, 0); }
-        for (int u = tid; u < U; u += EMD_THREADS) unass[u] = __hip_atomic_load(glist + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        for (int u = tid; u < U; u += EMD_THREADS) {          // GetMax (:181-194)
-            const int j = unass[u];
-            const int bid_id = ld_agent_i(bid + j);
-            if (bid_id < 0) continue;
-            const double bi = (double)ld_agent_f(binc + j), mx = (double)ld_agent_f(minc + bid_id);
-            if (bi - 1e-6 <= mx && mx <= bi + 1e-6) atomicMax(max_idx + bid_id, j);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const bool finish = last || U == 0;                   // U == 0: every point is assigned, the remaining rounds are no-ops
-        if (!last) {                                           // Assign (:196-215)
-            for (int u = tid; u < U; u += EMD_THREADS) {
-                const int j = unass[u];
-                const int bid_id = ld_agent_i(bid + j);
-                if (bid_id < 0 || ld_agent_i(max_idx + bid_id) != j) continue;
-                const int prev = ld_agent_i(ass_inv + bid_id);
-                if (prev != -1) st_agent_i(ass + prev, -1);
-                st_agent_i(ass_inv + bid_id, j);
-                st_agent_i(ass + j, bid_id);
-                st_agent_f(price + bid_id, ld_agent_f(price + bid_id) + ld_agent_f(binc + j));
-                st_agent_f(minc + bid_id, -1e9f);
-                st_agent_i(max_idx + bid_id, -1);
-            }
-        } else {
-            for (int u = tid; u < U; u += EMD_THREADS) {      // last round: bidders applied in ascending point order
-                const unsigned short mine = unass[u];
-                int rank = 0;
-                for (int t = 0; t < U; ++t) rank += unass[t] < mine ? 1 : 0;
-                reinterpret_cast<unsigned short *>(pr)[rank] = mine;
-            }
-            __syncthreads();
-            if (tid == 0) {
-                const unsigned short *srt = reinterpret_cast<const unsigned short *>(pr);
-                for (int u = 0; u < U; ++u) {
-                    const int j = srt[u];
-                    const int bid_id = ld_agent_i(bid + j);
-                    st_agent_i(ass + j, bid_id);
-                    if (bid_id < 0) continue;
-                    st_agent_i(ass_inv + bid_id, j);
-                    st_agent_f(price + bid_id, ld_agent_f(price + bid_id) + ld_agent_f(binc + j));
-                    st_agent_f(minc + bid_id, -1e9f);
-                }
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (!finish) {
-            if (tid == 0) {                                    // publish the next generation
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                st_agent_i(gen, it + 1);
-            }
-            continue;
-        }
-        // ---- the call ends here for this cloud: release the pollers (generation = iters), wait until every other workgroup has left (they still
-        // read the state words, which live in the row CalcDist is about to overwrite), then the squared distances
-        if (tid == 0) {
-            if (!last) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                st_agent_i(gen, iters);
-            }
-            int spins = 0;
-            while (ld_agent_i(depart) < G - 1 && ++spins <= EMD_SPIN_LIMIT) __builtin_amdgcn_s_sleep(8);
-        }
-        __syncthreads();
-        for (int j = tid; j < n; j += EMD_THREADS) {          // CalcDist (:217-226)
-            const int k = ld_agent_i(ass + j);
-            float d = 0.f;
-            if (k >= 0) {
-                const float dx = xyz1[j * 3 + 0] - x2[k], dy = xyz1[j * 3 + 1] - y2[k], dz = xyz1[j * 3 + 2] - z2[k];
-                d = dx * dx + dy * dy + dz * dz;
-            }
-            dist[j] = d;
-        }
-        return;
-    }
-    if (tid == 0) atomicAdd(depart, 1);                        // this workgroup will not touch the cloud's state words again
-}
-
-// ---- the auction's TAIL on chip: one workgroup per cloud, the bidder list kept INCREMENTALLY ----------------------------------------------------
-// After the first few dozen rounds an auction has a handful of unassigned points per cloud for hundreds of rounds (the reference call runs 1024).
-// A round is then a few thousand flops, and what it costs is its fixed part: the chip-wide round kernel pays a 512-workgroup launch, a scan of every
-// point for "unassigned" and ~8 dependent L2 round trips of the resolving workgroup (21 us per round); the one-workgroup kernel above rescans all n
-// points with eight barriers and resolves through global atomics (35 us).  This kernel takes over from the round kernel after `it0` rounds (any
-// switch point gives the same result: both implement the same deterministic round) and keeps everything a round touches in LDS:
-//   objects, prices, the per-object maximum increment and arg-max (112 KB at n = 4096), this round's bidders and their (object, increment) pairs;
-//   the NEXT round's bidders are known without a scan -- this round's losers plus the points this round's winners evicted -- and are appended
-//     with one LDS counter;
-//   a round is Bid (a wavefront per bidder, W wavefronts when there are fewer bidders than wavefronts) / barrier / GetMax / barrier / Assign +
-//     list rebuild / barrier: the only trip to memory on the round's dependent chain is the winner's read of assignment_inv.
-// Same arithmetic, same tie rules, same final state as the other forms and the oracle (tests/test_gpu_losses.py).  n <= 4096.
-__global__ __launch_bounds__(EMD_THREADS) void emd_tail_kernel(int n, const float *__restrict__ xyz1_all, const float *__restrict__ xyz2_all,
-                                                                float *dist_all, int *assignment_all, float *price_all, int *assignment_inv_all,
-                                                                int *bid_all, float *bid_inc_all, float *max_inc_all, int *max_idx_all, float eps,
-                                                                int it0, int iters)
-{
-    extern __shared__ float lds[];
-    float *x2 = lds, *y2 = lds + n, *z2 = lds + 2 * n, *pr = lds + 3 * n, *mincL = lds + 4 * n;
-    int *midxL = reinterpret_cast<int *>(lds + 5 * n);
-    int *bidL = reinterpret_cast<int *>(lds + 6 * n);                 // [n] object this round's bidder u bids for
-    float *incL = lds + 7 * n;                                         // [n] its increment
-    unsigned short *cur = reinterpret_cast<unsigned short *>(lds + 8 * n), *nxt = cur + n;      // bidder lists (point indices)
-    __shared__ int wcnt[EMD_WAVES];
-    __shared__ int n_next;
-    __shared__ Bid3 part_bid[EMD_WAVES];
-
-    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const size_t off = (size_t)i * n;
-    const float *xyz1 = xyz1_all + off * 3, *xyz2 = xyz2_all + off * 3;
-    int *ass = assignment_all + off, *ass_inv = assignment_inv_all + off, *bid = bid_all + off, *max_idx = max_idx_all + off;
-    float *price = price_all + off, *binc = bid_inc_all + off, *minc = max_inc_all + off, *dist = dist_all + off;
-
-    for (int k = tid; k < n; k += EMD_THREADS) {
-        x2[k] = xyz2[k * 3 + 0];
-        y2[k] = xyz2[k * 3 + 1];
-        z2[k] = xyz2[k * 3 + 2];
-        pr[k] = price[k];
-        mincL[k] = minc[k];
-        midxL[k] = max_idx[k];
-    }
-    // the unassigned points, once (ascending)
-    int U = 0;
-    for (int c = 0; c < n; c += EMD_THREADS) {
-        const int j = c + tid;
-        const bool un = ass[j] == -1;
-        const u64 mask = __ballot(un);
-        if (lane == 0) wcnt[wave] = __popcll(mask);
-        __syncthreads();
-        int before = 0, total = 0;
-        for (int w = 0; w < EMD_WAVES; ++w) {
-            const int cw = wcnt[w];
-            before += (w < wave) ? cw : 0;
-            total += cw;
-        }
-        if (un) cur[U + before + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)j;
-        U += total;
-        __syncthreads();
-    }
-
-    for (int it = it0; it < iters && U > 0; ++it) {
-        const bool last = it == iters - 1;
-        if (tid == 0) n_next = 0;
-        // ---- Bid (:95-179)
-        int W = 1;
-        while (W < EMD_WAVES && U * W * 2 <= EMD_WAVES) W *= 2;
-        const int slice = n / W;
-        for (int u0 = 0; u0 < U; u0 += EMD_WAVES / W) {
-            const int u = u0 + wave / W, part = wave % W;
-            Bid3 b = {-1e9f, -1e9f, -1};
-            if (u < U) {
-                const int j = cur[u];
-                const float x1 = xyz1[j * 3 + 0], y1 = xyz1[j * 3 + 1], z1 = xyz1[j * 3 + 2];
-                b = bid_scan(x2, y2, z2, pr, x1, y1, z1, part * slice, (part + 1) * slice, lane);
-#pragma unroll
-                for (int sft = 1; sft < 64; sft <<= 1) {
-                    const float ob = __shfl_xor(b.best, sft), obt = __shfl_xor(b.better, sft);
-                    const int oi = __shfl_xor(b.best_i, sft);
-                    b = bid_merge(b, ob, obt, oi);
-                }
-            }
-            if (W > 1) {
-                if (lane == 0) part_bid[wave] = b;
-                __syncthreads();
-                if (part == 0 && u < U)
-                    for (int q = 1; q < W; ++q) { const Bid3 o = part_bid[wave + q]; b = bid_merge(b, o.best, o.better, o.best_i); }
-                __syncthreads();
-            }
-            if (lane == 0 && part == 0 && u < U) {
-                const float inc = b.best - b.better + eps;
-                bidL[u] = b.best_i;
-                incL[u] = inc;
-                st_agent_i(bid + cur[u], b.best_i);                          // the caller's state tensors see every bid, as in the other forms
-                st_agent_f(binc + cur[u], inc);
-                if (b.best_i >= 0) atomic_max_f(mincL + b.best_i, inc);      // LDS float max by compare-and-swap
-            }
-        }
-        __syncthreads();
-        // ---- GetMax (:181-194): the highest-indexed bidder whose increment matches the maximum within 1e-6
-        for (int u = tid; u < U; u += EMD_THREADS) {
-            const int bid_id = bidL[u];
-            if (bid_id < 0) continue;
-            const double bi = (double)incL[u], mx = (double)mincL[bid_id];
-            if (bi - 1e-6 <= mx && mx <= bi + 1e-6) atomicMax(midxL + bid_id, (int)cur[u]);
-        }
-        __syncthreads();
-        if (!last) {
-            // ---- Assign (:196-215) + the next round's bidders: the losers and whoever the winners evicted
-            for (int u = tid; u < U; u += EMD_THREADS) {
-                const int j = cur[u];
-                const int bid_id = bidL[u];
-                const bool wins = bid_id >= 0 && midxL[bid_id] == j;
-                if (!wins) {
-                    nxt[atomicAdd(&n_next, 1)] = (unsigned short)j;
-                    continue;
-                }
-                const int prev = ld_agent_i(ass_inv + bid_id);
-                if (prev != -1) {
-                    st_agent_i(ass + prev, -1);
-                    nxt[atomicAdd(&n_next, 1)] = (unsigned short)prev;
-                }
-                st_agent_i(ass_inv + bid_id, j);
-                st_agent_i(ass + j, bid_id);
-                pr[bid_id] += incL[u];
-                mincL[bid_id] = -1e9f;
-                midxL[bid_id] = -1;
-            }
-            __syncthreads();
-            U = n_next;
-            unsigned short *t = cur; cur = nxt; nxt = t;
-            __syncthreads();
-        } else {
-            // last round: every bidder takes the object it bid for, in ASCENDING point order: rank-sort the list, one thread applies it
-            for (int u = tid; u < U; u += EMD_THREADS) {
-                const unsigned short mine = cur[u];
-                int rank = 0;
-                for (int t = 0; t < U; ++t) rank += cur[t] < mine ? 1 : 0;
-                nxt[rank] = (unsigned short)u;                  // position in `cur` (its bid / increment live at that position)
-            }
-            __syncthreads();
-            if (tid == 0) {
-                for (int r = 0; r < U; ++r) {
-                    const int u = nxt[r], j = cur[u], bid_id = bidL[u];
-                    st_agent_i(ass + j, bid_id);
-                    if (bid_id < 0) continue;
-                    st_agent_i(ass_inv + bid_id, j);
-                    pr[bid_id] += incL[u];
-                    mincL[bid_id] = -1e9f;
-                }
-            }
-            __syncthreads();
-            U = 0;
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    // ---- state back to the caller's tensors, CalcDist (:217-226)
-    for (int k = tid; k < n; k += EMD_THREADS) {
-        price[k] = pr[k];
-        minc[k] = mincL[k];
-        max_idx[k] = midxL[k];
-        const int a = ld_agent_i(ass + k);
-        float d = 0.f;
-        if (a >= 0) {
-            const float dx = xyz1[k * 3 + 0] - x2[a], dy = xyz1[k * 3 + 1] - y2[a], dz = xyz1[k * 3 + 2] - z2[a];
-            d = dx * dx + dy * dy + dz * dz;
-        }
-        dist[k] = d;
-    }
-}
-
-#endif  // PA_EXPERIMENTAL
 
 // NmDistanceGradKernel (:284-300): grad_xyz[i,j] += 2 g (xyz1[i,j] - xyz2[i,idx[i,j]]); one thread owns one point.
 __global__ void emd_backward_kernel(long total, int n, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
@@ -894,36 +507,9 @@ PA_API int pa_emd_forward(int b, int n, int m, const float *xyz1, const float *x
         pa_set_error("pa_emd_forward: hipMemset2DAsync failed");
         return PA_EINVAL;
     }
-#ifdef PA_EXPERIMENTAL
-    // resident form (OPT-IN, form 2 / PA_EMD_RESIDENT): every round inside one launch, the clouds' workgroups hand rounds over through a generation
-    // word.  Bit-exact, but measured SLOWER than a launch per round at (16, 4096, 3): 3.98 / 34.7 ms for 64 / 1024 rounds against 3.46 / 24.2 ms -- 31
-    // pollers per cloud on the line the resolver is writing, and a release / acquire pair per workgroup and round where the kernel boundary pays
-    // once.  Needs G * b <= 512 co-resident workgroups: 1024 threads + 18 n bytes of LDS each = two per CU on 256 CUs (n <= 4096; one per CU above).
-    static const bool resident_env = getenv("PA_EMD_RESIDENT") != nullptr;                 // A/B and test knob (measured slower: see below)
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const long slots = (long)cus * (lds_bytes <= 78 * 1024 ? 2 : 1);
-    const bool resident = g_emd_persistent == 2 || (g_emd_persistent < 0 && resident_env);
-    if (resident && iters > 1 && (long)G * b <= slots) {
-        hipError_t e2 = hipFuncSetAttribute((const void *)emd_resident_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-        if (e2 != hipSuccess) { pa_set_error("pa_emd_forward: cannot raise the LDS limit: %s", hipGetErrorString(e2)); return (int)e2; }
-        hipLaunchKernelGGL(emd_resident_kernel, dim3(G, b), dim3(EMD_THREADS), lds_bytes, (hipStream_t)stream, n, xyz1, xyz2, dist, assignment, price,
-                           assignment_inv, bid, bid_increments, max_increments, max_idx, eps, iters);
-        PA_CHECK_LAUNCH("pa_emd_forward (resident)");
-        return PA_OK;
-    }
-#endif  // PA_EXPERIMENTAL
     hipError_t e = hipFuncSetAttribute((const void *)emd_round_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
     if (e != hipSuccess) { pa_set_error("pa_emd_forward: cannot raise the LDS limit: %s", hipGetErrorString(e)); return (int)e; }
     int r1 = iters;
-#ifdef PA_EXPERIMENTAL
-    // the first rounds chip-wide, the long tail on chip (emd_tail_kernel; n <= 4096): PA_EMD_TAIL_FROM = first round of the tail kernel.  Measured at
-    // (16, 4096, 3), 1024 rounds: 30.6 / 27.6 / 26.0 ms switching at round 24 / 64 / 100 against 23.3 ms without it -- a cloud still has 36 / 18 / 7 / 3
-    // bidders at round 100 / 200 / 500 / 1000, and one workgroup's sixteen waves take longer over their scans (each bidder against all 4096 objects)
-    // than the chip-wide round's launch and resolve cost.
-    const int tail_from = getenv("PA_EMD_TAIL_FROM") ? atoi(getenv("PA_EMD_TAIL_FROM")) : (1 << 30);      // read per call: a test knob
-    if (n <= 4096 && g_emd_persistent != 0 && tail_from < iters) r1 = tail_from < 0 ? 0 : tail_from;
-#endif
     // The workgroups per cloud may follow a schedule over the round index (A/B knob PA_EMD_SCHED="from:G,from:G,...", default none: measured, one
     // workgroup per CU from the first round on is the best of them, profiles/r04_ab_log.txt) -- a function of the round only, so results cannot depend on
     // it: the slices are recomputed from the launch's own grid; the bidder list, the counters and the arrival count are per cloud and per launch.
@@ -953,15 +539,6 @@ PA_API int pa_emd_forward(int b, int n, int m, const float *xyz1, const float *x
         hipLaunchKernelGGL(emd_round_kernel, dim3(Gi, b), dim3(EMD_THREADS), lds_bytes, (hipStream_t)stream, n, xyz1, xyz2, dist, assignment, price,
                            assignment_inv, bid, bid_increments, max_increments, max_idx, eps, it == iters - 1 ? 1 : 0);
     }
-#ifdef PA_EXPERIMENTAL
-    if (r1 < iters) {
-        const size_t tail_lds = (size_t)n * 32 + (size_t)n * 4;       // eight float arrays + two 16-bit lists
-        hipError_t e3 = hipFuncSetAttribute((const void *)emd_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-        if (e3 != hipSuccess) { pa_set_error("pa_emd_forward: cannot raise the LDS limit: %s", hipGetErrorString(e3)); return (int)e3; }
-        hipLaunchKernelGGL(emd_tail_kernel, dim3(b), dim3(EMD_THREADS), tail_lds, (hipStream_t)stream, n, xyz1, xyz2, dist, assignment, price,
-                           assignment_inv, bid, bid_increments, max_increments, max_idx, eps, r1, iters);
-    }
-#endif
     PA_CHECK_LAUNCH("pa_emd_forward");
     return PA_OK;
 }

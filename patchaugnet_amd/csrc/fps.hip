@@ -14,12 +14,6 @@
 // LDS slot array with ONE barrier per round, and the winner's coordinates come from an LDS copy of the cloud.
 #include "pa_common.h"
 
-#ifndef PA_FPS_CPW_DEFAULT
-#define PA_FPS_CPW_DEFAULT 1
-#endif
-#ifndef PA_FPS_NT_DEFAULT
-#define PA_FPS_NT_DEFAULT 256
-#endif
 
 namespace {
 
@@ -296,51 +290,15 @@ __global__ __launch_bounds__(1024) void fps_stream_kernel(int n, int m, FpsOrder
     }
 }
 
-// Default: cloud copy in LDS.  PA_FPS_REG_XYZ=1 selects the 256-byte-LDS variant (winner coordinates from the owner's registers).  Measured
-// on MI355X at b = 32: bit-identical samples, but the round is longer (n = 4096: 0.70 -> 0.86 us, 719 -> 876 us per launch: the register-set
-// select + three v_readlane + the wider slot exchange sit on the serial chain) and the four-stream extraction rate drops 33.3 k -> 30.8 k
-// submaps/s even though the chain workgroups can now share a CU with it -- the launch's own length matters more than the LDS it pins.
-// The variant is measured-slower and therefore compiled into the test-only library only (PA_EXPERIMENTAL: libpatchaugnet_hip_exp.so).
-#ifdef PA_EXPERIMENTAL
-int g_fps_reg_xyz = -1;
-bool fps_lds_xyz()
-{
-    if (g_fps_reg_xyz < 0) { const char *e = getenv("PA_FPS_REG_XYZ"); g_fps_reg_xyz = (e && e[0] == '1') ? 1 : 0; }
-    return g_fps_reg_xyz == 0;
-}
-#endif
+// The launcher instantiates ONE form: cloud copy in LDS, one cloud per workgroup.  Forms that were built, bit-exact and slower (numbers in
+// DESIGN.md's appendix; the kernel template keeps their branches compiled out: LDSXYZ = false, CPW > 1): the 256-byte-LDS form with the winner's
+// coordinates from the owner's registers (the round 0.70 -> 0.86 us), two / three clouds per workgroup (0.76 -> 0.97 / 1.28 ms per launch),
+// 512 / 1024 threads per cloud (re-measured in round 5 on the ds_max_u64 selection: 485 -> 462 / 491 us per launch, no change in the pipeline rate).
 
 template <int NT, int PPT>
 int launch_reg(int b, int n, int m, FpsOrder ord, const float *xyz, float *temp, int *idx, float *new_xyz, hipStream_t st, int j_begin = 0, int j_end = -1)
 {
-#ifdef PA_EXPERIMENTAL
-    if (!fps_lds_xyz()) {
-        hipLaunchKernelGGL((fps_reg_kernel<NT, PPT, false>), dim3(b), dim3(NT), 2 * (NT / 64) * sizeof(FpsSlot), st, n, m, ord, xyz, temp, idx, new_xyz, j_begin, j_end);
-        return 0;
-    }
-#endif
     const size_t lds = ((size_t)16 << (ord.log2bs + ord.qbits)) + 2 * (NT / 64) * 8;      // the cloud by rank (see the kernel) + the slot pairs
-    // clouds per workgroup (see the kernel): PA_FPS_CPW = 1 / 2 / 3, default from the A/B in profiles/r04_ab_log.txt; only where a cloud is a
-    // 256-thread group and several clouds' copies fit the 160 KB of a CU
-    // MEASURED AND NOT SHIPPED (test-only library): packing clouds frees CUs for the other streams' dense kernels (a 132 KB chain workgroup cannot share
-    // a CU with a 48 KB sampling workgroup) but the waves of a SIMD slow each other's rounds -- 0.76 / 0.97 / 1.28 ms per launch at 1 / 2 / 3 clouds
-    // per workgroup -- and the four-stream rate falls 37.2 k -> 33.0 k -> 30.3 k submaps/s (eight streams: 36.6 / 32.3 / 29.6 k): the length of the
-    // sampling chain weighs more than the CUs it holds.
-#ifdef PA_EXPERIMENTAL
-    static const int cpw_env = getenv("PA_FPS_CPW") ? atoi(getenv("PA_FPS_CPW")) : PA_FPS_CPW_DEFAULT;
-    int cpw = (NT == 256 && b >= 4) ? cpw_env : 1;
-    while (cpw > 1 && (cpw * lds > 156 * 1024 || cpw * NT > 1024)) --cpw;
-    if (cpw == 3) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_reg_kernel<NT, PPT, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * lds));
-        hipLaunchKernelGGL((fps_reg_kernel<NT, PPT, true, 3>), dim3((b + 2) / 3), dim3(NT * 3), 3 * lds, st, n, m, ord, xyz, temp, idx, new_xyz, j_begin, j_end, b);
-        return 0;
-    }
-    if (cpw == 2) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_reg_kernel<NT, PPT, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds));
-        hipLaunchKernelGGL((fps_reg_kernel<NT, PPT, true, 2>), dim3((b + 1) / 2), dim3(NT * 2), 2 * lds, st, n, m, ord, xyz, temp, idx, new_xyz, j_begin, j_end, b);
-        return 0;
-    }
-#endif  // PA_EXPERIMENTAL
     if (lds > 48 * 1024)  // opt in to the large-LDS carve-out (gfx950: 160 KiB per CU)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_reg_kernel<NT, PPT, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -371,15 +329,6 @@ static int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int 
     else if (n <= 1024) launch_reg<256, 4>(b, n, m, ord, xyz, temp, idx, new_xyz, st, j_begin, j_end);
     else if (n <= 2048) launch_reg<256, 8>(b, n, m, ord, xyz, temp, idx, new_xyz, st, j_begin, j_end);
     else if (n <= 4096) {
-        // threads per cloud: the round is a fixed chain (wave maximum -> slot -> barrier -> decode -> winner's coordinates) plus the per-lane update of
-        // PPT points; more threads shorten the second part and lengthen the slot exchange.  PA_FPS_NT = 256 / 512 / 1024 (A/B knob).
-        // Measured (b = 32, m = 1024): 256 / 512 / 1024 threads per cloud = 0.76 / 0.92 / 1.46 ms per launch (37.3 / 35.7 / 31.9 k submaps/s): the
-        // exchange between more waves costs more than the shorter update saves.  The wider forms are in the test-only library.
-#ifdef PA_EXPERIMENTAL
-        static const int nt = getenv("PA_FPS_NT") ? atoi(getenv("PA_FPS_NT")) : PA_FPS_NT_DEFAULT;
-        if (nt == 1024) { launch_reg<1024, 4>(b, n, m, ord, xyz, temp, idx, new_xyz, st, j_begin, j_end); PA_CHECK_LAUNCH("pa_furthestsampling"); return PA_OK; }
-        if (nt == 512) { launch_reg<512, 8>(b, n, m, ord, xyz, temp, idx, new_xyz, st, j_begin, j_end); PA_CHECK_LAUNCH("pa_furthestsampling"); return PA_OK; }
-#endif
         launch_reg<256, 16>(b, n, m, ord, xyz, temp, idx, new_xyz, st, j_begin, j_end);
     }
     else if (n <= 8192) launch_reg<256, 32>(b, n, m, ord, xyz, temp, idx, new_xyz, st, j_begin, j_end);
@@ -392,9 +341,6 @@ static int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int 
     return PA_OK;
 }
 
-#ifdef PA_EXPERIMENTAL
-PA_API void pa_fps_reg_xyz_enable(int on) { g_fps_reg_xyz = on ? 1 : 0; }
-#endif
 
 PA_API int pa_furthestsampling(int b, int n, int m, const float *xyz, float *temp, int *idx, pa_stream_t stream)
 {

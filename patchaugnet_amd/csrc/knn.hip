@@ -238,9 +238,6 @@ __global__ __launch_bounds__(256) void knn_select_kernel(int n, int m, int k, co
 
 }  // namespace
 
-#ifdef PA_EXPERIMENTAL
-int pa_knn_lane_try(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx, float *dist2, hipStream_t st, long long *dbg);   // knn_lane.hip (test-only library)
-#endif
 
 int pa_knn_quad_try(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, int *idx, float *dist2, hipStream_t st, long long *dbg, int mq = 0,
                     const float *cells = nullptr);   // knn_quad.hip
@@ -264,13 +261,6 @@ PA_API int pa_knnquery(int b, int n, int m, int nsample, const float *xyz, const
         PA_CHECK_LAUNCH("pa_knnquery(quad)");
         return PA_OK;
     }
-#ifdef PA_EXPERIMENTAL
-    // opt-in, test-only library: one lane per query (knn_lane.hip; measured slower at the model's size)
-    if (pa_knn_lane_try(b, n, m, nsample, xyz, new_xyz, idx, dist2, st, g_knn_dbg)) {
-        PA_CHECK_LAUNCH("pa_knnquery(lane)");
-        return PA_OK;
-    }
-#endif
     // queries per workgroup: enough workgroups to fill 256 CUs several times over, but amortise the LDS staging
     int qpb = 4;
     while (qpb < 64 && (long)b * pa_div_up(m, qpb * 2) >= 1024) qpb *= 2;

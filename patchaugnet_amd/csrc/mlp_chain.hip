@@ -363,20 +363,6 @@ PA_API int pa_fp_chain_premul(int nlayers, const float *const *wt, const float *
                               bias0, out, ldo, stream);
 }
 
-#ifdef PA_EXPERIMENTAL   // measured net zero: test-only library
-// pa_fp_chain_premul with a fused tail: the chain's LAST layer (wt[nlayers - 1], relu_last = 0, zero bias) is the NEXT finer level's pre-multiply
-// applied to this level's output, which is the result of layer nlayers - 2 and leaves through `tap` (ldtap) -- one launch instead of the
-// chain + a pa_linear over the same rows, and the tile is contracted while it is still in LDS.
-PA_API int pa_fp_chain_premul_tap(int nlayers, const float *const *wt, const float *const *wpk, const float *const *bias, const int *kpad, const int *nout,
-                                  long rows, const float *g, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2,
-                                  int c1, const float *wskip, const float *wskip_p, const float *bias0, float *out, int ldo, float *tap, int ldtap,
-                                  int relu_last, pa_stream_t stream)
-{
-    PA_REQUIRE(tap, "pa_fp_chain_premul_tap: null tap");
-    return fp_premul_dispatch(nlayers, wt, wpk, nullptr, bias, kpad, nout, rows, g, idx3, w3, skip, n_unknown, m_known, c2, c1, wskip, wskip_p, nullptr,
-                              bias0, out, ldo, stream, tap, ldtap, relu_last);
-}
-#endif  // PA_EXPERIMENTAL
 
 // ---- fp16-operand variants (BASELINE configs[4], opt-in): same arguments, wp16[l] = pa_pack_weights_f16 of layer l -----------
 PA_API int pa_mlp_chain_f16(int mode, int pooled, int nlayers, const float *const *wt, const void *const *wp16, const float *const *bias,

@@ -1,12 +1,8 @@
 /* Private declarations of libpatchaugnet_hip.so -- NOT part of the drop-in boundary (include/patchaugnet_hip.h is).
  *
- * Two kinds of symbols live here:
- *   1. test / profiling hooks of the PRODUCT library: switches that force one of two shipping kernels for the same op (both bit-identical;
- *      the tests A/B them) and the cycle-stamp buffers of tools/chain_phases.py / tools/knn_phases.py;
- *   2. (under PA_EXPERIMENTAL) the entry points and switches of measured-slower kernel variants.  Those are compiled ONLY into the test-only
- *      library libpatchaugnet_hip_exp.so (csrc/Makefile: every source that mentions PA_EXPERIMENTAL is built a second time with
- *      -DPA_EXPERIMENTAL, fpx_reg.hip and knn_lane.hip only there); `nm -D libpatchaugnet_hip.so` shows none of them
- *      (tests/test_abi.py::test_product_library_has_no_experimental_symbols).
+ * What lives here: test / profiling hooks of the library -- switches that force one of two shipping kernels for the same op (the tests A/B
+ * them) and the cycle-stamp buffers of tools/chain_phases.py / tools/knn_phases.py.  Kernel variants that lost their A/B are deleted from the
+ * sources (DESIGN.md appendix lists them with their numbers); there is no second library.
  * Environment knobs (PA_CHAIN_*, PA_TGEMM_*, PA_KNN_*, ...) are tuning aids of the A/B tooling under tools/; they are documented where they
  * are read (grep getenv csrc/) and are not an interface.
  */
@@ -17,7 +13,6 @@
 extern "C" {
 #endif
 
-/* ---- 1. test / profiling hooks of the product library ------------------------------------------------------------------------------- */
 /* Profiling hook: when set to a device buffer of 512 x 8 int64, the chain kernels store cycle-counter stamps at their phase
  * boundaries (tile start, prologue done, each layer done) for the first 512 tiles.  NULL (the default) turns it off. */
 void pa_chain_debug_buffer(long long *buf);
@@ -48,34 +43,6 @@ void pa_linear_lds_enable(int on);
 void pa_emd_persistent_enable(int on);
 void pa_fpx16_enable(int mode);
 void pa_tgemm_cm_enable(int on);
-
-/* ---- 2. measured-slower variants: libpatchaugnet_hip_exp.so only --------------------------------------------------------------------- */
-#ifdef PA_EXPERIMENTAL
-/* Same with a fused tail: the last layer (wt[nlayers - 1], zero bias, relu_last = 0) is the next finer level's pre-multiply applied to this
- * level's output; that output (the result of layer nlayers - 2) leaves through tap (ldtap), the pre-multiplied rows through out. */
-int pa_fp_chain_premul_tap(int nlayers, const float *const *wt, const float *const *wpk, const float *const *bias, const int *kpad, const int *nout,
-                           long rows, const float *g, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c2,
-                           int c1, const float *wskip, const float *wskip_p, const float *bias0, float *out, int ldo, float *tap, int ldtap,
-                           int relu_last, pa_stream_t stream);
-
-/* EXPERIMENTAL, not used by default.  Finest feature-propagation level with register-resident activations (fpx_reg.hip):
- * pa_fp_chain_premul for 1 <= c1 <= 4 and exactly
- * two remaining 256 -> 256 layers (patch_aug_net.py:350-362 at the 4096-point level), computed with operand-swapped MFMAs so that a
- * layer's accumulators are the next layer's B operand (no activation tile in LDS; weights through a shared LDS stage; 16-point waves).  g (b*m_known, 256);
- * wp2 / wp3: the two layers' K-major (256 x 256) weights in the k-permuted packing
- *     wp[((q*16 + ot)*64 + l)*4 + s] = Wt[16q + 4(l/16) + s][16 ot + l%16],  q, ot in 0..15, l in 0..63, s in 0..3.
- * Contracts the channels in a different order than pa_fp_chain_premul: same values to fp32 rounding, not the same bits. */
-int pa_fpx256(long rows, const float *g, const int *idx3, const float *w3, const float *skip, int n_unknown, int m_known, int c1,
-              const float *wskip, const float *bias0, const float *wp2, const float *b2, const float *wp3, const float *b3,
-              float *out, int ldo, pa_stream_t stream);
-
-/* one lane per query over the cell grid (csrc/knn_lane.hip; 0.287 vs 0.149 ms at the model's size) */
-void pa_knn_lane_enable(int on);
-/* register-resident FPS without the LDS copy of the cloud (fps.hip; the round grows 0.70 -> 0.86 us) */
-void pa_fps_reg_xyz_enable(int on);
-/* pa_tgemm_nn's wave-private kernel (train_gemm.hip; a tie with the LDS-tiled kernel) */
-void pa_tgemm_wave_enable(int on);
-#endif /* PA_EXPERIMENTAL */
 
 #ifdef __cplusplus
 }

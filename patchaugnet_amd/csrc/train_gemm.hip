@@ -443,127 +443,6 @@ __global__ __launch_bounds__(256) void tgemm_nn_kernel(NNArgs a)
     }
 }
 
-#ifdef PA_EXPERIMENTAL   // measured a tie with the LDS-tiled kernel: test-only library (libpatchaugnet_hip_exp.so)
-// ------------------------------------------------------------------------------------------------ tgemm_nn, wave-private form
-// The same contraction for the aligned shapes that carry the step's FLOPs (M % 64 == 0, N % 64 == 0, K % 16 == 0, 16-byte aligned operands, no
-// tanh / distance epilogue): every WAVEFRONT owns a 64 x 64 output tile and runs its own software pipeline -- no LDS, no workgroup barrier.
-// (The LDS-tiled kernel above keeps 4-5 workgroups per CU whose four waves meet at a barrier every 32 MFMAs; at the 256 x 4096 x 256 layer the
-// workgroups convoy: 3.4 us per k-tile for 2.2 us of MFMA work on the CU, 51 % MFMA-busy, waves 57 % in s_waitcnt; deeper register prefetch
-// and LDS reads issued a k-step ahead changed nothing -- tools/probes/tgemm_scale.py, tools/pmc_tgemm.sh.)
-// Operands come straight from global memory / L2 in the MFMA fragment layout with 16-byte loads, eight loads per 64 MFMAs:
-//   * the contraction index is visited in the order k = 16 j + 4 (l / 16) + r (block j, MFMA step r = 0..3): a sum may take its terms in any order
-//     as long as both operands agree, and in this order a lane's four A values of a block (A k-contiguous) are ONE float4;
-//   * the tile's columns are n = n0 + 4 (l % 16) + u for MFMA column tile u: a lane's four B values of a step are ONE float4 of row k, and its
-//     four results per output row are four consecutive columns -> 16-byte stores.  With A m-contiguous (the dX GEMM) the rows are permuted the
-//     same way (m = m0 + 4 i + t) and a float4 of row k feeds the four row tiles.
-// The BatchNorm / ReLU operand transform is applied to the 16 B values of a block in registers (its per-channel parameters are float4 loads in the
-// same k order); statistics epilogue: 16-lane DPP-row sums, one fp64 atomic pair per row and wave.
-template <bool A_KCONTIG, int BMODE>
-__global__ __launch_bounds__(256) void tgemm_nnw_kernel(NNArgs a)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, q = lane >> 4;
-    const int nblk = blockIdx.x * (blockDim.x >> 6) + wave;
-    const int n0 = nblk * 64, m0 = blockIdx.y * 64, b = blockIdx.z;
-    if (n0 >= a.N) return;
-    const float *A = a.A + (size_t)b * a.sAb;
-    const float *B = a.B + (size_t)b * a.sBb + n0 + 4 * li;
-    const float *B2 = (BMODE >= TF_BN_BWD_RELU) ? a.tb.aux + (size_t)b * a.sBb + n0 + 4 * li : nullptr;
-    const float *P = a.tb.p + (size_t)b * a.sPb + 4 * q;
-    float *C = a.C + (size_t)b * a.sCb;
-    constexpr int NP = BMODE == TF_NONE ? 0 : (BMODE == TF_AFFINE_RELU ? 2 : 7);
-
-    floatx4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc[i][u] = (floatx4){0.f, 0.f, 0.f, 0.f};
-
-    constexpr int NPA = NP > 0 ? NP : 1;
-    floatx4 ac[4], bc[4], yc[4], pc[NPA], an[4], bn[4], yn[4], pn[NPA];
-    // everything block jb needs, requested together (the transform's parameters too: a load issued AFTER the next block's would make the wait for
-    // it a wait for all of them -- the counter is in order)
-    auto load = [&](int jb, floatx4 (&aa)[4], floatx4 (&bb)[4], floatx4 (&yy)[4], floatx4 (&pp)[NPA]) {
-#pragma unroll
-        for (int j = 0; j < NP; ++j) pp[j] = *reinterpret_cast<const floatx4 *>(P + (size_t)j * a.tb.nch + 16 * jb);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            aa[i] = A_KCONTIG ? *reinterpret_cast<const floatx4 *>(A + (size_t)(m0 + i * 16 + li) * a.lda + 16 * jb + 4 * q)
-                              : *reinterpret_cast<const floatx4 *>(A + (size_t)(16 * jb + 4 * q + i) * a.lda + m0 + 4 * li);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            bb[r] = *reinterpret_cast<const floatx4 *>(B + (size_t)(16 * jb + 4 * q + r) * a.ldb);
-            if (BMODE >= TF_BN_BWD_RELU) yy[r] = *reinterpret_cast<const floatx4 *>(B2 + (size_t)(16 * jb + 4 * q + r) * a.ldb);
-        }
-    };
-    // one block: transform the 16 B values in registers, then 64 MFMAs
-    auto compute = [&](floatx4 (&aa)[4], floatx4 (&bb)[4], floatx4 (&yy)[4], floatx4 (&pp)[NPA]) {
-        if (BMODE != TF_NONE) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                ChanP c;
-#pragma unroll
-                for (int j = 0; j < 7; ++j) c.v[j] = j < NP ? pp[j < NP ? j : 0][r] : 0.f;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) bb[r][u] = tf_apply<BMODE>(bb[r][u], BMODE >= TF_BN_BWD_RELU ? yy[r][u] : 0.f, c);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    acc[i][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_KCONTIG ? aa[i][r] : aa[r][i], bb[r][u], acc[i][u], 0, 0, 0);
-    };
-    // two register sets in turn (no copies: a copy placed after a component's last use made hipcc wait for the NEXT block's loads four MFMAs
-    // into the current block)
-    // into the current block); every load is UNCONDITIONAL (block index clamped: the last one or two are redundant) -- a load behind an `if` gives
-    // the two paths different numbers of outstanding loads, and hipcc then waits for all of them (s_waitcnt vmcnt(0)) in front of the MFMAs
-    const int nb = a.K / 16;
-    load(0, ac, bc, yc, pc);
-    int jb = 0;
-    for (; jb + 2 <= nb; jb += 2) {
-        load(min(jb + 1, nb - 1), an, bn, yn, pn);                 // in flight under this block's 64 MFMAs
-        __builtin_amdgcn_sched_barrier(0);                         // (left alone the scheduler sinks the loads into the MFMA stream, each into a
-        compute(ac, bc, yc, pc);                                   //  register that has just been freed, and waits for it a few MFMAs later)
-        __builtin_amdgcn_sched_barrier(0);
-        load(min(jb + 2, nb - 1), ac, bc, yc, pc);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(an, bn, yn, pn);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (jb < nb) compute(ac, bc, yc, pc);                          // odd number of blocks: the last one is already here
-
-    // ---- epilogue.  D layout of tile (i, u): column l % 16, row 4 (l / 16) + rr  ->  n = n0 + 4 (l % 16) + u (four consecutive columns per lane),
-    // m = m0 + 16 i + 4 (l / 16) + rr (A k-contiguous) or m0 + 4 (4 (l / 16) + rr) + i (A m-contiguous)
-    const unsigned slot = (unsigned)(nblk + b * (a.N / 64)) % PA_BN_STAT_SLOTS;
-    double *st = a.stats ? a.stats + (size_t)b * a.sStatb + (size_t)slot * 2 * a.M : nullptr;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int m = A_KCONTIG ? m0 + 16 * i + 4 * q + rr : m0 + 4 * (4 * q + rr) + i;
-            const float bias = a.bias ? a.bias[m] : 0.f;
-            floatx4 v = {acc[i][0][rr] + bias, acc[i][1][rr] + bias, acc[i][2][rr] + bias, acc[i][3][rr] + bias};
-            floatx4 *dst = reinterpret_cast<floatx4 *>(C + (size_t)m * a.ldc + n0 + 4 * li);
-            if (a.beta) {
-                const floatx4 o = *dst;
-                v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
-            }
-            *dst = v;
-            if (st) {
-                float t1 = (v[0] + v[1]) + (v[2] + v[3]), t2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { t1 += __shfl_xor(t1, o); t2 += __shfl_xor(t2, o); }
-                if (li == 0) {
-                    atomicAdd(st + m, (double)t1);
-                    atomicAdd(st + a.M + m, (double)t2);
-                }
-            }
-        }
-}
-
-#endif  // PA_EXPERIMENTAL
 
 // ------------------------------------------------------------------------------------------------ tgemm_kk
 // C (M x N) += sum over (batch, k) of fA(A_b)(m,k) * fB(B_b)(n,k); both operands k-contiguous: A_b(m,k) = A[b*sAb + m*lda + k].
@@ -998,11 +877,6 @@ int pa_tgemm_cm_try(int batch, int M, int N, int K, const float *A, long sAb, in
                     double *stats, int per_batch_stats, hipStream_t st, const float *ynext = nullptr, const float *pnext = nullptr, int relu_next = 0,
                     double *sums_next = nullptr);      // train_gemm_cm.hip
 
-#ifdef PA_EXPERIMENTAL
-static int g_tgemm_wave = -1;
-// test / A/B switch: 1 = the wave-private kernel wherever its shape rules hold, 0 = never, -1 = the environment (PA_TGEMM_WAVE, default off)
-PA_API void pa_tgemm_wave_enable(int on) { g_tgemm_wave = on; }
-#endif
 
 // C_b (M x N) = [beta C_b +] act(A_b . f(B_b) + bias): see tgemm_nn_kernel.  a_kcontig: A(m,k) = A[m*lda + k] (else A[k*lda + m]);
 // sAb = 0 shares A over the batch.  bmode 0 none / 1 affine+relu (bp: 2*K floats) / 2 bn-bwd with ReLU mask / 3 bn-bwd (baux = raw output,
@@ -1048,34 +922,6 @@ PA_API int pa_tgemm_nn(int batch, int M, int N, int K, const float *A, long sAb,
         if (took < 0) { pa_set_error("pa_tgemm_nn (LDS-resident weights): launch failed"); return PA_EINVAL; }
         if (took) return PA_OK;
     }
-#ifdef PA_EXPERIMENTAL
-    // the wave-private kernel for the aligned shapes (tgemm_nnw_kernel): OPT-IN (PA_TGEMM_WAVE=1 or pa_tgemm_wave_enable).  Measured against the
-    // LDS-tiled kernel on MI355X (tools/probes/tgemm_scale.py, 18 x (M x 4096 x 256)): M = 64: 54 vs 60 us, M = 256: 125 vs 123 us, M = 512: 211 vs
-    // 222 us; the training step 6.10 vs 6.15 ms -- a tie.  Both follow time = ~30 us + 21.5 us per 64 rows of M; the decomposition builds of the
-    // LDS-tiled kernel (PA_TGEMM_DBG_*) put its LDS-read + MFMA loop alone at 84-91 us of the 110-126 us: neither form is
-    // waiting for its operands, both sit at the ~0.75 of peak the MFMA pipe gives this chip's other kernels, plus launch, ramp, tail and the
-    // 75 MB of output traffic.
-    static const bool wave_env = getenv("PA_TGEMM_WAVE") && atoi(getenv("PA_TGEMM_WAVE")) != 0;
-    const bool wave_on = g_tgemm_wave > 0 || (g_tgemm_wave < 0 && wave_env);
-    static const long wave_min = getenv("PA_TGEMM_WAVE_MIN") ? atol(getenv("PA_TGEMM_WAVE_MIN")) : 1;
-    const long wtiles = (long)(M / 64) * (N / 64) * batch;
-    if (wave_on && act == 0 && !colv && M % 64 == 0 && N % 64 == 0 && K % 16 == 0 && wtiles >= wave_min && aligned16(A) && lda % 4 == 0 && sAb % 4 == 0 &&
-        aligned16(B) && ldb % 4 == 0 && sBb % 4 == 0 && (bmode < 2 || aligned16(baux)) && aligned16(C) && ldc % 4 == 0 && sCb % 4 == 0 &&
-        (bmode == 0 || (aligned16(bp) && a.sPb % 4 == 0)) && batch <= 65535 && M / 64 <= 65535) {
-        const int nblocks = N / 64;
-        static const int wforce = getenv("PA_TGEMM_WAVE_W") ? atoi(getenv("PA_TGEMM_WAVE_W")) : 0;      // waves per workgroup (A/B knob)
-        int W = nblocks % 4 == 0 ? 4 : (nblocks % 2 == 0 ? 2 : 1);
-        if (wforce > 0 && nblocks % wforce == 0 && wforce <= 4) W = wforce;
-        const dim3 wgrid(nblocks / W, M / 64, batch);
-#define PA_NNW(KC, MODE) hipLaunchKernelGGL((tgemm_nnw_kernel<KC, MODE>), wgrid, dim3(64 * W), 0, st, a)
-#define PA_NNW_MODE(KC) switch (bmode) { case 0: PA_NNW(KC, 0); break; case 1: PA_NNW(KC, 1); break; case 2: PA_NNW(KC, 2); break; default: PA_NNW(KC, 3); break; }
-        if (a_kcontig) { PA_NNW_MODE(true) } else { PA_NNW_MODE(false) }
-#undef PA_NNW_MODE
-#undef PA_NNW
-        PA_CHECK_LAUNCH("pa_tgemm_nn (wave-private)");
-        return PA_OK;
-    }
-#endif  // PA_EXPERIMENTAL
     dim3 grid((N + NN_BN - 1) / NN_BN, (M + (big ? 127 : 63)) / (big ? 128 : 64), batch);
 #define PA_NN(BMv, BKv, KC, MODE, VAv, VBv) hipLaunchKernelGGL((tgemm_nn_kernel<BMv, BKv, KC, MODE, VAv, VBv>), grid, dim3(256), 0, st, a)
 #define PA_NN_VEC(BMv, BKv, KC, MODE)                                                                       \

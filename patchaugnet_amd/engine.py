@@ -54,20 +54,6 @@ def pack_weights(wt):
     return wp
 
 
-def pack_weights_kperm(wt):
-    """K-major (256, 256) fp32 weights -> the k-permuted packing of pa_fpx256 (fpx_reg.hip):
-    wp[((q*16 + ot)*64 + l)*4 + s] = wt[16q + 4(l//16) + s, 16 ot + l%16]."""
-    assert tuple(wt.shape) == (256, 256)
-    dev = wt.device
-    q = torch.arange(16, device=dev).view(16, 1, 1, 1)
-    ot = torch.arange(16, device=dev).view(1, 16, 1, 1)
-    l = torch.arange(64, device=dev).view(1, 1, 64, 1)
-    sidx = torch.arange(4, device=dev).view(1, 1, 1, 4)
-    k = 16 * q + 4 * (l // 16) + sidx
-    n = 16 * ot + l % 16
-    return wt[k.expand(16, 16, 64, 4), n.expand(16, 16, 64, 4)].contiguous().view(-1)
-
-
 def pack_weights_f16(wt):
     """K-major (kpad, n) fp32 device tensor -> fp16 fragment packing for the fp16 chain kernels (pa_pack_weights_f16)."""
     kpad, n = wt.shape
@@ -149,7 +135,7 @@ class _Chain:
              ptr(known_feat), ptr(idx3), ptr(w3), ptr(skip), n_unknown, m_known, c2, c1, ptr(out), self.n_last)
         return out
 
-    def build_premul(self, c2, c1, kperm=False, x3=False):
+    def build_premul(self, c2, c1, x3=False):
         """Split and pack the first layer for pa_fp_chain_premul ONCE, at engine construction (on the constructing stream): nothing is
         packed lazily in the hot path, so pipeline streams never race a pack kernel issued on another stream."""
         wt0, b0, _, _, n0 = self.layers[0]
@@ -187,35 +173,15 @@ class _Chain:
             w1a3, inv1a = hilo(w1a)
             self._premul["x3"] = {"bufs": bufs, "wq": (ctypes.c_void_p * 2)(*[b.data_ptr() for b in bufs]), "inv": (ctypes.c_float * 2)(*inv),
                                   "w1a": w1a3, "inv1a": inv1a}
-        if kperm and not self.f16 and m == 2 and all(l[2] == 256 and l[4] == 256 for l in rest):
-            self._premul["kperm"] = [pack_weights_kperm(l[0]) for l in rest]
 
-    def attach_tail(self, finer):
-        """Fuse the NEXT finer level's pre-multiply into this level's chain (pa_fp_chain_premul_tap): its first-layer slice w1a becomes one
-        more layer (no bias, no ReLU) on this level's output tile while that is still in LDS.  Packed once, at engine construction."""
-        pm, fm = self._premul, finer._premul
-        assert pm["m"] + 1 <= 2 and fm["w1a"].shape[0] == self.n_last and not self.f16
-        m = pm["m"] + 1
-        rest = self.layers[1:]
-        zero = torch.zeros(fm["n0"], dtype=torch.float32, device=fm["w1a"].device)
-        packed = list(self.packed[1:]) + [fm["w1a_p"]]
-        self._tail = {
-            "m": m, "zero": zero, "n_tail": fm["n0"],
-            "wt": (ctypes.c_void_p * m)(*([l[0].data_ptr() for l in rest] + [fm["w1a"].data_ptr()])),
-            "wpk": (ctypes.c_void_p * m)(*[(p.data_ptr() if p is not None else None) for p in packed]),
-            "bias": (ctypes.c_void_p * m)(*([l[1].data_ptr() for l in rest] + [zero.data_ptr()])),
-            "kpad": (ctypes.c_int * m)(*([l[3] for l in rest] + [fm["w1a"].shape[0]])),
-            "nout": (ctypes.c_int * m)(*([l[4] for l in rest] + [fm["n0"]])),
-        }
-
-    def fp_premul(self, known_feat, idx3, w3, skip, B, n_unknown, m_known, c2, c1, mark=None, g_pre=None, tail=False, out16=False):
+    def fp_premul(self, known_feat, idx3, w3, skip, B, n_unknown, m_known, c2, c1, mark=None, out16=False):
         """Finest feature-propagation level: the first layer is applied to the m_known coarse points BEFORE interpolation
         (pa_fp_chain_premul; interpolation is linear), the skip (xyz) term is added in the kernel's prologue."""
         dev = known_feat.device
         if getattr(self, "_premul", None) is None or (self._premul["c2"], self._premul["c1"]) != (c2, c1):
             raise RuntimeError("fp_premul: build_premul(c2, c1) was not run for this level at engine construction")
         pm = self._premul
-        if pm["g16"] and g_pre is None:
+        if pm["g16"]:
             g16 = torch.empty((B * m_known, 256), dtype=torch.float16, device=dev)
             call("pa_fp_premul_g16", B * m_known, ptr(known_feat), c2, ptr(pm["w1a_p"]), ptr(g16))
             if mark is not None:
@@ -233,9 +199,7 @@ class _Chain:
                 call("pa_fp_chain_premul_g16", pm["m"], cast(pm["wpk"]), cast(pm["bias"]), cast(pm["kpad"]), cast(pm["nout"]), rows, ptr(g16), ptr(idx3),
                      ptr(w3), ptr(skip), n_unknown, m_known, pm["n0"], c1, ptr(pm["wskip"]), ptr(pm["bias0"]), ptr(out), self.n_last)
             return out
-        if g_pre is not None:       # the coarser level's chain already produced known_feat . w1a (attach_tail)
-            g = g_pre
-        elif pm.get("x3") is not None and not tail:      # opt-in f32x3: the pre-multiply in the same split-operand arithmetic
+        if pm.get("x3") is not None:      # opt-in f32x3: the pre-multiply in the same split-operand arithmetic
             g = torch.empty((B * m_known, pm["n0"]), dtype=torch.float32, device=dev)
             call("pa_linear_x3", B * m_known, ptr(known_feat), c2, ptr(pm["x3"]["w1a"]), ctypes.c_float(pm["x3"]["inv1a"]), ptr(g), pm["n0"])
         else:
@@ -247,27 +211,12 @@ class _Chain:
         rows = B * n_unknown
         out = torch.empty((rows, self.n_last), dtype=torch.float32, device=dev)
         rest = self.layers[1:]
-        if tail:                    # this level's output leaves through the tap, the finer level's pre-multiplied rows through `out`
-            tl = self._tail
-            g_next = torch.empty((rows, tl["n_tail"]), dtype=torch.float32, device=dev)
-            cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
-            call("pa_fp_chain_premul_tap", tl["m"], cast(tl["wt"]), cast(tl["wpk"]), cast(tl["bias"]), cast(tl["kpad"]), cast(tl["nout"]), rows,
-                 ptr(g), ptr(idx3), ptr(w3), ptr(skip), n_unknown, m_known, pm["n0"], c1, ptr(pm["wskip"]), ptr(pm["wskip_p"]), ptr(pm["bias0"]),
-                 ptr(g_next), tl["n_tail"], ptr(out), self.n_last, 0)
-            return out, g_next
-        if pm.get("x3") is not None and not tail:
+        if pm.get("x3") is not None:
             x3 = pm["x3"]
             cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
             for _ in range(getattr(self, "bench_repeat", 1)):
                 call("pa_fp_chain_premul_x3", pm["m"], cast(x3["wq"]), cast(x3["inv"]), cast(pm["bias"]), rows, ptr(g), ptr(idx3), ptr(w3), ptr(skip),
                      n_unknown, m_known, pm["n0"], c1, ptr(pm["wskip"]), ptr(pm["bias0"]), ptr(out), self.n_last)
-            return out
-        if (not self.f16 and c1 <= 4 and pm["n0"] == 256 and len(rest) == 2 and all(l[2] == 256 and l[4] == 256 for l in rest)
-                and "kperm" in pm):
-            # experimental register-resident variant (fpx_reg.hip, opt-in: slower than the LDS-tiled kernel so far); a function of the
-            # layer shapes and the environment only, never of the batch size
-            call("pa_fpx256", rows, ptr(g), ptr(idx3), ptr(w3), ptr(skip), n_unknown, m_known, c1, ptr(pm["wskip"]), ptr(pm["bias0"]),
-                 ptr(pm["kperm"][0]), ptr(rest[0][1]), ptr(pm["kperm"][1]), ptr(rest[1][1]), ptr(out), self.n_last)
             return out
         cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
         for _ in range(getattr(self, "bench_repeat", 1)):     # > 1 only under profiling.launch_time_ms: the same launch back to back (idempotent)
@@ -639,21 +588,7 @@ class PatchAugNetEngine:
                 ok = bool(self.premul and ok and chain.n >= 2 and c2 % 4 == 0 and chain.layers[0][4] % 16 == 0 and chain.layers[0][2] == c2 + c1)
                 self._fold_static.append(ok)
                 if ok:
-                    # PA_ENGINE_FPX_REG / PA_ENGINE_TAIL select measured-slower variants that only the test-only library exports
-                    # (`with _lib.experimental():`, csrc/pa_internal.h section 2); with the product library they are refused, not ignored
-                    chain.build_premul(c2, c1, kperm=self._exp_knob("PA_ENGINE_FPX_REG", "pa_fpx256"), x3=self.mlp_dtype == "f32x3")
-            # a level whose chain runs as [skip layer | one 256-wide layer] can carry the next finer level's pre-multiply as a third layer
-            # (pa_fp_chain_premul_tap).  Measured at B = 32 and NOT the default: the pre-multiply launch goes 0.050 -> 0.005 ms but the
-            # shared-tile chain that now carries it 0.072 -> 0.112 ms (the stand-alone launch runs the faster eight-wave tiling) -- net zero.
-            self._tail_static = [False] * nfp
-            if self._exp_knob("PA_ENGINE_TAIL", "pa_fp_chain_premul_tap", flag=True):
-                for j in range(1, nfp):
-                    c1 = self.sa[j - 1].n_last
-                    fine, here = self.fp[j - 1], self.fp[j]
-                    if (self._fold_static[j] and self._fold_static[j - 1] and c1 > 4 and not here.f16 and here._premul["m"] == 1 and here._premul["wskip_p"] is not None
-                            and fine._premul["w1a_p"] is not None and here.n_last % 64 == 0 and fine._premul["n0"] % 64 == 0):
-                        here.attach_tail(fine)
-                        self._tail_static[j] = True
+                    chain.build_premul(c2, c1, x3=self.mlp_dtype == "f32x3")
         self._tensors = list(model.parameters()) + list(model.buffers())
         self._key = self._params_key(model)
         self.timer = None     # optional profiling.StageTimer: per-stage HIP-event marks (bench.py kernel attribution)
@@ -670,14 +605,6 @@ class PatchAugNetEngine:
         self._fp0_half_ok = os.environ.get("PA_ENGINE_FP0_F16", "1") != "0"
         self._fp0_half = False
         self._geo_streams = {}
-
-    @staticmethod
-    def _exp_knob(env, symbol, flag=False):
-        on = (os.environ.get(env) is not None) if flag else (os.environ.get(env, "0") == "1")
-        if on and not _lib.has(symbol):
-            raise RuntimeError(f"{env} selects an experimental kernel variant ({symbol}) that only libpatchaugnet_hip_exp.so exports: "
-                               "build the engine inside `with patchaugnet_amd._lib.experimental():`")
-        return on
 
     @staticmethod
     def _presort_ok(n, m, ns):
@@ -864,7 +791,6 @@ class PatchAugNetEngine:
             l_c.append(cidx[i])
             c_feat = chain.n_last
         sa_feat = l_feat[1:]                       # the list entries are replaced (not written) by the decoder levels below
-        g_pre = None
         for i in range(-1, -(nfp + 1), -1):
             chain = self.fp[nfp + i]
             unknown, known = l_xyz[i - 1], l_xyz[i]
@@ -884,19 +810,10 @@ class PatchAugNetEngine:
             # c1 <= 4 (xyz skip): always; wider skips only at levels with enough points per cloud to amortise the extra pre-multiply
             # launch (a per-level rule, NOT a function of the batch size: results must not depend on how clouds are batched)
             if self._fold_static[nfp + i] and (c1 <= 4 or n_u >= 512) and n_u >= 2 * m_k:
-                # the finer level's pre-multiply rides on this level's chain when that level will take the pre-multiplied path too
-                # (a per-level rule on the architecture's point counts, like the condition above: never a function of the batch size)
-                fuse = False
-                if self._tail_static[nfp + i] and nfp + i >= 1:
-                    nn_u, nm_k = l_xyz[i - 2].shape[1], n_u
-                    nc1 = (3 if self.use_origin else 0) if nfp + i - 1 == 0 else self.sa[nfp + i - 2].n_last
-                    fuse = (nc1 <= 4 or nn_u >= 512) and nn_u >= 2 * nm_k
-                res = chain.fp_premul(known_feat.contiguous(), idx3_l, w3_l, skip.contiguous(), B, n_u, m_k, c2, c1,
-                                      mark=lambda k=nfp + i: self._mark(f"fp{k}.premul"), g_pre=g_pre, tail=fuse,
-                                      out16=bool(self._fp0_half and nfp + i == 0 and not fuse and g_pre is None and chain._premul["g16"]))
-                y, g_pre = res if fuse else (res, None)
+                y = chain.fp_premul(known_feat.contiguous(), idx3_l, w3_l, skip.contiguous(), B, n_u, m_k, c2, c1,
+                                    mark=lambda k=nfp + i: self._mark(f"fp{k}.premul"),
+                                    out16=bool(self._fp0_half and nfp + i == 0 and chain._premul["g16"]))
             else:
-                g_pre = None
                 y = chain.fp(known_feat.contiguous(), idx3_l, w3_l, skip.contiguous() if skip is not None else None, B, n_u, m_k, c2, c1)
             self._mark(f"fp{nfp + i}.chain")
             l_feat[i - 1] = y.view(B, n_u, chain.n_last)

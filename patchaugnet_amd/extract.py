@@ -30,6 +30,22 @@ def _prime_stream_queues(device):
     torch.cuda.synchronize(device)
 
 
+_POOL = {}
+
+
+def _pipeline_streams(device, n):
+    """The process's pipeline streams for `device`: created once (after the priming above) and handed to every StreamPipeline /
+    GraphedExtractor.  A second extractor that created four NEW streams landed them on whatever hardware queues the runtime had left: the same
+    model measured 57 k submaps/s in a fresh process and 37 k as the sixth extractor of a long-lived one (bench.py's extra configurations,
+    round 5).  A captured graph replays on whichever stream is current, so sharing the streams between extractors costs nothing."""
+    _prime_stream_queues(device)
+    key = (device.type, device.index)
+    pool = _POOL.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
+
+
 def _prepare(model, device):
     """Build the model's fused engine (folded + packed weights) on the CALLER's current stream before any pipeline stream touches it:
     a lazily built engine would enqueue its pack kernels on whichever pipeline stream runs the first batch, and the other streams would
@@ -43,8 +59,7 @@ def _prepare(model, device):
 class StreamPipeline:
     def __init__(self, n_streams=2, device=None):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        _prime_stream_queues(self.device)
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(max(1, n_streams))]
+        self.streams = list(_pipeline_streams(self.device, max(1, n_streams)))
         self._i = 0
 
     def begin(self):
@@ -85,13 +100,13 @@ class GraphedExtractor:
         slots' replays reading it on theirs, so run() refuses instead of giving silently wrong descriptors."""
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         assert not model.training, "hipGraph capture is for evaluation (fused engine, no autograd)"
-        _prime_stream_queues(self.device)
+        streams = _pipeline_streams(self.device, max(1, n_streams))
         self.slots = []
         cur = torch.cuda.current_stream(self.device)
         _prepare(model, self.device)                   # BatchNorm folding / weight packing on the caller's stream, before any slot stream runs
         with torch.no_grad():
             for i in range(max(1, n_streams)):
-                st = torch.cuda.Stream(device=self.device)
+                st = streams[i]
                 if resident_inputs:
                     x = resident_inputs[i % len(resident_inputs)]
                     assert x.is_cuda and tuple(x.shape) == tuple(batch_shape) and x.dtype == torch.float32 and x.is_contiguous()

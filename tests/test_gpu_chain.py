@@ -138,33 +138,6 @@ def test_fp_interpolate(B, n, m, c2, c1, dims):
     close(got, exp)
 
 
-def test_register_resident_fpx_variant_matches_shipped_kernel(monkeypatch):
-    """fpx_reg.hip (opt-in experiment: activations in registers, operand-swapped MFMA, k-permuted weights) computes the same finest FP level
-    as the shipped LDS-tiled kernel up to the order of the fp32 additions."""
-    from patchaugnet_amd.engine import _Chain
-    B, n, m, c2, c1, dims = 3, 4096, 1024, 256, 3, [259, 256, 256, 256]
-    ref, eng = make_layers(dims, seed=5)
-    g = torch.Generator().manual_seed(9)
-    known = torch.randn(B, m, c2, generator=g).cuda()
-    skip = torch.randn(B, n, c1, generator=g).cuda()
-    idx3 = torch.randint(0, m, (B, n, 3), generator=g).int().cuda()
-    w3 = torch.rand(B, n, 3, generator=g)
-    w3 = (w3 / w3.sum(-1, keepdim=True)).cuda().contiguous()
-    def chain(kperm):                       # the first-layer split is packed at construction time (engine.build_premul), never in a forward
-        ch = _Chain(eng)
-        ch.build_premul(c2, c1, kperm=kperm)
-        return ch
-    from patchaugnet_amd import _lib
-    a = chain(False).fp_premul(known, idx3, w3, skip, B, n, m, c2, c1)
-    tail_ref = chain(False).fp_premul(known[:1], idx3[:1, :1000].contiguous(), w3[:1, :1000].contiguous(), skip[:1, :1000].contiguous(), 1, 1000, m, c2, c1)
-    with _lib.experimental():              # pa_fpx256 is a measured-slower variant: exported by the test-only library only
-        b = chain(True).fp_premul(known, idx3, w3, skip, B, n, m, c2, c1)
-        tail = chain(True).fp_premul(known[:1], idx3[:1, :1000].contiguous(), w3[:1, :1000].contiguous(), skip[:1, :1000].contiguous(), 1, 1000, m, c2, c1)
-        torch.cuda.synchronize()
-    close(b, a.double(), rtol=2e-5)                                        # different summation order: equal to rounding, not bit for bit
-    close(tail, tail_ref.double(), rtol=2e-5)                              # rows not a multiple of the 64-point workgroup tile
-
-
 @pytest.mark.parametrize("B,n,m,ns,C,dims", [(32, 128, 16, 20, 256, [259, 256, 256, 512]), (2, 128, 16, 20, 256, [259, 256, 256, 512]),
                                               (5, 256, 37, 16, 128, [131, 128, 128, 256]), (3, 64, 7, 32, 61, [64, 64, 256, 128]),
                                               (1, 40, 3, 19, 61, [64, 64, 64])])

@@ -82,12 +82,11 @@ def test_knn_module_against_kdtree(nref, nquery, k, dim, batch):
     assert np.array_equal(D2.cpu().numpy().transpose(0, 2, 1), D) and np.array_equal(I2.cpu().numpy().transpose(0, 2, 1), I)
 
 
-EMD_FORMS = {"round_launches": 0, "one_workgroup": 1, "resident": 2, "default": -1}
+EMD_FORMS = {"round_launches": 0, "one_workgroup": 1, "default": -1}
 
 
 def _emd_form(form):
-    """Select the auction's launch form on the ACTIVE library: "default" / "round_launches" = one chip-wide launch per round; "one_workgroup" = the
-    round-1 persistent kernel; "resident" (test-only library) = every round inside one chip-wide launch."""
+    """Select the auction's launch form: "default" / "round_launches" = one chip-wide launch per round; "one_workgroup" = the round-1 persistent kernel."""
     import ctypes
     from patchaugnet_amd import _lib
     lib = _lib.lib()
@@ -110,7 +109,7 @@ def _emd_gpu(a, c, eps, iters):
     return rc, {k: v.cpu().numpy() for k, v in st.items()}
 
 
-@pytest.mark.parametrize("persistent", ["default", "one_workgroup", "resident", "tail_from_5", "tail_from_0"])
+@pytest.mark.parametrize("persistent", ["default", "one_workgroup"])
 @pytest.mark.parametrize("b,n,eps,iters,lat", [(2, 1024, 0.005, 60, False), (3, 1024, 0.02, 1, False), (2, 2048, 0.01, 25, True),
                                                (1, 4096, 0.02, 12, False), (2, 1024, 0.002, 400, False), (20, 1024, 0.02, 30, False),
                                                (1, 8192, 0.02, 5, False), (16, 1024, 0.01, 3000, False)])
@@ -118,25 +117,13 @@ def test_emd_forward_matches_oracle_bit_exact(b, n, eps, iters, lat, persistent)
     """a-E: assignment, squared distances and the whole auction state equal the deterministic CPU restatement
     (emd_cuda.cu:228-282; free choices fixed as documented in oracle_emd_forward) -- in both launch forms: chip-wide (one launch per round,
     G workgroups per cloud, the round resolved by the last workgroup to arrive) and one persistent workgroup per cloud."""
-    import contextlib
-    import os
-    from patchaugnet_amd import _lib
     a, c = pts(b, n, lat), pts(b, n, lat)
     st, rd, ra, rs = o.emd_forward(a, c, eps, iters, full_state=True)
-    # "resident" (every round in one chip-wide launch) and "tail_from_k" (an on-chip one-workgroup kernel takes over after k rounds) are measured-
-    # slower forms kept in the test-only library; the product runs one chip-wide launch per round, or the one-workgroup kernel on request
-    exp = persistent in ("resident", "tail_from_5", "tail_from_0")
-    if persistent.startswith("tail_from") and n > 4096:
-        pytest.skip("the on-chip tail kernel holds n <= 4096")
-    with (_lib.experimental() if exp else contextlib.nullcontext()):
-        if persistent.startswith("tail_from"):
-            os.environ["PA_EMD_TAIL_FROM"] = persistent.rsplit("_", 1)[1]
-        _emd_form(persistent if persistent in EMD_FORMS else "default")
-        try:
-            rc, g = _emd_gpu(a, c, eps, iters)
-        finally:
-            _emd_form("default")
-            os.environ.pop("PA_EMD_TAIL_FROM", None)
+    _emd_form(persistent)
+    try:
+        rc, g = _emd_gpu(a, c, eps, iters)
+    finally:
+        _emd_form("default")
     assert rc == 1 and st == 1
     assert np.array_equal(g["assignment"], ra)
     assert np.array_equal(g["dist"], rd)

@@ -49,33 +49,6 @@ def test_fps_bit_exact(P, b, n, m, kind):
     assert got.dtype == np.int32 and np.array_equal(got, ref), f"first mismatch col {np.argmax((got != ref).any(0))}"
 
 
-@pytest.mark.parametrize("b,n,m,kind", FPS_CASES)
-def test_fps_register_coordinate_variant_bit_exact(b, n, m, kind):
-    """pa_fps_reg_xyz_enable(1), a measured-slower variant kept in the test-only library (libpatchaugnet_hip_exp.so): no LDS copy of the cloud,
-    winner coordinates from the owning lane's registers (fps.hip).  Same samples, same gathered coordinates as the oracle."""
-    from patchaugnet_amd import _lib
-    x = cloud(b, n, kind)
-    xd = dev(x)
-    ref = o.furthestsampling(x, m)
-    idx = torch.empty((b, m), dtype=torch.int32, device="cuda")
-    idx2 = torch.empty((b, m), dtype=torch.int32, device="cuda")
-    nx = torch.empty((b, m, 3), device="cuda")
-    temp = torch.full((b, n), 1e10, device="cuda")
-    with _lib.experimental() as lib:
-        lib.pa_fps_reg_xyz_enable(1)
-        try:
-            _lib.call("pa_furthestsampling", b, n, m, _lib.ptr(xd), _lib.ptr(temp), _lib.ptr(idx))
-            if n <= 8192:
-                _lib.call("pa_furthestsampling_gather", b, n, m, _lib.ptr(xd), _lib.ptr(idx2), _lib.ptr(nx))
-            torch.cuda.synchronize()
-        finally:
-            lib.pa_fps_reg_xyz_enable(0)
-    assert np.array_equal(idx.cpu().numpy(), ref)
-    if n <= 8192:
-        assert np.array_equal(idx2.cpu().numpy(), ref)
-        assert np.array_equal(nx.cpu().numpy(), np.take_along_axis(x, ref[..., None].astype(np.int64), 1))
-
-
 def test_fps_leaves_temp_like_reference():
     """temp holds the final running minima after the call (sampling_cuda_kernel.cu:94-95 writes it back every round)."""
     from patchaugnet_amd import _lib
@@ -113,9 +86,9 @@ LANE_CASES = ["uniform", "lattice", "dup", "planar", "clustered", "outside", "no
 
 @pytest.mark.parametrize("kind", LANE_CASES)
 @pytest.mark.parametrize("k", [16, 20, 32])
-def test_knn_lane_kernel_bit_exact(P, kind, k):
-    """The one-lane-per-query kernel (csrc/knn_lane.hip: 2048..4096 source points, >= 256 queries, k in 16 / 20 / 32) on the shapes that
-    stress its grid walk: exact ties beyond the queue (lattice, duplicates -> direct-insertion path), a degenerate axis (planar, line),
+def test_knn_cell_grid_kernels_on_stress_shapes_bit_exact(P, kind, k):
+    """The cell-grid neighbour searches (csrc/knn_quad.hip: four lanes per query, the default at 2048..4096 source points; csrc/knn.hip: the
+    wave-per-query grid kernel behind pa_knn_quad_enable(0)) on the shapes that stress the grid walk: exact ties beyond the queue (lattice, duplicates -> direct-insertion path), a degenerate axis (planar, line),
     dense clusters with far outliers (many shells), queries outside the cloud's box (no early stop), non-finite points, ragged n."""
     import zlib
     rng = np.random.default_rng(zlib.crc32(f"{kind}-{k}".encode()))
@@ -147,16 +120,7 @@ def test_knn_lane_kernel_bit_exact(P, kind, k):
         q[:, ::5] += (rng.random((b, len(range(0, m, 5)), 3), dtype=np.float32) * 0.01).astype(np.float32)   # queries that are not cloud points
     ri, rd = o.knnquery(k, x, q)
     from patchaugnet_amd import _lib
-    with _lib.experimental() as xlib:      # the lane-per-query kernel lives in the test-only library (measured slower at the model's size)
-        xlib.pa_knn_lane_enable(1)
-        try:
-            gi, gd = P.knnquery_with_dist(k, dev(x), dev(q))
-            torch.cuda.synchronize()
-        finally:
-            xlib.pa_knn_lane_enable(0)
     lib = _lib.lib()
-    assert np.array_equal(gi.cpu().numpy(), ri)
-    assert np.array_equal(gd.cpu().numpy().view(np.uint32), rd.view(np.uint32))
     gi2, gd2 = P.knnquery_with_dist(k, dev(x), dev(q))                      # the default: four lanes per query (knn_quad.hip)
     assert np.array_equal(gi2.cpu().numpy(), ri) and np.array_equal(gd2.cpu().numpy().view(np.uint32), rd.view(np.uint32))
     lib.pa_knn_quad_enable.argtypes, lib.pa_knn_quad_enable.restype = [__import__("ctypes").c_int], None

@@ -457,37 +457,6 @@ def test_linear_rows_single_row_leaves_the_bias_parameter_alone():
             assert _rel(y, x.double() @ W.double().t() + keep.double()) <= 1e-5
 
 
-@pytest.mark.parametrize("a_kcontig,bmode", [(True, 0), (True, 1), (False, 2), (False, 3)])
-@pytest.mark.parametrize("B,M,N,K,beta,bias", [(3, 64, 128, 32, 0, False), (2, 256, 320, 256, 0, True), (1, 128, 64, 16, 1, False), (2, 64, 192, 48, 0, False)])
-def test_wave_private_gemm_matches_the_lds_tiled_kernel(a_kcontig, bmode, B, M, N, K, beta, bias):
-    """pa_tgemm_nn's opt-in wave-private kernel (no LDS, no barrier, operands as 16-byte fragment loads in a permuted contraction / column
-    order) against the default LDS-tiled kernel on the same operands: every operand transform, both A layouts, bias, beta, statistics.  The
-    contraction order differs, so fp32 rounding does: 2e-5 of the output scale."""
-    from patchaugnet_amd import _lib, train_ops
-    g = torch.Generator().manual_seed(M + N + K + bmode)
-    A = (torch.randn(M, K, generator=g) if a_kcontig else torch.randn(K, M, generator=g)).cuda() / K ** 0.5
-    X = torch.randn(B, K, N, generator=g).cuda()
-    aux = torch.randn(B, K, N, generator=g).cuda() if bmode >= 2 else None
-    pblk = (torch.rand(7, K, generator=g) + 0.25).cuda() if bmode else None
-    bvec = torch.randn(M, generator=g).cuda() if bias else None
-    outs, stats = [], []
-    with _lib.experimental() as lib:       # the wave-private kernel is a measured tie: test-only library
-        try:
-            for on in (0, 1):
-                lib.pa_tgemm_wave_enable(on)
-                C = torch.full((B, M, N), 0.5, device="cuda")
-                st = torch.zeros(train_ops.STAT_SLOTS, 2, M, dtype=torch.float64, device="cuda")
-                train_ops.tgemm_nn(B, M, N, K, A, 0, K if a_kcontig else M, a_kcontig, X, K * N, N, C, M * N, N, bmode=bmode, baux=aux, bp=pblk, beta=beta, bias=bvec, stats=st)
-                outs.append(C)
-                stats.append(st.sum(0))
-            torch.cuda.synchronize()
-        finally:
-            lib.pa_tgemm_wave_enable(-1)
-    scale = outs[0].abs().max().item()
-    assert (outs[0] - outs[1]).abs().max().item() <= 2e-5 * scale
-    assert torch.allclose(stats[0], stats[1], rtol=1e-5, atol=1e-4 * scale * N)
-
-
 def _cm_switch(on):
     import ctypes
     from patchaugnet_amd import _lib
