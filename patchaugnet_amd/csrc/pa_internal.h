@@ -19,7 +19,7 @@ void pa_chain_debug_buffer(long long *buf);
 void pa_knn_debug_buffer(long long *buf);   /* same for the pruned kNN kernel: 6 int64 (prologue cycles, query cycles, chunks visited, insertions, sort cycles, queries per wave) */
 
 /* 1 = wherever the kernel's shape rules hold, 0 = never, -1 = the default rule / environment:
- *   pa_knn_quad_enable        pa_knnquery at 2048..4096 source points on the four-lanes-per-query cell-grid kernel (csrc/knn_quad.hip); 0 forces the
+ *   pa_knn_quad_enable        pa_knnquery at 1024..4096 source points and >= 128 queries on the four-lanes-per-query cell-grid kernel (csrc/knn_quad.hip); 0 forces the
  *                             wave-per-query kernels
  *   pa_three_nn_grid_enable   pa_nearestneighbor / pa_three_nn_weights on the cell-grid kernel (csrc/three_nn_grid.hip); 0 forces the brute-force scan
  *   pa_chain_tiny_enable      the persistent first-set-abstraction kernel (csrc/sa_tiny.hip)
