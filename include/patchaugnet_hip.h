@@ -74,7 +74,7 @@ int pa_knnquery_window(int b, int n, int m, int nsample, int q0, int mq, const f
 /* The source cloud's counting sort as a launch of its own: cells = pa_cloud_cellsort_floats(b, n) floats (16-byte aligned), n <= 4096.  A caller
  * that knows the cloud before the queries (the engine: the input cloud vs the centres its sampling chain is still drawing) sorts early;
  * pa_knnquery_presorted then answers like pa_knnquery, bit for bit, without every workgroup repeating the sort.  PA_EUNSUPPORTED when the level's
- * shape does not run the cell-grid kernel (2048..4096 source points, >= 256 queries, nsample 16 / 20 / 32). */
+ * shape does not run the cell-grid kernel (1024..4096 source points, >= 128 queries, nsample 16 / 20 / 32). */
 long pa_cloud_cellsort_floats(int b, int n);
 int pa_cloud_cellsort(int b, int n, const float *xyz, float *cells, pa_stream_t stream);
 int pa_knnquery_presorted(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, const float *cells, int *idx, float *dist2, pa_stream_t stream);

@@ -617,7 +617,7 @@ class PatchAugNetEngine:
 
     def _first_level_chunks(self, npts, ns):
         """Sample ranges [j0, j1, ..., m] of the first level's sampling in latency mode (None = one launch): the level must run the kernels that take windows --
-        the cell-grid kNN (2048..4096 source points, >= 256 centres, 16 / 20 / 32 neighbours) and the persistent first-level chain
+        the cell-grid kNN (1024..4096 source points, >= 128 centres, 16 / 20 / 32 neighbours; the ranges / windows here only at the first level's 2048..4096 / >= 256) and the persistent first-level chain
         (<= 8 -> 32 -> 32 -> 64, fp32, no attention in between) -- rules on the architecture's shapes, never on the batch."""
         ch = self.sa[0]
         ok = (len(self.sa) > 1 and 2048 <= npts[0] <= 4096 and npts[1] >= 1024 and npts[1] % 16 == 0 and ns in (16, 20, 32) and 13 <= ns <= 20 and not ch.f16

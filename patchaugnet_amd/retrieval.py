@@ -219,9 +219,11 @@ def get_hard_negatives_batch(query_vectors, ref_latent_vectors, negative_index_l
     Candidate sets differ per query.  With the default kNN the whole refresh is ONE launch on the device: the index lists go up once as
     one padded (nq, L) tensor and a wavefront per query selects the num_hard_neg nearest of its own list in (distance, list position)
     order (pa_knn_candidates) -- 1400 queries x 3000 negatives: 1.66 s as one launch per query.  ``chunk`` is kept for callers that pass
-    it; it no longer has an effect.  A custom ``knn`` (tests, CPU stand-ins) keeps the per-query path."""
+    it; it has no effect on the one-launch path.  num_hard_neg > 64 and indices outside the reference set are handled on the host (above / IndexError).  A custom ``knn`` (tests, CPU stand-ins) keeps the per-query path."""
     nq = len(negative_index_lists)
     if knn is not hip_knn or nq == 0:
+        return [get_hard_negatives(q, ref_latent_vectors, negs, num_hard_neg, knn) for q, negs in zip(query_vectors, negative_index_lists)]
+    if num_hard_neg > 64:       # the one-launch kernel keeps its top-k in one wavefront (k <= 64): larger requests take the per-query path
         return [get_hard_negatives(q, ref_latent_vectors, negs, num_hard_neg, knn) for q, negs in zip(query_vectors, negative_index_lists)]
     lens = np.fromiter((len(l) for l in negative_index_lists), dtype=np.int64, count=nq)
     L = int(lens.max())
@@ -230,6 +232,10 @@ def get_hard_negatives_batch(query_vectors, ref_latent_vectors, negative_index_l
     idx = np.full((nq, L), -1, dtype=np.int64)
     for i, l in enumerate(negative_index_lists):
         idx[i, :len(l)] = l
+    # the kernel trusts its row indices (like the reference's gather): a bad index raises here, as the torch gather of earlier rounds did
+    nref = int(ref_latent_vectors.shape[0])
+    if idx.max() >= nref or (idx < -1).any():
+        raise IndexError(f"get_hard_negatives_batch: negative index outside [0, {nref}) in negative_index_lists")
     dev = ref_latent_vectors.device
     idx_d = torch.from_numpy(idx).to(dev)
     q_all = query_vectors if torch.is_tensor(query_vectors) else torch.stack(list(query_vectors))
