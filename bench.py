@@ -43,6 +43,7 @@ def parse():
     p.add_argument("--mlp-dtype", choices=["f32", "f16", "f32x3"], default="f32",
                    help="f16: shared-MLP chains on fp16 MFMA (fp32 accumulate; cosine >= 0.999 contract) -- not the headline configuration")
     p.add_argument("--no-graphs", action="store_true", help="issue every step's launches from Python instead of replaying one captured hipGraph per stream")
+    p.add_argument("--torch-adam", action="store_true", help="--config train: torch.optim.Adam (fused) instead of patchaugnet_amd.optim.Adam (csrc/adam.hip)")
     p.add_argument("--no-prefetch", action="store_true", help="--config train: no geometry prefetch of the next batch (one graph per step)")
     p.add_argument("--streams", type=int, default=4, help="HIP streams the consecutive steps are issued on (1 = strictly sequential)")
     p.add_argument("--reps", type=int, default=5, help="repetitions of the timed K-step region; the headline value is their median (min / max reported)")
@@ -380,7 +381,12 @@ def train_bench(a, emit=True, pmc=None):
     q, pos, neg, oth = (torch.rand(1, k, n, 3, generator=g) * 2 - 1 for k in (1, 2, 14, 1))
     nn_dict = {(0, 1): torch.randint(0, n, (1024, 1), generator=g).numpy(), (0, 2): torch.randint(0, n, (1024, 1), generator=g).numpy()}
     graphed = not a.no_graphs
-    opt = torch.optim.Adam(model.parameters(), lr=1e-5, capturable=graphed, fused=graphed)   # fused: one multi-tensor kernel instead of ~300 small ones
+    # the training loop's optimizer (train_place_recognition.py:386-392: torch.optim.Adam) on the HIP kernel of csrc/adam.hip: same update rule and
+    # state_dict layout, the tensor list in the kernel arguments (capturable); --torch-adam keeps torch's fused multi-tensor kernels for A/B
+    from patchaugnet_amd.optim import Adam as HipAdam
+    make_opt = (lambda: torch.optim.Adam(model.parameters(), lr=1e-5, capturable=graphed, fused=graphed)) if a.torch_adam else \
+               (lambda: HipAdam(model.parameters(), lr=1e-5))
+    opt = make_opt()
     q, pos, neg, oth = (t.cuda() for t in (q, pos, neg, oth))           # inputs resident in HBM before the clock starts
     if graphed:     # forward + losses + backward + Adam captured once (train.GraphedTrainer), one replay per step
         from patchaugnet_amd.train import GraphedTrainer
@@ -393,7 +399,7 @@ def train_bench(a, emit=True, pmc=None):
         except Exception as ex:
             print(f"bench.py: hipGraph capture of the training step failed ({ex!r}); eager launches instead", file=sys.stderr)
             graphed = False
-            opt = torch.optim.Adam(model.parameters(), lr=1e-5)
+            opt = make_opt()
     if not graphed:
         step = lambda: training_step(model, opt, q, pos, neg, oth, nn_dict=nn_dict, num_points=n)
     for _ in range(max(a.warmup, 2)):
@@ -432,7 +438,7 @@ def train_bench(a, emit=True, pmc=None):
                                "through the decoder, patch Chamfer + quadruplet loss, backward, Adam (BASELINE.json configs[3]), 1xMI355X",
                    "clouds_per_step": clouds, "points": n, "path": "HIP point ops + HIP training GEMMs (csrc/train_gemm_cm.hip, train_gemm.hip, fp_fold_train.hip), autograd graph in torch",
                    "weights": "key-seeded random init", "parallelism": "dp1",
-                   "launch": ("one hipGraph replay per step (forward + losses + backward + Adam)" + ("" if a.no_prefetch else
+                   "launch": ("one hipGraph replay per step (forward + losses + backward + Adam" + (" (torch fused)" if a.torch_adam else " (csrc/adam.hip)") + ")" + ("" if a.no_prefetch else
                               "; sampling / neighbour search / 3-NN of the next batch replayed on a side stream under it")) if graphed else "python launches"},
         "losses_last_step": losses,
         "losses_note": "place_recognition = 0.0 means the hinge of the quadruplet loss is inactive on this synthetic tuple (random-init descriptors of "

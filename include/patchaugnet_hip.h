@@ -116,6 +116,14 @@ int pa_fp_fold_forward(int b, int O, int m, int n, int C1, const float *Z, const
 int pa_fp_fold_backward(int b, int O, int n, int m, int C1, const float *g, const float *yraw, const float *p, int relu, const float *S,
                         const int *lists, float *G, float *dWb, int ldw, pa_stream_t stream);
 
+/* EdgeConv-style grouping of a set-abstraction level as one op each way (csrc/group_edge.hip; pointops.py:559-570 under autograd):
+ *   forward   out (b,3+c,m,k): channels 0..2 = grouped_xyz (b,3,m,k) as given, channel 3 + i = features[b,i,idx[b,j,s]] - features[b,i,center_idx[b,j]];
+ *   backward  dfeatures (b,c,n) WRITTEN = scatter of grad_out[:, 3:] over idx minus, at every centre, the sum over its k neighbours. */
+int pa_group_edge_forward(int b, int c, int n, int m, int k, const float *features, const int *center_idx, const int *idx, const float *grouped_xyz,
+                          float *out, pa_stream_t stream);
+int pa_group_edge_backward(int b, int c, int n, int m, int k, const float *grad_out, const int *center_idx, const int *idx, float *dfeatures,
+                           pa_stream_t stream);
+
 /* K9 with the FP module's inverse-distance weights fused in (patch_aug_net.py:350-353): weight (b,n,3), idx (b,n,3). */
 int pa_three_nn_weights(int b, int n, int m, const float *unknown, const float *known, float *weight, int *idx, pa_stream_t stream);
 
@@ -140,6 +148,12 @@ int pa_labelstat_idx(int b, int n, int m, int nsample, int nclass, const int *la
 int pa_chamfer_forward(int B, int n, int m, const float *xyz1, const float *xyz2, float *dist1, float *dist2, int *idx1, int *idx2, pa_stream_t stream);
 int pa_chamfer_backward(int B, int n, int m, const float *xyz1, const float *xyz2, const int *idx1, const int *idx2,
                         const float *grad_dist1, const float *grad_dist2, float *grad_xyz1, float *grad_xyz2, pa_stream_t stream);
+/* ChamferDistanceL1 (libs/chamfer_dist/__init__.py:79-84) in one call each way: forward also writes loss[0] =
+ * (mean(sqrt(dist1)) + mean(sqrt(dist2))) / 2; backward takes the distances and the scalar gout[0] (device) instead of per-point gradients. */
+int pa_chamfer_l1_forward(int B, int n, int m, const float *xyz1, const float *xyz2, float *dist1, float *dist2, int *idx1, int *idx2, float *loss,
+                          pa_stream_t stream);
+int pa_chamfer_l1_backward(int B, int n, int m, const float *xyz1, const float *xyz2, const int *idx1, const int *idx2, const float *dist1,
+                           const float *dist2, const float *gout, float *grad_xyz1, float *grad_xyz2, pa_stream_t stream);
 
 /* ---- Earth mover's distance, auction algorithm  (libs/emd_module/emd.cpp:6-30, emd_cuda.cu:228-317) ------------
  * forward: xyz1, xyz2 (b,n,3) with n == m, n % 1024 == 0, b <= 512 (the reference's rules, emd_cuda.cu:236-249; other
@@ -383,6 +397,18 @@ int pa_tgemm_nn(int batch, int M, int N, int K, const float *A, long sAb, int ld
 int pa_tgemm_kk(int batch, int M, int N, long K, const float *A, long sAb, int lda, int amode, const float *aaux, const float *ap,
                 const float *B, long sBb, int ldb, int bmode, const float *bp,
                 float *C, long sCb, int ldc, int per_batch, int per_batch_stats, pa_stream_t stream);
+/* pa_tgemm_kk (shared C) through `reps` zero-filled replicas of the output (scratch: reps x M x N floats) and a second launch that adds them to
+ * C: for small outputs contracted over very long k, where the split-K partial tiles otherwise queue their atomics on a few hundred addresses. */
+int pa_tgemm_kk_rep(int batch, int M, int N, long K, const float *A, long sAb, int lda, int amode, const float *aaux, const float *ap,
+                    const float *B, long sBb, int ldb, int bmode, const float *bp, float *C, int ldc, float *scratch, int reps, pa_stream_t stream);
+
+/* Adam over a list of fp32 tensors (csrc/adam.hip; torch.optim.Adam's arithmetic: amsgrad / maximize off, weight_decay as L2): pa_adam_tick
+ * advances the device step counter (step[0] += 1), pa_adam_step updates ntensors contiguous tensors -- HOST arrays of device pointers
+ * (parameter, gradient, exp_avg, exp_avg_sq) and element counts -- in ceil(ntensors / 84) launches; nothing host-side enters the arithmetic,
+ * so a captured hipGraph replays it. */
+int pa_adam_tick(float *step, pa_stream_t stream);
+int pa_adam_step(int ntensors, float *const *p, const float *const *g, float *const *m, float *const *v, const long *numel, const float *step,
+                 float lr, float beta1, float beta2, float eps, float weight_decay, pa_stream_t stream);
 /* BatchNorm (training): statistics -> rows 0..3 of p, running statistics updated in place (momentum, unbiased variance) when given;
  * *num_batches_tracked += groups when given (torch.nn.BatchNorm's int64 counter, one forward pass per statistics group). */
 int pa_bn_finalize(int nch, int groups, double count, const double *stats, const float *gamma, const float *beta, float eps, float momentum,

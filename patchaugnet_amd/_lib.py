@@ -28,6 +28,8 @@ _SIGS = {
     "pa_grouping_forward": "iiiiippp",
     "pa_grouping_backward": "iiiiippp",
     "pa_grouping_int_forward": "iiiiippp",
+    "pa_group_edge_forward": "iiiiippppp",
+    "pa_group_edge_backward": "iiiiipppp",
     "pa_nearestneighbor": "iiipppp",
     "pa_interpolation_forward": "iiiipppp",
     "pa_interpolation_backward": "iiiipppp",
@@ -42,6 +44,8 @@ _SIGS = {
     "pa_labelstat_idx": "iiiiippp",
     "pa_chamfer_forward": "iiipppppp",
     "pa_chamfer_backward": "iiipppppppp",
+    "pa_chamfer_l1_forward": "iiippppppp",
+    "pa_chamfer_l1_backward": "iiippppppppp",
     "pa_knn_generic": "pipiiipp",
     "pa_knn_candidates": "pipipiip",
     "pa_emd_forward": "iiippppppppppfi",
@@ -76,6 +80,9 @@ _SIGS = {
     "pa_vlad_maxpool": "iiipip",
     "pa_tgemm_nn": "iiiipliipliipppliippipi",
     "pa_tgemm_kk": "iiilpliipppliippliii",
+    "pa_tgemm_kk_rep": "iiilpliipppliippipi",
+    "pa_adam_tick": "p",
+    "pa_adam_step": "ippppppfffff",
     "pa_bn_finalize": "iidpppffpppp",
     "pa_bn_bwd_reduce": "iilpppipi",
     "pa_tgemm_nn_bnred": "iiiipiipliippplippip",

@@ -153,8 +153,8 @@ class SAModule(SAModuleMSG):
         else:
             center_idx, new_xyz, idx, coords, grouped = geo
         if grouped is None:
-            center_features = pointops.gathering(features, center_idx)
-            grouped, sample_idx = self.groupers[0](xyz, new_xyz, features, center_features, idx=idx, coords=coords)
+            # centres by index: gathering + grouping + subtract + cat as one op each way on the device (pointops.EdgeGroup)
+            grouped, sample_idx = self.groupers[0](xyz, new_xyz, features, None, idx=idx, coords=coords, center_idx=center_idx)
         else:                       # first level, everything about its input was coordinate-only (geometry(..., coordinate_features=...))
             sample_idx = idx
         y = self.mlps[0].forward_maxpool(grouped)

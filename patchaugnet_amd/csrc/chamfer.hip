@@ -73,11 +73,14 @@ __global__ __launch_bounds__(256) void chamfer_tiled_kernel(int n, int m, const 
     }
 }
 
-// one lane per (batch, point of xyz1): grad_xyz1[b,j] += g*(p-q);  grad_xyz2[b,idx] -= g*(p-q)   (chamfer.cu:173-201)
+// one lane per (batch, point of xyz1): grad_xyz1[b,j] += g*(p-q);  grad_xyz2[b,idx] -= g*(p-q)   (chamfer.cu:173-201).
+// L1: grad_dist1 is the distance itself and the incoming gradient is the L1 loss's, one scalar: d loss / d dist = gout * coef / sqrt(dist)
+// with coef = 1 / (4 * count) -- the sqrt, the mean and the halving of ChamferDistanceL1 (__init__.py:79-84) differentiated in place.
+template <bool L1>
 __global__ __launch_bounds__(256) void chamfer_grad_kernel(long total, int n, int m, const float *__restrict__ xyz1,
                                                              const float *__restrict__ xyz2, const float *__restrict__ grad_dist1,
                                                              const int *__restrict__ idx1, float *__restrict__ grad_xyz1,
-                                                             float *__restrict__ grad_xyz2)
+                                                             float *__restrict__ grad_xyz2, const float *__restrict__ gout, float coef)
 {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(256) void chamfer_grad_kernel(long total, int n, in
     const float x1 = xyz1[t * 3 + 0], y1 = xyz1[t * 3 + 1], z1 = xyz1[t * 3 + 2];
     const int j2 = idx1[t];
     const float *q = xyz2 + (i * m + j2) * 3;
-    const float g = grad_dist1[t] * 2;
+    const float g = (L1 ? gout[0] * coef / sqrtf(grad_dist1[t]) : grad_dist1[t]) * 2;
     atomicAdd(grad_xyz1 + t * 3 + 0, g * (x1 - q[0]));
     atomicAdd(grad_xyz1 + t * 3 + 1, g * (y1 - q[1]));
     atomicAdd(grad_xyz1 + t * 3 + 2, g * (z1 - q[2]));
@@ -93,6 +96,34 @@ __global__ __launch_bounds__(256) void chamfer_grad_kernel(long total, int n, in
     atomicAdd(o + 0, -(g * (x1 - q[0])));
     atomicAdd(o + 1, -(g * (y1 - q[1])));
     atomicAdd(o + 2, -(g * (z1 - q[2])));
+}
+
+// (mean(sqrt(dist1)) + mean(sqrt(dist2))) / 2 in one workgroup; fp64 partial sums so the value does not depend on the split
+__global__ __launch_bounds__(1024) void chamfer_l1_value_kernel(long t1, long t2, const float *__restrict__ dist1, const float *__restrict__ dist2,
+                                                                 float *__restrict__ loss)
+{
+    __shared__ double part[2][16];
+    const int tid = threadIdx.x;
+    double a = 0.0, b = 0.0;
+    for (long t = tid; t < t1; t += 1024) a += (double)sqrtf(dist1[t]);
+    for (long t = tid; t < t2; t += 1024) b += (double)sqrtf(dist2[t]);
+    for (int o = 32; o; o >>= 1) {
+        a += __shfl_xor(a, o);
+        b += __shfl_xor(b, o);
+    }
+    if ((tid & 63) == 0) {
+        part[0][tid >> 6] = a;
+        part[1][tid >> 6] = b;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double sa = 0.0, sb = 0.0;
+        for (int w = 0; w < 16; ++w) {
+            sa += part[0][w];
+            sb += part[1][w];
+        }
+        loss[0] = (float)((sa / (double)t1 + sb / (double)t2) * 0.5);
+    }
 }
 
 int one_direction(int B, int n, int m, const float *a, const float *bq, float *dist, int *idx, hipStream_t st)
@@ -132,8 +163,42 @@ PA_API int pa_chamfer_backward(int B, int n, int m, const float *xyz1, const flo
     (void)hipMemsetAsync(grad_xyz1, 0, sizeof(float) * (size_t)B * n * 3, st);  // chamfer.cu:212-213 (zeros_like)
     (void)hipMemsetAsync(grad_xyz2, 0, sizeof(float) * (size_t)B * m * 3, st);
     const long t1 = (long)B * n, t2 = (long)B * m;
-    hipLaunchKernelGGL(chamfer_grad_kernel, dim3(pa_div_up(t1, 256)), dim3(256), 0, st, t1, n, m, xyz1, xyz2, grad_dist1, idx1, grad_xyz1, grad_xyz2);
-    hipLaunchKernelGGL(chamfer_grad_kernel, dim3(pa_div_up(t2, 256)), dim3(256), 0, st, t2, m, n, xyz2, xyz1, grad_dist2, idx2, grad_xyz2, grad_xyz1);
+    hipLaunchKernelGGL(chamfer_grad_kernel<false>, dim3(pa_div_up(t1, 256)), dim3(256), 0, st, t1, n, m, xyz1, xyz2, grad_dist1, idx1, grad_xyz1, grad_xyz2,
+                       (const float *)nullptr, 0.f);
+    hipLaunchKernelGGL(chamfer_grad_kernel<false>, dim3(pa_div_up(t2, 256)), dim3(256), 0, st, t2, m, n, xyz2, xyz1, grad_dist2, idx2, grad_xyz2, grad_xyz1,
+                       (const float *)nullptr, 0.f);
     PA_CHECK_LAUNCH("pa_chamfer_backward");
+    return PA_OK;
+}
+
+// ChamferDistanceL1 (libs/chamfer_dist/__init__.py:79-84) as one call each way: pa_chamfer_forward plus the value
+// (mean(sqrt(dist1)) + mean(sqrt(dist2))) / 2 into loss[0] ...
+PA_API int pa_chamfer_l1_forward(int B, int n, int m, const float *xyz1, const float *xyz2, float *dist1, float *dist2, int *idx1, int *idx2,
+                                 float *loss, pa_stream_t stream)
+{
+    PA_REQUIRE(loss, "pa_chamfer_l1_forward: null pointer");
+    const int r = pa_chamfer_forward(B, n, m, xyz1, xyz2, dist1, dist2, idx1, idx2, stream);
+    if (r) return r;
+    hipLaunchKernelGGL(chamfer_l1_value_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (long)B * n, (long)B * m, dist1, dist2, loss);
+    PA_CHECK_LAUNCH("pa_chamfer_l1_forward");
+    return PA_OK;
+}
+
+// ... and its gradient from the scalar gout[0] (device memory): the chain through the halving, the means and the square roots
+// is applied per point inside the scatter kernels (a zero distance gives the same inf * 0 the unfused chain gives).
+PA_API int pa_chamfer_l1_backward(int B, int n, int m, const float *xyz1, const float *xyz2, const int *idx1, const int *idx2, const float *dist1,
+                                  const float *dist2, const float *gout, float *grad_xyz1, float *grad_xyz2, pa_stream_t stream)
+{
+    PA_REQUIRE(B > 0 && n > 0 && m > 0, "pa_chamfer_l1_backward: B=%d n=%d m=%d must be positive", B, n, m);
+    PA_REQUIRE(xyz1 && xyz2 && idx1 && idx2 && dist1 && dist2 && gout && grad_xyz1 && grad_xyz2, "pa_chamfer_l1_backward: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipMemsetAsync(grad_xyz1, 0, sizeof(float) * (size_t)B * n * 3, st);
+    (void)hipMemsetAsync(grad_xyz2, 0, sizeof(float) * (size_t)B * m * 3, st);
+    const long t1 = (long)B * n, t2 = (long)B * m;
+    hipLaunchKernelGGL(chamfer_grad_kernel<true>, dim3(pa_div_up(t1, 256)), dim3(256), 0, st, t1, n, m, xyz1, xyz2, dist1, idx1, grad_xyz1, grad_xyz2, gout,
+                       0.25f / (float)t1);
+    hipLaunchKernelGGL(chamfer_grad_kernel<true>, dim3(pa_div_up(t2, 256)), dim3(256), 0, st, t2, m, n, xyz2, xyz1, dist2, idx2, grad_xyz2, grad_xyz1, gout,
+                       0.25f / (float)t2);
+    PA_CHECK_LAUNCH("pa_chamfer_l1_backward");
     return PA_OK;
 }

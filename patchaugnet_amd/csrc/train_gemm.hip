@@ -459,6 +459,7 @@ struct KKArgs {
     int vecA, vecB;
     long sAPb, sBPb;                     // per-batch strides of ta.p / tb.p (floats); 0 = shared
     int xcd_order;
+    int reps; long srep;                 // > 0: C is `reps` zero-filled replicas srep floats apart; workgroup z adds into replica z % reps (pa_tgemm_kk_rep)
 };
 
 constexpr int KK_BM = 64, KK_BN = 64, KK_BK = 32, KK_S = KK_BK + 2;   // row stride 34: (2m + k) mod 32 distinct for m < 16, k < 2
@@ -599,7 +600,7 @@ __global__ __launch_bounds__(256) void tgemm_kk_kernel(KKArgs a)
         if (kt + 1 < nk) stash(cur ^ 1);
         __syncthreads();
     }
-    float *C = a.C + (a.per_batch ? (size_t)b * a.sCb : (size_t)0);
+    float *C = a.C + (a.per_batch ? (size_t)b * a.sCb : (size_t)0) + (a.reps > 0 ? (size_t)(tiz % (unsigned)a.reps) * a.srep : (size_t)0);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -943,9 +944,9 @@ PA_API int pa_tgemm_nn(int batch, int M, int N, int K, const float *A, long sAb,
 
 // C (M x N) += sum_b sum_k fA(A_b)(m,k) fB(B_b)(n,k)  (per_batch = 0: C must be zero-filled or hold the value to add to), or
 // C_b += ... per batch (per_batch = 1).  amode 0 / 2 / 3 (aaux, ap: 7*M floats), bmode 0 / 1 (bp: 2*N floats).
-PA_API int pa_tgemm_kk(int batch, int M, int N, long K, const float *A, long sAb, int lda, int amode, const float *aaux, const float *ap,
-                       const float *B, long sBb, int ldb, int bmode, const float *bp,
-                       float *C, long sCb, int ldc, int per_batch, int per_batch_stats, pa_stream_t stream)
+static int tgemm_kk_impl(int batch, int M, int N, long K, const float *A, long sAb, int lda, int amode, const float *aaux, const float *ap,
+                         const float *B, long sBb, int ldb, int bmode, const float *bp,
+                         float *C, long sCb, int ldc, int per_batch, int per_batch_stats, pa_stream_t stream, int reps, long srep)
 {
     PA_REQUIRE(batch > 0 && M > 0 && N > 0 && K > 0 && K < 2147483647L && A && B && C, "pa_tgemm_kk: bad arguments");
     PA_REQUIRE((amode == 0 || ((amode == 2 || amode == 3) && aaux && ap)) && (bmode == 0 || (bmode == 1 && bp)), "pa_tgemm_kk: transform arguments");
@@ -954,7 +955,7 @@ PA_API int pa_tgemm_kk(int batch, int M, int N, long K, const float *A, long sAb
     a.M = M; a.N = N; a.K = (int)K;
     a.A = A; a.sAb = sAb; a.lda = lda; a.ta = make_top(amode, aaux, ap, M);
     a.B = B; a.sBb = sBb; a.ldb = ldb; a.tb = make_top(bmode, nullptr, bp, N);
-    a.C = C; a.sCb = sCb; a.ldc = ldc; a.per_batch = per_batch;
+    a.C = C; a.sCb = sCb; a.ldc = ldc; a.per_batch = per_batch; a.reps = reps; a.srep = srep;
     a.sAPb = per_batch_stats ? 7L * M : 0;
     a.sBPb = per_batch_stats ? 7L * N : 0;
     a.vecA = aligned16(A) && lda % 4 == 0 && sAb % 4 == 0 && (amode == 0 || aligned16(aaux)) && K % 4 == 0 && K >= 4;
@@ -971,8 +972,9 @@ PA_API int pa_tgemm_kk(int batch, int M, int N, long K, const float *A, long sAb
     // at splits = sqrt(c (K / 32) / contributors per split); c = 30 from a sweep of the three first-level shapes (tools/kk_splits.py:
     // 32 splits: 186 / 85 / 92 us -> 100 / 69 / 72 us)
     {
-        const double per_split = per_batch ? 1.0 : (double)batch;
-        const long cap = (long)(sqrt(30.0 * ((double)K / KK_BK) / per_split) + 0.999);
+        // (replicated output, pa_tgemm_kk_rep: the contributors of an address are divided by the number of replicas)
+        const double per_split = per_batch ? 1.0 : (reps > 0 ? (double)batch / reps : (double)batch);
+        const long cap = (long)(sqrt(30.0 * ((double)K / KK_BK) / (per_split < 1.0 / 64 ? 1.0 / 64 : per_split)) + 0.999);
         if (splits > cap) splits = cap < 1 ? 1 : cap;
     }
     {
@@ -994,6 +996,41 @@ PA_API int pa_tgemm_kk(int batch, int M, int N, long K, const float *A, long sAb
     else { if (bmode == 0) PA_KK(3, 0); else PA_KK(3, 1); }
 #undef PA_KK
     PA_CHECK_LAUNCH("pa_tgemm_kk");
+    return PA_OK;
+}
+
+PA_API int pa_tgemm_kk(int batch, int M, int N, long K, const float *A, long sAb, int lda, int amode, const float *aaux, const float *ap,
+                       const float *B, long sBb, int ldb, int bmode, const float *bp,
+                       float *C, long sCb, int ldc, int per_batch, int per_batch_stats, pa_stream_t stream)
+{
+    return tgemm_kk_impl(batch, M, N, K, A, sAb, lda, amode, aaux, ap, B, sBb, ldb, bmode, bp, C, sCb, ldc, per_batch, per_batch_stats, stream, 0, 0);
+}
+
+namespace {
+// C[m * ldc + n] += sum_r scratch[r][m * N + n]: the replicas of pa_tgemm_kk_rep added up in replica order (deterministic given the replicas)
+__global__ __launch_bounds__(256) void kk_reduce_kernel(int M, int N, int reps, const float *__restrict__ scratch, float *__restrict__ C, int ldc)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * N) return;
+    float s = 0.f;
+    for (int r = 0; r < reps; ++r) s += scratch[(size_t)r * M * N + i];
+    C[(size_t)(i / N) * ldc + i % N] += s;
+}
+}  // namespace
+
+// pa_tgemm_kk (shared C, per_batch = 0) for SMALL outputs contracted over very long k: the (32 x 6) ... (64 x 64) weight gradients of the first
+// set-abstraction level over 18 x 20 480 grouped points.  There a few hundred workgroups queue their fp32 atomics on a few hundred addresses
+// (the splits were capped for it: 41-85 us for 100-140 MB of operands).  Here workgroup z adds its partial tile into replica z % reps of a
+// zero-filled scratch (reps x M x N floats, caller-provided), and a second small launch adds the replicas to C: more splits, a thirty-second of
+// the contention.
+PA_API int pa_tgemm_kk_rep(int batch, int M, int N, long K, const float *A, long sAb, int lda, int amode, const float *aaux, const float *ap,
+                           const float *B, long sBb, int ldb, int bmode, const float *bp, float *C, int ldc, float *scratch, int reps, pa_stream_t stream)
+{
+    PA_REQUIRE(scratch && reps > 0 && reps <= 256, "pa_tgemm_kk_rep: scratch of 1..256 replicas");
+    const int rc = tgemm_kk_impl(batch, M, N, K, A, sAb, lda, amode, aaux, ap, B, sBb, ldb, bmode, bp, scratch, 0, N, 0, 0, stream, reps, (long)M * N);
+    if (rc != PA_OK) return rc;
+    hipLaunchKernelGGL(kk_reduce_kernel, dim3(pa_div_up((long)M * N, 256)), dim3(256), 0, (hipStream_t)stream, M, N, reps, scratch, C, ldc);
+    PA_CHECK_LAUNCH("pa_tgemm_kk_rep");
     return PA_OK;
 }
 

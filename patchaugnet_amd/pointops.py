@@ -446,10 +446,46 @@ def grouped_coordinates(xyz, new_xyz, idx):
     return o_grouped_xyz, o_grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
 
 
-def _centred_groups(xyz, new_xyz, features, center_features, idx, use_xyz, coords=None):
+class EdgeGroup(Function):
+    """cat([grouped_xyz, grouping(features, idx) - gathering(features, center_idx)[..., None]], 1) as ONE op each way (csrc/group_edge.hip): the
+    EdgeConv grouping of pointops.py:559-570 for levels that carry features.  features (b,c,n) take the gradient; grouped_xyz (b,3,m,k) is
+    coordinate-only (no gradient)."""
+
+    @staticmethod
+    def forward(ctx, features, center_idx, idx, grouped_xyz):
+        check_device(features, center_idx, idx, grouped_xyz)
+        b, c, n = features.shape
+        _, m, k = idx.shape
+        out = _new(features, (b, 3 + c, m, k), torch.float32)
+        with _guard(features):
+            call("pa_group_edge_forward", b, c, n, m, k, ptr(features), ptr(center_idx), ptr(idx), ptr(grouped_xyz), ptr(out))
+        ctx.for_backwards = (center_idx, idx, n)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        center_idx, idx, n = ctx.for_backwards
+        b, c3, m, k = grad_out.shape
+        g = grad_out.contiguous()
+        grad = _new(g, (b, c3 - 3, n), torch.float32)
+        with _guard(g):
+            call("pa_group_edge_backward", b, c3 - 3, n, m, k, ptr(g), ptr(center_idx), ptr(idx), ptr(grad))
+        return grad, None, None, None
+
+
+edge_group = EdgeGroup.apply
+
+
+def _centred_groups(xyz, new_xyz, features, center_features, idx, use_xyz, coords=None, center_idx=None):
     """Shared tail of the QueryAndGroup_Edge* modules (pointops.py:559-570 / :617-630).  coords: grouped_coordinates(xyz, new_xyz, idx) when the
     caller already has it."""
     o_grouped_xyz, grouped_xyz = coords if coords is not None else grouped_coordinates(xyz, new_xyz, idx)
+    if (features is not None and center_idx is not None and use_xyz and features.is_cuda and features.dtype == torch.float32 and idx.shape[2] > 1
+            and not grouped_xyz.requires_grad and features.shape[2] <= 16384):
+        # centres given by index: gather, group, subtract and concatenate in one launch each way
+        return edge_group(features.contiguous(), center_idx.contiguous(), idx, grouped_xyz.contiguous()), o_grouped_xyz, grouped_xyz
+    if features is not None and center_features is None:
+        center_features = gathering(features, center_idx)
     if features is not None:
         grouped = grouping(features, idx)
         if grouped.size(3) > 1:
@@ -505,11 +541,13 @@ class QueryAndGroup_Edge(nn.Module):
             idx = idx.index_select(2, perm).contiguous()
         return idx
 
-    def forward(self, xyz, new_xyz=None, features=None, center_features=None, idx=None, coords=None):
+    def forward(self, xyz, new_xyz=None, features=None, center_features=None, idx=None, coords=None, center_idx=None):
+        """center_idx (b, m): the centres as indices into the cloud (= what center_features was gathered with); given INSTEAD of center_features
+        the level's grouping runs as one fused op each way (EdgeGroup)."""
         new_xyz = xyz if new_xyz is None else new_xyz
         if idx is None:
             idx = self.neighbours(xyz, new_xyz)
-        new_features, o_grouped_xyz, _ = _centred_groups(xyz, new_xyz, features, center_features, idx, self.use_xyz, coords)
+        new_features, o_grouped_xyz, _ = _centred_groups(xyz, new_xyz, features, center_features, idx, self.use_xyz, coords, center_idx=center_idx)
         res = new_features
         if self.ret_gxyz:
             res = res, o_grouped_xyz

@@ -25,6 +25,7 @@ from ._arena import zero_arena, zeros              # noqa: F401  (zero_arena is 
 from . import _lib as _lib_mod
 from ._lib import call, check_device, ptr
 
+KK_REPS = 32             # output replicas of pa_tgemm_kk_rep (small weight gradients over very long contractions)
 STAT_SLOTS = 32          # PA_BN_STAT_SLOTS (include/patchaugnet_hip.h): replicas of a layer's statistics block
 
 
@@ -55,6 +56,13 @@ def tgemm_nn(batch, M, N, K, A, sAb, lda, a_kcontig, B, sBb, ldb, C, sCb, ldc, *
 def tgemm_kk(batch, M, N, K, A, sAb, lda, B, sBb, ldb, C, sCb, ldc, *, amode=0, aaux=None, ap=None, bmode=0, bp=None, per_batch=0,
              per_batch_stats=0):
     """C (M x N) += sum_b sum_k fA(A_b)(m,k) fB(B_b)(n,k) -- include/patchaugnet_hip.h: pa_tgemm_kk."""
+    if not per_batch and not per_batch_stats and M * N <= 512 and batch * K >= (1 << 18):
+        # a small output over a very long contraction (first set-abstraction level: 32 x 6 over 18 x 20 480 points: 85 -> 54 us; from 32 x 32 outputs on the launch is bound by its operand traffic and the replicas gain nothing): partial tiles into
+        # zero-filled replicas (out of the step's zero arena: no fill launch), then one small reduce -- instead of queueing atomics on M N addresses
+        scratch = zeros((KK_REPS * M * N,), torch.float32, C.device)
+        call("pa_tgemm_kk_rep", batch, M, N, K, ptr(A), sAb, lda, amode, ptr(aaux), ptr(ap), ptr(B), sBb, ldb, bmode, ptr(bp), ptr(C), ldc,
+             ptr(scratch), KK_REPS)
+        return
     call("pa_tgemm_kk", batch, M, N, K, ptr(A), sAb, lda, amode, ptr(aaux), ptr(ap), ptr(B), sBb, ldb, bmode, ptr(bp), ptr(C), sCb, ldc,
          int(per_batch), int(per_batch_stats))
 

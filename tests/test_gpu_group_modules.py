@@ -189,3 +189,27 @@ def test_multi_scale_grouping_level_against_the_oracle(attention):
     with torch.no_grad():
         a, bb_ = one.eval().cuda()(xyz.cuda(), feats.cuda()), single.eval().cuda()(xyz.cuda(), feats.cuda())
     assert all(torch.equal(u, v) for u, v in zip(a, bb_))
+
+
+@pytest.mark.parametrize("b,c,n,m,k", [(3, 64, 1024, 128, 20), (2, 256, 128, 16, 20), (1, 5, 37, 7, 3), (2, 16, 5000, 33, 16)])
+def test_edge_group_fused_op_equals_the_unfused_statement(b, c, n, m, k):
+    """pointops.EdgeGroup (csrc/group_edge.hip: gathering + grouping + centre subtraction + cat with the grouped coordinates as one launch each
+    way) against the statement it replaces (pointops.py:559-570 spelled with pa_gathering / pa_grouping and torch subtract / cat under autograd):
+    the forward bit for bit (a gather and one subtraction), the feature gradient to fp32 summation order."""
+    from patchaugnet_amd import pointops as P
+    g = torch.Generator().manual_seed(b * 1000 + n)
+    feats = torch.randn(b, c, n, generator=g).cuda()
+    cidx = torch.stack([torch.randperm(n, generator=g)[:m] for _ in range(b)]).int().cuda()
+    idx = torch.randint(0, n, (b, m, k), generator=g).int().cuda()
+    idx[:, :, 0] = cidx                                         # a centre is its own first neighbour, as in the model
+    gxyz = torch.randn(b, 3, m, k, generator=g).cuda()
+    go = torch.randn(b, 3 + c, m, k, generator=g).cuda()
+    f1 = feats.clone().requires_grad_(True)
+    out1 = P.edge_group(f1, cidx, idx, gxyz)
+    out1.backward(go)
+    f0 = feats.clone().requires_grad_(True)
+    out0 = torch.cat([gxyz, P.grouping(f0, idx) - P.gathering(f0, cidx).unsqueeze(-1)], dim=1)
+    out0.backward(go)
+    assert torch.equal(out1, out0)
+    scale = f0.grad.abs().max().item()
+    assert (f1.grad - f0.grad).abs().max().item() <= 1e-5 * max(scale, 1.0)

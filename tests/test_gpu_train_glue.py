@@ -225,3 +225,44 @@ def test_interpolation_backward_with_prebuilt_lists_is_identical():
     cot_wide = torch.cat([cot, torch.randn(b, 5, n, generator=g).cuda()], dim=1)
     (wide * cot_wide).sum().backward()
     assert torch.equal(f.grad, grads[1])
+
+
+@pytest.mark.parametrize("wd", [0.0, 1e-2])
+def test_hip_adam_matches_torch_adam(wd):
+    """patchaugnet_amd.optim.Adam (csrc/adam.hip: the tensor list in the kernel arguments, a device step counter) against torch.optim.Adam on the
+    same parameters and gradient sequence: ragged sizes (1 .. 1 000 003 elements, more than one launch's 84 tensors), five steps, and the
+    state_dict moving both ways."""
+    from patchaugnet_amd.optim import Adam
+    g = torch.Generator().manual_seed(3)
+    sizes = [1, 3, 5, 17, 255, 256, 257, 4095, 4096, 4097, 60 * 1024, 1000003] + [37 + 11 * i for i in range(90)]
+    base = [torch.randn(n, generator=g) for n in sizes]
+    pa = [torch.nn.Parameter(t.clone().cuda()) for t in base]
+    pb = [torch.nn.Parameter(t.clone().cuda()) for t in base]
+    oa = Adam(pa, lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=wd)
+    ob = torch.optim.Adam(pb, lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=wd)
+    for step in range(5):
+        for x, y in zip(pa, pb):
+            gr = torch.randn(x.shape, generator=g).cuda() * (0.1 + step)
+            x.grad, y.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step()
+    torch.cuda.synchronize()
+    for x, y in zip(pa, pb):
+        assert torch.allclose(x, y, rtol=2e-5, atol=2e-6), (x.numel(), (x - y).abs().max().item())
+    sa = oa.state_dict()
+    assert float(sa["state"][0]["step"]) == 5.0 and set(sa["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    assert torch.allclose(sa["state"][5]["exp_avg"], ob.state_dict()["state"][5]["exp_avg"], rtol=2e-5, atol=1e-7)
+    # a torch checkpoint continues on the HIP optimizer (and the counter is adopted)
+    oc = Adam([torch.nn.Parameter(t.detach().clone()) for t in pb], lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=wd)
+    import copy
+    oc.load_state_dict(copy.deepcopy(ob.state_dict()))      # (load_state_dict keeps same-device tensors by reference: without the copy both optimizers would update ONE exp_avg)
+    pc = oc.param_groups[0]["params"]
+    for x, y, z in zip(pa, pb, pc):
+        gr = torch.randn(x.shape, generator=g).cuda()
+        y.grad, z.grad = gr.clone(), gr.clone()
+    ob.step(); oc.step()
+    for y, z in zip(pb, pc):
+        assert torch.allclose(y, z, rtol=2e-5, atol=2e-6)
+    with pytest.raises(RuntimeError):
+        bad = torch.nn.Parameter(torch.zeros(4))
+        bad.grad = torch.zeros(4)
+        Adam([bad]).step()

@@ -105,7 +105,8 @@ def test_tgemm_nn_128_row_tile_variant_in_a_subprocess():
     assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
 
 
-@pytest.mark.parametrize("M,N,K,batch", [(70, 37, 300, 3), (64, 64, 128, 1), (200, 259, 1001, 2), (18, 256, 21504, 1), (5, 3, 7, 2)])
+@pytest.mark.parametrize("M,N,K,batch", [(70, 37, 300, 3), (64, 64, 128, 1), (200, 259, 1001, 2), (18, 256, 21504, 1), (5, 3, 7, 2),
+                                        (32, 6, 20480, 18), (64, 64, 90001, 3)])      # small outputs over long contractions: the replicated path (pa_tgemm_kk_rep)
 @pytest.mark.parametrize("amode", [0, 2, 3])
 @pytest.mark.parametrize("bmode", [0, 1])
 def test_tgemm_kk(M, N, K, batch, amode, bmode):

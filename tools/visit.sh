@@ -1,4 +1,6 @@
 cd /root/repo; export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_train_ops.py -m gpu -q -x -k "tgemm_kk" 2>&1 | tail -3
-timeout 300 python tools/tgemm_kk_time.py 2>&1 | grep -v amdgpu.ids
-for sp in 4 8 16; do echo "splits=$sp"; PA_KK128_SPLITS=$sp timeout 300 python tools/tgemm_kk_time.py 2>&1 | grep -E "fp0|fp1 dW"; done
+timeout 900 python -m pytest tests/test_gpu_group_modules.py tests/test_gpu_models.py tests/test_gpu_train_full.py -m gpu -q 2>&1 | tail -3
+timeout 1500 python -m pytest tests/test_gpu_train_ops.py tests/test_gpu_train_glue.py tests/test_gpu_extract.py -m gpu -q 2>&1 | tail -3
+for i in 1 2; do
+timeout 300 python bench.py --config train --steps 30 --warmup 5 --no-pmc 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('step ms', d['ms_per_step'], d['losses_last_step'])"
+done
