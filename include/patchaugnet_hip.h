@@ -149,9 +149,9 @@ int pa_chamfer_forward(int B, int n, int m, const float *xyz1, const float *xyz2
 int pa_chamfer_backward(int B, int n, int m, const float *xyz1, const float *xyz2, const int *idx1, const int *idx2,
                         const float *grad_dist1, const float *grad_dist2, float *grad_xyz1, float *grad_xyz2, pa_stream_t stream);
 /* ChamferDistanceL1 (libs/chamfer_dist/__init__.py:79-84) in one call each way: forward also writes loss[0] =
- * (mean(sqrt(dist1)) + mean(sqrt(dist2))) / 2; backward takes the distances and the scalar gout[0] (device) instead of per-point gradients. */
+ * (mean(sqrt(dist1)) + mean(sqrt(dist2))) / 2 (partial: scratch of B * (ceil(n/256) + ceil(m/256)) doubles); backward takes the distances and the scalar gout[0] (device) instead of per-point gradients. */
 int pa_chamfer_l1_forward(int B, int n, int m, const float *xyz1, const float *xyz2, float *dist1, float *dist2, int *idx1, int *idx2, float *loss,
-                          pa_stream_t stream);
+                          double *partial, pa_stream_t stream);
 int pa_chamfer_l1_backward(int B, int n, int m, const float *xyz1, const float *xyz2, const int *idx1, const int *idx2, const float *dist1,
                            const float *dist2, const float *gout, float *grad_xyz1, float *grad_xyz2, pa_stream_t stream);
 

@@ -44,7 +44,7 @@ _SIGS = {
     "pa_labelstat_idx": "iiiiippp",
     "pa_chamfer_forward": "iiipppppp",
     "pa_chamfer_backward": "iiipppppppp",
-    "pa_chamfer_l1_forward": "iiippppppp",
+    "pa_chamfer_l1_forward": "iiipppppppp",
     "pa_chamfer_l1_backward": "iiippppppppp",
     "pa_knn_generic": "pipiiipp",
     "pa_knn_candidates": "pipipiip",

@@ -85,8 +85,9 @@ class ChamferL1Function(torch.autograd.Function):
         dist = torch.empty((B * (n + m),), dtype=torch.float32, device=xyz1.device)
         idx = torch.empty((B * (n + m),), dtype=torch.int32, device=xyz1.device)
         loss = torch.empty((), dtype=torch.float32, device=xyz1.device)
+        partial = torch.empty((B * (-(-n // 256) - (-m // 256)),), dtype=torch.float64, device=xyz1.device)
         with torch.cuda.device(xyz1.device):
-            call("pa_chamfer_l1_forward", B, n, m, ptr(xyz1), ptr(xyz2), ptr(dist), ptr(dist[B * n:]), ptr(idx), ptr(idx[B * n:]), ptr(loss))
+            call("pa_chamfer_l1_forward", B, n, m, ptr(xyz1), ptr(xyz2), ptr(dist), ptr(dist[B * n:]), ptr(idx), ptr(idx[B * n:]), ptr(loss), ptr(partial))
         ctx.save_for_backward(xyz1, xyz2, dist, idx)
         return loss
 

@@ -28,24 +28,37 @@ __device__ __forceinline__ void chamfer_scan(const float *__restrict__ q, int cn
     }
 }
 
+// L1 loss: the workgroup's sum of sqrt(dist) as one double (uniform call: every thread of the 256 arrives)
+__device__ __forceinline__ void sqrt_sum_to_partial(float d, double *__restrict__ out)
+{
+    __shared__ double wsum[4];
+    double a = (double)sqrtf(d);
+    for (int o = 32; o; o >>= 1) a += __shfl_xor(a, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
 // one lane per (batch, point of xyz1); xyz2[batch] (<= 512 points) read from global/L2
 __global__ __launch_bounds__(256) void chamfer_small_kernel(long total, int n, int m, const float *__restrict__ xyz1,
                                                               const float *__restrict__ xyz2, float *__restrict__ dist,
-                                                              int *__restrict__ indexes)
+                                                              int *__restrict__ indexes, double *__restrict__ partial)
 {
     const long g = (long)blockIdx.x * 256 + threadIdx.x;
-    if (g >= total) return;
-    const long i = g / n;
-    const float *p = xyz1 + g * 3;
-    float bd;
-    int bi;
-    chamfer_scan(xyz2 + i * m * 3, m, 0, p[0], p[1], p[2], bd, bi);
-    dist[g] = bd;
-    indexes[g] = bi;
+    float bd = 0.f;
+    if (g < total) {
+        const long i = g / n;
+        const float *p = xyz1 + g * 3;
+        int bi;
+        chamfer_scan(xyz2 + i * m * 3, m, 0, p[0], p[1], p[2], bd, bi);
+        dist[g] = bd;
+        indexes[g] = bi;
+    }
+    if (partial) sqrt_sum_to_partial(g < total ? bd : 0.f, partial + blockIdx.x);
 }
 
 __global__ __launch_bounds__(256) void chamfer_tiled_kernel(int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
-                                                              float *__restrict__ dist, int *__restrict__ indexes)
+                                                              float *__restrict__ dist, int *__restrict__ indexes, double *__restrict__ partial)
 {
     __shared__ float buf[CT_TILE * 3];
     const int i = blockIdx.y, tid = threadIdx.x;
@@ -71,6 +84,7 @@ __global__ __launch_bounds__(256) void chamfer_tiled_kernel(int n, int m, const 
         dist[(size_t)i * n + j] = res_d;
         indexes[(size_t)i * n + j] = res_i;
     }
+    if (partial) sqrt_sum_to_partial(j < n ? res_d : 0.f, partial + (size_t)blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // one lane per (batch, point of xyz1): grad_xyz1[b,j] += g*(p-q);  grad_xyz2[b,idx] -= g*(p-q)   (chamfer.cu:173-201).
@@ -98,15 +112,14 @@ __global__ __launch_bounds__(256) void chamfer_grad_kernel(long total, int n, in
     atomicAdd(o + 2, -(g * (z1 - q[2])));
 }
 
-// (mean(sqrt(dist1)) + mean(sqrt(dist2))) / 2 in one workgroup; fp64 partial sums so the value does not depend on the split
-__global__ __launch_bounds__(1024) void chamfer_l1_value_kernel(long t1, long t2, const float *__restrict__ dist1, const float *__restrict__ dist2,
-                                                                 float *__restrict__ loss)
+// (mean(sqrt(dist1)) + mean(sqrt(dist2))) / 2 from the search kernels' per-workgroup sums (fp64, fixed order: the value does not depend on timing)
+__global__ __launch_bounds__(256) void chamfer_l1_value_kernel(int np1, int np2, double t1, double t2, const double *__restrict__ partial, float *__restrict__ loss)
 {
-    __shared__ double part[2][16];
+    __shared__ double part[2][4];
     const int tid = threadIdx.x;
     double a = 0.0, b = 0.0;
-    for (long t = tid; t < t1; t += 1024) a += (double)sqrtf(dist1[t]);
-    for (long t = tid; t < t2; t += 1024) b += (double)sqrtf(dist2[t]);
+    for (int t = tid; t < np1; t += 256) a += partial[t];
+    for (int t = tid; t < np2; t += 256) b += partial[np1 + t];
     for (int o = 32; o; o >>= 1) {
         a += __shfl_xor(a, o);
         b += __shfl_xor(b, o);
@@ -117,23 +130,22 @@ __global__ __launch_bounds__(1024) void chamfer_l1_value_kernel(long t1, long t2
     }
     __syncthreads();
     if (tid == 0) {
-        double sa = 0.0, sb = 0.0;
-        for (int w = 0; w < 16; ++w) {
-            sa += part[0][w];
-            sb += part[1][w];
-        }
-        loss[0] = (float)((sa / (double)t1 + sb / (double)t2) * 0.5);
+        const double sa = (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]), sb = (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]);
+        loss[0] = (float)((sa / t1 + sb / t2) * 0.5);
     }
 }
 
-int one_direction(int B, int n, int m, const float *a, const float *bq, float *dist, int *idx, hipStream_t st)
+// number of per-workgroup partial sums one direction writes
+int partial_count(int B, int n, int m) { return m <= CT_TILE ? (int)pa_div_up((long)B * n, 256) : B * (int)pa_div_up(n, 256); }
+
+int one_direction(int B, int n, int m, const float *a, const float *bq, float *dist, int *idx, double *partial, hipStream_t st)
 {
     if (m <= CT_TILE) {
         const long total = (long)B * n;
-        hipLaunchKernelGGL(chamfer_small_kernel, dim3(pa_div_up(total, 256)), dim3(256), 0, st, total, n, m, a, bq, dist, idx);
+        hipLaunchKernelGGL(chamfer_small_kernel, dim3(pa_div_up(total, 256)), dim3(256), 0, st, total, n, m, a, bq, dist, idx, partial);
     } else {
         PA_REQUIRE(B <= 65535, "pa_chamfer_forward: B=%d exceeds the grid limit for clouds above 512 points", B);
-        hipLaunchKernelGGL(chamfer_tiled_kernel, dim3(pa_div_up(n, 256), B), dim3(256), 0, st, n, m, a, bq, dist, idx);
+        hipLaunchKernelGGL(chamfer_tiled_kernel, dim3(pa_div_up(n, 256), B), dim3(256), 0, st, n, m, a, bq, dist, idx, partial);
     }
     return PA_OK;
 }
@@ -146,9 +158,9 @@ PA_API int pa_chamfer_forward(int B, int n, int m, const float *xyz1, const floa
     PA_REQUIRE(B > 0 && n > 0 && m > 0, "pa_chamfer_forward: B=%d n=%d m=%d must be positive", B, n, m);
     PA_REQUIRE(xyz1 && xyz2 && dist1 && dist2 && idx1 && idx2, "pa_chamfer_forward: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    int r = one_direction(B, n, m, xyz1, xyz2, dist1, idx1, st);
+    int r = one_direction(B, n, m, xyz1, xyz2, dist1, idx1, nullptr, st);
     if (r) return r;
-    r = one_direction(B, m, n, xyz2, xyz1, dist2, idx2, st);
+    r = one_direction(B, m, n, xyz2, xyz1, dist2, idx2, nullptr, st);
     if (r) return r;
     PA_CHECK_LAUNCH("pa_chamfer_forward");
     return PA_OK;
@@ -172,14 +184,19 @@ PA_API int pa_chamfer_backward(int B, int n, int m, const float *xyz1, const flo
 }
 
 // ChamferDistanceL1 (libs/chamfer_dist/__init__.py:79-84) as one call each way: pa_chamfer_forward plus the value
-// (mean(sqrt(dist1)) + mean(sqrt(dist2))) / 2 into loss[0] ...
+// (mean(sqrt(dist1)) + mean(sqrt(dist2))) / 2 into loss[0]; partial = scratch of B * (ceil(n / 256) + ceil(m / 256)) doubles ...
 PA_API int pa_chamfer_l1_forward(int B, int n, int m, const float *xyz1, const float *xyz2, float *dist1, float *dist2, int *idx1, int *idx2,
-                                 float *loss, pa_stream_t stream)
+                                 float *loss, double *partial, pa_stream_t stream)
 {
-    PA_REQUIRE(loss, "pa_chamfer_l1_forward: null pointer");
-    const int r = pa_chamfer_forward(B, n, m, xyz1, xyz2, dist1, dist2, idx1, idx2, stream);
+    PA_REQUIRE(B > 0 && n > 0 && m > 0, "pa_chamfer_l1_forward: B=%d n=%d m=%d must be positive", B, n, m);
+    PA_REQUIRE(xyz1 && xyz2 && dist1 && dist2 && idx1 && idx2 && loss && partial, "pa_chamfer_l1_forward: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int np1 = partial_count(B, n, m), np2 = partial_count(B, m, n);
+    int r = one_direction(B, n, m, xyz1, xyz2, dist1, idx1, partial, st);
     if (r) return r;
-    hipLaunchKernelGGL(chamfer_l1_value_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (long)B * n, (long)B * m, dist1, dist2, loss);
+    r = one_direction(B, m, n, xyz2, xyz1, dist2, idx2, partial + np1, st);
+    if (r) return r;
+    hipLaunchKernelGGL(chamfer_l1_value_kernel, dim3(1), dim3(256), 0, st, np1, np2, (double)B * n, (double)B * m, partial, loss);
     PA_CHECK_LAUNCH("pa_chamfer_l1_forward");
     return PA_OK;
 }
