@@ -123,6 +123,14 @@ int pa_group_edge_forward(int b, int c, int n, int m, int k, const float *featur
                           float *out, pa_stream_t stream);
 int pa_group_edge_backward(int b, int c, int n, int m, int k, const float *grad_out, const int *center_idx, const int *idx, float *dfeatures,
                            pa_stream_t stream);
+/* The coordinate-only part of the same grouping (pointops.py:559-562) in one launch: o_grouped (b,3,m,k) = xyz[b,idx[b,j,s],:] (NULL = not wanted),
+ * centred (b,3*reps,m,k) = that minus new_xyz[b,j,:], written reps (1|2) times along the channel axis -- reps = 2 is the first level's whole grouped
+ * input, whose features are the coordinates.  xyz (b,n,3), new_xyz (b,m,3), idx (b,m,k). */
+int pa_group_xyz(int b, int n, int m, int k, int reps, const float *xyz, const float *new_xyz, const int *idx, float *o_grouped, float *centred,
+                 pa_stream_t stream);
+/* out (b,count) = table (b,n) indexed by idx (b,count), int32: the level-local centre / neighbour indices mapped to input-cloud indices
+ * (torch.gather in patch_aug_net.py:169-177). */
+int pa_compose_indices(int b, int n, long count, const int *table, const int *idx, int *out, pa_stream_t stream);
 
 /* K9 with the FP module's inverse-distance weights fused in (patch_aug_net.py:350-353): weight (b,n,3), idx (b,n,3). */
 int pa_three_nn_weights(int b, int n, int m, const float *unknown, const float *known, float *weight, int *idx, pa_stream_t stream);

@@ -30,6 +30,8 @@ _SIGS = {
     "pa_grouping_int_forward": "iiiiippp",
     "pa_group_edge_forward": "iiiiippppp",
     "pa_group_edge_backward": "iiiiipppp",
+    "pa_group_xyz": "iiiiippppp",
+    "pa_compose_indices": "iilppp",
     "pa_nearestneighbor": "iiipppp",
     "pa_interpolation_forward": "iiiipppp",
     "pa_interpolation_backward": "iiiipppp",

@@ -135,20 +135,25 @@ class SAModule(SAModuleMSG):
         grouped input or None) -- the sampling and the grouper's search / permutation, exactly as forward() computes them.  coordinate_features:
         the level's input features when they are the coordinates themselves (the first level: (B, 3, n) = xyz transposed); the grouper's whole
         output is then coordinate-only work too."""
-        center_idx = pointops.furthestsampling(xyz, self.npoint)
-        new_xyz = pointops.gathering(xyz.transpose(1, 2).contiguous(), center_idx).transpose(1, 2).contiguous()
+        center_idx, new_xyz = pointops.furthestsampling_gather(xyz, self.npoint)
         idx = self.groupers[0].neighbours(xyz, new_xyz)
-        coords = pointops.grouped_coordinates(xyz, new_xyz, idx)
         grouped = None
-        if coordinate_features is not None:
-            center_features = pointops.gathering(coordinate_features, center_idx)
-            grouped = self.groupers[0](xyz, new_xyz, coordinate_features, center_features, idx=idx, coords=coords)[0]
+        fused_first = (coordinate_features is not None and xyz.dtype == torch.float32 and idx.shape[2] > 1 and self.groupers[0].use_xyz
+                       and type(self.groupers[0]) is pointops.QueryAndGroup_Edge)
+        if fused_first:
+            # the features ARE the coordinates: grouped features minus centre features repeat the centred coordinates (same subtraction, same operands)
+            o_grouped, grouped = pointops.grouped_coordinates_fused(xyz, new_xyz, idx, 2)
+            coords = (o_grouped, grouped[:, :3])
+        else:
+            coords = pointops.grouped_coordinates(xyz, new_xyz, idx)
+            if coordinate_features is not None:
+                center_features = pointops.gathering(coordinate_features, center_idx)
+                grouped = self.groupers[0](xyz, new_xyz, coordinate_features, center_features, idx=idx, coords=coords)[0]
         return center_idx, new_xyz, idx, coords, grouped
 
     def forward(self, xyz, features, geo=None):
         if geo is None:
-            center_idx = pointops.furthestsampling(xyz, self.npoint)
-            new_xyz = pointops.gathering(xyz.transpose(1, 2).contiguous(), center_idx).transpose(1, 2).contiguous()
+            center_idx, new_xyz = pointops.furthestsampling_gather(xyz, self.npoint)
             idx = coords = grouped = None
         else:
             center_idx, new_xyz, idx, coords, grouped = geo
@@ -177,9 +182,7 @@ class FPModule(nn.Module):
     def geometry(unknown, known, lists_for_channels=0):
         """(3-NN indices, inverse-distance weights, backward lists or None): the coordinate-only part of forward().  lists_for_channels = the
         channel count of the features that will be interpolated under autograd (0 = no backward pass follows)."""
-        dist, idx = pointops.nearestneighbor(unknown, known)
-        dist_recip = 1.0 / (dist + 1e-8)
-        weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+        idx, weight = pointops.three_nn_weights(unknown, known)
         lists = None
         if lists_for_channels and pointops._gather_form(idx.shape[0], lists_for_channels, idx.shape[1], known.shape[1]):
             lists = pointops.interpolation_backward_lists(idx, weight, known.shape[1])      # the backward pass's inverted lists, off the step's path
@@ -187,9 +190,7 @@ class FPModule(nn.Module):
 
     def forward(self, unknown, known, unknown_feats, known_feats, geo=None):
         if geo is None:
-            dist, idx = pointops.nearestneighbor(unknown, known)
-            dist_recip = 1.0 / (dist + 1e-8)
-            weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+            idx, weight = pointops.three_nn_weights(unknown, known)     # search + inverse-distance weights (patch_aug_net.py:350-353), no gradient
             lists = None
         else:
             idx, weight, lists = geo
@@ -206,6 +207,11 @@ class FPModule(nn.Module):
 def origin_indices(l_center_idx, l_sample_idx):
     """Map level-local centre / neighbour indices back to indices of the input cloud (patch_aug_net.py:169-177)."""
     c_o, s_o = [l_center_idx[0]], [l_sample_idx[0]]
+    if all(t.is_cuda and t.dtype == torch.int32 for t in list(l_center_idx) + list(l_sample_idx)):
+        for i in range(1, len(l_center_idx)):
+            c_o.append(pointops.compose_indices(c_o[i - 1], l_center_idx[i]))
+            s_o.append(pointops.compose_indices(c_o[i - 1], l_sample_idx[i]))
+        return c_o, s_o
     for i in range(1, len(l_center_idx)):
         c_o.append(torch.gather(c_o[i - 1], -1, l_center_idx[i].long()))
         s_o.append(torch.gather(c_o[i - 1].unsqueeze(1).expand(-1, l_sample_idx[i].shape[1], -1), -1, l_sample_idx[i].long()))

@@ -51,7 +51,51 @@ __global__ __launch_bounds__(256) void group_edge_bwd_kernel(int c, int n, int m
     for (int i = tid; i < n; i += 256) dst[i] = row[i];
 }
 
+// grid (ceil(m k / 256), b): the coordinate-only part of the grouping -- neighbour coordinates and neighbour minus centre, channel-major
+__global__ __launch_bounds__(256) void group_xyz_kernel(int n, int m, int k, int reps, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                        const int *__restrict__ idx, float *__restrict__ o_grouped, float *__restrict__ centred)
+{
+    const int b = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x, mk = m * k;
+    if (t >= mk) return;
+    const float *p = xyz + ((size_t)b * n + idx[(size_t)b * mk + t]) * 3;
+    const float *q = new_xyz + ((size_t)b * m + t / k) * 3;
+    for (int d = 0; d < 3; ++d) {
+        const float v = p[d], w = v - q[d];
+        if (o_grouped) o_grouped[((size_t)b * 3 + d) * mk + t] = v;
+        for (int r = 0; r < reps; ++r) centred[((size_t)b * 3 * reps + r * 3 + d) * mk + t] = w;
+    }
+}
+
+// out[b, t] = table[b, idx[b, t]] (int32): level-local indices composed into indices of the input cloud (patch_aug_net.py:169-177)
+__global__ __launch_bounds__(256) void compose_indices_kernel(int n, long count, const int *__restrict__ table, const int *__restrict__ idx, int *__restrict__ out)
+{
+    const int b = blockIdx.y;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t < count) out[(size_t)b * count + t] = table[(size_t)b * n + idx[(size_t)b * count + t]];
+}
+
 }  // namespace
+
+// Coordinate-only grouping (pointops.py:559-562): o_grouped (b, 3, m, k) = xyz[b, idx[b, j, s], :] (may be NULL) and centred (b, 3 * reps, m, k) =
+// that minus new_xyz[b, j, :], written reps times along the channel axis (reps = 2: the first level, whose features ARE the coordinates, so the
+// module's cat([grouped_xyz, grouped_features - centre_features]) is the same three channels twice).  xyz (b, n, 3), new_xyz (b, m, 3), idx (b, m, k).
+PA_API int pa_group_xyz(int b, int n, int m, int k, int reps, const float *xyz, const float *new_xyz, const int *idx, float *o_grouped, float *centred,
+                        pa_stream_t stream)
+{
+    PA_REQUIRE(b > 0 && b <= 65535 && n > 0 && m > 0 && k > 0 && (reps == 1 || reps == 2) && xyz && new_xyz && idx && centred, "pa_group_xyz: bad arguments");
+    hipLaunchKernelGGL(group_xyz_kernel, dim3(pa_div_up((long)m * k, 256), b), dim3(256), 0, (hipStream_t)stream, n, m, k, reps, xyz, new_xyz, idx, o_grouped, centred);
+    PA_CHECK_LAUNCH("pa_group_xyz");
+    return PA_OK;
+}
+
+// out (b, count) = table (b, n) indexed by idx (b, count), all int32 (torch.gather on the level-local index lists, patch_aug_net.py:169-177)
+PA_API int pa_compose_indices(int b, int n, long count, const int *table, const int *idx, int *out, pa_stream_t stream)
+{
+    PA_REQUIRE(b > 0 && b <= 65535 && n > 0 && count > 0 && table && idx && out, "pa_compose_indices: bad arguments");
+    hipLaunchKernelGGL(compose_indices_kernel, dim3(pa_div_up(count, 256), b), dim3(256), 0, (hipStream_t)stream, n, count, table, idx, out);
+    PA_CHECK_LAUNCH("pa_compose_indices");
+    return PA_OK;
+}
 
 // out (b, 3 + c, m, k); features (b, c, n), center_idx (b, m), idx (b, m, k), grouped_xyz (b, 3, m, k): see the header comment
 PA_API int pa_group_edge_forward(int b, int c, int n, int m, int k, const float *features, const int *center_idx, const int *idx, const float *grouped_xyz,

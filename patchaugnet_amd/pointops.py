@@ -51,6 +51,49 @@ class FurthestSampling(Function):
 furthestsampling = FurthestSampling.apply
 
 
+@torch.no_grad()
+def furthestsampling_gather(xyz, m):
+    """(idx (b,m) int32, new_xyz (b,m,3)): furthestsampling plus the gathering of the sampled coordinates (patch_aug_net.py:222-225) as the one launch
+    the inference engine uses (pa_furthestsampling_gather: running minima in registers, no temp tensor).  Coordinates carry no gradient here."""
+    check_device(xyz)
+    b, n, _ = xyz.shape
+    if n > 8192 or xyz.dtype != torch.float32:
+        idx = furthestsampling(xyz, m)
+        return idx, gathering(xyz.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
+    xyz = xyz.contiguous()
+    idx = _new(xyz, (b, m), torch.int32)
+    new_xyz = _new(xyz, (b, m, 3), torch.float32)
+    with _guard(xyz):
+        call("pa_furthestsampling_gather", b, n, m, ptr(xyz), ptr(idx), ptr(new_xyz))
+    return idx, new_xyz
+
+
+@torch.no_grad()
+def three_nn_weights(unknown, known):
+    """(idx (b,n,3) int32, weight (b,n,3)): nearestneighbor plus the FP module's inverse-distance weights (patch_aug_net.py:350-353: d = sqrt(d2),
+    r = 1 / (d + 1e-8), w = r / sum r) in one launch; the search has no gradient (pointops.py:79-82), so neither have the weights."""
+    unknown, known = unknown.contiguous(), known.contiguous()
+    check_device(unknown, known)
+    b, n, _ = unknown.shape
+    weight = _new(unknown, (b, n, 3), torch.float32)
+    idx = _new(unknown, (b, n, 3), torch.int32)
+    with _guard(unknown):
+        call("pa_three_nn_weights", b, n, known.shape[1], ptr(unknown), ptr(known), ptr(weight), ptr(idx))
+    return idx, weight
+
+
+@torch.no_grad()
+def compose_indices(table, idx):
+    """table (b,n) int32 indexed by idx (b,...) int32 along the last axis of table: torch.gather(table[:, None].expand(...), -1, idx.long()) without the
+    int64 copy of idx."""
+    table, idx = table.contiguous(), idx.contiguous()
+    check_device(table, idx)
+    out = torch.empty_like(idx)
+    with _guard(table):
+        call("pa_compose_indices", table.shape[0], table.shape[1], idx[0].numel(), ptr(table), ptr(idx), ptr(out))
+    return out
+
+
 class Gathering(Function):
     """pointops.py:32-57 -- features (b,c,n), idx (b,m) -> (b,c,m)."""
 
@@ -442,8 +485,25 @@ def _neighbours(radius, nsample, xyz, new_xyz):
 def grouped_coordinates(xyz, new_xyz, idx):
     """(neighbour coordinates, neighbour coordinates minus their centre), (B, 3, m, k) each: the coordinate-only part of the QueryAndGroup_Edge*
     modules (pointops.py:559-562) -- a training loop computes it with the prefetched neighbour searches (backbone geometry())."""
+    if xyz.is_cuda and xyz.dtype == torch.float32 and not (torch.is_grad_enabled() and (xyz.requires_grad or new_xyz.requires_grad)):
+        return grouped_coordinates_fused(xyz, new_xyz, idx, 1)
     o_grouped_xyz = grouping(xyz.transpose(1, 2).contiguous(), idx)
     return o_grouped_xyz, o_grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
+
+
+@torch.no_grad()
+def grouped_coordinates_fused(xyz, new_xyz, idx, reps):
+    """grouped_coordinates in one launch (pa_group_xyz); reps = 2 returns the centred coordinates twice along the channel axis, (B, 6, m, k): the first
+    level's whole grouped input, whose features are the coordinates (cat([grouped_xyz, grouped_features - centre_features]), pointops.py:563-570)."""
+    xyz, new_xyz, idx = xyz.contiguous(), new_xyz.contiguous(), idx.contiguous()
+    check_device(xyz, new_xyz, idx)
+    b, n, _ = xyz.shape
+    _, m, k = idx.shape
+    o_grouped = _new(xyz, (b, 3, m, k), torch.float32)
+    centred = _new(xyz, (b, 3 * reps, m, k), torch.float32)
+    with _guard(xyz):
+        call("pa_group_xyz", b, n, m, k, reps, ptr(xyz), ptr(new_xyz), ptr(idx), ptr(o_grouped), ptr(centred))
+    return o_grouped, centred
 
 
 class EdgeGroup(Function):

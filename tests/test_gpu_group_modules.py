@@ -213,3 +213,36 @@ def test_edge_group_fused_op_equals_the_unfused_statement(b, c, n, m, k):
     assert torch.equal(out1, out0)
     scale = f0.grad.abs().max().item()
     assert (f1.grad - f0.grad).abs().max().item() <= 1e-5 * max(scale, 1.0)
+
+
+@pytest.mark.parametrize("b,n,m,k", [(3, 4096, 1024, 20), (2, 128, 16, 20), (1, 37, 7, 3)])
+def test_coordinate_only_geometry_ops_equal_the_unfused_statements(b, n, m, k):
+    """The one-launch forms the training loop's geometry prefetch uses, against the statements they replace: furthestsampling + gathering
+    (patch_aug_net.py:222-225), grouping of the coordinates minus the centre (pointops.py:559-562; twice along the channel axis = the first level's
+    cat with its own features), the inverse-distance weights (patch_aug_net.py:350-353) and torch.gather on the index lists (:169-177)."""
+    from patchaugnet_amd import pointops as P
+    g = torch.Generator().manual_seed(n)
+    xyz = (torch.rand(b, n, 3, generator=g) * 2 - 1).cuda()
+    ci, nx = P.furthestsampling_gather(xyz, m)
+    ci0 = P.furthestsampling(xyz, m)
+    nx0 = P.gathering(xyz.transpose(1, 2).contiguous(), ci0).transpose(1, 2).contiguous()
+    assert torch.equal(ci, ci0) and torch.equal(nx, nx0)
+    idx = P.knnquery(k, xyz, nx)
+    og0 = P.grouping(xyz.transpose(1, 2).contiguous(), idx)
+    cen0 = og0 - nx.transpose(1, 2).unsqueeze(-1)
+    og, cen = P.grouped_coordinates(xyz, nx, idx)
+    assert torch.equal(og, og0) and torch.equal(cen, cen0)
+    og2, cen2 = P.grouped_coordinates_fused(xyz, nx, idx, 2)
+    feats = xyz.transpose(1, 2).contiguous()
+    first = torch.cat([cen0, P.grouping(feats, idx) - P.gathering(feats, ci).unsqueeze(-1)], dim=1)
+    assert torch.equal(og2, og0) and torch.equal(cen2, first)
+    i3, w3 = P.three_nn_weights(xyz, nx)
+    d, i0 = P.nearestneighbor(xyz, nx)
+    r = 1.0 / (d + 1e-8)
+    w0 = r / torch.sum(r, dim=2, keepdim=True)
+    assert torch.equal(i3, i0) and (w3 - w0).abs().max().item() <= 2e-7
+    table = torch.randint(0, 10 ** 6, (b, n), generator=g).int().cuda()
+    for ix in (ci, idx):
+        ref = torch.gather(table.unsqueeze(1).expand(-1, ix.shape[1], -1), -1, ix.long()) if ix.dim() == 3 else torch.gather(table, -1, ix.long())
+        got = P.compose_indices(table, ix)
+        assert got.dtype == torch.int32 and torch.equal(got, ref)
