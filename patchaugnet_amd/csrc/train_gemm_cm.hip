@@ -22,6 +22,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "pa_common.h"
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
@@ -141,21 +143,44 @@ __global__ __launch_bounds__(WAVES * 64) void tgemm_cm_kernel(CMArgs a)
         const int rows = 64 * MH, K = KS * 4;
         // (consecutive lanes take consecutive ROWS: the fragment order puts rows m, m + 1 four floats apart and m, m + 16 one float apart, so a
         // wave's 4-byte LDS writes land in 64 different banks; with consecutive lanes along k every lane of a write hit the same bank: 104 vs 113 us)
+        // (the loads of a batch of PU iterations are issued before their first LDS write: one L2 round trip per batch, not per iteration)
+#ifndef CM_PU
+#define CM_PU 6
+#endif
+        constexpr int PU = CM_PU;
         if (a.a_kcontig) {                              // 16-byte reads along k: element e of the read is k = 4 s + e, i.e. k-step s, lane row kq = e
-            for (int q = tid; q < rows * KS; q += NT) {
-                const int m = q % rows, s = q / rows;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);          // rows past M (M not a multiple of 64): zero fragments, never stored
-                if (mbase + m < a.M) v = *reinterpret_cast<const float4 *>(a.A + (size_t)(mbase + m) * a.lda + 4 * s);
-                float *dst = smem + ((size_t)(s * MH + (m >> 6)) * 64 + (m & 15)) * 4 + ((m & 63) >> 4);
-                dst[0] = v.x; dst[64] = v.y; dst[128] = v.z; dst[192] = v.w;       // kq = 0..3: lane + 16 -> + 64 floats
+            for (int q0 = tid; q0 < rows * KS; q0 += NT * PU) {
+                float4 v[PU];
+#pragma unroll
+                for (int u = 0; u < PU; ++u) {
+                    const int q = q0 + u * NT, m = q % rows, s = q / rows;
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);          // rows past M (M not a multiple of 64): zero fragments, never stored
+                    if (q < rows * KS && mbase + m < a.M) v[u] = *reinterpret_cast<const float4 *>(a.A + (size_t)(mbase + m) * a.lda + 4 * s);
+                }
+#pragma unroll
+                for (int u = 0; u < PU; ++u) {
+                    const int q = q0 + u * NT, m = q % rows, s = q / rows;
+                    if (q >= rows * KS) break;
+                    float *dst = smem + ((size_t)(s * MH + (m >> 6)) * 64 + (m & 15)) * 4 + ((m & 63) >> 4);
+                    dst[0] = v[u].x; dst[64] = v[u].y; dst[128] = v[u].z; dst[192] = v[u].w;       // kq = 0..3: lane + 16 -> + 64 floats
+                }
             }
         } else {                                        // 16-byte reads along m: four consecutive rows of one k
-            for (int q = tid; q < (rows / 4) * K; q += NT) {
-                const int k = q / (rows / 4), m = (q - k * (rows / 4)) * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (mbase + m < a.M) v = *reinterpret_cast<const float4 *>(a.A + (size_t)k * a.lda + mbase + m);      // M % 4 == 0 (host)
-                float *dst = smem + ((size_t)((k >> 2) * MH + (m >> 6)) * 64 + (k & 3) * 16 + (m & 15)) * 4 + ((m & 63) >> 4);
-                dst[0] = v.x; dst[4] = v.y; dst[8] = v.z; dst[12] = v.w;           // m % 16 + 1 -> next lane -> + 4 floats
+            for (int q0 = tid; q0 < (rows / 4) * K; q0 += NT * PU) {
+                float4 v[PU];
+#pragma unroll
+                for (int u = 0; u < PU; ++u) {
+                    const int q = q0 + u * NT, k = q / (rows / 4), m = (q - k * (rows / 4)) * 4;
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (q < (rows / 4) * K && mbase + m < a.M) v[u] = *reinterpret_cast<const float4 *>(a.A + (size_t)k * a.lda + mbase + m);      // M % 4 == 0 (host)
+                }
+#pragma unroll
+                for (int u = 0; u < PU; ++u) {
+                    const int q = q0 + u * NT, k = q / (rows / 4), m = (q - k * (rows / 4)) * 4;
+                    if (q >= (rows / 4) * K) break;
+                    float *dst = smem + ((size_t)((k >> 2) * MH + (m >> 6)) * 64 + (k & 3) * 16 + (m & 15)) * 4 + ((m & 63) >> 4);
+                    dst[0] = v[u].x; dst[4] = v[u].y; dst[8] = v[u].z; dst[12] = v[u].w;           // m % 16 + 1 -> next lane -> + 4 floats
+                }
             }
         }
         if (MODE) {
@@ -176,9 +201,25 @@ __global__ __launch_bounds__(WAVES * 64) void tgemm_cm_kernel(CMArgs a)
     }
     __syncthreads();
 
+#ifdef CM_STAGGER                                        // experiment: the SIMD's second / third wave start a third / two thirds of a tile late
+    for (int d = 0; d < (wave >> 2); ++d) __builtin_amdgcn_s_sleep(CM_STAGGER);
+#endif
     const float4 *wl = wf + h * 64 + lane;              // + s * MH * 64 per k-step
     const float4 *pl = ptab + 2 * kq;                   // + 8 s per k-step (channel 4 s + kq)
     double *myst = sst + (size_t)wave * 128;
+    const bool plain = mbase + 64 * MH <= a.M && !a.bias && !a.beta;            // uniform: the epilogue without guards, bias or read-back
+
+    // the LDS pipeline's state entering k-step 0: fragments of steps 0 and 1, parameters of step 1, the transformed B fragments of step 0
+    float4 w0 = wl[0], w1 = wl[(size_t)MH * 64];
+    float4 c0n = make_float4(0.f, 0.f, 0.f, 0.f), c1n = c0n;
+    float bf[CT];
+    {
+        float4 c00 = c0n, c10 = c0n;
+        if (MODE) { c00 = pl[0]; c0n = pl[8]; }
+        if (MODE >= 2) { c10 = pl[1]; c1n = pl[9]; }
+#pragma unroll
+        for (int t = 0; t < CT; ++t) bf[t] = cm_tf<MODE>(G0.x[0].v[t], MODE >= 2 ? G0.y[0].v[t] : 0.f, c00, c10);
+    }
 
     for (; tile < t_end; tile += WAVES) {
         unsigned nbo, nco;
@@ -189,42 +230,34 @@ __global__ __launch_bounds__(WAVES * 64) void tgemm_cm_kernel(CMArgs a)
 #pragma unroll
             for (int t = 0; t < CT; ++t) acc[i][t] = (floatx4){0.f, 0.f, 0.f, 0.f};
 
-        // One register group = GS k-steps.  Per k-step: the NEXT k-step's fragment / parameter reads are issued first (a scheduling fence keeps
-        // them in front of the MFMAs: left alone hipcc sinks them to their first use and every k-step waits out the LDS round trip, or hoists the
-        // whole group's reads and spills), then this k-step's 4 CT MFMAs with the next k-step's operand transform in their shadow.
-        auto compute = [&](Group &G, int g) {
-            float4 w = wl[(size_t)(g * GS) * MH * 64];
-            float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
-            if (MODE) c0 = pl[(g * GS) * 8];
-            if (MODE >= 2) c1 = pl[(g * GS) * 8 + 1];
-            float bf[CT];
-#pragma unroll
-            for (int t = 0; t < CT; ++t) bf[t] = cm_tf<MODE>(G.x[0].v[t], MODE >= 2 ? G.y[0].v[t] : 0.f, c0, c1);
+        // One register group = GS k-steps.  The LDS side is ONE software pipeline that runs through the groups and tiles of the wave (the k-steps of
+        // every tile read the same fragment / parameter addresses): in k-step s the reads of step s + 2 are issued first (a scheduling fence
+        // keeps them in front of the MFMAs: left alone hipcc sinks them to their first use, or hoists a group's reads and spills), then half of
+        // the step's 4 CT MFMAs, the operand transform of step s + 1 (parameters read one step earlier: sixteen MFMAs of cover for an LDS round
+        // trip; with one step of cover a wave sat in s_waitcnt lgkmcnt for a fifth of its cycles, SQ_WAIT_ANY in profiles/r05_tgemm_cm_pmc.txt),
+        // the other half.  Gn = the register group that follows G (the next tile's first group after the tile's last).
+        auto compute = [&](Group &G, Group &Gn, int g) {
 #pragma unroll
             for (int j = 0; j < GS; ++j) {
-                const int s = g * GS + j;
-                float4 wn = w;
-                if (j + 1 < GS) {
-                    wn = wl[(size_t)(s + 1) * MH * 64];
-                    if (MODE) c0 = pl[(s + 1) * 8];
-                    if (MODE >= 2) c1 = pl[(s + 1) * 8 + 1];
-                }
+                const int s2 = (g * GS + j + 2) % KS;
+                const float4 w2 = wl[(size_t)s2 * MH * 64];
+                float4 c02 = c0n, c12 = c1n;
+                if (MODE) c02 = pl[s2 * 8];
+                if (MODE >= 2) c12 = pl[s2 * 8 + 1];
                 __builtin_amdgcn_sched_barrier(0);
 #define CM_ROW(i, wi)                                                                                                   \
                 _Pragma("unroll") for (int t = 0; t < CT; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wi, bf[t], acc[i][t], 0, 0, 0);
-                CM_ROW(0, w.x) CM_ROW(1, w.y)
-                __builtin_amdgcn_sched_barrier(0);      // the first half of the MFMAs covers the LDS round trip before the first use of the reads above
+                CM_ROW(0, w0.x) CM_ROW(1, w0.y)
+                __builtin_amdgcn_sched_barrier(0);
                 float nf[CT];
+                const Vec &xn = j + 1 < GS ? G.x[j + 1 < GS ? j + 1 : 0] : Gn.x[0];
+                const Vec &yn = j + 1 < GS ? G.y[MODE >= 2 ? (j + 1 < GS ? j + 1 : 0) : 0] : Gn.y[0];
 #pragma unroll
-                for (int t = 0; t < CT; ++t) nf[t] = bf[t];
-                if (j + 1 < GS) {                       // the next k-step's B fragments, under this k-step's MFMAs
-#pragma unroll
-                    for (int t = 0; t < CT; ++t) nf[t] = cm_tf<MODE>(G.x[j + 1 < GS ? j + 1 : j].v[t], MODE >= 2 ? G.y[j + 1 < GS ? j + 1 : j].v[t] : 0.f, c0, c1);
-                }
-                CM_ROW(2, w.z) CM_ROW(3, w.w)
+                for (int t = 0; t < CT; ++t) nf[t] = cm_tf<MODE>(xn.v[t], MODE >= 2 ? yn.v[t] : 0.f, c0n, c1n);
+                CM_ROW(2, w0.z) CM_ROW(3, w0.w)
 #undef CM_ROW
                 __builtin_amdgcn_sched_barrier(0);
-                w = wn;
+                w0 = w1; w1 = w2; c0n = c02; c1n = c12;
 #pragma unroll
                 for (int t = 0; t < CT; ++t) bf[t] = nf[t];
             }
@@ -235,70 +268,85 @@ __global__ __launch_bounds__(WAVES * 64) void tgemm_cm_kernel(CMArgs a)
 #ifndef CM_DBG_NOLOAD                                    // decomposition probe (never built into the library): the k-loop without its global loads
             load(G1, bo, g + 1);
 #endif
-            compute(G0, g);
+            compute(G0, G1, g);
 #ifndef CM_DBG_NOLOAD
             if (g + 2 < NGR) load(G0, bo, g + 2);
             else load(G0, nbo, 0);                      // next tile's first group under this tile's last MFMAs and the epilogue
 #endif
-            compute(G1, g + 1);
+            compute(G1, G0, g + 1);
         }
 
-        // ---- epilogue: lane (slot, kq) holds C[m = 16 i + 4 kq + r][n0 + CT slot + t] in acc[i][t][r]: one 16- (8-) byte store per (i, r)
+        // ---- epilogue: lane (slot, kq) holds C[m = 16 i + 4 kq + r][n0 + CT slot + t] in acc[i][t][r]: one 16- (8-) byte store per (i, r).
+        // Nothing in the common form waits: stores are fire-and-forget, the statistics go to the wave's LDS block as fp64 LDS adds without
+        // return (a wave's LDS operations execute in order: fixed summation order).  The first build read-modified-wrote that block (a round
+        // trip per row) behind a per-row `bias ? load : 0` whose s_waitcnt vmcnt(0) also waited out the previous row's STORE: 16 write
+        // acknowledgements per tile in series, SQ_WAIT_ANY = 22 % of a wave's cycles (profiles/r05_tgemm_cm_pmc.txt).
         const int mrow0 = mbase + 64 * h + 4 * kq;
+        auto add_stat = [&](int rowslot, float t1, float t2) {
+            if (slot == 15) {
+                double *d = myst + rowslot * 2;
+                (void)__hip_atomic_fetch_add(d, (double)t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                (void)__hip_atomic_fetch_add(d + 1, (double)t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        };
+        auto epilogue = [&](auto plain_tag) {
+            constexpr bool PLAIN = decltype(plain_tag)::value;          // whole row block inside M, no bias, beta = 0
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
+                Vec yv[4];
+                if (STATS == 2) {                       // the four rows' raw outputs of the next layer first: one wait for the four
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = mrow0 + 16 * i + r;
-                if (m >= a.M) continue;                 // padding rows of the last row block
-                const float bs = a.bias ? a.bias[m] : 0.f;
-                float v[CT];
-#pragma unroll
-                for (int t = 0; t < CT; ++t) v[t] = acc[i][t][r] + bs;
-                const unsigned so = (unsigned)(16 * i + r) * 4u * (unsigned)a.ldc;
-                if (a.beta) {
-                    const Vec old = ldv(crs, co, so);
-#pragma unroll
-                    for (int t = 0; t < CT; ++t) v[t] += old.v[t];
+                    for (int r = 0; r < 4; ++r) yv[r] = ldv(nrs, co, (unsigned)(16 * i + r) * 4u * (unsigned)a.ldc);
                 }
-                if constexpr (CT == 4) {
-                    const u32x4 uv = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-                    __builtin_amdgcn_raw_buffer_store_b128(uv, crs, co, so, 0);
-                } else {
-                    const u32x2 uv = {__float_as_uint(v[0]), __float_as_uint(v[1])};
-                    __builtin_amdgcn_raw_buffer_store_b64(uv, crs, co, so, 0);
-                }
-                if (STATS == 1) {
-                    float p1, p2;
-                    if constexpr (CT == 4) { p1 = (v[0] + v[1]) + (v[2] + v[3]); p2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]); }
-                    else { p1 = v[0] + v[1]; p2 = v[0] * v[0] + v[1] * v[1]; }
-                    const float t1 = dpp_row_sum16(p1), t2 = dpp_row_sum16(p2);
-                    if (slot == 15) {
-                        double *d = myst + (16 * i + 4 * kq + r) * 2;
-                        d[0] += (double)t1;
-                        d[1] += (double)t2;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mrow0 + 16 * i + r;
+                    if (!PLAIN && m >= a.M) continue;   // padding rows of the last row block
+                    float v[CT];
+#pragma unroll
+                    for (int t = 0; t < CT; ++t) v[t] = acc[i][t][r];
+                    const unsigned so = (unsigned)(16 * i + r) * 4u * (unsigned)a.ldc;
+                    if (!PLAIN) {
+                        const float bs = a.bias ? a.bias[m] : 0.f;
+#pragma unroll
+                        for (int t = 0; t < CT; ++t) v[t] += bs;
+                        if (a.beta) {
+                            const Vec old = ldv(crs, co, so);
+#pragma unroll
+                            for (int t = 0; t < CT; ++t) v[t] += old.v[t];
+                        }
                     }
-                }
-                if (STATS == 2) {
-                    // C is the gradient of the NEXT (earlier) layer's activation: that layer's BatchNorm-backward sums ride on this epilogue
-                    // (sum mask(g), sum mask(g) xhat per row; train_gemm.hip: bn_bwd_reduce_kernel) instead of a pass of their own over (g, y)
-                    const Vec yv = ldv(nrs, co, so);
-                    const float4 q = qtab[64 * h + 16 * i + 4 * kq + r];
-                    float p1 = 0.f, p2 = 0.f;
-#pragma unroll
-                    for (int t = 0; t < CT; ++t) {
-                        const float gm = (!a.relu_next || fmaf(yv.v[t], q.x, q.y) > 0.f) ? v[t] : 0.f;
-                        p1 += gm;
-                        p2 += gm * ((yv.v[t] - q.z) * q.w);
+                    if constexpr (CT == 4) {
+                        const u32x4 uv = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                        __builtin_amdgcn_raw_buffer_store_b128(uv, crs, co, so, 0);
+                    } else {
+                        const u32x2 uv = {__float_as_uint(v[0]), __float_as_uint(v[1])};
+                        __builtin_amdgcn_raw_buffer_store_b64(uv, crs, co, so, 0);
                     }
-                    const float t1 = dpp_row_sum16(p1), t2 = dpp_row_sum16(p2);
-                    if (slot == 15) {
-                        double *d = myst + (16 * i + 4 * kq + r) * 2;
-                        d[0] += (double)t1;
-                        d[1] += (double)t2;
+                    if (STATS == 1) {
+                        float p1, p2;
+                        if constexpr (CT == 4) { p1 = (v[0] + v[1]) + (v[2] + v[3]); p2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]); }
+                        else { p1 = v[0] + v[1]; p2 = v[0] * v[0] + v[1] * v[1]; }
+                        add_stat(16 * i + 4 * kq + r, dpp_row_sum16(p1), dpp_row_sum16(p2));
+                    }
+                    if (STATS == 2) {
+                        // C is the gradient of the NEXT (earlier) layer's activation: that layer's BatchNorm-backward sums ride on this epilogue
+                        // (sum mask(g), sum mask(g) xhat per row; train_gemm.hip: bn_bwd_reduce_kernel) instead of a pass of their own over (g, y)
+                        const float4 q = qtab[64 * h + 16 * i + 4 * kq + r];
+                        float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+                        for (int t = 0; t < CT; ++t) {
+                            const float gm = (!a.relu_next || fmaf(yv[r].v[t], q.x, q.y) > 0.f) ? v[t] : 0.f;
+                            p1 += gm;
+                            p2 += gm * ((yv[r].v[t] - q.z) * q.w);
+                        }
+                        add_stat(16 * i + 4 * kq + r, dpp_row_sum16(p1), dpp_row_sum16(p2));
                     }
                 }
             }
+        };
+        if (plain) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
         bo = nbo; co = nco;
     }
     if (STATS) {
