@@ -46,7 +46,7 @@ struct CMArgs {
     int coltiles_per_cloud;                            // N / (16 CT)
     long coltiles;                                     // batch * N / (16 CT)
     long tiles_per_group;                              // wave tiles (column tile x 64-row half) per workgroup
-    int dbg;                                           // PA_TGEMM_CM_DBG (measurement only): 1 = no tiles (the fixed cost of a launch)
+    int dbg;                                           // PA_TGEMM_CM_DBG (measurement only): 1 = no tiles (the fixed cost of a launch), 2 = tiles without the weight copy
 };
 
 
@@ -148,7 +148,8 @@ __global__ __launch_bounds__(WAVES * 64) void tgemm_cm_kernel(CMArgs a)
 #define CM_PU 6
 #endif
         constexpr int PU = CM_PU;
-        if (a.a_kcontig) {                              // 16-byte reads along k: element e of the read is k = 4 s + e, i.e. k-step s, lane row kq = e
+        if (a.dbg == 2) {                               // measurement only: tiles without the weight copy
+        } else if (a.a_kcontig) {                              // 16-byte reads along k: element e of the read is k = 4 s + e, i.e. k-step s, lane row kq = e
             for (int q0 = tid; q0 < rows * KS; q0 += NT * PU) {
                 float4 v[PU];
 #pragma unroll
@@ -296,7 +297,10 @@ __global__ __launch_bounds__(WAVES * 64) void tgemm_cm_kernel(CMArgs a)
                 Vec yv[4];
                 if (STATS == 2) {                       // the four rows' raw outputs of the next layer first: one wait for the four
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) yv[r] = ldv(nrs, co, (unsigned)(16 * i + r) * 4u * (unsigned)a.ldc);
+                    for (int r = 0; r < 4; ++r) {
+                        if (!PLAIN && mrow0 + 16 * i + r >= a.M) { yv[r] = Vec{}; continue; }         // padding rows: nothing behind them to read
+                        yv[r] = ldv(nrs, co, (unsigned)(16 * i + r) * 4u * (unsigned)a.ldc);
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -319,6 +323,14 @@ __global__ __launch_bounds__(WAVES * 64) void tgemm_cm_kernel(CMArgs a)
                     if constexpr (CT == 4) {
                         const u32x4 uv = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
                         __builtin_amdgcn_raw_buffer_store_b128(uv, crs, co, so, 0);
+                        // gfx950 reads the data registers of a store wider than 64 bits for two more cycles after issue; hipcc covers that for
+                        // the forms it knows (immediate offset) and exempts the SGPR-offset form, whose extra issue cycle hides ONE of the two:
+                        // the next row's gather (v_mov into the same four registers) then overwrote lanes 12..15 of each row of the first dword
+                        // about once in two thousand stores.  Found by the engine-vs-module test at 8192 points; tests/test_gpu_train_ops.py
+                        // now runs the K = 32 / 64 shapes many times over.
+                        __builtin_amdgcn_sched_barrier(0);
+                        asm volatile("s_nop 2" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
                     } else {
                         const u32x2 uv = {__float_as_uint(v[0]), __float_as_uint(v[1])};
                         __builtin_amdgcn_raw_buffer_store_b64(uv, crs, co, so, 0);

@@ -513,6 +513,69 @@ def test_lds_resident_weights_gemm_against_float64_and_the_lds_tiled_kernel(a_kc
         assert torch.allclose(sts[0], sts[1], rtol=1e-5, atol=1e-4 * scale * N)
 
 
+@pytest.mark.parametrize("B,M,N,K,bmode", [(3, 64, 40960, 32, 1), (3, 64, 40960, 32, 0), (3, 64, 40960, 64, 1), (18, 64, 20480, 32, 1), (3, 128, 40960, 32, 1),
+                                           (3, 256, 8192, 256, 1)])
+def test_lds_resident_weights_gemm_short_tiles_repeated(B, M, N, K, bmode):
+    """Tiles of 8 / 16 k-steps with 16-byte stores (K = 32 / 64, the first set-abstraction level at 8192-point clouds), twenty launches each
+    compared with the LDS-tiled kernel element for element: a build without wait states behind its 16-byte buffer stores lost lanes 12..15 of a
+    store's first dword about once in two thousand stores (gfx950 reads wide store data for two cycles after issue; the next row's gather wrote
+    the same registers) -- invisible to a single launch of the other shapes."""
+    from patchaugnet_amd import train_ops as T
+    g = torch.Generator().manual_seed(K + M)
+    A = (torch.randn(M, K, generator=g) / K ** 0.5).cuda()
+    X = torch.randn(B, K, N, generator=g).cuda()
+    p = (torch.rand(7, K, generator=g) + 0.25).cuda() if bmode else None
+    try:
+        _cm_switch(0)
+        ref = torch.empty(B, M, N, device="cuda")
+        T.tgemm_nn(B, M, N, K, A, 0, K, True, X, K * N, N, ref, M * N, N, bmode=bmode, bp=p)
+        _cm_switch(1)
+        scale = max(ref.abs().max().item(), 1.0)
+        for rep in range(20):
+            C = torch.zeros(B, M, N, device="cuda")
+            T.tgemm_nn(B, M, N, K, A, 0, K, True, X, K * N, N, C, M * N, N, bmode=bmode, bp=p)
+            bad = ((C - ref).abs() > 2e-5 * scale).sum().item()
+            assert bad == 0, (rep, bad)
+    finally:
+        _cm_switch(-1)
+
+
+@pytest.mark.parametrize("B,M,N,K,relu_next", [(18, 32, 20480, 64, 1), (4, 96, 4096, 32, 1), (3, 256, 4096, 256, 0), (2, 160, 2048, 128, 1)])
+def test_input_gradient_gemm_with_the_next_layers_bn_backward_sums_on_its_epilogue(B, M, N, K, relu_next):
+    """pa_tgemm_nn_bnred (train_gemm.hip / train_gemm_cm.hip STATS 2: dX = W^T . bn_bwd(dY, Y) with the BatchNorm-backward sums of the layer that
+    produced X accumulated on the epilogue) against the unfused pair it replaces (pa_tgemm_nn then pa_bn_bwd_reduce over (dX, raw X)), with the
+    LDS-resident-weights kernel forced and with it off: row blocks with padding rows (M = 32, 96, 160: rows past M of the last cloud lie past the
+    end of the tensors -- a build that read the next layer's raw output before the row guard faulted here), whole blocks, both ReLU settings."""
+    from patchaugnet_amd import train_ops as T
+    from patchaugnet_amd._lib import call, ptr
+    g = torch.Generator().manual_seed(M + N + K)
+    W = (torch.randn(K, M, generator=g) / K ** 0.5).cuda()                      # (O = K, C = M): A(m = c, k = o) = W[o * M + c]
+    dY, Y = torch.randn(B, K, N, generator=g).cuda(), torch.randn(B, K, N, generator=g).cuda()
+    p = _p_block(K, g).cuda().contiguous()
+    ynext, pnext = torch.randn(B, M, N, generator=g).cuda(), _p_block(M, g).cuda().contiguous()
+    res = []
+    try:
+        for on in (1, 0):
+            _cm_switch(on)
+            gp = torch.full((B, M, N), 7.0, device="cuda")
+            sums = torch.zeros(2 * M, dtype=torch.float64, device="cuda")
+            call("pa_tgemm_nn_bnred", B, M, N, K, ptr(W), M, 0, ptr(dY), K * N, N, 2, ptr(Y), ptr(p), ptr(gp), M * N, N, ptr(ynext), ptr(pnext), relu_next,
+                 ptr(sums))
+            res.append((gp, sums))
+        _cm_switch(0)
+        gp0 = torch.empty((B, M, N), device="cuda")
+        T.tgemm_nn(B, M, N, K, W, 0, M, False, dY, K * N, N, gp0, M * N, N, bmode=2, baux=Y, bp=p)
+        sums0 = torch.zeros(2 * M, dtype=torch.float64, device="cuda")
+        call("pa_bn_bwd_reduce", B, M, N, ptr(gp0), ptr(ynext), ptr(pnext), relu_next, ptr(sums0), 0)
+        torch.cuda.synchronize()
+    finally:
+        _cm_switch(-1)
+    scale = max(gp0.abs().max().item(), 1.0)
+    for gp, sums in res:
+        assert (gp - gp0).abs().max().item() <= 2e-5 * scale
+        assert torch.allclose(sums, sums0, rtol=1e-5, atol=1e-4 * scale * (B * N) ** 0.5), (sums - sums0).abs().max()
+
+
 @pytest.mark.parametrize("B,C1,m,n,spec", [(2, 3, 256, 1024, [259, 256, 256]), (3, 3, 512, 2048, [67, 64, 32, 48]), (2, 8, 1024, 4096, [136, 128, 128]),
                                            (18, 3, 1024, 4096, [259, 256, 256, 256])])
 def test_fp_level_with_the_first_layer_folded_through_the_interpolation(B, C1, m, n, spec):

@@ -12,6 +12,11 @@ shapes = [("fp0 fwd", 18, 256, 4096, 256, True, 1, True), ("fp0 dX", 18, 256, 40
           ("sa1 L3 fwd", 18, 256, 2560, 64, True, 1, True), ("sa1 dX", 18, 64, 2560, 256, False, 2, False), ("sa2 L3", 18, 512, 320, 256, True, 1, True),
           ("fp2 L2", 18, 256, 128, 256, True, 1, True), ("sa0 L3 fwd", 18, 64, 20480, 32, True, 1, True), ("sa0 L2 fwd", 18, 32, 20480, 32, True, 1, True),
           ("sa0 L3 dX", 18, 32, 20480, 64, False, 2, False), ("sa0 L2 dX", 18, 32, 20480, 32, False, 2, False)]
+if os.environ.get('PA_TGEMM_CM_DECOMP'):          # the fp0 shape without the operand transform and / or the statistics epilogue
+    shapes = [("fp0 fwd", 18, 256, 4096, 256, True, 1, True), ("fp0 tf only", 18, 256, 4096, 256, True, 1, False), ("fp0 stats only", 18, 256, 4096, 256, True, 0, True),
+              ("fp0 plain", 18, 256, 4096, 256, True, 0, False), ("fp0 plain 36", 36, 256, 4096, 256, True, 0, False)]
+if os.environ.get('PA_TGEMM_CM_SWEEP'):          # time against batch: intercept = what a launch costs beyond its tiles
+    shapes = [(f"fp0 plain {b}", b, 256, 4096, 256, True, 0, False) for b in (6, 12, 18, 24, 36, 54)] + [(f"fp0 fwd {b}", b, 256, 4096, 256, True, 1, True) for b in (6, 12, 18, 24, 36, 54)]
 only = os.environ.get('PA_TGEMM_CM_ONLY')
 for name, B, M, N, K, kc, bmode, stats in shapes:
     if only and not name.startswith(only):
