@@ -294,7 +294,18 @@ __global__ __launch_bounds__(WAVES * 64) void tgemm_cm_kernel(CMArgs a)
             constexpr bool PLAIN = decltype(plain_tag)::value;          // whole row block inside M, no bias, beta = 0
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                Vec yv[4];
+                Vec yv[4], oldv[4];
+                float bsv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (!PLAIN) {                           // bias and (beta) the values already in C for the four rows first: one wait for the four
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = mrow0 + 16 * i + r;
+                        oldv[r] = Vec{};
+                        if (m >= a.M) continue;
+                        if (a.bias) bsv[r] = a.bias[m];
+                        if (a.beta) oldv[r] = ldv(crs, co, (unsigned)(16 * i + r) * 4u * (unsigned)a.ldc);
+                    }
+                }
                 if (STATS == 2) {                       // the four rows' raw outputs of the next layer first: one wait for the four
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -311,14 +322,8 @@ __global__ __launch_bounds__(WAVES * 64) void tgemm_cm_kernel(CMArgs a)
                     for (int t = 0; t < CT; ++t) v[t] = acc[i][t][r];
                     const unsigned so = (unsigned)(16 * i + r) * 4u * (unsigned)a.ldc;
                     if (!PLAIN) {
-                        const float bs = a.bias ? a.bias[m] : 0.f;
 #pragma unroll
-                        for (int t = 0; t < CT; ++t) v[t] += bs;
-                        if (a.beta) {
-                            const Vec old = ldv(crs, co, so);
-#pragma unroll
-                            for (int t = 0; t < CT; ++t) v[t] += old.v[t];
-                        }
+                        for (int t = 0; t < CT; ++t) v[t] = (v[t] + bsv[r]) + oldv[r].v[t];
                     }
                     if constexpr (CT == 4) {
                         const u32x4 uv = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};

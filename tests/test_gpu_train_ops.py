@@ -540,6 +540,34 @@ def test_lds_resident_weights_gemm_short_tiles_repeated(B, M, N, K, bmode):
         _cm_switch(-1)
 
 
+@pytest.mark.parametrize("B,M,N,K,bmode,bias", [(18, 256, 4096, 64, 3, False), (4, 96, 4096, 32, 2, True), (3, 64, 8192, 128, 0, True), (2, 160, 2048, 256, 1, False)])
+def test_lds_resident_weights_gemm_accumulating_into_c(B, M, N, K, bmode, bias):
+    """beta = 1 (C += A . f(B) [+ bias]: the second gradient contribution of a tensor with two consumers, train_ops._NetVladFused) on the
+    LDS-resident-weights kernel against the LDS-tiled one: whole and padded row blocks, with and without bias -- the guarded epilogue reads the
+    four rows' old values and biases in one batch before its stores."""
+    from patchaugnet_amd import train_ops as T
+    g = torch.Generator().manual_seed(3 * M + K)
+    A = (torch.randn(K, M, generator=g) / K ** 0.5).cuda()
+    X, aux = torch.randn(B, K, N, generator=g).cuda(), torch.randn(B, K, N, generator=g).cuda()
+    p = _p_block(K, g).cuda().contiguous()
+    C0 = torch.randn(B, M, N, generator=g).cuda()
+    bvec = torch.randn(M, generator=g).cuda()
+    outs = []
+    try:
+        for on in (0, 1):
+            _cm_switch(on)
+            C = C0.clone()
+            T.tgemm_nn(B, M, N, K, A, 0, M, False, X, K * N, N, C, M * N, N, bmode=bmode, baux=aux if bmode >= 2 else None, bp=p if bmode else None,
+                       beta=1, bias=bvec if bias else None)
+            outs.append(C)
+        torch.cuda.synchronize()
+    finally:
+        _cm_switch(-1)
+    scale = max(outs[0].abs().max().item(), 1.0)
+    assert (outs[0] - outs[1]).abs().max().item() <= 2e-5 * scale
+    assert (outs[0] - C0).abs().max().item() > 0.1                               # something was added
+
+
 @pytest.mark.parametrize("B,M,N,K,relu_next", [(18, 32, 20480, 64, 1), (4, 96, 4096, 32, 1), (3, 256, 4096, 256, 0), (2, 160, 2048, 128, 1)])
 def test_input_gradient_gemm_with_the_next_layers_bn_backward_sums_on_its_epilogue(B, M, N, K, relu_next):
     """pa_tgemm_nn_bnred (train_gemm.hip / train_gemm_cm.hip STATS 2: dX = W^T . bn_bwd(dY, Y) with the BatchNorm-backward sums of the layer that
