@@ -34,8 +34,13 @@ agg = collections.OrderedDict()
 for kind, b, M, N, K, s, e in rec:
     key = (kind, b, M, N, K)
     a = agg.setdefault(key, [0, 0.0]); a[0] += 1; a[1] += s.elapsed_time(e)
+# the first contraction of the backward pass is bracketed by an event recorded before the autograd engine's thread has started feeding the stream:
+# its pair measures host time (tens of ms), not the kernel -- listed apart, not in the total
+host = {k: v for k, v in agg.items() if v[1] / v[0] > 20.0}
+for k in host:
+    del agg[k]
 tot = sum(v[1] for v in agg.values())
-print(f"{len(rec)} GEMM launches, {tot:.2f} ms")
+print(f"{len(rec)} GEMM launches, {tot:.2f} ms" + (f" (+ {len(host)} whose event pair timed the host: {[k[:5] for k in host]})" if host else ""))
 print(f"{'kind':28s} {'batch':>5s} {'M':>6s} {'N':>6s} {'K':>7s} {'n':>3s} {'us/call':>8s} {'TFLOP/s':>8s} {'GB/s':>7s}")
 for (kind, b, M, N, K), (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     us = ms / n * 1e3

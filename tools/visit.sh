@@ -1,5 +1,1 @@
-cd /root/repo
-timeout 900 python -m pytest tests/test_gpu_train_ops.py tests/test_gpu_head.py -m gpu -q -x 2>&1 | tail -3
-for i in 1 2; do python bench.py --config train --steps 30 --warmup 5 --no-pmc 2>/dev/null | python -c "
-import sys, json
-d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('step ms', d['ms_per_step'], d['roofline']['frac'])"; done
+bash tools/final_r05.sh
