@@ -17,3 +17,16 @@ def test_fuzz_family(family, capsys):
     ok = fuzz_gpu.run(family, fams[family], budget=4.0)
     out = capsys.readouterr().out
     assert ok, out
+
+
+def test_fuzz_training_gemm_on_lds_resident_weights():
+    """tools/fuzz_tgemm_cm.py, a seeded slice: random (batch, M, N, K) with every operand transform, both layouts of A, bias, beta, statistics and
+    the fused BatchNorm-backward sums through pa_tgemm_nn / pa_tgemm_nn_bnred on the LDS-resident-weights kernel, twice each, against the
+    LDS-tiled kernel.  (The fixed shapes of test_gpu_train_ops.py did not contain the one that exposed the store-data hazard of round 5.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_tgemm_cm.py"), "60", "11"], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "60 cases, 0 mismatches" in r.stdout, r.stdout[-2000:]
