@@ -412,11 +412,12 @@ int pa_tgemm_kk_rep(int batch, int M, int N, long K, const float *A, long sAb, i
 
 /* Adam over a list of fp32 tensors (csrc/adam.hip; torch.optim.Adam's arithmetic: amsgrad / maximize off, weight_decay as L2): pa_adam_tick
  * advances the device step counter (step[0] += 1), pa_adam_step updates ntensors contiguous tensors -- HOST arrays of device pointers
- * (parameter, gradient, exp_avg, exp_avg_sq) and element counts -- in ceil(ntensors / 84) launches; nothing host-side enters the arithmetic,
- * so a captured hipGraph replays it. */
+ * (parameter, gradient, exp_avg, exp_avg_sq) and element counts -- in ceil(ntensors / 84) launches.  step and lr are DEVICE scalars: no host
+ * value that changes from step to step enters the arithmetic, so a captured hipGraph replays it and a learning-rate schedule
+ * (train_place_recognition.py:531-568) reaches the graph by rewriting lr[0]. */
 int pa_adam_tick(float *step, pa_stream_t stream);
 int pa_adam_step(int ntensors, float *const *p, const float *const *g, float *const *m, float *const *v, const long *numel, const float *step,
-                 float lr, float beta1, float beta2, float eps, float weight_decay, pa_stream_t stream);
+                 const float *lr, float beta1, float beta2, float eps, float weight_decay, pa_stream_t stream);
 /* BatchNorm (training): statistics -> rows 0..3 of p, running statistics updated in place (momentum, unbiased variance) when given;
  * *num_batches_tracked += groups when given (torch.nn.BatchNorm's int64 counter, one forward pass per statistics group). */
 int pa_bn_finalize(int nch, int groups, double count, const double *stats, const float *gamma, const float *beta, float eps, float momentum,

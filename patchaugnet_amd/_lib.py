@@ -84,7 +84,7 @@ _SIGS = {
     "pa_tgemm_kk": "iiilpliipppliippliii",
     "pa_tgemm_kk_rep": "iiilpliipppliippipi",
     "pa_adam_tick": "p",
-    "pa_adam_step": "ippppppfffff",
+    "pa_adam_step": "ipppppppffff",
     "pa_bn_finalize": "iidpppffpppp",
     "pa_bn_bwd_reduce": "iilpppipi",
     "pa_tgemm_nn_bnred": "iiiipiipliippplippip",

@@ -15,6 +15,28 @@ void pa_set_error(const char *fmt, ...)
 }
 
 PA_API const char *pa_last_error(void) { return g_err; }
+
+// ---- stream-ordered fills as kernel launches (pa_common.h: why not hipMemset*Async)
+namespace {
+__global__ __launch_bounds__(256) void pa_fill32_kernel(unsigned *__restrict__ dst, size_t pitch_words, unsigned value, size_t words, size_t rows)
+{
+    const size_t total = words * rows;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / words, c = i - r * words;
+        dst[r * pitch_words + c] = value;
+    }
+}
+}  // namespace
+
+int pa_fill32_2d(void *dst, size_t pitch_words, unsigned value, size_t words, size_t rows, hipStream_t st)
+{
+    if (!dst || words == 0 || rows == 0) return PA_OK;
+    const size_t blocks = (words * rows + 255) / 256;
+    hipLaunchKernelGGL(pa_fill32_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, (unsigned *)dst, pitch_words, value, words, rows);
+    return hipGetLastError() == hipSuccess ? PA_OK : PA_EINVAL;
+}
+
+int pa_fill32(void *dst, unsigned value, size_t words, hipStream_t st) { return pa_fill32_2d(dst, words, value, words, 1, st); }
 PA_API int pa_abi_version(void) { return 1; }
 
 // ---- group 2: the reference's launcher symbols --------------------------------------------------------------

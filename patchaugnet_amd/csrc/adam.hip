@@ -26,7 +26,7 @@ struct AdamList {
 
 __global__ void adam_tick_kernel(float *step) { step[0] += 1.0f; }
 
-__global__ __launch_bounds__(256) void adam_kernel(AdamList L, const float *__restrict__ step, float lr, float b1, float b2, float eps, float wd)
+__global__ __launch_bounds__(256) void adam_kernel(AdamList L, const float *__restrict__ step, const float *__restrict__ lrp, float b1, float b2, float eps, float wd)
 {
     // the tensor of this workgroup: binary search over <= 85 block offsets (wave-uniform)
     int lo = 0, hi = L.count;
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamList L, const float *__re
     const float *__restrict__ g = L.g[t];
     float *__restrict__ m = L.m[t];
     float *__restrict__ v = L.v[t];
-    const float tt = step[0];
+    const float tt = step[0], lr = lrp[0];
     const float bc1 = 1.0f - powf(b1, tt), bc2 = 1.0f - powf(b2, tt);
     const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2);
     const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
@@ -82,11 +82,12 @@ PA_API int pa_adam_tick(float *step, pa_stream_t stream)
 }
 
 // One Adam update of ntensors fp32 tensors (HOST arrays of device pointers p / g / m / v and element counts numel; contiguous tensors); step: device
-// scalar holding t >= 1 (pa_adam_tick advances it).  ceil(ntensors / 84) launches.
+// scalar holding t >= 1 (pa_adam_tick advances it); lr: DEVICE scalar too -- a learning-rate schedule (train_place_recognition.py:531-568) then
+// reaches a captured hipGraph of the step by rewriting that scalar, not by re-capturing.  ceil(ntensors / 84) launches.
 PA_API int pa_adam_step(int ntensors, float *const *p, const float *const *g, float *const *m, float *const *v, const long *numel, const float *step,
-                        float lr, float beta1, float beta2, float eps, float weight_decay, pa_stream_t stream)
+                        const float *lr, float beta1, float beta2, float eps, float weight_decay, pa_stream_t stream)
 {
-    PA_REQUIRE(ntensors > 0 && p && g && m && v && numel && step, "pa_adam_step: bad arguments");
+    PA_REQUIRE(ntensors > 0 && p && g && m && v && numel && step && lr, "pa_adam_step: bad arguments");
     for (int t0 = 0; t0 < ntensors; t0 += AD_MAXT) {
         AdamList L;
         const int cnt = ntensors - t0 < AD_MAXT ? ntensors - t0 : AD_MAXT;

@@ -138,6 +138,24 @@ __global__ __launch_bounds__(256) void chamfer_l1_value_kernel(int np1, int np2,
 // number of per-workgroup partial sums one direction writes
 int partial_count(int B, int n, int m) { return m <= CT_TILE ? (int)pa_div_up((long)B * n, 256) : B * (int)pa_div_up(n, 256); }
 
+// grad_xyz1 (n1 floats) and grad_xyz2 (n2 floats) := 0 in ONE launch.  Not hipMemsetAsync: inside a captured hipGraph (train.GraphedTrainer) the two
+// memset nodes were not reliably ordered in front of the scatter kernels that accumulate into these buffers -- replays then added this step's
+// gradient to stale memory (|gradient| of 1e20 .. inf in the whole reconstruction branch, more often when an eager launch ran between replays;
+// tools/probes/dbg_perturb2.py).  A kernel node is.
+__global__ __launch_bounds__(256) void chamfer_zero2_kernel(float *__restrict__ a, long n1, float *__restrict__ b, long n2)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n1 + n2; i += (long)gridDim.x * 256) {
+        if (i < n1) a[i] = 0.f;
+        else b[i - n1] = 0.f;
+    }
+}
+
+void zero_two(float *a, long n1, float *b, long n2, hipStream_t st)
+{
+    const long blocks = pa_div_up(n1 + n2, 256);
+    hipLaunchKernelGGL(chamfer_zero2_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, a, n1, b, n2);
+}
+
 int one_direction(int B, int n, int m, const float *a, const float *bq, float *dist, int *idx, double *partial, hipStream_t st)
 {
     if (m <= CT_TILE) {
@@ -172,8 +190,7 @@ PA_API int pa_chamfer_backward(int B, int n, int m, const float *xyz1, const flo
     PA_REQUIRE(B > 0 && n > 0 && m > 0, "pa_chamfer_backward: B=%d n=%d m=%d must be positive", B, n, m);
     PA_REQUIRE(xyz1 && xyz2 && idx1 && idx2 && grad_dist1 && grad_dist2 && grad_xyz1 && grad_xyz2, "pa_chamfer_backward: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    (void)hipMemsetAsync(grad_xyz1, 0, sizeof(float) * (size_t)B * n * 3, st);  // chamfer.cu:212-213 (zeros_like)
-    (void)hipMemsetAsync(grad_xyz2, 0, sizeof(float) * (size_t)B * m * 3, st);
+    zero_two(grad_xyz1, (long)B * n * 3, grad_xyz2, (long)B * m * 3, st);      // chamfer.cu:212-213 (zeros_like)
     const long t1 = (long)B * n, t2 = (long)B * m;
     hipLaunchKernelGGL(chamfer_grad_kernel<false>, dim3(pa_div_up(t1, 256)), dim3(256), 0, st, t1, n, m, xyz1, xyz2, grad_dist1, idx1, grad_xyz1, grad_xyz2,
                        (const float *)nullptr, 0.f);
@@ -209,8 +226,7 @@ PA_API int pa_chamfer_l1_backward(int B, int n, int m, const float *xyz1, const 
     PA_REQUIRE(B > 0 && n > 0 && m > 0, "pa_chamfer_l1_backward: B=%d n=%d m=%d must be positive", B, n, m);
     PA_REQUIRE(xyz1 && xyz2 && idx1 && idx2 && dist1 && dist2 && gout && grad_xyz1 && grad_xyz2, "pa_chamfer_l1_backward: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    (void)hipMemsetAsync(grad_xyz1, 0, sizeof(float) * (size_t)B * n * 3, st);
-    (void)hipMemsetAsync(grad_xyz2, 0, sizeof(float) * (size_t)B * m * 3, st);
+    zero_two(grad_xyz1, (long)B * n * 3, grad_xyz2, (long)B * m * 3, st);
     const long t1 = (long)B * n, t2 = (long)B * m;
     hipLaunchKernelGGL(chamfer_grad_kernel<true>, dim3(pa_div_up(t1, 256)), dim3(256), 0, st, t1, n, m, xyz1, xyz2, dist1, idx1, grad_xyz1, grad_xyz2, gout,
                        0.25f / (float)t1);

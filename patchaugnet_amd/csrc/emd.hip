@@ -503,8 +503,8 @@ PA_API int pa_emd_forward(int b, int n, int m, const float *xyz1, const float *x
     if (G < 1) G = 1;
     while (G > 1 && n / G < 64) G >>= 1;
     // round state in every cloud's dist row (see the kernels): five words from int index n/2 -- zero them, stream-ordered
-    if (hipMemset2DAsync(dist + n / 2, (size_t)n * sizeof(float), 0, 5 * sizeof(int), (size_t)b, (hipStream_t)stream) != hipSuccess) {
-        pa_set_error("pa_emd_forward: hipMemset2DAsync failed");
+    if (pa_fill32_2d(dist + n / 2, (size_t)n, 0u, 5, (size_t)b, (hipStream_t)stream) != PA_OK) {      // a kernel, not a memset node (pa_common.h)
+        pa_set_error("pa_emd_forward: zero fill failed");
         return PA_EINVAL;
     }
     hipError_t e = hipFuncSetAttribute((const void *)emd_round_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);

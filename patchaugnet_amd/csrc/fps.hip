@@ -365,7 +365,7 @@ PA_API int pa_furthestsampling_range(int b, int n, int m, int j_begin, int j_end
 {
     PA_REQUIRE(temp && n <= 8192, "pa_furthestsampling_range: needs the running-minima buffer and n <= 8192 (n=%d)", n);
     PA_REQUIRE(j_begin >= 0 && j_begin < j_end && j_end <= m, "pa_furthestsampling_range: bad range [%d, %d) of %d", j_begin, j_end, m);
-    if (j_begin == 0 && hipMemsetD32Async((hipDeviceptr_t)temp, 0x501502f9u /* 1e10f */, (size_t)b * n, (hipStream_t)stream) != hipSuccess) {
+    if (j_begin == 0 && pa_fill32(temp, 0x501502f9u /* 1e10f */, (size_t)b * n, (hipStream_t)stream) != PA_OK) {      // a kernel, not a memset node (pa_common.h)
         pa_set_error("pa_furthestsampling_range: could not initialise temp");
         return PA_EINVAL;
     }

@@ -262,7 +262,7 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
         }
     } else if (atomic_pool) {
         PA_REQUIRE(split && (RTv == 1 || RTv == 2), "pa_mlp_chain: the atomic pooled epilogue is built for the shared-tile tilings (rows=%ld)", total_rows);
-        if (hipMemsetAsync(out, 0, (size_t)rows * ldo * sizeof(float), st) != hipSuccess) { pa_set_error("pa_mlp_chain: hipMemsetAsync failed"); return PA_EINVAL; }
+        if (pa_fill32(out, 0u, (size_t)rows * ldo, st) != PA_OK) { pa_set_error("pa_mlp_chain: zero fill failed"); return PA_EINVAL; }      // a kernel, not a memset node (pa_common.h)
         pa_chain_launch_split_sa(a, RTv, true, ntiles, st);
     } else if (split) {
         if (mode == MODE_PLAIN) pa_chain_launch_split_plain(a, RTv, ntiles, st);

@@ -35,6 +35,13 @@ void pa_set_error(const char *fmt, ...);
 
 static inline int pa_div_up(long a, long b) { return (int)((a + b - 1) / b); }
 
+/* dst[0 .. words) = value (32-bit words), or `rows` runs of `words` words `pitch_words` apart: a KERNEL launch (csrc/abi.hip).  Used instead of
+ * hipMemset*Async everywhere a launch sequence may be captured into a hipGraph: memset NODES of a captured graph were not reliably ordered in
+ * front of the kernel nodes that accumulate into the buffer (ROCm 7.2, MI355X: the patch-Chamfer gradient of train.GraphedTrainer came out as
+ * |g| = 1e20 .. inf in a fraction of the replays).  Kernel nodes are. */
+int pa_fill32(void *dst, unsigned value, size_t words, hipStream_t st);
+int pa_fill32_2d(void *dst, size_t pitch_words, unsigned value, size_t words, size_t rows, hipStream_t st);
+
 // libs/pointops/src/cuda_utils.h:15-18 -- the reference's block-size rule; it fixes the FPS
 // tie-break order, so it is computed with the same double-precision log ratio.
 static inline int pa_opt_n_threads(int work_size)

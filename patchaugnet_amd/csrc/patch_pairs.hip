@@ -119,8 +119,7 @@ PA_API int pa_patch_pairs_count(int nrec, const int *idx1, const int *near_off, 
     PA_REQUIRE(nrec > 0 && idx1 && near_off && far_off && center_m && center_n && scratch_inv && counts, "pa_patch_pairs_count: bad arguments");
     PA_REQUIRE(m0 > 0 && m0 <= 32 * PP_MAXW && npoints > 0, "pa_patch_pairs_count: centre lists of up to %d positions (got %d)", 32 * PP_MAXW, m0);
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(scratch_inv, 0x7f, sizeof(int) * 2 * (size_t)npoints, st);
-    if (e != hipSuccess) { pa_set_error("pa_patch_pairs_count: memset failed: %s", hipGetErrorString(e)); return (int)e; }
+    if (pa_fill32(scratch_inv, 0x7f7f7f7fu, 2 * (size_t)npoints, st) != PA_OK) { pa_set_error("pa_patch_pairs_count: fill failed"); return PA_EINVAL; }   // a kernel, not a memset node
     hipLaunchKernelGGL(pp_invmap_kernel, dim3(pa_div_up(m0, 256)), dim3(256), 0, st, npoints, m0, center_m, center_n, scratch_inv);
     hipLaunchKernelGGL(pp_record_kernel<false>, dim3(nrec), dim3(64), 0, st, nrec, idx1, near_off, near_v, far_off, far_v, npoints, m0, scratch_inv, 0ull, counts,
                        (const int *)nullptr, (int *)nullptr, (int *)nullptr, (int *)nullptr);

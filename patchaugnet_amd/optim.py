@@ -3,9 +3,13 @@
 
 Same hyper-parameters, same update rule and the same ``state_dict`` layout as ``torch.optim.Adam`` (per parameter: ``step``, ``exp_avg``,
 ``exp_avg_sq``), so checkpoints move both ways; ``amsgrad`` / ``maximize`` / ``foreach`` variants are not built (the reference uses none).
-The step counter lives on the device (one scalar per parameter group, shared by its parameters' ``state['step']``) and the tensor list
-travels in the kernel arguments: an optimizer step is ``1 + ceil(n / 84)`` launches with nothing host-side in the arithmetic, so
-``train.GraphedTrainer`` captures it like torch's ``capturable=True`` optimizers.  CPU parameters are refused (no fallback)."""
+The step counter and the learning rate live on the device (one scalar each per parameter group; the counter is shared by its parameters'
+``state['step']``) and the tensor list travels in the kernel arguments: an optimizer step is ``1 + ceil(n / 84)`` launches with nothing
+host-side that changes between steps in the arithmetic, so ``train.GraphedTrainer`` captures it like torch's ``capturable=True`` optimizers --
+and a learning-rate scheduler (train_place_recognition.py:531-568 steps one per epoch) still takes effect on the captured graph:
+``sync_hyperparameters()`` writes a changed ``param_groups[i]['lr']`` into the group's device scalar (``step()`` calls it when it is not
+being captured, ``GraphedTrainer.step`` calls it before every replay).  betas / eps / weight_decay are launch constants: changing them after
+a capture needs a new capture (``GraphedTrainer`` checks).  CPU parameters are refused (no fallback)."""
 import ctypes
 
 import torch
@@ -20,6 +24,7 @@ class Adam(torch.optim.Optimizer):
         # capturable / fused are accepted for signature compatibility with torch.optim.Adam call sites: this optimizer is always both
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=True, fused=True))
         self._step = {}          # group index -> the group's device step counter (kept out of param_groups: state_dict() copies those)
+        self._lr = {}            # group index -> (device scalar, the host value it holds)
         self._keep = {}          # group index -> gradient tensors of the launches in flight
 
     def _init_group(self, gi, group):
@@ -46,15 +51,35 @@ class Adam(torch.optim.Optimizer):
         return ps
 
     @torch.no_grad()
+    def sync_hyperparameters(self):
+        """Write every group's current ``lr`` into its device scalar if it changed (a scheduler stepped).  A no-op launch-wise otherwise; must not
+        be called while a hipGraph is being captured (the fill would be baked into the graph as a constant)."""
+        for gi, group in enumerate(self.param_groups):
+            ent = self._lr.get(gi)
+            if ent is None:
+                ps = [p for p in group["params"] if p.is_cuda]
+                if not ps:
+                    continue
+                ent = self._lr[gi] = [torch.full((), float(group["lr"]), dtype=torch.float32, device=ps[0].device), float(group["lr"])]
+            elif ent[1] != float(group["lr"]):
+                ent[0].fill_(float(group["lr"]))
+                ent[1] = float(group["lr"])
+
+    @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_hyperparameters()
         for gi, group in enumerate(self.param_groups):
             ps = self._init_group(gi, group)
             if ps is None:
                 continue
+            if gi not in self._lr:
+                raise RuntimeError("patchaugnet_amd.optim.Adam: first step of a parameter group inside a hipGraph capture; run one eager step (or "
+                                   "sync_hyperparameters()) before capturing")
             n = len(ps)
             grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
             arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
@@ -64,6 +89,6 @@ class Adam(torch.optim.Optimizer):
                 step = self._step[gi]
                 call("pa_adam_tick", ptr(step))
                 call("pa_adam_step", n, arr(ps), arr(grads), arr([self.state[p]["exp_avg"] for p in ps]), arr([self.state[p]["exp_avg_sq"] for p in ps]),
-                     numel, ptr(step), float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]))
+                     numel, ptr(step), ptr(self._lr[gi][0]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]))
             self._keep[gi] = grads                                 # the launches read these buffers asynchronously
         return loss

@@ -207,6 +207,7 @@ class GraphedTrainer:
         self._k = 0                                    # buffer set of the next step
         self._ready = None                             # (set, ids of the batch tensors) whose geometry the side stream has produced
         self._ev_side = None
+        self._captured_hyper = self._hyper()           # the launch constants the graphs were captured with (_check_hyperparameters)
         torch.cuda.synchronize(dev)
 
     def _set_perm_buffers(self, k):
@@ -254,6 +255,7 @@ class GraphedTrainer:
         The copies are asynchronous on the side stream: pinned host sources must stay untouched until that following call has been
         issued (pageable sources are staged by the runtime before the copy call returns)."""
         batch = (queries, positives, negatives, other_neg)
+        self._check_hyperparameters()
         if not self.prefetch:
             self._load(0, batch)
             self.graph.replay()
@@ -284,6 +286,26 @@ class GraphedTrainer:
         self._k = 1 - k
         self.losses = self.losses_k[k]
         return self.losses
+
+    def _hyper(self):
+        return [{k: v for k, v in g.items() if k != "params" and isinstance(v, (int, float, tuple, bool))} for g in self.optimizer.param_groups]
+
+    def _check_hyperparameters(self):
+        """A captured step replays the launch constants it was captured with.  An optimizer that keeps its learning rate on the device
+        (patchaugnet_amd.optim.Adam) takes a scheduler's new value here; any other hyper-parameter that changed since the capture -- or a
+        changed learning rate of an optimizer without that hook (torch's capturable Adam with a float lr) -- would be silently ignored by the
+        replay, so it raises instead."""
+        now = self._hyper()
+        if now == self._captured_hyper:
+            return
+        sync = getattr(self.optimizer, "sync_hyperparameters", None)
+        for a, b in zip(now, self._captured_hyper):
+            changed = {k for k in set(a) | set(b) if a.get(k) != b.get(k)}
+            if changed - ({"lr"} if sync is not None else set()):
+                raise RuntimeError(f"GraphedTrainer: optimizer hyper-parameters {sorted(changed)} changed after the step was captured; the replay "
+                                   "would ignore them -- build a new GraphedTrainer (patchaugnet_amd.optim.Adam follows a changed lr without that)")
+        sync()
+        self._captured_hyper = now
 
     def close(self):
         """Nothing to undo on the model (the permutation buffers are the trainer's own); kept for symmetry with GraphedExtractor."""

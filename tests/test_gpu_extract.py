@@ -282,3 +282,30 @@ def test_graphed_extractor_with_shared_resident_input_refuses_foreign_tensors():
         torch.cuda.synchronize()
         for o, r in zip(outs, (ref_x, ref_o, ref_x, ref_o, ref_o)):
             assert torch.equal(o, r)
+
+
+def test_graphed_extractor_distinct_batches_with_eager_work_between_replays():
+    """Batch 32 (the headline shape: the set-abstraction tiling whose max-pool is an atomic max into a zero-filled output), a DIFFERENT batch per
+    replay, and eager launches / allocations / read-backs between replays: every replay must equal the plain forward of its batch bit for bit.
+    The zero fill in front of the atomic max is a kernel launch (csrc/abi.hip pa_fill32), not a hipMemsetAsync node: memset nodes of a captured
+    graph were found not to be reliably ordered in front of the kernels that accumulate into the buffer (tests/test_gpu_train_ops.py:
+    test_graphed_training_step_with_eager_launches_between_replays) -- a stale output would carry the PREVIOUS batch's maxima into this one."""
+    from patchaugnet_amd.extract import GraphedExtractor
+    m = _model("patch_aug_net")
+    xs = [synthetic_submaps(32, 4096, 70 + i, "street" if i % 3 == 0 else "uniform").cuda() for i in range(10)]
+    with torch.no_grad():
+        ref = [m(x, return_feat=False).clone() for x in xs]
+    gx = GraphedExtractor(m, (32, 1, 4096, 3), n_streams=2)
+    out = torch.empty(10, 32, 256, device="cuda")
+    scratch = torch.empty(1 << 20, device="cuda")
+    gx.begin()
+    for i, x in enumerate(xs):
+        gx.run(x, out=out[i])
+        scratch.fill_(float(i))
+        junk = torch.full((1 << 22,), float("nan"), device="cuda")
+        float(scratch[0])
+        del junk
+    gx.end()
+    torch.cuda.synchronize()
+    for i in range(10):
+        assert torch.equal(out[i], ref[i]), i

@@ -266,3 +266,50 @@ def test_hip_adam_matches_torch_adam(wd):
         bad = torch.nn.Parameter(torch.zeros(4))
         bad.grad = torch.zeros(4)
         Adam([bad]).step()
+
+
+def test_hip_adam_follows_a_learning_rate_schedule_eagerly_and_under_graph_replay():
+    """A learning-rate scheduler (train_place_recognition.py:531-568: StepLR / CosineAnnealingLR stepping per epoch) on patchaugnet_amd.optim.Adam:
+    the learning rate is a device scalar, so (a) eager steps match torch.optim.Adam under the same StepLR, (b) a hipGraph captured around
+    optimizer.step() applies a LATER learning rate once sync_hyperparameters() has run (what train.GraphedTrainer.step does before a replay) --
+    with a launch-constant learning rate the replay would keep the captured one."""
+    from patchaugnet_amd.optim import Adam
+    g = torch.Generator().manual_seed(9)
+    base = [torch.randn(n, generator=g) for n in (1000, 33, 4097)]
+    pa = [torch.nn.Parameter(t.clone().cuda()) for t in base]
+    pb = [torch.nn.Parameter(t.clone().cuda()) for t in base]
+    oa, ob = Adam(pa, lr=1e-2), torch.optim.Adam(pb, lr=1e-2)
+    sa, sb = torch.optim.lr_scheduler.StepLR(oa, step_size=2, gamma=0.1), torch.optim.lr_scheduler.StepLR(ob, step_size=2, gamma=0.1)
+    grads = [[torch.randn(t.shape, generator=g).cuda() for t in base] for _ in range(6)]
+    for step in range(6):
+        for x, y, gr in zip(pa, pb, grads[step]):
+            x.grad, y.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step(); sa.step(); sb.step()
+    for x, y in zip(pa, pb):
+        assert torch.allclose(x, y, rtol=2e-5, atol=2e-6)
+    assert abs(oa.param_groups[0]["lr"] - 1e-5) < 1e-12
+    # (b) capture one optimizer step on static gradients, then change lr and replay
+    pc = [torch.nn.Parameter(t.clone().cuda()) for t in base]
+    pd = [torch.nn.Parameter(t.clone().cuda()) for t in base]
+    oc, od = Adam(pc, lr=1e-2), torch.optim.Adam(pd, lr=1e-2)
+    for x, gr in zip(pc, grads[0]):
+        x.grad = gr.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        oc.step()                                       # state and device scalars exist before the capture
+    torch.cuda.current_stream().wait_stream(side)
+    gph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gph):
+        oc.step()
+    for x, gr in zip(pd, grads[0]):
+        x.grad = gr.clone()
+    od.step(); od.step()                                # the eager step + the captured one (capture does not execute; replay below does)
+    gph.replay()
+    oc.param_groups[0]["lr"] = od.param_groups[0]["lr"] = 1e-3
+    oc.sync_hyperparameters()
+    gph.replay()
+    od.step()
+    torch.cuda.synchronize()
+    for x, y in zip(pc, pd):
+        assert torch.allclose(x, y, rtol=2e-5, atol=2e-6), (x - y).abs().max().item()

@@ -395,6 +395,94 @@ def test_graphed_training_step_equals_the_eager_step():
         tr.close()
 
 
+def test_graphed_training_step_with_eager_launches_between_replays():
+    """Two replays of the captured step at learning rate 0 (same weights, same inputs, same kNN permutation) must produce the same parameter
+    gradients -- also when other work (allocations, a fill launch, a device-to-host read: what any real loop does between steps) runs on the
+    stream between them.  Until round 5 the patch-Chamfer backward zeroed its accumulation targets with hipMemsetAsync; as memset NODES of the
+    captured graph those were not reliably ordered in front of the scatter kernels, and a fraction of the replays accumulated onto stale memory:
+    |gradient| of 1e20 .. inf through the whole reconstruction branch (decoder, coarse FP levels, every SA level)."""
+    import copy
+    from patchaugnet_amd import configs, patch_aug_net
+    from patchaugnet_amd.train import DEFAULTS, GraphedTrainer
+    from patchaugnet_amd.weights import seeded_state_dict
+    n = 1024
+    cfg = configs.scaled_config(configs.patch_aug_net_config(), n)
+    m = patch_aug_net.Network(param=cfg, use_a2a_recon=True, use_l2_norm=True)
+    m.load_state_dict(seeded_state_dict(m.state_dict()))
+    m = m.cuda()
+    g = torch.Generator().manual_seed(5)
+    batch = tuple((torch.rand(1, k, n, 3, generator=g) * 2 - 1).cuda() for k in (1, 2, 4, 1))
+    opt = torch.optim.SGD(m.parameters(), lr=0.0)
+    tr = GraphedTrainer(m, opt, *batch, {(0, 1): None, (0, 2): None}, num_points=n, args=dict(DEFAULTS, TRAIN_NEGATIVES_PER_QUERY=4), warmup=2)
+    scratch = torch.empty(1 << 20, device="cuda")
+    torch.manual_seed(1)
+    tr.step(*batch)
+    torch.cuda.synchronize()
+    ref = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    for rep in range(6):
+        scratch.fill_(float(rep))                                               # an eager launch ...
+        junk = [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(8)]      # ... allocations whose content must never be seen ...
+        float(scratch[0])                                                       # ... and a read-back between replays
+        del junk
+        torch.manual_seed(1)
+        tr.step(*batch)
+        torch.cuda.synchronize()
+        for k, p in m.named_parameters():
+            if k in ref:
+                a, b = ref[k], p.grad
+                assert torch.isfinite(b).all(), (rep, k)
+                assert (a - b).norm().item() <= 2e-2 * max(a.norm().item(), 1e-3), (rep, k, a.norm().item(), (a - b).norm().item())
+    tr.close()
+
+
+def test_graphed_trainer_and_changed_optimizer_hyperparameters():
+    """A captured step replays its launch constants.  With patchaugnet_amd.optim.Adam (learning rate in a device scalar) a scheduler's new
+    learning rate takes effect on the next replay: after lr -> 0 a step leaves the weights where they were.  With torch's capturable Adam
+    (float lr baked into the captured launches) the same change raises instead of being ignored, and so does a changed beta on either."""
+    import copy
+    from patchaugnet_amd import configs, patch_aug_net
+    from patchaugnet_amd.optim import Adam
+    from patchaugnet_amd.train import DEFAULTS, GraphedTrainer
+    from patchaugnet_amd.weights import seeded_state_dict
+    n = 1024
+    cfg = configs.scaled_config(configs.patch_aug_net_config(), n)
+    base = patch_aug_net.Network(param=cfg, use_a2a_recon=True, use_l2_norm=True)
+    base.load_state_dict(seeded_state_dict(base.state_dict()))
+    base = base.cuda()
+    g = torch.Generator().manual_seed(5)
+    batch = tuple((torch.rand(1, k, n, 3, generator=g) * 2 - 1).cuda() for k in (1, 2, 4, 1))
+    nn_dict = {(0, 1): None, (0, 2): None}
+    args = dict(DEFAULTS, TRAIN_NEGATIVES_PER_QUERY=4)
+    m = copy.deepcopy(base)
+    opt = Adam(m.parameters(), lr=1e-3)
+    tr = GraphedTrainer(m, opt, *batch, nn_dict, num_points=n, args=args, warmup=2)
+    tr.step(*batch)
+    torch.cuda.synchronize()
+    w = {k: v.clone() for k, v in m.state_dict().items() if v.dtype == torch.float32 and "running" not in k}
+    tr.step(*batch)
+    torch.cuda.synchronize()
+    moved = max((m.state_dict()[k] - w[k]).abs().max().item() for k in w)
+    assert moved > 1e-5                                                         # lr = 1e-3: the step moves the weights
+    opt.param_groups[0]["lr"] = 0.0                                             # what a scheduler does
+    w = {k: v.clone() for k, v in m.state_dict().items() if k in w}
+    tr.step(*batch)
+    torch.cuda.synchronize()
+    diffs = {k: (m.state_dict()[k] - w[k]).abs().max().item() for k in w}
+    assert all(d == 0.0 for d in diffs.values()), {k: d for k, d in diffs.items() if d != 0.0}     # the replay used the new learning rate
+    opt.param_groups[0]["betas"] = (0.5, 0.999)
+    with pytest.raises(RuntimeError):
+        tr.step(*batch)
+    tr.close()
+    m2 = copy.deepcopy(base)
+    opt2 = torch.optim.Adam(m2.parameters(), lr=1e-3, capturable=True)
+    tr2 = GraphedTrainer(m2, opt2, *batch, nn_dict, num_points=n, args=args, warmup=2)
+    tr2.step(*batch)
+    opt2.param_groups[0]["lr"] = 1e-4
+    with pytest.raises(RuntimeError):
+        tr2.step(*batch)
+    tr2.close()
+
+
 def test_graphed_trainer_with_geometry_prefetch_equals_the_eager_steps():
     """GraphedTrainer(prefetch=True): sampling / neighbour search / 3-NN of the NEXT batch replayed on a side stream under the current step,
     two buffer sets alternating.  Three SGD steps on three different batches against train.training_step from the same weights; the host
