@@ -153,7 +153,10 @@ class GraphedTrainer:
         """prefetch=True: sampling, neighbour search and 3-NN weights -- everything that depends on the coordinates but not on the weights,
         ~1 ms of an 8 ms step, most of it the serial furthest point sampling on 18 CUs -- are captured as a SECOND graph and replayed for the
         NEXT batch on a side stream while the current batch trains (``step(..., next_batch=...)``); two buffer sets alternate.  The step
-        graph then starts from the prefetched indices.  Same arithmetic, same losses and parameters as prefetch=False."""
+        graph then starts from the prefetched indices.  Same arithmetic, same losses and parameters as prefetch=False.  Each buffer set's graph
+        owns its gradient tensors and its optimizer launches read exactly those; ``p.grad`` keeps referencing the tensors of the set captured
+        LAST, so code that inspects ``p.grad`` between steps (logging, clipping) sees every second step's gradients only -- such code belongs
+        in the captured body or with prefetch=False."""
         from . import pointops
         self.model, self.optimizer, self.args, self.num_points = model, optimizer, dict(args), num_points
         self.nn_dict = nn_dict
