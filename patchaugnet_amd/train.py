@@ -246,8 +246,12 @@ class GraphedTrainer:
     def _load(self, k, batch):
         for dst, src in zip(self.statics[k], batch):
             dst.copy_(_as_tensor(src), non_blocking=True)
-        for g, buf in zip(self.groupers, self._perm_sets[k]):
-            buf.copy_(torch.randperm(g.nsample), non_blocking=True)
+        # the host permutations are pageable temporaries: kept referenced until this set is loaded again, so that an asynchronous copy that has
+        # not been staged yet can never read freed host memory (whatever the runtime's staging policy for small unpinned copies is)
+        host = [torch.randperm(g.nsample) for g in self.groupers]
+        for hp, buf in zip(host, self._perm_sets[k]):
+            buf.copy_(hp, non_blocking=True)
+        self.__dict__.setdefault("_perm_host", {})[k] = host
 
     def step(self, queries, positives, negatives, other_neg, next_batch=None):
         """Copy the batch into the graph's input buffers, draw the step's kNN permutations, replay.  Returns the dict of weighted losses
