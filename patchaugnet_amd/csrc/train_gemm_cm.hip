@@ -423,7 +423,9 @@ int pa_tgemm_cm_try(int batch, int M, int N, int K, const float *A, long sAb, in
                     double *stats, int per_batch_stats, hipStream_t st, const float *ynext, const float *pnext, int relu_next, double *sums_next)
 {
     static const bool off = getenv("PA_TGEMM_NO_CM") != nullptr;
-    static const long min_tiles = getenv("PA_TGEMM_CM_MIN_TILES") ? atol(getenv("PA_TGEMM_CM_MIN_TILES")) : 1024;
+    // (default from a sweep of the whole training step after the round-5 epilogue work, 1024 / 512 / 256 / 128 / 32: 4.778 / 4.765 / 4.743 / 4.722 /
+    // 4.730 ms -- the kernel's launch cost fell, so it now also wins on the N = 128 .. 320 levels it used to leave to the LDS-tiled kernel)
+    static const long min_tiles = getenv("PA_TGEMM_CM_MIN_TILES") ? atol(getenv("PA_TGEMM_CM_MIN_TILES")) : 128;
     if (g_tgemm_cm == 0 || (g_tgemm_cm < 0 && off)) return 0;
     if (act != 0 || (beta && (stats || sums_next)) || colv || sAb != 0 || (per_batch_stats && (bmode || stats)) || (stats && bmode >= 2)) return 0;
     if (sums_next && (bmode < 2 || stats || per_batch_stats || !ynext || !pnext || !aligned16(ynext))) return 0;
