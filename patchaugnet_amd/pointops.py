@@ -51,20 +51,22 @@ class FurthestSampling(Function):
 furthestsampling = FurthestSampling.apply
 
 
-@torch.no_grad()
 def furthestsampling_gather(xyz, m):
     """(idx (b,m) int32, new_xyz (b,m,3)): furthestsampling plus the gathering of the sampled coordinates (patch_aug_net.py:222-225) as the one launch
-    the inference engine uses (pa_furthestsampling_gather: running minima in registers, no temp tensor).  Coordinates carry no gradient here."""
+    the inference engine uses (pa_furthestsampling_gather: running minima in registers, no temp tensor).  When the coordinates carry a gradient
+    (train.run_model(input_grad=True): the reference's feed.requires_grad_) the two differentiable ops run instead -- new_xyz feeds the centred
+    neighbour coordinates, so d loss / d xyz has a term through it."""
     check_device(xyz)
     b, n, _ = xyz.shape
-    if n > 8192 or xyz.dtype != torch.float32:
+    if n > 8192 or xyz.dtype != torch.float32 or (torch.is_grad_enabled() and xyz.requires_grad):
         idx = furthestsampling(xyz, m)
         return idx, gathering(xyz.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
-    xyz = xyz.contiguous()
-    idx = _new(xyz, (b, m), torch.int32)
-    new_xyz = _new(xyz, (b, m, 3), torch.float32)
-    with _guard(xyz):
-        call("pa_furthestsampling_gather", b, n, m, ptr(xyz), ptr(idx), ptr(new_xyz))
+    with torch.no_grad():
+        xyz = xyz.contiguous()
+        idx = _new(xyz, (b, m), torch.int32)
+        new_xyz = _new(xyz, (b, m, 3), torch.float32)
+        with _guard(xyz):
+            call("pa_furthestsampling_gather", b, n, m, ptr(xyz), ptr(idx), ptr(new_xyz))
     return idx, new_xyz
 
 

@@ -246,3 +246,24 @@ def test_coordinate_only_geometry_ops_equal_the_unfused_statements(b, n, m, k):
         ref = torch.gather(table.unsqueeze(1).expand(-1, ix.shape[1], -1), -1, ix.long()) if ix.dim() == 3 else torch.gather(table, -1, ix.long())
         got = P.compose_indices(table, ix)
         assert got.dtype == torch.int32 and torch.equal(got, ref)
+
+
+def test_sampled_centres_keep_their_gradient_path_when_the_coordinates_need_one():
+    """furthestsampling_gather is one no-gradient launch for plain inputs, but with coordinates that require a gradient (train.run_model(...,
+    input_grad=True): the reference's feed.requires_grad_, train_place_recognition.py:155) the sampled centres must stay differentiable: they
+    enter the centred neighbour coordinates.  d sum(new_xyz) / d xyz = 1 on the sampled rows, 0 elsewhere; same indices either way."""
+    from patchaugnet_amd import pointops as P
+    g = torch.Generator().manual_seed(2)
+    xyz = (torch.rand(3, 500, 3, generator=g) * 2 - 1).cuda()
+    ci0, nx0 = P.furthestsampling_gather(xyz, 64)
+    assert nx0.grad_fn is None and not nx0.requires_grad
+    xg = xyz.clone().requires_grad_(True)
+    ci, nx = P.furthestsampling_gather(xg, 64)
+    assert torch.equal(ci, ci0) and torch.equal(nx.detach(), nx0) and nx.requires_grad
+    nx.sum().backward()
+    want = torch.zeros_like(xyz)
+    want.scatter_(1, ci.long().unsqueeze(-1).expand(-1, -1, 3), 1.0)
+    assert torch.equal(xg.grad, want)
+    with torch.no_grad():
+        _, nx2 = P.furthestsampling_gather(xg, 64)
+    assert not nx2.requires_grad
