@@ -1,3 +1,2 @@
 cd /root/repo
-timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -4 > gpurun_out/r05i_gpu_tests.log; tail -1 gpurun_out/r05i_gpu_tests.log
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+timeout 900 python tools/probes/train_soak.py 300 2>&1 | grep -v amdgpu.ids | tail -3 | cut -c1-1200
