@@ -441,6 +441,10 @@ int pa_bn_bwd_finalize(int nch, int groups, double count, const double *sums, fl
  * out (B, C, P/pool) and arg (int8 winning slot, first maximum).  pa_maxpool_bwd scatters a pooled gradient back: rows = B*C. */
 int pa_bn_apply(int B, int C, long P, int pool, int relu, const float *y, const float *p, float *out, signed char *arg, int per_batch_stats, pa_stream_t stream);
 int pa_maxpool_bwd(int rows, long Pout, int pool, const float *gp, const signed char *arg, float *g, pa_stream_t stream);
+/* pa_maxpool_bwd plus the pooled layer's pa_bn_bwd_reduce in one launch: the BatchNorm-backward sums (2 x C doubles, accumulated) come from the
+ * Pout pooled gradients and the raw outputs y (B, C, Pout * pool) at their arg-max positions -- the dense (gradient, output) pair is not read. */
+int pa_maxpool_bwd_bnred(int B, int C, long Pout, int pool, const float *gp, const signed char *arg, float *g, const float *y, const float *p, int relu,
+                         double *sums, pa_stream_t stream);
 
 /* ---- Descriptor losses of the training step in one launch (csrc/losses.hip; losses/pointnetvlad_loss.py:18-45, :53-105): value and gradient.
  * desc (b, 1 + p + nn + 1, d): per tuple the query, p positives, nn negatives, the other negative.  quad != 0: quadruplet_loss, else

@@ -105,6 +105,7 @@ _SIGS = {
     "pa_bn_bwd_finalize": "iidpppp",
     "pa_bn_apply": "iiliippppi",
     "pa_maxpool_bwd": "ilippp",
+    "pa_maxpool_bwd_bnred": "iilipppppip",
     "pa_knn_mfma_select": "pliiiippppiippp",
     "pa_patch_pairs_count": "ipppppiipppp",
     "pa_patch_pairs_fill": "ipppppiipqpppp",

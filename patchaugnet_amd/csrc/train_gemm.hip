@@ -862,6 +862,46 @@ __global__ __launch_bounds__(256) void maxpool_bwd_vec_kernel(long Pout, int poo
         }
 }
 
+// maxpool_bwd with the pooled layer's BatchNorm-backward sums on the way: the scattered gradient is zero except at the arg-max position of every
+// pooled point, so   sum_P mask(g) = sum_j mask_j gp[j],   sum_P mask(g) xhat = sum_j mask_j gp[j] xhat(y[j pool + arg[j]])
+// -- Pout gathered values of y per row instead of bn_bwd_reduce_kernel's pass over the dense (g, y) pair (pool = 20: a twentieth of 2 x 94 MB at
+// the first set-abstraction level).  grid (chunks of Pout, C, B) like the dense reduce; one fp64 atomic pair per workgroup.
+template <bool RELU, bool VEC>
+__global__ __launch_bounds__(256) void maxpool_bwd_bnred_kernel(int C, long Pout, int pool, const float *__restrict__ gp, const signed char *__restrict__ arg,
+                                                                  float *__restrict__ g, const float *__restrict__ y, const float *__restrict__ p,
+                                                                  double *__restrict__ sums)
+{
+    __shared__ float red[8];
+    const int c = blockIdx.y, b = blockIdx.z;
+    const float scale = p[c], shift = p[C + c], mean = p[2 * C + c], rstd = p[3 * C + c];
+    const size_t row = (size_t)b * C + c;
+    float s1 = 0.f, s2 = 0.f;
+    for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < Pout; j += (long)gridDim.x * 256) {
+        const float v = gp[row * Pout + j];
+        const int a = arg[row * Pout + j];
+        const size_t o = (row * Pout + j) * pool;
+        if (VEC) {
+            float4 *dst = reinterpret_cast<float4 *>(g + o);
+            for (int q = 0; q < pool / 4; ++q)
+                dst[q] = make_float4(4 * q == a ? v : 0.f, 4 * q + 1 == a ? v : 0.f, 4 * q + 2 == a ? v : 0.f, 4 * q + 3 == a ? v : 0.f);
+        } else {
+            for (int q = 0; q < pool; ++q) g[o + q] = q == a ? v : 0.f;
+        }
+        const float yy = y[o + a];
+        const float gm = (!RELU || fmaf(yy, scale, shift) > 0.f) ? v : 0.f;
+        s1 += gm;
+        s2 += gm * ((yy - mean) * rstd);
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s1; red[4 + (threadIdx.x >> 6)] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(sums + c, (double)((red[0] + red[1]) + (red[2] + red[3])));
+        atomicAdd(sums + C + c, (double)((red[4] + red[5]) + (red[6] + red[7])));
+    }
+}
+
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 TOp make_top(int mode, const float *aux, const float *p, int nch)
@@ -1069,6 +1109,26 @@ PA_API int pa_bn_bwd_reduce(int B, int C, long P, const float *g, const float *y
     if (relu) hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, C, P, g, y, p, sums, vec, sPb, sSumb);
     else hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, C, P, g, y, p, sums, vec, sPb, sSumb);
     PA_CHECK_LAUNCH("pa_bn_bwd_reduce");
+    return PA_OK;
+}
+
+// pa_maxpool_bwd(B * C, Pout, pool, gp, arg, g) together with pa_bn_bwd_reduce(B, C, Pout * pool, g, y, p, relu, sums) of the pooled layer: the sums
+// come from the Pout pooled gradients and the raw outputs at their arg-max positions (the dense pair is not read).  y (B, C, Pout * pool) raw layer
+// output, p its 7 x C parameter block, sums 2 x C doubles (accumulated: zero-filled by the caller).
+PA_API int pa_maxpool_bwd_bnred(int B, int C, long Pout, int pool, const float *gp, const signed char *arg, float *g, const float *y, const float *p, int relu,
+                                double *sums, pa_stream_t stream)
+{
+    PA_REQUIRE(B > 0 && C > 0 && Pout > 0 && pool > 0 && pool <= 127 && gp && arg && g && y && p && sums && B <= 65535 && C <= 65535, "pa_maxpool_bwd_bnred: bad arguments");
+    long chunks = (Pout + 1023) / 1024;                          // four pooled points per thread
+    if (chunks > 64) chunks = 64;
+    const dim3 grid((unsigned)chunks, (unsigned)C, (unsigned)B);
+    const bool vec = pool % 4 == 0 && aligned16(g);
+    hipStream_t st = (hipStream_t)stream;
+#define PA_MPB(R, V) hipLaunchKernelGGL((maxpool_bwd_bnred_kernel<R, V>), grid, dim3(256), 0, st, C, Pout, pool, gp, arg, g, y, p, sums)
+    if (relu) { if (vec) PA_MPB(true, true); else PA_MPB(true, false); }
+    else { if (vec) PA_MPB(false, true); else PA_MPB(false, false); }
+#undef PA_MPB
+    PA_CHECK_LAUNCH("pa_maxpool_bwd_bnred");
     return PA_OK;
 }
 

@@ -169,12 +169,17 @@ class _ChainTrain(Function):
         for o in outs:
             so.append(so[-1] + G * 2 * o)
         with _guard(x):
+            reduced = False          # this layer's BatchNorm-backward sums already rode on the launch that produced its activation gradient
             if pool:
                 O = outs[-1]
                 full = torch.empty((B, O, P), dtype=torch.float32, device=dev)
-                call("pa_maxpool_bwd", B * O, P // pool, int(pool), ptr(g), ptr(arg), ptr(full))
+                if groups:
+                    call("pa_maxpool_bwd", B * O, P // pool, int(pool), ptr(g), ptr(arg), ptr(full))
+                else:        # ... here: the pooled gradient is zero off the arg-max positions, so the last layer's sums need only those
+                    call("pa_maxpool_bwd_bnred", B, O, P // pool, int(pool), ptr(g), ptr(arg), ptr(full), ptr(ys[-1]), ptr(ps[-1]), int(layers[-1].relu),
+                         ptr(sums_all[so[-2]:so[-1]]))
+                    reduced = True
                 g = full
-            reduced = False          # this layer's BatchNorm-backward sums already rode on the contraction that produced its activation gradient
             for i in range(len(layers) - 1, -1, -1):
                 L, W, y, p = layers[i], Ws[i], ys[i], ps[i]
                 O, C = outs[i], ins[i]

@@ -132,6 +132,29 @@ def test_tgemm_kk(M, N, K, batch, amode, bmode):
         assert err <= 2e-5 * max(scale, 1.0) + 2e-7 * K, (per_batch, err, scale)
 
 
+@pytest.mark.parametrize("B,C,Pout,pool,relu", [(18, 64, 1024, 20, 1), (3, 256, 128, 20, 1), (2, 5, 37, 3, 0), (2, 32, 300, 16, 1)])
+def test_maxpool_backward_with_the_pooled_layers_bn_backward_sums(B, C, Pout, pool, relu):
+    """pa_maxpool_bwd_bnred (the scatter of the pooled gradient + the pooled layer's BatchNorm-backward sums from the Pout pooled gradients and the
+    raw outputs at their arg-max positions) against the pair it replaces: pa_maxpool_bwd, then pa_bn_bwd_reduce over the dense (gradient, raw
+    output) tensors -- the scattered gradient bit for bit, the sums to fp64 summation order."""
+    from patchaugnet_amd._lib import call, ptr
+    g = torch.Generator().manual_seed(B * 100 + C + Pout)
+    gp = torch.randn(B, C, Pout, generator=g).cuda()
+    arg = torch.randint(0, pool, (B, C, Pout), generator=g).to(torch.int8).cuda()
+    y = torch.randn(B, C, Pout * pool, generator=g).cuda()
+    p = _p_block(C, g).cuda().contiguous()
+    full0 = torch.empty(B, C, Pout * pool, device="cuda")
+    call("pa_maxpool_bwd", B * C, Pout, pool, ptr(gp), ptr(arg), ptr(full0))
+    s0 = torch.zeros(2 * C, dtype=torch.float64, device="cuda")
+    call("pa_bn_bwd_reduce", B, C, Pout * pool, ptr(full0), ptr(y), ptr(p), relu, ptr(s0), 0)
+    full1 = torch.full((B, C, Pout * pool), 9.0, device="cuda")
+    s1 = torch.zeros(2 * C, dtype=torch.float64, device="cuda")
+    call("pa_maxpool_bwd_bnred", B, C, Pout, pool, ptr(gp), ptr(arg), ptr(full1), ptr(y), ptr(p), relu, ptr(s1))
+    torch.cuda.synchronize()
+    assert torch.equal(full0, full1)
+    assert torch.allclose(s0, s1, rtol=1e-5, atol=1e-4 * (B * Pout) ** 0.5), (s0 - s1).abs().max()
+
+
 def _grads(mod, x, fn, gout_seed=3):
     for p in mod.parameters():
         p.grad = None
