@@ -223,9 +223,11 @@ __global__ __launch_bounds__(NT) void knn_quad_kernel(int n, int m, int q_per_bl
         // (x, y) as one packed subtract / multiply on the register pair the LDS read delivers, z scalar: the same IEEE operations in the same order
         // (dx*dx + dy*dy) + dz*dz; left to itself the compiler pairs components of TWO candidates and spends nine v_mov per trip assembling them
         typedef float kq_f2 __attribute__((ext_vector_type(2)));
-        const kq_f2 qxy = (kq_f2){qx, qy};
+        // the subtraction as a plain packed add of the negated query, p + (-q) = -(q - p) exactly and the square drops the sign: no operand modifiers on
+        // packed fp32 (pa_common.h, pa_pk_plain)
+        const kq_f2 nqxy = pa_pk_plain((kq_f2){-qx, -qy});
         auto dist = [&](const float4 &p) {                                                                                       // :31
-            kq_f2 d = qxy - (kq_f2){p.x, p.y};
+            kq_f2 d = (kq_f2){p.x, p.y} + nqxy;
             d = d * d;
             const float dz = qz - p.z;
             return (d.x + d.y) + dz * dz;

@@ -284,14 +284,16 @@ def test_graphed_extractor_with_shared_resident_input_refuses_foreign_tensors():
             assert torch.equal(o, r)
 
 
-def test_graphed_extractor_distinct_batches_with_eager_work_between_replays():
+@pytest.mark.parametrize("name,dtype", [("patch_aug_net", "f32"), ("pptnet", "f32"), ("pptnet", "f16"), ("patch_aug_net", "f16")])
+def test_graphed_extractor_distinct_batches_with_eager_work_between_replays(name, dtype):
     """Batch 32 (the headline shape: the set-abstraction tiling whose max-pool is an atomic max into a zero-filled output), a DIFFERENT batch per
     replay, and eager launches / allocations / read-backs between replays: every replay must equal the plain forward of its batch bit for bit.
     The zero fill in front of the atomic max is a kernel launch (csrc/abi.hip pa_fill32), not a hipMemsetAsync node: memset nodes of a captured
     graph were found not to be reliably ordered in front of the kernels that accumulate into the buffer (tests/test_gpu_train_ops.py:
     test_graphed_training_step_with_eager_launches_between_replays) -- a stale output would carry the PREVIOUS batch's maxima into this one."""
     from patchaugnet_amd.extract import GraphedExtractor
-    m = _model("patch_aug_net")
+    m = _model(name)
+    m.mlp_dtype = dtype
     xs = [synthetic_submaps(32, 4096, 70 + i, "street" if i % 3 == 0 else "uniform").cuda() for i in range(10)]
     with torch.no_grad():
         ref = [m(x, return_feat=False).clone() for x in xs]
