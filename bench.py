@@ -88,13 +88,14 @@ def grouping_roofline():
 
 # The sampling round's latency model (latency-bound kernels report achieved time against a stated model).
 # fps_reg_kernel<256,16> is one workgroup (4 wavefronts, one per SIMD) per cloud running m - 1 strictly serial rounds; a round of the shipped ISA
-# (hipcc --cuda-device-only -S csrc/fps.hip) is 128 VALU instructions for the 16 points of a lane (8 pair blocks: 3 v_pk_add + 3 v_pk_mul + 2 v_pk_add,
+# (hipcc --cuda-device-only -S csrc/fps.hip) is 3 v_xor + 3 v_mov (the selected point as negated register pairs: no operand modifiers on packed fp32,
+# csrc/pa_common.h) + 128 VALU instructions for the 16 points of a lane (8 pair blocks: 3 v_pk_add + 3 v_pk_mul + 2 v_pk_add,
 # 2 v_min, 2 x (v_cmp_gt_u64 + 2 v_cndmask)), the wave maximum (6 DPP steps + v_readlane), and the selection tail (ds_max_u64 -> s_waitcnt ->
 # s_barrier -> ds_read_b64 -> ds_read_b96 of the winner's coordinates).  tools/probes/fps_model.hip times each of those instruction blocks ALONE on
 # the same occupancy (one wave per SIMD, s_memtime) and the three blocks chained as one dependent stream; profiles/r05_fps_model.txt is its output
-# on the MI355X: pair block 88.2 cycles (x 8), wave maximum 136.0, tail 331.8; chained 1037 cycles per round (the tail's LDS round trips overlap the
-# head of the next round's VALU block; the blocks' plain sum is 1173).  Model = the chained figure at the clock the launch holds.
-FPS_MODEL = {"pair_block_cycles": 88.2, "pair_blocks_per_round": 8, "wave_max_cycles": 136.0, "tail_cycles": 331.8, "chained_round_cycles": 1037.0,
+# on the MI355X: pair block 88.1 cycles (x 8), wave maximum 140.0, tail 333.0; chained 1030 cycles per round (the tail's LDS round trips overlap the
+# head of the next round's VALU block; the blocks' plain sum is 1178).  Model = the chained figure at the clock the launch holds.
+FPS_MODEL = {"pair_block_cycles": 88.1, "pair_blocks_per_round": 8, "wave_max_cycles": 140.0, "tail_cycles": 333.0, "chained_round_cycles": 1030.2,
              "clock_ghz": 2.36, "source": "tools/probes/fps_model.hip -> profiles/r05_fps_model.txt (s_memtime, one wave per SIMD, 32 workgroups)"}
 
 
@@ -114,7 +115,7 @@ def fps_latency_roofline(batch, points, m):
             "bound": "latency (serial rounds; neither HBM nor MFMA)", "rounds": rounds, "ms_per_launch": ms, "us_per_round": us_round,
             "model_us_per_round": model_us, "frac": model_us / us_round,
             "model": "cycles of the round's three instruction blocks measured alone at the kernel's occupancy and chained as one dependent stream "
-                     "(8 x 16-instruction pair block + 6-step DPP wave maximum + ds_max_u64 / barrier / two LDS reads), / the clock the launch holds",
+                     "(3 v_xor + 3 v_mov + 8 x 16-instruction pair block + 6-step DPP wave maximum + ds_max_u64 / barrier / two LDS reads), / the clock the launch holds",
             "model_terms": FPS_MODEL,
             "counters": "profiles/r05_fps_pmc_sq.txt (SQ_WAVE_CYCLES / SQ_BUSY_CYCLES / SQ_INSTS_VALU / SQ_INSTS_LDS of the same kernel)"}
 

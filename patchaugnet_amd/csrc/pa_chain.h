@@ -282,23 +282,19 @@ __device__ __forceinline__ void chain_prologue(T *act, float *scratch, const PaC
                     const float sx = s4[0], sy = s4[1], sz = s4[2], sw = s4[3];
                     // fixed fmaf order (bias, skip channels, then the three interpolation terms): the generic path below uses the same
                     // chain, so the result does not depend on which tiling a batch size selects
-                    // two channels per instruction (v_pk_fma_f32, each half the same fused operation as fmaf): the row's scalar goes into a materialised
-                    // (s, s) pair first, so the instruction carries no operand modifier (pa_common.h, pa_pk_plain)
-                    pa_f2 v01 = (pa_f2){bz.x, bz.y}, v23 = (pa_f2){bz.z, bz.w};
+                    float v[4] = {bz.x, bz.y, bz.z, bz.w};
                     const float sv[4] = {sx, sy, sz, sw};
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const pa_f2 s2 = pa_pk_plain((pa_f2){sv[t], sv[t]});
-                        v01 = __builtin_elementwise_fma(s2, (pa_f2){wv[t].x, wv[t].y}, v01);
-                        v23 = __builtin_elementwise_fma(s2, (pa_f2){wv[t].z, wv[t].w}, v23);
+                        v[0] = fmaf(sv[t], wv[t].x, v[0]); v[1] = fmaf(sv[t], wv[t].y, v[1]);
+                        v[2] = fmaf(sv[t], wv[t].z, v[2]); v[3] = fmaf(sv[t], wv[t].w, v[3]);
                     }
 #pragma unroll
                     for (int t = 0; t < 3; ++t) {
-                        const pa_f2 s2 = pa_pk_plain((pa_f2){w[u][t], w[u][t]});
-                        v01 = __builtin_elementwise_fma(s2, (pa_f2){f[u][t].x, f[u][t].y}, v01);
-                        v23 = __builtin_elementwise_fma(s2, (pa_f2){f[u][t].z, f[u][t].w}, v23);
+                        v[0] = fmaf(w[u][t], f[u][t].x, v[0]); v[1] = fmaf(w[u][t], f[u][t].y, v[1]);
+                        v[2] = fmaf(w[u][t], f[u][t].z, v[2]); v[3] = fmaf(w[u][t], f[u][t].w, v[3]);
                     }
-                    pa_store4(act + (r0 + u) * stride + lane * 4, fmaxf(v01.x, 0.f), fmaxf(v01.y, 0.f), fmaxf(v23.x, 0.f), fmaxf(v23.y, 0.f));
+                    pa_store4(act + (r0 + u) * stride + lane * 4, fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
                 }
             }
         } else

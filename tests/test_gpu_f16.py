@@ -271,3 +271,42 @@ def test_descriptor_only_call_keeps_the_finest_map_in_fp16(name):
     assert np.isfinite(a).all()
     assert _cos(a, ref).min() >= 0.999, _cos(a, ref).min()
     assert _cos(a, b).min() >= 0.9999, _cos(a, b).min()
+
+
+@pytest.mark.parametrize("victim", ["sampling", "knn"])
+def test_index_kernels_beside_fp16_chain_kernels_on_another_stream(victim):
+    """The gfx950 fault of DESIGN.md section 5 (packed fp32 with operand modifiers beside 16x16x32 MFMA kernels), at the op level: the sampling and the kNN
+    search must return their serial results while pa_linear_f16 loops on another stream.  Before the fix the sampling differed in 11 of 12 such launches
+    (tools/probes/corun_linear16.py); tests/test_abi.py holds the build to the rule, this holds the two kernels that do packed arithmetic by hand."""
+    from patchaugnet_amd import pointops
+    from patchaugnet_amd._lib import call, ptr
+    from patchaugnet_amd.engine import pack_weights_f16
+    from patchaugnet_amd.weights import synthetic_submaps
+    clouds = [synthetic_submaps(32, 4096, 90 + i, "street" if i % 2 else "uniform").cuda().squeeze(1).contiguous() for i in range(3)]
+
+    def run(x):
+        if victim == "sampling":
+            idx, new_xyz = pointops.furthestsampling_gather(x, 1024)
+            return idx, new_xyz
+        centres = x[:, :1024].contiguous()
+        return pointops.knnquery_with_dist(20, x, centres)
+
+    serial = [tuple(t.clone() for t in run(x)) for x in clouds]
+    rows, k, n = 131072, 256, 256
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn(rows, k, generator=g).cuda()
+    wt = (torch.randn(k, n, generator=g) / k ** 0.5).cuda().contiguous()
+    wp = pack_weights_f16(wt)
+    bias = torch.zeros(n, device="cuda")
+    out = torch.empty(rows, n, device="cuda")
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for t in range(9):
+        with torch.cuda.stream(sa):
+            for _ in range(8):
+                call("pa_linear_f16", rows, k, n, ptr(a), k, ptr(wt), ptr(wp), ptr(bias), 1, None, 0, ptr(out), n)
+        with torch.cuda.stream(sb):
+            got = run(clouds[t % 3])
+        torch.cuda.synchronize()
+        for u, v in zip(got, serial[t % 3]):
+            assert torch.equal(u, v), (victim, t)

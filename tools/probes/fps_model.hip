@@ -2,7 +2,7 @@
 // what ONE wave per SIMD (the sampling kernel's occupancy: 256 threads per cloud, one cloud per CU) pays per instruction class, in shader
 // cycles (s_memtime), on the instruction classes the round of fps_reg_kernel<256,16> is made of -- and the same with two waves per SIMD
 // (512 threads) to see which classes a second wave would overlap.
-//   hipcc --offload-arch=gfx950 -O3 tools/probes/fps_model.hip -o tools/probes/fps_model.bin && tools/probes/fps_model.bin
+//   hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -fno-vectorize tools/probes/fps_model.hip -o tools/probes/fps_model.bin && tools/probes/fps_model.bin
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
@@ -15,12 +15,12 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 enum { K_ADD_IND, K_ADD_DEP, K_PKADD_IND, K_PKMUL_DEP, K_PKMIX, K_MIN_IND, K_KEY64, K_DPP, K_ATOMIC, K_BARRIER, K_LDS64, K_LDS96, K_TAIL, K_ROUND, K_COUNT };
 static const char *NAMES[K_COUNT] = {"v_add_f32 x16 independent", "v_add_f32 x16 dependent", "v_pk_add_f32 x16 independent", "v_pk_mul_f32 x16 dependent",
-                                     "pair block: 3 pk_sub + 3 pk_mul + 2 pk_add + 2 v_min + 2 x (cmp_u64 + 2 cndmask)  [16 instr]", "v_min_f32 x16 independent",
+                                     "pair block: 3 pk_add + 3 pk_mul + 2 pk_add + 2 v_min + 2 x (cmp_u64 + 2 cndmask) [16 instr] + per round 3 v_xor + 3 v_mov", "v_min_f32 x16 independent",
                                      "v_cmp_gt_u64 + 2 v_cndmask (dependent key maximum) x8  [24 instr]", "wave max: 6 x (v_max_u32_dpp + s_nop 1) + v_readlane",
                                      "ds_max_u64 (one lane) + s_waitcnt lgkmcnt(0)", "s_barrier (all waves of the workgroup)", "ds_read_b64 + wait (dependent address)",
                                      "ds_read_b96 + wait (dependent address)", "tail: ds_max_u64 + wait + s_barrier + ds_read_b64 + wait + not/lshl_add + ds_read_b96 + wait",
-                                     "whole synthetic round: 8 pair blocks + wave max + tail"};
-static const int INSTR[K_COUNT] = {16, 16, 16, 16, 16, 16, 24, 13, 2, 1, 2, 2, 9, 8 * 16 + 13 + 9};
+                                     "whole synthetic round: 3 v_xor + 3 v_mov + 8 pair blocks + wave max + tail"};
+static const int INSTR[K_COUNT] = {16, 16, 16, 16, 16 + 6, 16, 24, 13, 2, 1, 2, 2, 9, 6 + 8 * 16 + 13 + 9};
 
 __device__ __forceinline__ u64 now() { return __builtin_amdgcn_s_memtime(); }
 
@@ -71,10 +71,13 @@ __global__ void probe(int iters, u64 *out, float seed)
             // the kernel's pair block (fps.hip, PAIRED): two points' distances, minima and the running 64-bit key maximum
             u64 best = 0;
             asm volatile("" : "+v"(o));
+            // the shipped form (round 5): (-o, -o) pairs materialised once per round (3 v_xor + 3 v_mov), the subtractions as plain v_pk_add_f32 -- no operand
+            // modifiers on packed fp32 (csrc/pa_common.h, pa_pk_plain)
+            f2 nx = (f2){-o.x, -o.x}, ny = (f2){-o.y, -o.y}, nz = (f2){-o.x, -o.x};
+            asm("" : "+v"(nx), "+v"(ny), "+v"(nz));
 #pragma unroll
             for (int h = 0; h < (KIND == K_ROUND ? 8 : 1); ++h) {
-                const f2 ox = (f2){o.x, o.x}, oy = (f2){o.y, o.y}, oz = (f2){o.x, o.x};
-                const f2 dx = p[h & 7] - ox, dy = p[(h + 1) & 7] - oy, dz = p[(h + 2) & 7] - oz;
+                const f2 dx = p[h & 7] + nx, dy = p[(h + 1) & 7] + ny, dz = p[(h + 2) & 7] + nz;
                 const f2 d = dx * dx + dy * dy + dz * dz;
                 float m0, m1;
                 asm("v_min_f32 %0, %1, %2" : "=v"(m0) : "v"(d.x), "v"(tmin[2 * h]));

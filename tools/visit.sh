@@ -1,5 +1,6 @@
 cd /root/repo
-python bench.py --config train > gpurun_out/r05j_bench_train.json 2>/dev/null; tail -1 gpurun_out/r05j_bench_train.json | python -c "
-import sys, json
-d = json.loads(sys.stdin.read()); print('train full', d['ms_per_step'], d['value'], d['roofline']['frac'], d['roofline']['traffic'])"
-bash tools/prof_train_diff.sh r05j 10 50 2>&1 | head -3
+echo "== pre-fix library (commit a0a1c2c)"
+PA_LIB_PATH=/root/repo/patchaugnet_amd/csrc/ab/lib_prefix.so timeout 900 python -m pytest tests/test_gpu_f16.py -q -k "beside_fp16" 2>&1 | grep -v amdgpu.ids | tail -4
+PA_LIB_PATH=/root/repo/patchaugnet_amd/csrc/ab/lib_prefix.so timeout 900 python -m pytest tests/test_gpu_extract.py -q -k "graphed_extractor_distinct" 2>&1 | grep -v amdgpu.ids | tail -4
+echo "== shipped library"
+timeout 900 python -m pytest tests/test_gpu_f16.py tests/test_gpu_extract.py -q -k "beside_fp16 or graphed_extractor_distinct" 2>&1 | grep -v amdgpu.ids | tail -2
