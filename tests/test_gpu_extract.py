@@ -20,9 +20,11 @@ def _model(name):
 
 @pytest.mark.parametrize("name", ["patch_aug_net", "pptnet"])
 @pytest.mark.parametrize("graphs", [False, True])
-def test_extract_descriptors_matches_plain_forward(name, graphs):
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_extract_descriptors_matches_plain_forward(name, graphs, dtype):
     from patchaugnet_amd.extract import extract_descriptors
     m = _model(name)
+    m.mlp_dtype = dtype            # "f16": the same bits on four streams as on one (the packed-fp32 fault)
     x = torch.cat([synthetic_submaps(50, 4096, 21, "uniform"), synthetic_submaps(25, 4096, 22, "street")]).cuda()
     batches = [x[i:i + 8].contiguous() for i in range(0, 75, 8)]          # 9 batches of 8 and one of 3
     with torch.no_grad():

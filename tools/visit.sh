@@ -1,6 +1,5 @@
 cd /root/repo
-echo "== pre-fix library (commit a0a1c2c)"
-PA_LIB_PATH=/root/repo/patchaugnet_amd/csrc/ab/lib_prefix.so timeout 900 python -m pytest tests/test_gpu_f16.py -q -k "beside_fp16" 2>&1 | grep -v amdgpu.ids | tail -4
-PA_LIB_PATH=/root/repo/patchaugnet_amd/csrc/ab/lib_prefix.so timeout 900 python -m pytest tests/test_gpu_extract.py -q -k "graphed_extractor_distinct" 2>&1 | grep -v amdgpu.ids | tail -4
-echo "== shipped library"
-timeout 900 python -m pytest tests/test_gpu_f16.py tests/test_gpu_extract.py -q -k "beside_fp16 or graphed_extractor_distinct" 2>&1 | grep -v amdgpu.ids | tail -2
+bash tools/pmc_pass.sh gpurun_out/fps_pmc_a.txt "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"
+bash tools/pmc_pass.sh gpurun_out/fps_pmc_b.txt "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC"
+grep -h "fps_reg_kernel<256, 16" gpurun_out/fps_pmc_a.txt gpurun_out/fps_pmc_b.txt | cut -c1-220
+timeout 900 python -m pytest tests/test_gpu_extract.py -q -k "matches_plain_forward" 2>&1 | tail -2
