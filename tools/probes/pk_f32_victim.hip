@@ -26,6 +26,18 @@ __global__ __launch_bounds__(256) void pk_victim_kernel(int rounds, unsigned lds
                 asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(dx) : "v"(qx[h]), "v"(oxy));
                 asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(dy) : "v"(qy[h]), "v"(oxy));
                 asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(dz) : "v"(qz[h]), "v"(oz_));
+            } else if (FORM == 2) {   // negation modifiers only: the broadcast is done beforehand
+                f2 bx = (f2){oxy.x, oxy.x}, by = (f2){oxy.y, oxy.y}, bz = (f2){oz_.x, oz_.x};
+                asm volatile("" : "+v"(bx), "+v"(by), "+v"(bz));
+                asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(dx) : "v"(qx[h]), "v"(bx));
+                asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(dy) : "v"(qy[h]), "v"(by));
+                asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(dz) : "v"(qz[h]), "v"(bz));
+            } else if (FORM == 3) {   // broadcast modifiers only: the negation is done beforehand
+                f2 nxy = (f2){-oxy.x, -oxy.y}, nz_ = (f2){-oz_.x, 0.f};
+                asm volatile("" : "+v"(nxy), "+v"(nz_));
+                asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(dx) : "v"(qx[h]), "v"(nxy));
+                asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(dy) : "v"(qy[h]), "v"(nxy));
+                asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(dz) : "v"(qz[h]), "v"(nz_));
             } else {   // no operand modifiers: the broadcast and the negation are done beforehand with moves
                 f2 nx = (f2){-oxy.x, -oxy.x}, ny = (f2){-oxy.y, -oxy.y}, nz = (f2){-oz_.x, -oz_.x};
                 asm volatile("" : "+v"(nx), "+v"(ny), "+v"(nz));
@@ -64,7 +76,11 @@ extern "C" int pk_victim_launch(int form, int blocks, int rounds, int lds_bytes,
 {
     (void)hipFuncSetAttribute((const void *)pk_victim_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     (void)hipFuncSetAttribute((const void *)pk_victim_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    if (form) hipLaunchKernelGGL(pk_victim_kernel<1>, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, rounds, (unsigned)lds_bytes / 4, bad, example);
+    (void)hipFuncSetAttribute((const void *)pk_victim_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    (void)hipFuncSetAttribute((const void *)pk_victim_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (form == 2) hipLaunchKernelGGL(pk_victim_kernel<2>, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, rounds, (unsigned)lds_bytes / 4, bad, example);
+    else if (form == 3) hipLaunchKernelGGL(pk_victim_kernel<3>, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, rounds, (unsigned)lds_bytes / 4, bad, example);
+    else if (form) hipLaunchKernelGGL(pk_victim_kernel<1>, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, rounds, (unsigned)lds_bytes / 4, bad, example);
     else hipLaunchKernelGGL(pk_victim_kernel<0>, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, rounds, (unsigned)lds_bytes / 4, bad, example);
     return (int)hipGetLastError();
 }
