@@ -1,2 +1,2 @@
 cd /root/repo
-for f in 0 2 3 1; do echo "== victim form $f"; VICTIM_FORM=$f CORUN_MODES=30,8,13 timeout 600 python tools/probes/pk_f32_victim2.py 8 2>&1 | grep -v amdgpu.ids | tail -3; done
+timeout 1500 python tools/probes/stream_determinism_soak.py 40 2>&1 | grep -v amdgpu.ids | tail -5
