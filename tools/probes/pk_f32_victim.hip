@@ -72,13 +72,49 @@ __global__ __launch_bounds__(256) void pk_victim_kernel(int rounds, unsigned lds
     }
     if (nbad) atomicAdd(bad, nbad);
 }
+// v_fma_mix_f32 with op_sel / op_sel_hi on its fp16 operand (how fpx16_kernel interpolates its fp16 table) against v_cvt_f32_f16 + v_fma_f32 on the same values.
+__global__ __launch_bounds__(256) void mix_victim_kernel(int rounds, unsigned *bad, float *example)
+{
+    unsigned s = blockIdx.x * 7919u + threadIdx.x * 104729u + 1u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)(s >> 8) * (1.f / 16777216.f) * 8.f - 4.f; };
+    unsigned h[NP];
+    float acc0[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const _Float16 a = (_Float16)rnd(), b = (_Float16)rnd();
+        h[i] = (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+        acc0[i] = rnd();
+    }
+    unsigned nbad = 0;
+    for (int r = 0; r < rounds; ++r) {
+        const float w = rnd();
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            float mlo, mhi, tlo, thi, elo, ehi;
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(mlo) : "v"(w), "v"(h[i]), "v"(acc0[i]));
+            asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(mhi) : "v"(w), "v"(h[i]), "v"(acc0[i]));
+            unsigned hs;
+            asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(tlo) : "v"(h[i]));
+            asm volatile("v_lshrrev_b32 %0, 16, %1" : "=v"(hs) : "v"(h[i]));
+            asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(thi) : "v"(hs));
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(elo) : "v"(w), "v"(tlo), "v"(acc0[i]));
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(ehi) : "v"(w), "v"(thi), "v"(acc0[i]));
+            if (__float_as_uint(mlo) != __float_as_uint(elo) || __float_as_uint(mhi) != __float_as_uint(ehi)) {
+                if (!nbad) { example[0] = mlo; example[1] = elo; example[2] = mhi; example[3] = ehi; example[4] = w; example[5] = acc0[i]; example[6] = (float)r; example[7] = (float)i; }
+                ++nbad;
+            }
+        }
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
 extern "C" int pk_victim_launch(int form, int blocks, int rounds, int lds_bytes, unsigned *bad, float *example, void *stream)
 {
     (void)hipFuncSetAttribute((const void *)pk_victim_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     (void)hipFuncSetAttribute((const void *)pk_victim_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     (void)hipFuncSetAttribute((const void *)pk_victim_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     (void)hipFuncSetAttribute((const void *)pk_victim_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    if (form == 2) hipLaunchKernelGGL(pk_victim_kernel<2>, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, rounds, (unsigned)lds_bytes / 4, bad, example);
+    if (form == 4) hipLaunchKernelGGL(mix_victim_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rounds, bad, example);
+    else if (form == 2) hipLaunchKernelGGL(pk_victim_kernel<2>, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, rounds, (unsigned)lds_bytes / 4, bad, example);
     else if (form == 3) hipLaunchKernelGGL(pk_victim_kernel<3>, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, rounds, (unsigned)lds_bytes / 4, bad, example);
     else if (form) hipLaunchKernelGGL(pk_victim_kernel<1>, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, rounds, (unsigned)lds_bytes / 4, bad, example);
     else hipLaunchKernelGGL(pk_victim_kernel<0>, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, rounds, (unsigned)lds_bytes / 4, bad, example);

@@ -1,2 +1,2 @@
 cd /root/repo
-timeout 1500 python tools/probes/stream_determinism_soak.py 40 2>&1 | grep -v amdgpu.ids | tail -5
+for f in 4 0; do echo "== victim form $f"; VICTIM_FORM=$f CORUN_MODES=30,8,13,-1 timeout 600 python tools/probes/pk_f32_victim2.py 8 2>&1 | grep -v amdgpu.ids | tail -4; done
