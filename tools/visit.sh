@@ -1,2 +1,4 @@
+# scratch script for one gpurun visit (bash tools/gpr.sh gpurun_out/vNNN.log TIMEOUT 'bash tools/visit.sh'); the round's measurement set is tools/final_r05.sh
 cd /root/repo
-for f in 4 0; do echo "== victim form $f"; VICTIM_FORM=$f CORUN_MODES=30,8,13,-1 timeout 600 python tools/probes/pk_f32_victim2.py 8 2>&1 | grep -v amdgpu.ids | tail -4; done
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 | cut -c1-400
