@@ -1,4 +1,5 @@
-# scratch script for one gpurun visit (bash tools/gpr.sh gpurun_out/vNNN.log TIMEOUT 'bash tools/visit.sh'); the round's measurement set is tools/final_r05.sh
 cd /root/repo
-timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 | cut -c1-400
+for S in 4 8 4 8 7 3; do
+python bench.py --gpus 1 --steps 20 --warmup 5 --streams $S --no-cpu-baseline --no-kernel-pass --no-pmc --no-extras 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('20 steps, streams $S', round(d['value']), d['ms_per_step'], [round(v) for v in d['repetitions']['submaps_per_s']])"
+done
