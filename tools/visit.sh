@@ -1,5 +1,4 @@
 cd /root/repo
-for i in 1 2 3; do for M in 1 2 4; do
-PA_SA_TINY_GRID_MULT=$M python bench.py --steps 60 --reps 3 --no-cpu-baseline --no-kernel-pass --no-pmc --no-extras 2>/dev/null | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('grid mult $M', round(d['value']), d['ms_per_step'])"
-done; done
+for shape in "4 8192" "64 2048" "16 1024"; do
+timeout 900 python tools/probes/stream_determinism_soak.py 10 $shape 2>&1 | grep -v amdgpu.ids | tail -4
+done
