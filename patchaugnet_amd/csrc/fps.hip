@@ -161,7 +161,7 @@ __global__ __launch_bounds__(NT * CPW) void fps_reg_kernel(int n, int m, FpsOrde
         if (PAIRED) {
             // (-o, -o) as materialised register pairs, the subtraction as a plain packed add of them (x - o and x + (-o) are the same IEEE operation): the
             // compiler's own form folds the broadcast and the negation into operand modifiers of v_pk_add_f32 (op_sel / neg_lo / neg_hi), and that form
-            // returns wrong low halves on gfx950 while a neighbouring wave of the SIMD alternates 16x16x32 MFMAs with VALU work (every fp16 chain kernel
+            // returns wrong low halves on gfx950 while a neighbouring wave of the SIMD issues 16x16x32 MFMAs (every fp16 chain kernel
             // does): pa_common.h, pa_pk_plain; tools/probes/pk_f32_victim.hip is the self-contained reproduction.  Three v_xor and
             // three v_mov per round: 484 -> 500 us per first-level launch.  (Measured and not kept: the lane's points negated once and the selected point
             // read as ready-made (x, x) pairs by three ds_read2_b32 with both offsets on one word -- no VALU on the chain, but 554 us.)

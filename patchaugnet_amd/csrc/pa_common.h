@@ -73,9 +73,9 @@ __device__ __forceinline__ u64 pa_max_u64(u64 a, u64 b) { return a > b ? a : b; 
 
 // A pair of floats pinned to a register pair, opaque to the compiler: packed fp32 arithmetic on it is the PLAIN instruction form (v_pk_add_f32 / v_pk_mul_f32 without
 // op_sel / op_sel_hi / neg_lo / neg_hi).  The library issues no packed fp32 instruction with operand modifiers: on gfx950 (MI355X, ROCm 7.2) those return wrong values
-// -- the low half of the result, at rates up to 1e-3 of the lane-operations -- while another wave of the SIMD alternates v_mfma_f32_16x16x32_{f16,bf16} with VALU
+// -- the low half of the result, at rates up to 1e-3 of the lane-operations -- while another wave of the SIMD issues v_mfma_f32_16x16x32_{f16,bf16}
 // instructions, which is what every fp16 chain / attention / NetVLAD kernel of the "f16" mode does; the plain form and scalar fp32 are not affected (measured:
-// tools/probes/pk_f32_victim.hip + corun_stress.hip, profiles/r05_pk_f32_modifier_fault.txt; it is the half-select modifiers op_sel / op_sel_hi that fail, the
+// tools/probes/pk_f32_fault_repro.hip (standalone), pk_f32_victim.hip + corun_stress.hip, profiles/r05_pk_f32_modifier_fault.txt; it is the half-select modifiers op_sel / op_sel_hi that fail, the
 // negation modifiers alone measured clean -- the rule bans both, the test cannot tell a safe modifier from an unsafe one on the next toolchain).  Two rules keep the forms out: the library is built with
 // -fno-slp-vectorize (the compiler's own pairing of scalar fp32 code is where most of them came from), and hand-written pair arithmetic negates / broadcasts into a
 // pa_pk_plain() pair first.  tests/test_abi.py disassembles the library and fails on any v_pk_*_f32 that carries a modifier.
