@@ -1,5 +1,7 @@
-# scratch script for one gpurun visit (bash tools/gpr.sh gpurun_out/vNNN.log TIMEOUT 'bash tools/visit.sh'); the round's measurement set is tools/final_r05.sh
 cd /root/repo
-timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 | cut -c1-400
+for Q in 0 1; do
+echo "== PA_ATTN_F16_QV=$Q"
+PA_ATTN_F16_QV=$Q python tools/f16_cos.py 2>&1 | grep -v amdgpu.ids | tail -6
+for i in 1 2; do PA_ATTN_F16_QV=$Q python bench.py --model pptnet --mlp-dtype f16 --steps 60 --reps 3 --no-cpu-baseline --no-kernel-pass --no-pmc --no-extras 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('pptnet f16', round(d['value']), d['ms_per_step'])"; done
+done
