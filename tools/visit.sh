@@ -1,3 +1,5 @@
+# scratch script for one gpurun visit (bash tools/gpr.sh gpurun_out/vNNN.log TIMEOUT 'bash tools/visit.sh'); the round's measurement set is tools/final_r05.sh
 cd /root/repo
-timeout 1200 python -m pytest tests/test_gpu_ops.py tests/test_gpu_properties.py tests/test_gpu_f16.py tests/test_gpu_fuzz.py tests/test_gpu_extract.py tests/test_gpu_boundary.py -x -q -k "fps or furthest or sampling or beside or fuzz or latency or ahead or range" 2>&1 | tail -2
-python tools/fps_time.py 2>&1 | grep -v amdgpu.ids | cut -c1-110
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 | cut -c1-400
