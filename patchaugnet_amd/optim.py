@@ -2,7 +2,8 @@
 ``torch.optim.Adam(model.parameters(), lr)``).
 
 Same hyper-parameters, same update rule and the same ``state_dict`` layout as ``torch.optim.Adam`` (per parameter: ``step``, ``exp_avg``,
-``exp_avg_sq``), so checkpoints move both ways; ``amsgrad`` / ``maximize`` / ``foreach`` variants are not built (the reference uses none).
+``exp_avg_sq``), so checkpoints move both ways (``state_dict()`` writes an own copy of the counter per parameter, ``load_state_dict()`` drops
+the device scalars of the steps taken before it); ``amsgrad`` / ``maximize`` / ``foreach`` variants are not built (the reference uses none).
 The step counter and the learning rate live on the device (one scalar each per parameter group; the counter is shared by its parameters'
 ``state['step']``) and the tensor list travels in the kernel arguments: an optimizer step is ``1 + ceil(n / 84)`` launches with nothing
 host-side that changes between steps in the arithmetic, so ``train.GraphedTrainer`` captures it like torch's ``capturable=True`` optimizers --
@@ -26,6 +27,26 @@ class Adam(torch.optim.Optimizer):
         self._step = {}          # group index -> the group's device step counter (kept out of param_groups: state_dict() copies those)
         self._lr = {}            # group index -> (device scalar, the host value it holds)
         self._keep = {}          # group index -> gradient tensors of the launches in flight
+
+    def state_dict(self):
+        """torch.optim.Adam's layout with ONE step tensor PER PARAMETER: the live state shares a single device scalar per group, and that aliasing
+        would survive torch.save / torch.load into a torch.optim.Adam, whose ``_foreach_add_`` then advances the shared counter once per
+        parameter per step (bias correction wrong from the first resumed step)."""
+        sd = super().state_dict()
+        for st in sd["state"].values():
+            if torch.is_tensor(st.get("step")):
+                st["step"] = st["step"].detach().clone()
+        return sd
+
+    def load_state_dict(self, state_dict):
+        """The loaded counters / learning rates replace whatever this optimizer held: the per-group device scalars of earlier steps are
+        dropped, so the next step adopts the checkpoint's counter (``_init_group``) and re-creates the learning-rate scalar from the loaded
+        ``param_groups``.  A hipGraph captured before the load holds the OLD scalars' addresses and must be re-captured (GraphedTrainer does
+        not survive a load, like torch's capturable optimizers)."""
+        super().load_state_dict(state_dict)
+        self._step.clear()
+        self._lr.clear()
+        self._keep.clear()
 
     def _init_group(self, gi, group):
         ps = [p for p in group["params"] if p.grad is not None]

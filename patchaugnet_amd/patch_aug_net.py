@@ -108,6 +108,7 @@ class Network(nn.Module):
         st = self.__dict__.copy()
         st["_engine"] = None
         st.pop("_related_cache", None)
+        st.pop("_graphed_extractors", None)      # captured hipGraphs of distributed.extract_dataset: bound to THIS module's engine
         return st
 
     def related_index(self, device, related):

@@ -55,6 +55,7 @@ class Network(nn.Module):
     def __getstate__(self):
         st = self.__dict__.copy()
         st["_engine"] = None               # ctypes pointer arrays: never copied or pickled
+        st.pop("_graphed_extractors", None)      # captured hipGraphs of distributed.extract_dataset: bound to THIS module's engine
         return st
 
     def forward(self, x, return_feat=True, use_engine=None):

@@ -736,12 +736,20 @@ class _NetVladFused(Function):
         c1, c2 = _Bag(), _Bag()
         pre = _ChainTrain.forward(c1, x, [layer], 0, False, training, W, gamma, beta)
         out = _NetVladTail.forward(c2, pre, x, cw2)
+        # the two bags' tensors go through autograd's own saved-tensor mechanism (version check on an in-place change between forward and
+        # backward, saved-tensor hooks, release with the graph); the bags keep only their non-tensor attributes
+        t1, t2 = tuple(getattr(c1, "saved_tensors", ())), tuple(getattr(c2, "saved_tensors", ()))
+        ctx.save_for_backward(*t1, *t2)
+        ctx.n1 = len(t1)
+        c1.saved_tensors = c2.saved_tensors = ()
         ctx.c1, ctx.c2 = c1, c2
         return out
 
     @staticmethod
     def backward(ctx, gout):
         c1, c2 = ctx.c1, ctx.c2
+        saved = ctx.saved_tensors
+        c1.saved_tensors, c2.saved_tensors = saved[:ctx.n1], saved[ctx.n1:]
         need_x = ctx.needs_input_grad[0]
         c2.needs_input_grad = (True, need_x, ctx.needs_input_grad[3])
         dpre, dx, dcw2 = _NetVladTail.backward(c2, gout)

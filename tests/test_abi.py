@@ -98,7 +98,8 @@ def test_library_exports_its_hooks_and_no_deleted_variant(libpath):
     assert not [n for n in exported if any(t in n for t in ("knn_lane", "fpx256", "tgemm_nnw", "tgemm_wave", "reg_xyz", "premul_tap"))]
     assert all(n in exported for n in hooks), [n for n in hooks if n not in exported]
     csrc = os.path.join(ROOT, "patchaugnet_amd", "csrc")
-    assert not os.path.exists(os.path.join(csrc, "libpatchaugnet_hip_exp.so")) or True      # a stale build artefact is harmless; the Makefile no longer makes it
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    assert not [l for l in mk.splitlines() if l.startswith(("exp:", "exp ", "libpatchaugnet_hip_exp.so:"))], "the Makefile builds a second (experimental) library again"
     assert "PA_EXPERIMENTAL" not in "".join(open(os.path.join(csrc, f)).read() for f in os.listdir(csrc) if f.endswith((".hip", ".h")))
 
 

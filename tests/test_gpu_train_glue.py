@@ -266,6 +266,49 @@ def test_hip_adam_matches_torch_adam(wd):
         bad = torch.nn.Parameter(torch.zeros(4))
         bad.grad = torch.zeros(4)
         Adam([bad]).step()
+    # ... and the other way: a HIP checkpoint through torch.save / torch.load into torch.optim.Adam.  The live state shares one
+    # device counter per group; the checkpoint must not (torch's _foreach_add_ would advance a shared tensor once per parameter per step)
+    import io
+    sa = oa.state_dict()
+    steps = [st["step"] for st in sa["state"].values()]
+    assert len({t.data_ptr() for t in steps}) == len(steps), "state_dict() step tensors alias one storage"
+    buf = io.BytesIO()
+    torch.save(sa, buf)
+    buf.seek(0)
+    od = torch.optim.Adam([torch.nn.Parameter(t.detach().clone()) for t in pa], lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=wd)
+    od.load_state_dict(torch.load(buf, weights_only=False))
+    pd_ = od.param_groups[0]["params"]
+    for x, w in zip(pa, pd_):
+        gr = torch.randn(x.shape, generator=g).cuda()
+        x.grad, w.grad = gr.clone(), gr.clone()
+    oa.step(); od.step()
+    torch.cuda.synchronize()
+    assert all(float(st["step"]) == 6.0 for st in od.state_dict()["state"].values())
+    assert float(oa.state_dict()["state"][0]["step"]) == 6.0
+    for x, w in zip(pa, pd_):
+        assert torch.allclose(x, w, rtol=2e-5, atol=2e-6), (x.numel(), (x - w).abs().max().item())
+    # load_state_dict on an optimizer that has ALREADY stepped adopts the checkpoint's counter and learning rate (not its own stale ones)
+    ck = copy.deepcopy(ob.state_dict())                      # torch optimizer at step 6, lr 1e-2
+    ck["param_groups"][0]["lr"] = 5e-3
+    oe = Adam([torch.nn.Parameter(t.detach().clone()) for t in pb], lr=1e-1, betas=(0.9, 0.99), eps=1e-8, weight_decay=wd)
+    for z in oe.param_groups[0]["params"]:
+        z.grad = torch.ones_like(z)
+    oe.step(); oe.step()                                     # own counter at 2, own lr scalar at 1e-1
+    pe = oe.param_groups[0]["params"]
+    with torch.no_grad():
+        for y, z in zip(pb, pe):
+            z.copy_(y)
+    oe.load_state_dict(ck)
+    for gq in ob.param_groups:
+        gq["lr"] = 5e-3
+    for y, z in zip(pb, pe):
+        gr = torch.randn(y.shape, generator=g).cuda()
+        y.grad, z.grad = gr.clone(), gr.clone()
+    ob.step(); oe.step()
+    torch.cuda.synchronize()
+    assert float(oe.state_dict()["state"][0]["step"]) == 7.0
+    for y, z in zip(pb, pe):
+        assert torch.allclose(y, z, rtol=2e-5, atol=2e-6), (y.numel(), (y - z).abs().max().item())
 
 
 def test_hip_adam_follows_a_learning_rate_schedule_eagerly_and_under_graph_replay():
