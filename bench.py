@@ -155,7 +155,7 @@ def dominant_kernel_roofline(st, cfg, batch, points, grouping, pmc=None, pmc_not
     premul = "fp0.premul" in st
     if premul:   # first layer folded into the prologue (pa_fp_chain_premul): the launch runs layers 2.. on MFMA + 2*3*256 VALU FLOPs per row
         flops = 2.0 * rows * (sum(k * n for k, n in zip(dims[1:-1], dims[2:])) + (dims[0] - fs[1]) * dims[1])
-        kname = "chain_kernel<1,16,FPX,0,1> (pa_fp_chain_premul, fp0: 3-NN interpolation of the pre-multiplied coarse features + xyz term, then 256->256->256 on MFMA)"
+        kname = "fpx32_kernel<1,4,3,2> (pa_fp_chain_premul, csrc/fpx_f32.hip, fp0: 3-NN interpolation of the pre-multiplied coarse features + xyz term, then 256->256->256 on MFMA in half-K passes)"
     else:
         flops = 2.0 * rows * sum(k * n for k, n in zip(dims[:-1], dims[1:]))
         kname = "chain_kernel<2,16,FP,0,1> (pa_mlp_chain, fp0: 3-NN interpolate + 259->256->256->256 shared MLP)"
@@ -178,7 +178,7 @@ def dominant_kernel_roofline(st, cfg, batch, points, grouping, pmc=None, pmc_not
 
 
 TRAIN_DOMINANT_KERNEL_RE = r"tgemm_cm_kernel<8, 1, 2, 1, 2, 12>"     # pa_tgemm_nn at 18 x (256 x 4096 x 256), forward form (csrc/train_gemm_cm.hip)
-DOMINANT_KERNEL_RE = r"chain_kernel<[12], 16, 3, false, 1[,>]"     # fp0 feature-propagation chain (pa_fp_chain_premul): 16-row tiles (32 with PA_CHAIN_FPX_RT2)
+DOMINANT_KERNEL_RE = r"fpx32_kernel<|chain_kernel<[12], 16, 3, false, 1[,>]"     # fp0 feature-propagation chain (pa_fp_chain_premul): csrc/fpx_f32.hip, or the 16-row tile kernel (PA_CHAIN_NO_FPX32)
 GROUPING_KERNEL_RE = r"group_lds_kernel<4>"
 
 
@@ -283,12 +283,12 @@ def step_algorithmic_flops(model, batch, points):
 # The trace pass below reads every kernel's average duration out of rocprofv3's kernel trace of this very script; a row whose regex matches nothing
 # (a kernel was renamed / re-tiled) is reported as unmatched, never silently dropped.
 HEADLINE_KERNELS = [
-    ("fp0.chain", r"chain_kernel<1, 16, 3, false, 1, false>", 1024, "mfma"),
+    ("fp0.chain", r"fpx32_kernel<1, 4, 3, 2>", None, "mfma"),
     ("fp0.premul", r"linear_lds_kernel<64, 8>", None, "mfma"),
     ("vlad.k64", r"vlad_accum_kernel<4>", None, "mfma"),
     ("fp1.chain", r"chain_kernel<2, 8, 2, false, 4, false>", None, "mfma"),
     ("sa2.chain", r"chain_kernel<1, 8, 1, false, 4, true>", None, "mfma"),
-    ("sa0.chain", r"sa_tiny_kernel<5, 8, false>", None, "mfma"),
+    ("sa0.chain", r"sa_tiny_reg_kernel<5, 8, false>", None, "mfma"),
     ("sa1.chain", r"chain_kernel<5, 2, 1, true, 4, false>", None, "mfma"),
     ("fp2.chain", r"chain_kernel<1, 8, 2, false, 4, false>", None, "mfma"),
     ("fp1.premul", r"chain_kernel<1, 8, 0, false, 4, false>", None, "mfma"),
@@ -566,6 +566,27 @@ def train_bench(a, emit=True, pmc=None):
         pm, tnote = measure_traffic(0, 0, target=[os.path.join(ROOT, "tools", "tgemm_target.py"), "6", str(clouds)],
                                     patterns=(("dominant", TRAIN_DOMINANT_KERNEL_RE),))
         traffic = pm["dominant"]["bytes_per_launch"] if pm and "dominant" in pm else None
+    # the whole step against the fp32 MFMA peak: forward dense FLOPs of the 18 clouds (the same per-stage count as the extraction
+    # line, stage_algorithmic_flops on an eval() copy: set-abstraction / feature-propagation chains, NetVLAD, head) + the decoder over the related
+    # clouds' patch features (256 -> 1024 -> 1024 -> 3 k per patch, pointnet_autoencoder.py:85-111), times 3 (input-gradient and weight-gradient
+    # contractions of the backward pass each repeat the forward's FLOPs; sampling, searches, losses, BatchNorm and Adam are VALU / memory work)
+    step_frac = None
+    try:
+        import copy
+        ev = copy.deepcopy(model).eval()
+        fwd = sum(stage_algorithmic_flops(ev, clouds, n).values())
+        dec = model.decoder
+        related = len({i for pair in nn_dict for i in pair})
+        patches = cfg["SAMPLING"][0]
+        dec_fl = 2.0 * related * patches * (dec.fc1.in_features * dec.fc1.out_features + dec.fc2.in_features * dec.fc2.out_features + dec.fc3.in_features * dec.fc3.out_features)
+        del ev
+        tot = 3.0 * (fwd + dec_fl)
+        step_frac = {"algorithmic_flops_per_step": tot, "forward_flops": fwd + dec_fl, "decoder_forward_flops": dec_fl, "achieved_tflops": tot / (dt / a.steps) / 1e12,
+                     "peak_tflops": MFMA_F32_PEAK_TFLOPS, "frac": tot / (dt / a.steps) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                     "note": "3 x (forward dense FLOPs of the 18 clouds + decoder over the related clouds) / ms_per_step / fp32 MFMA peak; the step also holds ~1.2 ms of "
+                             "sampling / search / loss / BatchNorm / optimizer kernels that are not matrix work"}
+    except Exception as ex:
+        step_frac = {"error": repr(ex)}
     line = {
         "metric": "training steps/sec (PatchAugNet quadruplet step, patch Chamfer reconstruction loss)", "value": a.steps / dt, "unit": "steps/s",
         "clouds_per_s": clouds * a.steps / dt, "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -576,6 +597,7 @@ def train_bench(a, emit=True, pmc=None):
                    "weights": "key-seeded random init", "parallelism": "dp1",
                    "launch": ("one hipGraph replay per step (forward + losses + backward + Adam" + (" (torch fused)" if a.torch_adam else " (csrc/adam.hip)") + ")" + ("" if a.no_prefetch else
                               "; sampling / neighbour search / 3-NN of the next batch replayed on a side stream under it")) if graphed else "python launches"},
+        "step_mfma_frac": step_frac,
         "losses_last_step": losses,
         "losses_note": "place_recognition = 0.0 means the hinge of the quadruplet loss is inactive on this synthetic tuple (random-init descriptors of "
                        "unrelated clouds); the captured graph replays every kernel of the step regardless, so the timing is representative",
@@ -732,7 +754,7 @@ def extras(a):
         b = copy.copy(a)
         b.steps, b.warmup, b.no_graphs, b.no_prefetch = 20, 3, False, False
         line = train_bench(b, emit=False, pmc=True)
-        return {k: line[k] for k in ("ms_per_step", "value", "unit", "clouds_per_s", "roofline", "losses_last_step", "losses_note")} | {"workload": line["config"]["workload"]}
+        return {k: line[k] for k in ("ms_per_step", "value", "unit", "clouds_per_s", "roofline", "step_mfma_frac", "losses_last_step", "losses_note")} | {"workload": line["config"]["workload"]}
 
     def extract_rate(model_name, mlp_dtype):
         from patchaugnet_amd import configs, patch_aug_net, pptnet
@@ -787,7 +809,7 @@ def extras(a):
                 if mlp_dtype == "f32x3":
                     fl = 3.0 * 2.0 * rows * (256 * 256 * 2) + 2.0 * rows * 3 * 256      # ISSUED on the fp16 pipe: three MFMAs per product of the two dense layers
                 byts = rows * 256 * 4.0 + rows * (3 * 4 + 3 * 4 + 3 * 4) + (rows // 4) * 256 * (2.0 if mlp_dtype == "f16" else 4.0)      # output + (idx3, w3, xyz) + the pre-multiplied known rows once
-                res["roofline"] = {"kernel": {"f16": "fpx16_kernel<4,2,2> (fpx_f16.hip: weights shared through LDS, activations in registers, fp16 pre-multiplied table)", "f32": "chain_kernel<1,16,FPX,0,1>",
+                res["roofline"] = {"kernel": {"f16": "fpx16_kernel<4,2,2> (fpx_f16.hip: weights shared through LDS, activations in registers, fp16 pre-multiplied table)", "f32": "fpx32_kernel<1,4,3,2> (fpx_f32.hip)",
                                               "f32x3": "fpx3_kernel<4> (fpx_f32x3.hip: three fp16 MFMAs per product from (hi, lo) operand pairs)"}[mlp_dtype] + " (fp0: finest feature-propagation chain)",
                                    "bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / peak,
                                    "traffic": None, "algorithmic_flops_per_launch": fl, "ms_per_launch": ms, "timing": "one launch bracketed by HIP events on the launch stream (stage pass)"}

@@ -50,6 +50,7 @@ bool pa_sa_tiny_applies(const PaChain &a, int rt);                              
 int pa_sa_tiny_launch(const PaChain &a, int rt, long ntiles, hipStream_t st);
 bool pa_sa_mid_applies(const PaChain &a, int rt);                                                                       // sa_mid.hip
 int pa_sa_mid_launch(const PaChain &a, int rt, long ntiles, hipStream_t st);
+int pa_fpx32_try(const PaChain &a, hipStream_t st);                                                                      // fpx_f32.hip
 int pa_linear_lds_try(long rows, int k, int n, const float *x, int ldx, const float *wt, const float *bias, int relu, const float *residual, int ldr,
                       float *out, int ldo, hipStream_t st);                                                                    // linear_lds.hip
 
@@ -148,7 +149,10 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
     if (!is_pooled) {
         const long t32 = (total_rows + 31) / 32;
         static const long rt2_above = getenv("PA_CHAIN_SPLIT_RT2_ABOVE") ? atol(getenv("PA_CHAIN_SPLIT_RT2_ABOVE")) : 512;          // tuning knob
-        if (can_split && t32 < split_below) { split = true; RTv = t32 >= rt2_above ? 2 : 1; }
+        // MODE_FP (interpolate + skip in the prologue) keeps the shared-tile tiling at EVERY size: its wave-private form is 2.3 x slower (fp1 at batch 64:
+        // 282 vs 126 us, batch 256: 1150 vs 461 us -- the 3-NN gather prologue of a 32-row wave-private tile has nothing to hide under), and the former
+        // 2048-tile threshold sat between batch 32 and batch 64 of the 1024-point level (profiles/r06_stage_scaling.txt)
+        if (can_split && (t32 < split_below || mode == MODE_FP)) { split = true; RTv = t32 >= rt2_above ? 2 : 1; }
         // Measured and dropped (round 1): 128-row tiles shared by four waves for all-256-wide chains (slower than wave-private tiles
         // once the weights are packed) and 16-row wave-private tiles with eight waves per workgroup (no gain over 32-row tiles).
     } else {
@@ -233,10 +237,12 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
     while (wpw > 1 && wpw * per_wave > 156 * 1024) wpw = rt1 ? wpw - 1 : wpw >> 1;
     const long ntiles = is_pooled ? (rows + 3) / 4 : (total_rows + R - 1) / R;
 
-    // the finest set-abstraction level of both models (<= 8 -> 32 -> 32 -> 64): persistent workgroups with the weights resident in LDS and the
-    // gather pipelined across tiles (sa_tiny.hip); bit-identical to the generic pooled kernel, so which one runs is a matter of speed only
+    // the finest set-abstraction level of both models (<= 8 -> 32 -> 32 -> 64): persistent workgroups with the weights and the activations in
+    // registers and the gather pipelined across tiles (sa_tiny.hip); equal to the generic pooled kernel up to the order of the fp32 additions
     static const bool no_tiny = getenv("PA_CHAIN_NO_TINY") != nullptr;                                               // A/B knob
-    static const long tiny_min = getenv("PA_CHAIN_TINY_MIN_TILES") ? atol(getenv("PA_CHAIN_TINY_MIN_TILES")) : 1024;  // tuning knob
+    // (round 6: the register-chained kernel contracts in another order than the generic one, so the choice must not depend on the batch size: every
+    // launch of this shape takes it)
+    static const long tiny_min = getenv("PA_CHAIN_TINY_MIN_TILES") ? atol(getenv("PA_CHAIN_TINY_MIN_TILES")) : 1;  // test knob
     const bool tiny_on = g_chain_tiny < 0 ? (!no_tiny && ntiles >= tiny_min) : g_chain_tiny > 0;
     // the second set-abstraction level (67 -> 64 -> 64 -> n2): weights resident in LDS, activations in registers (sa_mid.hip)
     // Default rule (a function of the layer shapes only, never of the batch size: the kernel contracts in another order than the generic one):
@@ -268,6 +274,8 @@ static int chain_dispatch(int mode, int pooled, int nlayers, const float *const 
         if (mode == MODE_PLAIN) pa_chain_launch_split_plain(a, RTv, ntiles, st);
         else if (mode == MODE_SA) pa_chain_launch_split_sa(a, RTv, false, ntiles, st);
         else pa_chain_launch_split_fp(a, mode, RTv, ntiles, st);
+    } else if (mode == MODE_FPX && rt1 && pa_fpx32_try(a, st)) {
+        // the finest level's shape in half-K passes (fpx_f32.hip): same bits as the wave-private tile kernel below, three / four waves per SIMD
     } else if (mode == MODE_FPX) pa_chain_launch_wp_fpx(a, RTv, wpw, ntiles, st);
     else pa_chain_launch_wp_rows(a, mode, RTv, wpw, ntiles, st);
     PA_CHECK_LAUNCH("pa_mlp_chain");

@@ -22,7 +22,10 @@ void pa_knn_debug_buffer(long long *buf);   /* same for the pruned kNN kernel: 6
  *   pa_knn_quad_enable        pa_knnquery at 1024..4096 source points and >= 128 queries on the four-lanes-per-query cell-grid kernel (csrc/knn_quad.hip); 0 forces the
  *                             wave-per-query kernels
  *   pa_three_nn_grid_enable   pa_nearestneighbor / pa_three_nn_weights on the cell-grid kernel (csrc/three_nn_grid.hip); 0 forces the brute-force scan
- *   pa_chain_tiny_enable      the persistent first-set-abstraction kernel (csrc/sa_tiny.hip)
+ *   pa_chain_tiny_enable      the persistent first-set-abstraction kernel (csrc/sa_tiny.hip; since round 6 register-chained: equal to the generic
+ *                             kernel up to the order of the fp32 additions, not bit for bit)
+ *   pa_chain_fpx32_enable     the finest feature-propagation level in half-K passes, 9 KB of LDS per wavefront (csrc/fpx_f32.hip); 0 forces the
+ *                             16-row wave-private tile kernel of pa_chain_kernel.h (same bits)
  *   pa_chain_mid_enable       the LDS-resident second-set-abstraction kernel (csrc/sa_mid.hip; equal to the generic kernel up to the order of the
  *                             fp32 additions, not bit for bit)
  *   pa_linear_lds_enable      pa_linear at k = 256 on LDS-resident weights (csrc/linear_lds.hip)
@@ -39,6 +42,7 @@ void pa_knn_quad_enable(int on);
 void pa_three_nn_grid_enable(int on);
 void pa_chain_tiny_enable(int on);
 void pa_chain_mid_enable(int on);
+void pa_chain_fpx32_enable(int on);
 void pa_linear_lds_enable(int on);
 void pa_emd_persistent_enable(int on);
 void pa_fpx16_enable(int mode);

@@ -162,10 +162,12 @@ def test_sa_atomic_pooled_epilogue_equals_unpooled_then_max(B, n, m, ns, C, dims
 
 @pytest.mark.parametrize("B,n,m,ns,C", [(8, 4096, 1024, 20, 3), (3, 1024, 250, 20, 3), (2, 333, 41, 17, 3), (5, 512, 128, 16, 3), (1, 100, 9, 13, 2),
                                          (32, 4096, 1024, 20, 3)])
-def test_sa_first_level_persistent_kernel_is_bit_identical_to_the_generic_one(B, n, m, ns, C):
-    """sa_tiny.hip (weights resident in LDS, twelve looping wavefronts per workgroup, gather pipelined across tiles) against the generic pooled
-    chain kernel on the first level's shape <= 8 -> 32 -> 32 -> 64: same bits -- ragged group counts (the last tile partly empty, fewer tiles than
-    wavefronts), nsample 13 .. 20 (both row-tile counts), two feature channels."""
+def test_sa_first_level_persistent_register_chained_kernel(B, n, m, ns, C):
+    """sa_tiny.hip (round 6: persistent workgroups, the level's weights in registers, every layer fed straight from the previous layer's MFMA
+    accumulators, gather pipelined across tiles) on the first level's shape <= 8 -> 32 -> 32 -> 64: against float64 and against the generic pooled
+    chain kernel -- equal up to the ORDER of the fp32 additions inside a dot product (k-steps follow the accumulator layout), not bit for bit;
+    deterministic from launch to launch.  Ragged group counts (the last tile partly empty, fewer tiles than wavefronts), nsample 13 .. 20 (both
+    row-tile counts), two feature channels."""
     import ctypes
     from patchaugnet_amd import _lib
     from patchaugnet_amd.engine import _Chain
@@ -181,12 +183,17 @@ def test_sa_first_level_persistent_kernel_is_bit_identical_to_the_generic_one(B,
         lib.pa_chain_tiny_enable(1)
         tiny = chain.sa(*args, pooled=True)
         tiny2 = chain.sa(*args, pooled=True)
+        lib.pa_chain_tiny_enable(-1)
+        default = chain.sa(*args, pooled=True)
     finally:
         lib.pa_chain_tiny_enable(-1)
-    assert torch.equal(tiny, generic) and torch.equal(tiny2, generic)
+    assert torch.equal(tiny, tiny2)
+    assert torch.equal(default, tiny), "the default rule must pick this kernel for every batch size of the shape (results must not depend on batching)"
     rows = sa_rows_ref(xyz, feat, cidx, nbr).double()
     exp = mlp_ref(rows, [(w.float().double(), b.float().double()) for w, b in ref]).max(dim=2)[0].reshape(B * m, -1)
     close(tiny, exp)
+    close(generic, exp)
+    close(tiny, generic.double(), rtol=2e-5)
 
 
 @pytest.mark.parametrize("B,n,m,c1", [(3, 4096, 1024, 3), (1, 1000, 256, 3), (2, 77, 19, 1), (1, 300, 64, 4)])
@@ -221,6 +228,46 @@ def test_finest_fp_level_from_split_fp16_operands_meets_the_fp32_tolerance(B, n,
     close(got, exp)
     close(exact, exp)
     assert e3 <= 4e-6
+
+
+@pytest.mark.parametrize("B,n,m,c1", [(32, 4096, 1024, 3), (3, 4096, 1024, 3), (1, 1000, 256, 3), (2, 77, 19, 1), (5, 300, 64, 4), (16, 4096, 1024, 3)])
+def test_finest_fp_level_in_half_k_passes_is_bit_identical_to_the_tile_kernel(B, n, m, c1):
+    """fpx_f32.hip (round 6: the 16 x 256 activation tile as two 16 x 128 halves through 9 KB of LDS per wavefront, the second layer's input kept in
+    registers, twelve wavefronts per workgroup) against the wave-private 16-row tile kernel of pa_chain_kernel.h on the finest level's shape
+    (xyz skip, 256 -> 256 -> 256): same fp32 MFMA with k ascending -> the same bits, ragged last tiles and 1 / 3 / 4 skip channels included; and
+    against float64."""
+    import ctypes
+    from patchaugnet_amd import _lib
+    from patchaugnet_amd.engine import _Chain
+    lib = _lib.lib()
+    lib.pa_chain_fpx32_enable.argtypes, lib.pa_chain_fpx32_enable.restype = [ctypes.c_int], None
+    c2 = 256
+    ref, eng = make_layers([c2 + c1, 256, 256, 256], seed=31 + c1)
+    g = torch.Generator().manual_seed(n + B)
+    known = torch.randn(B, m, c2, generator=g)
+    skip = torch.randn(B, n, c1, generator=g)
+    idx3 = torch.randint(0, m, (B, n, 3), generator=g).int()
+    w3 = torch.rand(B, n, 3, generator=g)
+    w3 = (w3 / w3.sum(-1, keepdim=True)).contiguous()
+    args = (known.cuda(), idx3.cuda(), w3.cuda(), skip.cuda(), B, n, m, c2, c1)
+    ch = _Chain(eng)
+    ch.build_premul(c2, c1)
+    outs = []
+    try:
+        for on in (0, 1, 1):
+            lib.pa_chain_fpx32_enable(on)
+            outs.append(ch.fp_premul(*args).clone())
+    finally:
+        lib.pa_chain_fpx32_enable(-1)
+    torch.cuda.synchronize()
+    if B * n >= 30000:          # the tile kernel's 16-row wave-private form (what the half-K kernel replaces) runs from 30 000 rows; below, the shared-tile tilings
+        assert torch.equal(outs[1], outs[0])
+    assert torch.equal(outs[2], outs[1])
+    bi = torch.arange(B)[:, None]
+    interp = sum(w3[..., t:t + 1].double() * known.double()[bi, idx3[:, :, t].long()] for t in range(3))
+    exp = mlp_ref(torch.cat([interp, skip.double()], -1), [(w.float().double(), b.float().double()) for w, b in ref]).reshape(B * n, -1)
+    close(outs[1], exp)
+    close(outs[0], exp)
 
 
 @pytest.mark.parametrize("B,n,m,ns,n2", [(32, 1024, 128, 20, 256), (40, 1024, 256, 20, 128), (3, 300, 50, 17, 256), (2, 100, 13, 16, 64), (1, 64, 3, 13, 128)])

@@ -1,4 +1,4 @@
-"""Phase stamps of the persistent first-level kernel (sa_tiny.hip), split by wave group: python tools/probes/sa_tiny_phases.py"""
+"""Per-wave stamps of the persistent first-level kernel (sa_tiny.hip, register form): python tools/probes/sa_tiny_phases.py"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -26,7 +26,11 @@ with torch.no_grad():
     chain.sa = wrapped
     model(x, return_feat=False)
     torch.cuda.synchronize()
-t = buf.view(512, 8).cpu().numpy()
-d = t[:, 1:5] - t[:, 0:4]
-for name, sel in (("waves 0-3", (np.arange(512) % 8) < 4), ("waves 4-7", (np.arange(512) % 8) >= 4)):
-    print(name, "prologue/L0/L1/L2 medians:", [int(np.median(d[sel, i])) for i in range(4)], "tile total", int(np.median(t[sel, 4] - t[sel, 0])))
+t = buf.view(512, 8).cpu().numpy().astype(np.int64)
+t0 = t[:, 0].min()
+names = ["entry", "weights in place", "first tile gathered", "tile 1 done", "tile 2 done", "tile 3 done", "tile 4 done"]
+for grp, sel in (("waves 0-3 of a workgroup", (np.arange(512) % 8) < 4), ("waves 4-7 (staggered)", (np.arange(512) % 8) >= 4)):
+    print(grp)
+    for i, nm in enumerate(names):
+        v = t[sel, i] - t0
+        print(f"   {nm:22s} median {int(np.median(v)):8d}  min {int(v.min()):8d}  max {int(v.max()):8d}   (cycles after the first wave's entry; 100 MHz ticks if < 10 k total)")
