@@ -114,7 +114,8 @@ def fps_latency_roofline(batch, points, m):
     rounds = m - 1
     us_round = ms * 1e3 / rounds
     model_us = FPS_MODEL["chained_round_cycles"] / (FPS_MODEL["clock_ghz"] * 1e3)
-    return {"kernel": "fps_reg_kernel<256,16> (pa_furthestsampling_gather: first level, one workgroup of 4 wavefronts per cloud, %d CUs of 256 busy)" % min(batch, 256),
+    return {"kernel": "fps_reg_kernel<512,8> (pa_furthestsampling_gather: first level, one workgroup of 8 wavefronts per cloud -- two per SIMD, eight points per lane -- %d CUs of 256 busy; "
+                      "the model is the 256-thread round's instruction chain: the same blocks, a lane's 16 points split over the two waves of its SIMD)" % min(batch, 256),
             "bound": "latency (serial rounds; neither HBM nor MFMA)", "rounds": rounds, "ms_per_launch": ms, "us_per_round": us_round,
             "model_us_per_round": model_us, "frac": model_us / us_round,
             "model": "cycles of the round's three instruction blocks measured alone at the kernel's occupancy and chained as one dependent stream "
@@ -296,7 +297,7 @@ HEADLINE_KERNELS = [
     ("vlad.k4", r"vlad_accum_kernel<1>", 2, "mfma"),
     ("afa", r"afa_cluster_kernel|afa_combine_kernel", None, "mfma"),
     ("vlad.finalize", r"vlad_finalize_multi_kernel", None, "latency"),
-    ("sa0.fps", r"fps_reg_kernel<256, 16", None, "latency"),
+    ("sa0.fps", r"fps_reg_kernel<(512, 8|256, 16)", None, "latency"),
     ("sa1.fps", r"fps_reg_kernel<256, 4", None, "latency"),
     ("sa2.fps", r"fps_reg_kernel<64, 2", None, "latency"),
     ("sa0.knn", r"knn_quad_kernel", 8, "valu"),
@@ -339,7 +340,7 @@ def trace_kernel_times(a, streams):
         gy = "grid_y" if "grid_y" in cols else "grid_size_y"
         wx = "workgroup_x" if "workgroup_x" in cols else "workgroup_size_x"
         rows = list(c.execute(f"select name, {gx}, {gy}, {wx}, start, end from {view} order by start"))
-        marks = [i for i, r in enumerate(rows) if re.search(r"fps_reg_kernel<256, 16", r[0]) and r[1] // max(r[3], 1) == a.batch]
+        marks = [i for i, r in enumerate(rows) if re.search(r"fps_reg_kernel<(512, 8|256, 16)", r[0]) and r[1] // max(r[3], 1) == a.batch]
         if len(marks) < 8:
             return None, 0, "trace holds fewer than 8 steps"
         lo, hi = marks[len(marks) // 4], marks[3 * len(marks) // 4]
@@ -675,17 +676,27 @@ def oxford_eval(a, world=1, rank=0):
         knn_s[0] += time.perf_counter() - t
         knn_s[1] += 1
         return r
-    retrieval.get_recall_precision(desc, sizes, tuples, top_k=top_k, skip_trip_itself=True)          # warm-up
+    # the positives as arrays, once per dataset (retrieval.PositiveTable: what loading the reference's pickles is to its evaluation loop); the
+    # per-pair dict path (the reference's own data structure walked per query trip / reference trip pair) is timed beside it
+    t0 = time.perf_counter()
+    table = retrieval.PositiveTable(tuples, sizes)
+    t_table = time.perf_counter() - t0
+    retrieval.get_recall_precision(desc, sizes, table, top_k=top_k, skip_trip_itself=True)          # warm-up
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    res = retrieval.get_recall_precision(desc, sizes, tuples, top_k=top_k, skip_trip_itself=True)
+    res = retrieval.get_recall_precision(desc, sizes, table, top_k=top_k, skip_trip_itself=True)
     torch.cuda.synchronize()
     t_ret = time.perf_counter() - t0
-    retrieval.get_recall_precision(desc, sizes, tuples, top_k=top_k, skip_trip_itself=True, knn=timed_knn)      # same call, the kNN launches bracketed
+    retrieval.get_recall_precision(desc, sizes, table, top_k=top_k, skip_trip_itself=True, knn=timed_knn)      # same call, the kNN launches bracketed
+    t0 = time.perf_counter()
+    res_pp = retrieval.get_recall_precision(desc, sizes, tuples, top_k=top_k, skip_trip_itself=True)
+    torch.cuda.synchronize()
+    t_ret_pp = time.perf_counter() - t0
+    same_res = sorted(res) == sorted(res_pp) and all(all(np.array_equal(u, v) if isinstance(u, np.ndarray) else u == v for u, v in zip(res[k], res_pp[k])) for k in res)
     if dist is not None:
-        tt = torch.tensor([t_res, t_host, t_ret, knn_s[0], t_gen], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([t_res, t_host, t_ret, knn_s[0], t_gen, t_ret_pp, t_table], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)                    # a stage takes as long as its slowest rank
-        t_res, t_host, t_ret, knn_s[0], t_gen = tt.tolist()
+        t_res, t_host, t_ret, knn_s[0], t_gen, t_ret_pp, t_table = tt.tolist()
     if rank != 0:
         return None
     ave = retrieval.average(res, top_k)
@@ -701,7 +712,9 @@ def oxford_eval(a, world=1, rank=0):
         "extraction_s": t_res, "extraction_submaps_per_s": n / t_res,
         "extraction_from_pinned_host_s": t_host, "extraction_from_pinned_host_submaps_per_s": n / t_host, "host_and_resident_descriptors_identical": same,
         "all_gather_ms": ag_ms, "retrieval_ms": t_ret * 1e3, "retrieval_knn_ms": knn_s[0] * 1e3, "retrieval_knn_launches": knn_s[1],
-        "retrieval_host_bookkeeping_ms": max(t_ret - knn_s[0], 0.0) * 1e3, "end_to_end_s": e2e, "cloud_generation_s_untimed": t_gen,
+        "retrieval_host_bookkeeping_ms": max(t_ret - knn_s[0], 0.0) * 1e3, "retrieval_per_pair_dict_path_ms": t_ret_pp * 1e3,
+        "positive_table_build_ms_once_per_dataset": t_table * 1e3, "table_and_dict_paths_identical": bool(same_res),
+        "end_to_end_s": e2e, "end_to_end_with_table_build_s": e2e + t_table, "cloud_generation_s_untimed": t_gen,
         "recall_at_1": float(ave[0][0]), "recall_at_5": float(ave[0][4]), "one_percent_recall": float(ave[2]),
         "reference_recall_at_1": float(ref_rec[0]), "reference_recall_at_5": float(ref_rec[4]), "reference_one_percent_recall": ref_opr,
         "recall_delta_pp": {"at_1": float(ave[0][0] - ref_rec[0]), "at_5": float(ave[0][4] - ref_rec[4]), "max_over_N": float(np.abs(ave[0] - ref_rec).max()),

@@ -12,6 +12,8 @@
 // so that a plain unsigned max is the reference's argmax (temp >= 0, so its bit pattern is monotone).
 // The wave maximum is taken with DPP row shifts / broadcasts (no LDS), waves meet through one double-buffered
 // LDS slot array with ONE barrier per round, and the winner's coordinates come from an LDS copy of the cloud.
+#include <stdlib.h>
+
 #include "pa_common.h"
 
 
@@ -304,7 +306,14 @@ __global__ __launch_bounds__(1024) void fps_stream_kernel(int n, int m, FpsOrder
 template <int NT, int PPT>
 int launch_reg(int b, int n, int m, FpsOrder ord, const float *xyz, float *temp, int *idx, float *new_xyz, hipStream_t st, int j_begin = 0, int j_end = -1)
 {
-    const size_t lds = ((size_t)16 << (ord.log2bs + ord.qbits)) + 2 * (NT / 64) * 8;      // the cloud by rank (see the kernel) + the slot pairs
+    size_t lds = ((size_t)16 << (ord.log2bs + ord.qbits)) + 2 * (NT / 64) * 8;      // the cloud by rank (see the kernel) + the slot pairs
+    // LDS RESERVE of the long sampling chains (round 6).  A first-level launch is ~1000 strictly serial rounds on one CU per cloud; every other stream's
+    // workgroup that becomes resident beside it takes issue slots and LDS bandwidth from those rounds (0.502 -> 0.550 us per launch inside the four-stream
+    // pipeline), and the step follows the chain's length.  Asking for 128 KB instead of the 64 KB the cloud copy needs keeps all but the smallest
+    // workgroups (<= 32 KB) off the sampling CUs: + 1.0 / + 1.8 / + 0.6 % of the pipeline's rate at 104 / 128 / 156 KB (profiles/r06_ab_log.txt).  Only
+    // for chains of >= 512 rounds over clouds that fill a workgroup's registers (the first level of both models); PA_FPS_LDS_RESERVE overrides (bytes, 0 = off).
+    static const long reserve = getenv("PA_FPS_LDS_RESERVE") ? atol(getenv("PA_FPS_LDS_RESERVE")) : 128 * 1024;
+    if (m >= 512 && n >= 2048 && lds < (size_t)reserve && reserve <= 160 * 1024 - 2048) lds = (size_t)reserve;
     if (lds > 48 * 1024)  // opt in to the large-LDS carve-out (gfx950: 160 KiB per CU)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_reg_kernel<NT, PPT, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -335,7 +344,11 @@ static int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int 
     else if (n <= 1024) launch_reg<256, 4>(b, n, m, ord, xyz, temp, idx, new_xyz, st, j_begin, j_end);
     else if (n <= 2048) launch_reg<256, 8>(b, n, m, ord, xyz, temp, idx, new_xyz, st, j_begin, j_end);
     else if (n <= 4096) {
-        launch_reg<256, 16>(b, n, m, ord, xyz, temp, idx, new_xyz, st, j_begin, j_end);
+        // 512 threads (two waves per SIMD, eight points per lane) since round 6: 0.46 vs 0.50 ms per first-level launch; together with the LDS reserve
+        // of launch_reg + 1.2 % of the four-stream rate (alone + 0.3 %; round 5 measured "no change" without the reserve).  PA_FPS_NT256 = the former form.
+        static const bool nt256 = getenv("PA_FPS_NT256") != nullptr;
+        if (nt256) launch_reg<256, 16>(b, n, m, ord, xyz, temp, idx, new_xyz, st, j_begin, j_end);
+        else launch_reg<512, 8>(b, n, m, ord, xyz, temp, idx, new_xyz, st, j_begin, j_end);
     }
     else if (n <= 8192) launch_reg<256, 32>(b, n, m, ord, xyz, temp, idx, new_xyz, st, j_begin, j_end);
     else {

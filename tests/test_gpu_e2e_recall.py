@@ -108,6 +108,11 @@ def test_oxford_sized_recall_from_clouds_matches_reference_within_0p1_percent():
     top_k = int(z["top_k"])
     res = retrieval.get_recall_precision(desc, sizes, tuples, top_k=top_k, skip_trip_itself=True)
     assert len(res) == 23 * 22
+    # the array form of the positives (retrieval.PositiveTable, one bookkeeping pass per reference trip): identical 8-tuples for all 506 pairs
+    res_t = retrieval.get_recall_precision(desc, sizes, retrieval.PositiveTable(tuples, sizes), top_k=top_k, skip_trip_itself=True)
+    assert sorted(res_t) == sorted(res)
+    for k in res:
+        assert all(np.array_equal(a, b) if isinstance(a, np.ndarray) else a == b for a, b in zip(res[k], res_t[k])), k
     # Descriptors agree with the reference run to ~1e-5, not bit for bit, so a query whose k-th and (k+1)-th neighbours are a near-tie may take
     # them in the other order.  The check is stated in QUERIES, not in percentage points: per trip pair the largest Recall@N / one-percent-recall
     # difference is converted back to a number of queries (pairs have ~130 queries: one query = 0.77 points); no pair may differ by more than

@@ -16,11 +16,11 @@ def short(n, x, y, w):
     m = re.search(r"(\w+_kernel(<[^>]*>)?)", n)
     return (m.group(1) if m else n[:40]) + f"[{x // max(w, 1)},{y}]"
 # steady state: the middle half of the fps<256,16> launches
-marks = [i for i, r in enumerate(rows) if "fps_reg_kernel<256, 16" in r[0]]
+marks = [i for i, r in enumerate(rows) if "fps_reg_kernel<512, 8" in r[0]]
 lo, hi = marks[len(marks) // 4], marks[3 * len(marks) // 4]
 win = rows[lo:hi]
 t0, t1 = win[0][4], win[-1][4]
-nsteps = sum(1 for r in win if "fps_reg_kernel<256, 16" in r[0])
+nsteps = sum(1 for r in win if "fps_reg_kernel<512, 8" in r[0])
 print(f"window {(t1 - t0) / 1e6:.3f} ms, {nsteps} steps -> {(t1 - t0) / 1e3 / nsteps:.1f} us per step; columns: {cols}")
 byq = collections.defaultdict(list)
 for r in win:
