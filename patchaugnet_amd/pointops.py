@@ -388,17 +388,13 @@ class LabelStatAndBallQuery(Function):
 labelstat_and_ballquery = LabelStatAndBallQuery.apply
 
 
-def pairwise_distances(x, y=None):
-    """pointops.py:347-363 -- ||x_i - y_j||^2 via the expanded form, clamped at 0.  x (N, d), y (M, d) -> (N, M).
-    The reference's statement is plain differentiable torch; it stays the form whenever a gradient could flow (an input requires grad while
-    grad mode is on), for mixed devices and for non-fp32 inputs.  Two fp32 device tensors outside autograd run on the hand-written MFMA GEMM
-    with the norms and the clamp in its epilogue (pa_tgemm_nn, act = 2: csrc/train_gemm.hip -- the kernel the retrieval search uses);
-    strided views are made contiguous first."""
-    y = x if y is None else y
-    needs_grad = torch.is_grad_enabled() and (x.requires_grad or y.requires_grad)
-    if x.is_cuda and y.is_cuda and x.device == y.device and x.dtype == torch.float32 and y.dtype == torch.float32 and not needs_grad \
-            and x.dim() == 2 and y.dim() == 2:
-        x, y = x.detach().contiguous(), y.detach().contiguous()
+class _PairwiseDistances(Function):
+    """||x_i - y_j||^2 clamped at 0 on the MFMA GEMM kernel (pa_tgemm_nn, act = 2: norms and clamp in the epilogue), with its gradient on the same
+    kernel: with G' = g where the clamp was inactive (out > 0), dx = 2 (rowsum(G') x - G' y), dy = 2 (colsum(G') y - G'^T x)."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = x.contiguous(), y.contiguous()
         n, d = x.shape
         m = y.shape[0]
         yt = y.t().contiguous()                                              # (d, M): the GEMM's B operand
@@ -406,7 +402,38 @@ def pairwise_distances(x, y=None):
         out = torch.empty((n, m), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             call("pa_tgemm_nn", 1, n, m, d, ptr(x), 0, d, 1, ptr(yt), 0, m, 0, ptr(None), ptr(None), ptr(out), 0, m, 0, ptr(xn), ptr(yn), 2, ptr(None), 0)
+        ctx.save_for_backward(x, y, out)
         return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, out = ctx.saved_tensors
+        n, d = x.shape
+        m = y.shape[0]
+        gm = (g * (out > 0)).contiguous()                                    # torch.clamp(min=0): no gradient where the clamp acted
+        dx = dy = None
+        with torch.cuda.device(x.device):
+            if ctx.needs_input_grad[0]:
+                t = torch.empty((n, d), dtype=torch.float32, device=x.device)
+                call("pa_tgemm_nn", 1, n, d, m, ptr(gm), 0, m, 1, ptr(y), 0, d, 0, ptr(None), ptr(None), ptr(t), 0, d, 0, ptr(None), ptr(None), 0, ptr(None), 0)
+                dx = 2.0 * (gm.sum(1, keepdim=True) * x - t)
+            if ctx.needs_input_grad[1]:
+                t = torch.empty((m, d), dtype=torch.float32, device=x.device)
+                call("pa_tgemm_nn", 1, m, d, n, ptr(gm), 0, m, 0, ptr(x), 0, d, 0, ptr(None), ptr(None), ptr(t), 0, d, 0, ptr(None), ptr(None), 0, ptr(None), 0)
+                dy = 2.0 * (gm.sum(0).unsqueeze(1) * y - t)
+        return dx, dy
+
+
+def pairwise_distances(x, y=None):
+    """pointops.py:347-363 -- ||x_i - y_j||^2 via the expanded form, clamped at 0.  x (N, d), y (M, d) -> (N, M).
+    Two fp32 matrices on the MI355X run on the hand-written MFMA GEMM with the norms and the clamp in its epilogue (pa_tgemm_nn, act = 2:
+    csrc/train_gemm.hip -- the kernel the retrieval search uses), with or without autograd (round 6: the gradient runs on the same kernel; until
+    then a gradient sent the call to torch.mm).  The reference's plain torch statement remains the form for CPU tensors, mixed devices and
+    non-fp32 inputs.  y = None: both operands are x (the gradient of either use accumulates into x)."""
+    same = y is None
+    y = x if same else y
+    if x.is_cuda and y.is_cuda and x.device == y.device and x.dtype == torch.float32 and y.dtype == torch.float32 and x.dim() == 2 and y.dim() == 2:
+        return _PairwiseDistances.apply(x, y)
     x_norm = (x ** 2).sum(1).view(-1, 1)
     y_norm = (y ** 2).sum(1).view(1, -1)
     return torch.clamp(x_norm + y_norm - 2.0 * torch.mm(x, y.t()), min=0.0)

@@ -487,11 +487,13 @@ def test_knn_presorted_cloud_equals_the_oracle(kind):
 
 
 def test_pairwise_distances_device_path_and_autograd():
-    """pointops.py:347-363.  Outside autograd two fp32 device tensors run on the MFMA GEMM (norms + clamp in the epilogue); strided views are
-    accepted; with a gradient required the reference's differentiable torch statement runs and the gradient flows."""
+    """pointops.py:347-363.  Two fp32 device tensors run on the MFMA GEMM (norms + clamp in the epilogue) with AND without autograd (round 6: the
+    gradient is two more launches of the same kernel, no torch.mm); strided views are accepted; gradients for x, for y, for the y = None form and
+    with a non-uniform cotangent against float64 autograd of the reference's statement (the clamp's zero gradient included: duplicated rows)."""
     from patchaugnet_amd import pointops
     g = torch.Generator().manual_seed(3)
     x, y = torch.randn(300, 256, generator=g).cuda(), torch.randn(170, 256, generator=g).cuda()
+    y[5] = x[7]                                                                   # an exact zero distance: the clamp decides its gradient
     ref = torch.clamp((x.double() ** 2).sum(1)[:, None] + (y.double() ** 2).sum(1)[None, :] - 2.0 * x.double() @ y.double().t(), min=0.0)
     with torch.no_grad():
         d = pointops.pairwise_distances(x, y)
@@ -501,11 +503,19 @@ def test_pairwise_distances_device_path_and_autograd():
         assert torch.allclose(ds.double(), ref[:, ::2], rtol=1e-5, atol=1e-3)
         dself = pointops.pairwise_distances(x)
         assert dself.shape == (300, 300) and float(dself.diagonal().abs().max()) < 1e-2
-    xg = x.clone().requires_grad_(True)
-    dg = pointops.pairwise_distances(xg, y)
-    assert dg.grad_fn is not None
-    dg.sum().backward()
-    gref = 2.0 * (x.double()[:, None, :] - y.double()[None, :, :]).sum(1)
-    assert torch.allclose(xg.grad.double(), gref, rtol=1e-4, atol=1e-2)
-    d2 = pointops.pairwise_distances(x.detach(), y.detach())                       # no gradient required: the GEMM path, same values
-    assert d2.grad_fn is None and torch.allclose(d2, dg.detach(), rtol=1e-5, atol=1e-3)
+    cot = torch.randn(300, 170, generator=g).cuda()
+    xg, yg = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    dg = pointops.pairwise_distances(xg, yg)
+    assert dg.grad_fn is not None and "PairwiseDistances" in type(dg.grad_fn).__name__
+    (dg * cot).sum().backward()
+    xr, yr = x.double().clone().requires_grad_(True), y.double().clone().requires_grad_(True)
+    dr = torch.clamp((xr ** 2).sum(1).view(-1, 1) + (yr ** 2).sum(1).view(1, -1) - 2.0 * torch.mm(xr, yr.t()), min=0.0)
+    live = (dg.detach() > 0).double()                                             # the fp32 kernel's own clamp decisions (a distance of ~1e-5 may land on either side)
+    (dr * cot.double() * live).sum().backward()
+    assert torch.allclose(xg.grad.double(), xr.grad, rtol=1e-4, atol=2e-2) and torch.allclose(yg.grad.double(), yr.grad, rtol=1e-4, atol=2e-2)
+    xs = x.clone().requires_grad_(True)                                           # y = None: both roles accumulate into x
+    pointops.pairwise_distances(xs).sum().backward()
+    gs = 4.0 * (x.double()[:, None, :] - x.double()[None, :, :]).sum(1)
+    assert torch.allclose(xs.grad.double(), gs, rtol=1e-4, atol=5e-2)
+    d2 = pointops.pairwise_distances(x.detach(), y.detach())                       # no gradient required: same kernel, same values
+    assert d2.grad_fn is None and torch.equal(d2, dg.detach())

@@ -1,3 +1,2 @@
 cd /root/repo; export TMPDIR=/tmp; mkdir -p gpurun_out
-python tools/probes/phase_offset.py 20 2>&1 | grep -v amdgpu.ids
-python tools/probes/phase_offset.py 100 2>&1 | grep -v amdgpu.ids | head -8
+timeout 900 python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "pairwise" 2>&1 | tail -15
