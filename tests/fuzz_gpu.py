@@ -315,6 +315,81 @@ def f_sa_mid():
         return f"B={B} n={n} m={m} ns={ns} n2={n2} err={err} vs generic={errg}"
 
 
+def f_sa_tiny():
+    """the register-chained first-level kernel (sa_tiny.hip): <= 8 -> 32 -> 32 -> 64, 13..20 neighbours, 1..3 feature channels, any group count (ragged
+    last tile, fewer tiles than wavefronts, several tiles per wave), features = coordinates or not; against float64, against the generic pooled kernel
+    (equal up to the order of the fp32 additions) and against itself (deterministic)"""
+    from tests.test_gpu_chain import make_layers, mlp_ref, sa_inputs, sa_rows_ref
+    from patchaugnet_amd.engine import _Chain
+    B, n, ns, C = int(rng.integers(1, 40)), logint(2, 5000), int(rng.integers(13, 21)), int(rng.integers(1, 4))
+    m = logint(1, min(n, 1200))
+    if B * m * ns > 8e5:
+        return None
+    seed = int(rng.integers(0, 1 << 30))
+    ref, eng = make_layers([3 + C, 32, 32, 64], seed=seed)
+    xyz, feat, cidx, nbr = sa_inputs(B, n, m, ns, C, seed=seed + 1)
+    xyz_d = xyz.cuda()
+    feat_d = xyz_d if (C == 3 and rng.integers(0, 2)) else feat.cuda().contiguous()       # the engine's first level passes the coordinates as features
+    if feat_d is xyz_d:
+        feat = xyz
+    rows = sa_rows_ref(xyz, feat, cidx, nbr).double()
+    exp = mlp_ref(rows, [(w.float().double(), b.float().double()) for w, b in ref]).max(dim=2)[0].reshape(B * m, -1)
+    args = (xyz_d, feat_d, cidx.cuda(), nbr.cuda(), C)
+    lib = _lib.lib()
+    try:
+        lib.pa_chain_tiny_enable(1)
+        got = _Chain(eng).sa(*args, pooled=True)
+        again = _Chain(eng).sa(*args, pooled=True)
+        lib.pa_chain_tiny_enable(0)
+        gen = _Chain(eng).sa(*args, pooled=True)
+        torch.cuda.synchronize()
+    finally:
+        lib.pa_chain_tiny_enable(-1)
+    scale = exp.abs().max().item() + 1e-12
+    err, errg = (got.double().cpu() - exp).abs().max().item(), (got.double() - gen.double()).abs().max().item()
+    if not (err <= 2e-5 * scale and errg <= 2e-5 * scale and torch.equal(got, again)):
+        return f"B={B} n={n} m={m} ns={ns} C={C} same={feat_d is xyz_d} err={err} vs generic={errg} deterministic={torch.equal(got, again)}"
+
+
+def f_fpx32():
+    """the finest FP level in half-K passes (fpx_f32.hip) forced on / off: it takes launches of >= 65 536 rows (below, the shared-tile tilings run either
+    way), 1..4 skip channels, ragged last tiles; the same bits as the 16-row tile kernel, and float64"""
+    from tests.test_gpu_chain import make_layers, mlp_ref
+    from patchaugnet_amd.engine import _Chain
+    B, c1 = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+    n = int(rng.integers(65536 // B + 1, 100000 // B + 2)) if rng.integers(0, 4) else logint(1, 30000)
+    m = logint(1, 3000)
+    seed = int(rng.integers(0, 1 << 30))
+    ref, eng = make_layers([256 + c1, 256, 256, 256], seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    known = torch.randn(B, m, 256, generator=g)
+    skip = torch.randn(B, n, c1, generator=g)
+    idx3 = torch.randint(0, m, (B, n, 3), generator=g).int()
+    w3 = torch.rand(B, n, 3, generator=g)
+    w3 = (w3 / w3.sum(-1, keepdim=True)).contiguous()
+    args = (known.cuda(), idx3.cuda(), w3.cuda(), skip.cuda(), B, n, m, 256, c1)
+    ch = _Chain(eng)
+    ch.build_premul(256, c1)
+    lib = _lib.lib()
+    try:
+        lib.pa_chain_fpx32_enable(1)
+        got = ch.fp_premul(*args).clone()
+        lib.pa_chain_fpx32_enable(0)
+        tile = ch.fp_premul(*args).clone()
+        torch.cuda.synchronize()
+    finally:
+        lib.pa_chain_fpx32_enable(-1)
+    if not torch.equal(got, tile):
+        return f"B={B} n={n} m={m} c1={c1}: half-K kernel and tile kernel differ, max {float((got - tile).abs().max())}"
+    sel = torch.randperm(B * n, generator=g)[:4096]                       # float64 reference on a sample of the rows (the whole tensor is up to 100 k x 256)
+    bsel, psel = sel // n, sel % n
+    interp = sum(w3[bsel, psel, t:t + 1].double() * known.double()[bsel, idx3[bsel, psel, t].long()] for t in range(3))
+    exp = mlp_ref(torch.cat([interp, skip[bsel, psel].double()], -1), [(w.float().double(), b.float().double()) for w, b in ref])
+    err = (got[sel.cuda()].double().cpu() - exp).abs().max().item()
+    if not err <= 2e-5 * (exp.abs().max().item() + 1e-12):
+        return f"B={B} n={n} m={m} c1={c1} err={err}"
+
+
 def f_fpx16():
     """the fp16 path's finest FP level (fpx_f16.hip): both workgroup shapes, fp16 and fp32 pre-multiplied table, any row count; reference with
     the same operand roundings in float64 (2e-3 of the scale: a hidden value next to an fp16 tie may round the other way)"""
@@ -542,7 +617,7 @@ def f_train_glue():
 
 FAMILIES = (("fps", f_fps), ("knn", f_knn), ("3nn", f_3nn), ("knn_grid", f_knn_grid), ("3nn_grid", f_3nn_grid), ("gather", f_gather), ("backward", f_backward), ("linear", f_linear),
             ("attention", f_attention), ("chain_sa", f_chain_sa), ("chain_fp", f_chain_fp), ("netvlad", f_netvlad), ("afa", f_afa), ("linear_lds", f_linear_lds), ("train_glue", f_train_glue),
-            ("sa_mid", f_sa_mid), ("fpx16", f_fpx16), ("attention_f16", f_attention_f16), ("fpx3", f_fpx3))
+            ("sa_mid", f_sa_mid), ("sa_tiny", f_sa_tiny), ("fpx32", f_fpx32), ("fpx16", f_fpx16), ("attention_f16", f_attention_f16), ("fpx3", f_fpx3))
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:

@@ -5,7 +5,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-NAMES = ["fps", "knn", "3nn", "knn_grid", "3nn_grid", "gather", "backward", "linear", "attention", "chain_sa", "chain_fp", "netvlad", "afa", "linear_lds", "train_glue", "sa_mid", "fpx16", "attention_f16", "fpx3"]
+NAMES = ["fps", "knn", "3nn", "knn_grid", "3nn_grid", "gather", "backward", "linear", "attention", "chain_sa", "chain_fp", "netvlad", "afa", "linear_lds", "train_glue", "sa_mid", "sa_tiny", "fpx32", "fpx16", "attention_f16", "fpx3"]
 
 
 @pytest.mark.parametrize("family", NAMES)
