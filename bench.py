@@ -39,6 +39,9 @@ def parse():
     p.add_argument("--no-kernel-pass", action="store_true")
     p.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic (it is then null)")
     p.add_argument("--no-trace", action="store_true", help="skip the two rocprofv3 --kernel-trace passes behind stage_rooflines / roofline.frac (the roofline then carries the HIP-event figure only)")
+    p.add_argument("--no-lookahead", action="store_true", help="the plain pipeline: one captured graph of the WHOLE step per stream (extract.GraphedExtractor) instead of the "
+                                                                "first-level sampling of groups of batches one group ahead (extract.SampledAheadExtractor)")
+    p.add_argument("--group", type=int, default=8, help="batches per sampling launch of the look-ahead pipeline (8 x 32 clouds = one workgroup per CU)")
     p.add_argument("--only-steps", action="store_true", help="the timed steps and nothing else (the child run of the kernel-trace passes)")
     p.add_argument("--cpu-batch", type=int, default=8)
     p.add_argument("--model", choices=["patch_aug_net", "pptnet"], default="patch_aug_net", help="pptnet = BASELINE.json configs[4]")
@@ -340,7 +343,7 @@ def trace_kernel_times(a, streams):
         gy = "grid_y" if "grid_y" in cols else "grid_size_y"
         wx = "workgroup_x" if "workgroup_x" in cols else "workgroup_size_x"
         rows = list(c.execute(f"select name, {gx}, {gy}, {wx}, start, end from {view} order by start"))
-        marks = [i for i, r in enumerate(rows) if re.search(r"fps_reg_kernel<(512, 8|256, 16)", r[0]) and r[1] // max(r[3], 1) == a.batch]
+        marks = [i for i, r in enumerate(rows) if re.search(DOMINANT_KERNEL_RE, r[0])]      # one launch of the finest FP level per step (the child runs the headline shape only)
         if len(marks) < 8:
             return None, 0, "trace holds fewer than 8 steps"
         lo, hi = marks[len(marks) // 4], marks[3 * len(marks) // 4]
@@ -781,18 +784,20 @@ def extras(a):
         x = synthetic_submaps(a.batch, a.points, seed=1234).cuda()
         steps = 40
         with torch.no_grad():
-            gx = GraphedExtractor(model, tuple(x.shape), a.streams)
+            # the headline's pipeline (extract.SampledAheadExtractor: first-level sampling of 8 batches a group ahead) on 40 distinct resident batches
+            from patchaugnet_amd.extract import SampledAheadExtractor
+            xs = torch.stack([synthetic_submaps(a.batch, a.points, seed=4321 + i) for i in range(steps)]).cuda()
+            out = torch.empty(steps, a.batch, 256, device="cuda")
+            gx = SampledAheadExtractor(model, tuple(x.shape), a.streams, group=a.group)
             rates = []
             for rep in range(4):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                gx.begin()
-                for _ in range(steps):
-                    gx.run(x)
-                gx.end()
+                gx.extract(xs, out)
                 torch.cuda.synchronize()
                 if rep:
                     rates.append(steps * a.batch / (time.perf_counter() - t0))
+            del xs, out
         rates.sort()
         res = {"value": rates[1], "unit": "submaps/s", "min": rates[0], "max": rates[-1], "batch": a.batch, "steps": steps,
                "dtype": {"f32": "f32", "f16": "f16 MFMA operands in the shared-MLP chains and the self-attention contractions, fp32 accumulate / soft-max / everything else fp32",
@@ -994,18 +999,42 @@ def main():
             torch.cuda.synchronize()
     if not use_graphs:
         pipe = StreamPipeline(a.streams)
+    # Look-ahead pipeline (default): the K steps' batches are K DISTINCT resident batches (one (K, B, 1, N, 3) tensor: the dataset in HBM); the first-level
+    # sampling of `--group` consecutive batches is one launch a group ahead of the graphs that consume it (extract.SampledAheadExtractor).  Every
+    # step's descriptors come from its own batch through the same kernels; nothing is cached between steps or repetitions.
+    ahead = None
+    x_steps = None
+    if use_graphs and not a.no_lookahead and a.streams >= 2:
+        try:
+            from patchaugnet_amd.extract import SampledAheadExtractor
+            uniq = min(a.steps, 64)                                      # distinct batches (a 64-batch dataset is 100 MB; steps beyond reuse them in order)
+            x_steps = torch.stack([synthetic_submaps(a.batch, a.points, seed=1234 + rank * 1000 + i) for i in range(uniq)]).cuda()
+            if uniq < a.steps:
+                x_steps = torch.cat([x_steps] * ((a.steps + uniq - 1) // uniq))[:a.steps].contiguous()
+            with torch.no_grad():
+                ahead = SampledAheadExtractor(model, tuple(x.shape), a.streams, group=a.group)
+        except Exception as ex:
+            print(f"bench.py: look-ahead pipeline unavailable ({ex!r}); plain per-stream graphs", file=sys.stderr)
+            ahead = None
 
     def one(i):
         d = model(x, return_feat=False)
         if i >= 0:
             descs[i].copy_(d)
 
+    def run_steps(n, warm=False):
+        """n steps of the hot path; descriptors of step i -> descs[i] (warm-up steps write nowhere that is read)"""
+        if ahead is not None:
+            ahead.extract(x_steps[:n] if n <= x_steps.shape[0] else x_steps, descs[:n] if n <= descs.shape[0] else descs)
+            return
+        pipe.begin()
+        for i in range(n):
+            pipe.submit(one, -1 if warm else i)
+        pipe.end()
+
     with torch.no_grad():
         torch.manual_seed(0)
-        pipe.begin()
-        for _ in range(max(a.warmup, a.streams)):   # every stream (and its allocator pool) gets warmed
-            pipe.submit(one, -1)
-        pipe.end()
+        run_steps(min(max(a.warmup, a.streams), a.steps), warm=True)   # every stream (and its allocator pool) gets warmed
         if dist is not None:   # communicator and buffers for the one collective of the timed region are set up before the clock starts
             gathered = torch.empty(world * a.steps * a.batch, 256, device="cuda")
             dist.all_gather_into_tensor(gathered, descs.view(-1, 256))
@@ -1019,10 +1048,7 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            pipe.begin()
-            for i in range(a.steps):
-                pipe.submit(one, i)
-            pipe.end()
+            run_steps(a.steps)
             ag_ms = None
             if dist is not None:   # the one exchange step: every rank's descriptors to every rank (its own duration is reported beside the total)
                 torch.cuda.synchronize()
@@ -1066,8 +1092,31 @@ def main():
                    "batch_per_gpu": a.batch, "points": a.points,
                    "path": "fused HIP engine" if model.fused_eval else "HIP point ops + torch dense ops (module path)",
                    "weights": "key-seeded random init", "parallelism": f"dp{world}", "streams": a.streams,
-                   "launch": "hipGraph replay per stream (the HBM-resident batch is read in place; descriptors copied to the result buffer)" if use_graphs else "python launches"},
+                   "launch": ((f"look-ahead pipeline: the first-level sampling of {a.group} consecutive batches ({a.group * a.batch} clouds) is one launch on a sampling stream, a group ahead; "
+                               f"the rest of every step is one hipGraph replay on {a.streams} feature streams reading the group's coordinates and samples in place "
+                               "(extract.SampledAheadExtractor); K distinct HBM-resident batches, descriptors copied to the result buffer") if ahead is not None else
+                              "hipGraph replay of the whole step per stream (the HBM-resident batch is read in place; descriptors copied to the result buffer)") if use_graphs else "python launches"},
     }
+    if ahead is not None and world == 1 and use_graphs and not a.only_steps:
+        # the plain pipeline beside it, same run: one captured graph of the whole step per stream, the resident batch read in place (the headline of rounds 2-5)
+        try:
+            with torch.no_grad():
+                rates = []
+                for rep in range(4):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    pipe.begin()
+                    for i in range(a.steps):
+                        pipe.submit(one, i)
+                    pipe.end()
+                    torch.cuda.synchronize()
+                    if rep:
+                        rates.append(a.steps * a.batch / (time.perf_counter() - t0))
+            rates.sort()
+            line["plain_graph_pipeline"] = {"value": rates[1], "unit": "submaps/s", "min": rates[0], "max": rates[-1], "steps": a.steps,
+                                            "note": "extract.GraphedExtractor: the first-level sampling inside every step's graph; after a synchronisation its four graphs run in lock-step for ~16 steps"}
+        except Exception as ex:
+            line["plain_graph_pipeline"] = {"error": repr(ex)}
     line["repetitions"] = {"count": len(rep_dt), "statistic": "median", "submaps_per_s": [round(submaps / t, 1) for t in rep_dt],
                            "min": submaps / max(rep_dt), "max": submaps / min(rep_dt)}
     if ag_ms is not None:

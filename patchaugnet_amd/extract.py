@@ -161,6 +161,134 @@ class GraphedExtractor:
             cur.wait_stream(st)
 
 
+class SampledAheadExtractor:
+    """Descriptor extraction over a KNOWN list of batches (the reference's ``SceneDataSet.make_descs`` loop, datasets/scene_dataset.py:510-523, walks a
+    dataset whose submaps are all there before the first forward) with the first-level sampling taken out of the per-batch graphs:
+
+      * the farthest-point sampling of a whole GROUP of batches (``group`` x B clouds: one workgroup per CU at 8 x 32) is ONE launch on a sampling
+        stream, a group ahead of the batches that consume it -- ~1000 serial rounds per cloud that depend on coordinates only;
+      * the rest of a batch's step is a captured hipGraph per (buffer set, position in the group) on ``n_streams`` feature streams, reading the
+        group's coordinates and samples IN PLACE (``PatchAugNetEngine.forward(s0=...)``; graphs of one stream share a memory pool).
+
+    Why: after a synchronisation the four plain graphs of ``GraphedExtractor`` run in lock-step -- four samplings at once
+    on 128 of 256 CUs with nothing else to do, then four dense phases sharing the chip -- and need ~16 steps to drift apart; a 20-step region
+    (the driver's protocol) runs at 39.3 k submaps/s that way and at 41.5-42.0 k with the sampling a group ahead.  Long regions converge (41 k both):
+    the dense phases' co-run is the bound there.  Descriptors are bit-identical to the plain forward (tests/test_gpu_extract.py).
+
+    Only for a fixed batch shape and the fused engine; ``GraphedExtractor`` stays the tool for one batch at a time."""
+
+    def __init__(self, model, batch_shape, n_streams=4, group=8, device=None, warmup=1):
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        assert not model.training, "hipGraph capture is for evaluation (fused engine, no autograd)"
+        B, _, N, _ = batch_shape
+        self.shape, self.group = tuple(batch_shape), int(group)
+        streams = _pipeline_streams(self.device, max(1, n_streams))
+        self.feat = streams
+        # the sampling stream is one stream MORE than the feature streams (it shares a hardware queue with one of them; with one launch per group
+        # that costs nothing -- a sampling stream INSTEAD of a feature stream does: 39.2-39.7 k against 41.5 k)
+        self.samp = _sampling_stream(self.device)
+        cur = torch.cuda.current_stream(self.device)
+        _prepare(model, self.device)
+        with torch.no_grad():
+            x0 = torch.zeros(batch_shape, dtype=torch.float32, device=self.device)
+            model(x0, return_feat=False)                                  # builds the engine
+            eng = self._engine = model._engine
+            m0 = eng.sampling[0]
+            self.sets = []
+            pools = [None] * len(streams)
+            for q in range(2):
+                xbig = torch.zeros((group,) + self.shape, dtype=torch.float32, device=self.device)
+                cbig = torch.zeros((group * B, m0), dtype=torch.int32, device=self.device)
+                nbig = torch.zeros((group * B, m0, 3), dtype=torch.float32, device=self.device)
+                eng.sample_first_level(xbig.view(group * B, N, 3), cbig, nbig)
+                graphs = []
+                for p in range(group):
+                    k = p % len(streams)
+                    st = streams[k]
+                    s0 = (cbig[p * B:(p + 1) * B], nbig[p * B:(p + 1) * B])
+                    st.wait_stream(cur)
+                    with torch.cuda.stream(st):
+                        for _ in range(warmup if pools[k] is None else 0):
+                            eng.forward(xbig[p], views=False, s0=s0)
+                    cur.wait_stream(st)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=st, pool=pools[k], capture_error_mode="thread_local"):
+                        y, _ = eng.forward(xbig[p], views=False, s0=s0)
+                    if pools[k] is None:
+                        pools[k] = g.pool()                               # graphs of one stream never overlap: one pool (their outputs are copied out before the next replay)
+                    graphs.append((g, y, st))
+                self.sets.append((xbig, cbig, nbig, graphs))
+        torch.cuda.synchronize(self.device)
+        self._model = model
+
+    def extract(self, batches, out):
+        """batches: (nb, B, 1, N, 3) tensor or a sequence of (B, 1, N, 3) tensors (device, or pinned host: copied on the sampling stream);
+        out: (nb, B, 256) device tensor.  Returns ``out``; the caller's stream waits for everything before this returns (like ``GraphedExtractor.end``)."""
+        eng = getattr(self._model, "_engine", None)
+        if eng is not self._engine or self._model.training or (eng is not None and eng.stale(self._model)):
+            raise RuntimeError("SampledAheadExtractor: the model's weights or mode changed after capture (load_state_dict / train()); build a new one")
+        nb = len(batches)
+        G, B = self.group, self.shape[0]
+        N = self.shape[2]
+        cur = torch.cuda.current_stream(self.device)
+        samp = self.samp
+        samp.wait_stream(cur)
+        for s in self.feat:
+            s.wait_stream(cur)
+        ngroups = (nb + G - 1) // G
+        consumed = [None, None]               # per buffer set: the end events of the graphs that last read it
+        ev_s = [None] * ngroups
+        contiguous = torch.is_tensor(batches)
+
+        def sample(gi):
+            q = gi % 2
+            xbig, cbig, nbig, _ = self.sets[q]
+            n = min(G, nb - gi * G)
+            with torch.cuda.stream(samp):
+                for e in consumed[q] or ():
+                    samp.wait_event(e)
+                if contiguous:
+                    xbig[:n].copy_(batches[gi * G:gi * G + n], non_blocking=True)
+                else:
+                    for j in range(n):
+                        xbig[j].copy_(batches[gi * G + j], non_blocking=True)
+                self._engine.sample_first_level(xbig.view(G * B, N, 3)[:n * B], cbig[:n * B], nbig[:n * B])
+                ev_s[gi] = torch.cuda.Event()
+                ev_s[gi].record(samp)
+        sample(0)
+        for gi in range(ngroups):
+            q = gi % 2
+            n = min(G, nb - gi * G)
+            ends = []
+            for j in range(n):
+                g, y, st = self.sets[q][3][j]
+                with torch.cuda.stream(st):
+                    st.wait_event(ev_s[gi])
+                    g.replay()
+                    out[gi * G + j].copy_(y, non_blocking=True)
+                    e = torch.cuda.Event()
+                    e.record(st)
+                    ends.append(e)
+                if j == 0 and gi + 1 < ngroups:
+                    sample(gi + 1)            # queued right behind this group's first graph: runs under the group's dense kernels
+            consumed[q] = ends
+        cur.wait_stream(samp)
+        for s in self.feat:
+            cur.wait_stream(s)
+        return out
+
+
+_SAMP = {}
+
+
+def _sampling_stream(device):
+    key = (device.type, device.index)
+    if key not in _SAMP:
+        _pipeline_streams(device, 4)                                     # the feature streams take their hardware queues first
+        _SAMP[key] = torch.cuda.Stream(device=device)
+    return _SAMP[key]
+
+
 @torch.no_grad()
 def extract_descriptors(model, batches, n_streams=4, out=None, graphs=False):
     """batches: iterable of (B,1,N,3) device tensors -> (sum B, 256) descriptors in input order.  graphs=True replays a captured

@@ -313,3 +313,35 @@ def test_graphed_extractor_distinct_batches_with_eager_work_between_replays(name
     torch.cuda.synchronize()
     for i in range(10):
         assert torch.equal(out[i], ref[i]), i
+
+
+@pytest.mark.parametrize("name,dtype", [("patch_aug_net", "f32"), ("pptnet", "f32"), ("pptnet", "f16"), ("patch_aug_net", "f16")])
+def test_sampled_ahead_extractor_is_bit_identical_to_the_plain_forward(name, dtype):
+    """extract.SampledAheadExtractor (round 6): the first-level sampling of groups of batches as one launch a group ahead on a sampling stream, the rest of
+    every step as a captured graph reading the group's coordinates and samples in place.  21 distinct batches (two full groups of 8 and a ragged one,
+    both buffer sets reused) as one resident tensor, then as a list of pinned host tensors, then again after eager work: every descriptor block must
+    equal the plain forward of its batch bit for bit."""
+    from patchaugnet_amd.extract import SampledAheadExtractor
+    m = _model(name)
+    m.mlp_dtype = dtype
+    nb = 21
+    xs = torch.stack([synthetic_submaps(8, 4096, 300 + i, "street" if i % 4 == 0 else "uniform") for i in range(nb)])
+    xd = xs.cuda()
+    with torch.no_grad():
+        ref = torch.stack([m(xd[i], return_feat=False) for i in range(nb)])
+        ex = SampledAheadExtractor(m, (8, 1, 4096, 3), n_streams=4, group=8)
+        out = torch.full((nb, 8, 256), float("nan"), device="cuda")
+        ex.extract(xd, out)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+        host = [xs[i].pin_memory() for i in range(nb)]
+        out2 = torch.full((nb, 8, 256), float("nan"), device="cuda")
+        junk = torch.full((1 << 22,), float("nan"), device="cuda")
+        del junk
+        ex.extract(host[:5], out2[:5])                    # a region shorter than a group
+        ex.extract(host, out2)
+        torch.cuda.synchronize()
+        assert torch.equal(out2, ref)
+    m.train()
+    with pytest.raises(RuntimeError):
+        ex.extract(xd, out)
