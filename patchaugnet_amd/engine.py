@@ -663,7 +663,43 @@ class PatchAugNetEngine:
         launch extract.GraphedExtractor puts on its sampling streams; hand the buffers to forward(..., s0=(cidx0, nxyz0))."""
         call("pa_furthestsampling_gather", xyz.shape[0], xyz.shape[1], self.sampling[0], ptr(xyz), ptr(cidx0), ptr(nxyz0))
 
-    def backbone(self, xyz, early=None, s0=None):
+    def geometry_buffers(self, clouds, points, device=None):
+        """Caller-owned buffers for everything of `clouds` clouds that depends on the coordinates only: per set-abstraction level the centre
+        indices, centre coordinates and neighbour lists, per feature-propagation level the 3-NN indices and weights.  compute_geometry fills them,
+        forward(..., geo=a per-batch slice) consumes them in place (extract.SampledAheadExtractor computes a whole group of batches ahead)."""
+        dev = self.device if device is None else device
+        L, nfp = len(self.sa), len(self.fp)
+        npts = [points] + list(self.sampling[:L])
+        off = L - nfp
+        return {"cidx": [torch.empty((clouds, npts[i + 1]), dtype=torch.int32, device=dev) for i in range(L)],
+                "nxyz": [torch.empty((clouds, npts[i + 1], 3), dtype=torch.float32, device=dev) for i in range(L)],
+                "nbr": [torch.empty((clouds, npts[i + 1], self.knn[i]), dtype=torch.int32, device=dev) for i in range(L)],
+                "d2": [torch.empty((clouds, npts[i + 1], self.knn[i]), dtype=torch.float32, device=dev) for i in range(L)],
+                "w3": [torch.empty((clouds, npts[j + off], 3), dtype=torch.float32, device=dev) for j in range(nfp)],
+                "idx3": [torch.empty((clouds, npts[j + off], 3), dtype=torch.int32, device=dev) for j in range(nfp)]}
+
+    @staticmethod
+    def geometry_slice(geo, lo, hi):
+        """The buffers of clouds lo .. hi - 1 of a geometry_buffers() set (views: the batch's graphs read them in place)."""
+        return {k: [t[lo:hi] for t in v] for k, v in geo.items()}
+
+    def compute_geometry(self, xyz, geo, first_level_only=False):
+        """Sampling, centre gather, neighbour search of every level and the 3-NN weights of every decoder level for xyz (clouds, N, 3) into `geo`
+        (geometry_buffers(clouds)), on the current stream: exactly the launches backbone() would issue between its chains, for any number of clouds at once."""
+        B = xyz.shape[0]
+        L, nfp = len(self.sa), len(self.fp)
+        npts = [xyz.shape[1]] + list(self.sampling[:L])
+        off = L - nfp
+        l_xyz = [xyz] + [t[:B] for t in geo["nxyz"]]
+        for i in range(L):
+            call("pa_furthestsampling_gather", B, npts[i], npts[i + 1], ptr(l_xyz[i]), ptr(geo["cidx"][i]), ptr(geo["nxyz"][i]))
+            if first_level_only:
+                return
+            call("pa_knnquery", B, npts[i], npts[i + 1], self.knn[i], ptr(l_xyz[i]), ptr(geo["nxyz"][i]), ptr(geo["nbr"][i]), ptr(geo["d2"][i]))
+        for j in range(nfp - 1, -1, -1):
+            call("pa_three_nn_weights", B, npts[j + off], npts[j + off + 1], ptr(l_xyz[j + off]), ptr(l_xyz[j + off + 1]), ptr(geo["w3"][j]), ptr(geo["idx3"][j]))
+
+    def backbone(self, xyz, early=None, s0=None, geo=None):
         """xyz (B, N, 3) -> point-major features per level + level-0 centre indices.  early(l_feat): called once the decoder has written every
         level but the finest (the engine issues the coarse NetVLAD scales there).
 
@@ -677,37 +713,45 @@ class PatchAugNetEngine:
         L, nfp = len(self.sa), len(self.fp)
         npts = [xyz.shape[1]] + list(self.sampling[:L])
         # outputs of the geometry kernels, allocated on the main stream before any fork
-        cidx = [torch.empty((B, npts[i + 1]), dtype=torch.int32, device=dev) for i in range(L)]
-        nxyz = [torch.empty((B, npts[i + 1], 3), dtype=torch.float32, device=dev) for i in range(L)]
-        nbr = [torch.empty((B, npts[i + 1], self.knn[i]), dtype=torch.int32, device=dev) for i in range(L)]
-        d2 = [torch.empty((B, npts[i + 1], self.knn[i]), dtype=torch.float32, device=dev) for i in range(L)]
         off = L - nfp                              # FP level j interpolates level j + off + 1's features onto level j + off's points
-        w3 = [torch.empty((B, npts[j + off], 3), dtype=torch.float32, device=dev) for j in range(nfp)]
-        idx3 = [torch.empty((B, npts[j + off], 3), dtype=torch.int32, device=dev) for j in range(nfp)]
+        if geo is not None:                        # everything that depends on coordinates only was computed ahead (compute_geometry): read in place
+            cidx, nxyz, nbr, d2, w3, idx3 = (list(geo[k]) for k in ("cidx", "nxyz", "nbr", "d2", "w3", "idx3"))
+        else:
+            cidx = [torch.empty((B, npts[i + 1]), dtype=torch.int32, device=dev) for i in range(L)]
+            nxyz = [torch.empty((B, npts[i + 1], 3), dtype=torch.float32, device=dev) for i in range(L)]
+            nbr = [torch.empty((B, npts[i + 1], self.knn[i]), dtype=torch.int32, device=dev) for i in range(L)]
+            d2 = [torch.empty((B, npts[i + 1], self.knn[i]), dtype=torch.float32, device=dev) for i in range(L)]
+            w3 = [torch.empty((B, npts[j + off], 3), dtype=torch.float32, device=dev) for j in range(nfp)]
+            idx3 = [torch.empty((B, npts[j + off], 3), dtype=torch.int32, device=dev) for j in range(nfp)]
         if s0 is not None:                         # first level already sampled (sample_first_level on another stream)
             cidx[0], nxyz[0] = s0
         l_xyz = [xyz] + nxyz
 
         def fps(i):
-            call("pa_furthestsampling_gather", B, npts[i], npts[i + 1], ptr(l_xyz[i]), ptr(cidx[i]), ptr(nxyz[i]))
+            if geo is None:
+                call("pa_furthestsampling_gather", B, npts[i], npts[i + 1], ptr(l_xyz[i]), ptr(cidx[i]), ptr(nxyz[i]))
 
         # first level: the input cloud's cell sort does not depend on the centres, so it is issued BEFORE the sampling chain (one workgroup per
         # cloud, ~15 us, next to nothing in CU-time); the neighbour search then copies the record instead of sorting in each of its workgroups
         cells = None
-        if self._presort_ok(npts[0], npts[1], self.knn[0]):
+        if geo is None and self._presort_ok(npts[0], npts[1], self.knn[0]):
             cells = torch.empty(_lib.lib().pa_cloud_cellsort_floats(B, npts[0]), dtype=torch.float32, device=dev)
             call("pa_cloud_cellsort", B, npts[0], ptr(xyz), ptr(cells))
 
         def knn(i):
+            if geo is not None:
+                return
             if i == 0 and cells is not None:
                 call("pa_knnquery_presorted", B, npts[0], npts[1], self.knn[0], ptr(xyz), ptr(nxyz[0]), ptr(cells), ptr(nbr[0]), ptr(d2[0]))
                 return
             call("pa_knnquery", B, npts[i], npts[i + 1], self.knn[i], ptr(l_xyz[i]), ptr(nxyz[i]), ptr(nbr[i]), ptr(d2[i]))
 
         def tnn(j):      # patch_aug_net.py:350-353
+            if geo is not None:
+                return
             call("pa_three_nn_weights", B, npts[j + off], npts[j + off + 1], ptr(l_xyz[j + off]), ptr(l_xyz[j + off + 1]), ptr(w3[j]), ptr(idx3[j]))
 
-        overlap = self.geo_overlap and self.timer is None and L > 1 and not torch.cuda.is_current_stream_capturing()
+        overlap = self.geo_overlap and self.timer is None and L > 1 and geo is None and not torch.cuda.is_current_stream_capturing()
         ev_sa, ev_fp = [None] * L, [None] * nfp
         main = torch.cuda.current_stream(dev)
         # Latency mode, first level in CHUNKS: the sampling order is prefix-stable, so the first quarter of the centres is final when a quarter
@@ -823,15 +867,15 @@ class PatchAugNetEngine:
             self.last_geometry = {"center_idx": list(cidx), "sample_idx": list(nbr), "sa_features": list(sa_feat)}
         return l_feat, l_c
 
-    def forward(self, x, views=True, s0=None):
+    def forward(self, x, views=True, s0=None, geo=None):
         """-> desc (B, 256), (fp_features views, level-0 centre indices); views=False skips the index mapping (descriptor-only callers).
         s0: (indices, centres) of the first level when sample_first_level already ran for this x."""
         if x.device.index is not None and x.device.index != torch.cuda.current_device():
             with torch.cuda.device(x.device):        # the C ABI launches on the CURRENT device's stream: follow the tensor
-                return self._forward(x, views, s0)
-        return self._forward(x, views, s0)
+                return self._forward(x, views, s0, geo)
+        return self._forward(x, views, s0, geo)
 
-    def _forward(self, x, views, s0=None):
+    def _forward(self, x, views, s0=None, geo=None):
         xyz = x.squeeze(1).contiguous()
         self._mark("start")
         nfp = len(self.fp)
@@ -850,7 +894,7 @@ class PatchAugNetEngine:
         fine = self.vlads[-1] if self.vlads else None
         self._fp0_half = bool(not views and pyr is not None and pyr.f16 and self._fp0_half_ok and fine is not None and fine.k > 48 and fine.c == 256
                               and xyz.shape[1] >= 2048 and (getattr(self.fp[0], "_premul", None) or {}).get("g16"))
-        l_feat, l_c = self.backbone(xyz, early if split else None, s0)
+        l_feat, l_c = self.backbone(xyz, early if split else None, s0, geo)
         half_map = self._fp0_half and l_feat[0].dtype == torch.float16
         self._fp0_half = False
         feats = [l_feat[j] for j in range(nfp - 1, -1, -1)]                                   # coarse -> fine, (B, N_i, 256)

@@ -177,7 +177,7 @@ class SampledAheadExtractor:
 
     Only for a fixed batch shape and the fused engine; ``GraphedExtractor`` stays the tool for one batch at a time."""
 
-    def __init__(self, model, batch_shape, n_streams=4, group=8, device=None, warmup=1):
+    def __init__(self, model, batch_shape, n_streams=4, group=8, device=None, warmup=1, ahead=None):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         assert not model.training, "hipGraph capture is for evaluation (fused engine, no autograd)"
         B, _, N, _ = batch_shape
@@ -193,31 +193,36 @@ class SampledAheadExtractor:
             x0 = torch.zeros(batch_shape, dtype=torch.float32, device=self.device)
             model(x0, return_feat=False)                                  # builds the engine
             eng = self._engine = model._engine
-            m0 = eng.sampling[0]
+            # what runs a group ahead: "sampling" (default) = the first level's sampling alone; "geometry" = every launch that depends on coordinates only
+            # (sampling, centre gathers and neighbour search of all levels, the decoder's 3-NN weights).  Measured (profiles/r06_ab_log.txt): 20 steps
+            # 41.0-41.3 k (sampling) vs 39.0-39.8 k (geometry) vs 39.2-40.1 k (plain graphs); 100 steps 41.0 vs 40.4 vs 41.4 k -- the group's
+            # chip-filling search launches on the side stream take from the dense kernels what they save the graphs.
+            import os
+            self.mode = ahead or os.environ.get("PA_AHEAD", "sampling")
             self.sets = []
             pools = [None] * len(streams)
             for q in range(2):
                 xbig = torch.zeros((group,) + self.shape, dtype=torch.float32, device=self.device)
-                cbig = torch.zeros((group * B, m0), dtype=torch.int32, device=self.device)
-                nbig = torch.zeros((group * B, m0, 3), dtype=torch.float32, device=self.device)
-                eng.sample_first_level(xbig.view(group * B, N, 3), cbig, nbig)
+                geo = eng.geometry_buffers(group * B, N, self.device)
+                eng.compute_geometry(xbig.view(group * B, N, 3), geo)
                 graphs = []
                 for p in range(group):
                     k = p % len(streams)
                     st = streams[k]
-                    s0 = (cbig[p * B:(p + 1) * B], nbig[p * B:(p + 1) * B])
+                    gs = eng.geometry_slice(geo, p * B, (p + 1) * B)
+                    kw = {"geo": gs} if self.mode == "geometry" else {"s0": (gs["cidx"][0], gs["nxyz"][0])}
                     st.wait_stream(cur)
                     with torch.cuda.stream(st):
                         for _ in range(warmup if pools[k] is None else 0):
-                            eng.forward(xbig[p], views=False, s0=s0)
+                            eng.forward(xbig[p], views=False, **kw)
                     cur.wait_stream(st)
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=st, pool=pools[k], capture_error_mode="thread_local"):
-                        y, _ = eng.forward(xbig[p], views=False, s0=s0)
+                        y, _ = eng.forward(xbig[p], views=False, **kw)
                     if pools[k] is None:
                         pools[k] = g.pool()                               # graphs of one stream never overlap: one pool (their outputs are copied out before the next replay)
                     graphs.append((g, y, st))
-                self.sets.append((xbig, cbig, nbig, graphs))
+                self.sets.append((xbig, geo, graphs))
         torch.cuda.synchronize(self.device)
         self._model = model
 
@@ -242,7 +247,7 @@ class SampledAheadExtractor:
 
         def sample(gi):
             q = gi % 2
-            xbig, cbig, nbig, _ = self.sets[q]
+            xbig, geo, _ = self.sets[q]
             n = min(G, nb - gi * G)
             with torch.cuda.stream(samp):
                 for e in consumed[q] or ():
@@ -252,7 +257,7 @@ class SampledAheadExtractor:
                 else:
                     for j in range(n):
                         xbig[j].copy_(batches[gi * G + j], non_blocking=True)
-                self._engine.sample_first_level(xbig.view(G * B, N, 3)[:n * B], cbig[:n * B], nbig[:n * B])
+                self._engine.compute_geometry(xbig.view(G * B, N, 3)[:n * B], self._engine.geometry_slice(geo, 0, n * B), first_level_only=self.mode != "geometry")
                 ev_s[gi] = torch.cuda.Event()
                 ev_s[gi].record(samp)
         sample(0)
@@ -261,7 +266,7 @@ class SampledAheadExtractor:
             n = min(G, nb - gi * G)
             ends = []
             for j in range(n):
-                g, y, st = self.sets[q][3][j]
+                g, y, st = self.sets[q][2][j]
                 with torch.cuda.stream(st):
                     st.wait_event(ev_s[gi])
                     g.replay()

@@ -315,8 +315,9 @@ def test_graphed_extractor_distinct_batches_with_eager_work_between_replays(name
         assert torch.equal(out[i], ref[i]), i
 
 
-@pytest.mark.parametrize("name,dtype", [("patch_aug_net", "f32"), ("pptnet", "f32"), ("pptnet", "f16"), ("patch_aug_net", "f16")])
-def test_sampled_ahead_extractor_is_bit_identical_to_the_plain_forward(name, dtype):
+@pytest.mark.parametrize("name,dtype,ahead", [("patch_aug_net", "f32", "sampling"), ("pptnet", "f32", "sampling"), ("pptnet", "f16", "sampling"), ("patch_aug_net", "f16", "sampling"),
+                                              ("patch_aug_net", "f32", "geometry"), ("pptnet", "f16", "geometry")])
+def test_sampled_ahead_extractor_is_bit_identical_to_the_plain_forward(name, dtype, ahead):
     """extract.SampledAheadExtractor (round 6): the first-level sampling of groups of batches as one launch a group ahead on a sampling stream, the rest of
     every step as a captured graph reading the group's coordinates and samples in place.  21 distinct batches (two full groups of 8 and a ragged one,
     both buffer sets reused) as one resident tensor, then as a list of pinned host tensors, then again after eager work: every descriptor block must
@@ -329,7 +330,7 @@ def test_sampled_ahead_extractor_is_bit_identical_to_the_plain_forward(name, dty
     xd = xs.cuda()
     with torch.no_grad():
         ref = torch.stack([m(xd[i], return_feat=False) for i in range(nb)])
-        ex = SampledAheadExtractor(m, (8, 1, 4096, 3), n_streams=4, group=8)
+        ex = SampledAheadExtractor(m, (8, 1, 4096, 3), n_streams=4, group=8, ahead=ahead)      # "geometry": every coordinate-only launch a group ahead (engine.compute_geometry / forward(geo=...))
         out = torch.full((nb, 8, 256), float("nan"), device="cuda")
         ex.extract(xd, out)
         torch.cuda.synchronize()
