@@ -782,22 +782,22 @@ class PatchAugNetEngine:
             fps(0)
         self._mark("sa0.fps")
         if overlap:
-            geo = self._geo_streams.get(main.cuda_stream)
-            if geo is None:
-                geo = self._geo_streams[main.cuda_stream] = torch.cuda.Stream(device=dev)
+            gstream = self._geo_streams.get(main.cuda_stream)
+            if gstream is None:
+                gstream = self._geo_streams[main.cuda_stream] = torch.cuda.Stream(device=dev)
             ev0 = torch.cuda.Event()
             ev0.record(main)
-            geo.wait_event(ev0)
-            with torch.cuda.stream(geo):
+            gstream.wait_event(ev0)
+            with torch.cuda.stream(gstream):
                 for i in range(1, L):
                     fps(i)
                     knn(i)
                     ev_sa[i] = torch.cuda.Event()
-                    ev_sa[i].record(geo)
+                    ev_sa[i].record(gstream)
                 for j in range(nfp - 1, -1, -1):           # coarsest first: the order the FP chains consume them
                     tnn(j)
                     ev_fp[j] = torch.cuda.Event()
-                    ev_fp[j].record(geo)
+                    ev_fp[j].record(gstream)
         l_feat, l_c, c_feat = [xyz], [], 3
         for i, chain in enumerate(self.sa):
             src = l_xyz[i]

@@ -296,8 +296,9 @@ def _sampling_stream(device):
 
 @torch.no_grad()
 def extract_descriptors(model, batches, n_streams=4, out=None, graphs=False):
-    """batches: iterable of (B,1,N,3) device tensors -> (sum B, 256) descriptors in input order.  graphs=True replays a captured
-    hipGraph for every batch of the most common shape (GraphedExtractor) and runs the remaining (ragged) batches eagerly."""
+    """batches: iterable of (B,1,N,3) device tensors -> (sum B, 256) descriptors in input order.  graphs=True runs every batch of the first
+    batch's shape through the look-ahead pipeline (SampledAheadExtractor: sampling a group ahead, one captured hipGraph per batch) and the
+    remaining (ragged) batches eagerly."""
     batches = list(batches)
     total = sum(b.shape[0] for b in batches)
     dev = batches[0].device
@@ -305,21 +306,21 @@ def extract_descriptors(model, batches, n_streams=4, out=None, graphs=False):
         out = torch.empty(total, 256, device=dev)
     shape = tuple(batches[0].shape)
     _prepare(model, dev)
-    gx = GraphedExtractor(model, shape, n_streams, dev) if graphs and sum(tuple(b.shape) == shape for b in batches) >= 2 * n_streams else None
+    use_graphs = graphs and sum(tuple(b.shape) == shape for b in batches) >= 2 * n_streams
     pipe = StreamPipeline(n_streams, dev)
     pipe.begin()
-    if gx is not None:
-        gx.begin()
     off = 0
+    common, views = [], []
     for x in batches:
         n = x.shape[0]
         dst = out[off:off + n]
-        if gx is not None and tuple(x.shape) == shape:
-            gx.run(x, out=dst)
+        if use_graphs and tuple(x.shape) == shape:
+            common.append(x)                      # the common-shape batches go through the look-ahead pipeline below, in order
+            views.append(dst)
         else:
             pipe.submit(lambda x=x, dst=dst: dst.copy_(model(x, return_feat=False)))
         off += n
     pipe.end()
-    if gx is not None:
-        gx.end()
+    if common:
+        SampledAheadExtractor(model, shape, n_streams, device=dev).extract(common, views)
     return out

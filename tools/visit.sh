@@ -1,10 +1,2 @@
 cd /root/repo; export TMPDIR=/tmp; mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_extract.py -x -q -m gpu -k "sampled_ahead" 2>&1 | tail -5
-PA_AHEAD=sampling timeout 900 python -m pytest tests/test_gpu_extract.py -x -q -m gpu -k "sampled_ahead" 2>&1 | tail -2
-B="python bench.py --gpus 1 --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-pmc --no-kernel-pass --no-trace"
-for i in 1 2 3; do for E in "PA_AHEAD=geometry" "PA_AHEAD=sampling"; do env $E $B 2>/dev/null | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('driver protocol $E', round(d['value']), d['repetitions']['submaps_per_s'], 'plain', round(d.get('plain_graph_pipeline',{}).get('value',0)))"; done; done
-for E in "PA_AHEAD=geometry" "PA_AHEAD=sampling"; do env $E python bench.py --no-extras --no-cpu-baseline --no-pmc --no-kernel-pass --no-trace 2>/dev/null | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('100 steps $E', round(d['value']), d['repetitions']['submaps_per_s'], 'plain', round(d.get('plain_graph_pipeline',{}).get('value',0)))"; done
+timeout 1200 python -X faulthandler -m pytest tests/test_gpu_extract.py -x -q -m gpu > gpurun_out/v35_extract.log 2>&1; echo "rc=$?"; grep -n "passed\|failed\|Fatal\|Error\|error\|test_gpu_extract.py" gpurun_out/v35_extract.log | head -30; head -60 gpurun_out/v35_extract.log | cut -c1-250
