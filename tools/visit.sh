@@ -1,2 +1,2 @@
 cd /root/repo; export TMPDIR=/tmp; mkdir -p gpurun_out
-timeout 1200 python -X faulthandler -m pytest tests/test_gpu_extract.py -x -q -m gpu > gpurun_out/v35_extract.log 2>&1; echo "rc=$?"; grep -n "passed\|failed\|Fatal\|Error\|error\|test_gpu_extract.py" gpurun_out/v35_extract.log | head -30; head -60 gpurun_out/v35_extract.log | cut -c1-250
+timeout 2400 python -X faulthandler -m pytest tests -m gpu -q > gpurun_out/v36_tests.log 2>&1; echo "rc=$?"; tail -4 gpurun_out/v36_tests.log | cut -c1-200
