@@ -683,7 +683,7 @@ class PatchAugNetEngine:
         """The buffers of clouds lo .. hi - 1 of a geometry_buffers() set (views: the batch's graphs read them in place)."""
         return {k: [t[lo:hi] for t in v] for k, v in geo.items()}
 
-    def compute_geometry(self, xyz, geo, first_level_only=False):
+    def compute_geometry(self, xyz, geo, first_level_only=False, samplings_only=False):
         """Sampling, centre gather, neighbour search of every level and the 3-NN weights of every decoder level for xyz (clouds, N, 3) into `geo`
         (geometry_buffers(clouds)), on the current stream: exactly the launches backbone() would issue between its chains, for any number of clouds at once."""
         B = xyz.shape[0]
@@ -695,7 +695,10 @@ class PatchAugNetEngine:
             call("pa_furthestsampling_gather", B, npts[i], npts[i + 1], ptr(l_xyz[i]), ptr(geo["cidx"][i]), ptr(geo["nxyz"][i]))
             if first_level_only:
                 return
-            call("pa_knnquery", B, npts[i], npts[i + 1], self.knn[i], ptr(l_xyz[i]), ptr(geo["nxyz"][i]), ptr(geo["nbr"][i]), ptr(geo["d2"][i]))
+            if not samplings_only:
+                call("pa_knnquery", B, npts[i], npts[i + 1], self.knn[i], ptr(l_xyz[i]), ptr(geo["nxyz"][i]), ptr(geo["nbr"][i]), ptr(geo["d2"][i]))
+        if samplings_only:
+            return
         for j in range(nfp - 1, -1, -1):
             call("pa_three_nn_weights", B, npts[j + off], npts[j + off + 1], ptr(l_xyz[j + off]), ptr(l_xyz[j + off + 1]), ptr(geo["w3"][j]), ptr(geo["idx3"][j]))
 
@@ -714,11 +717,15 @@ class PatchAugNetEngine:
         npts = [xyz.shape[1]] + list(self.sampling[:L])
         # outputs of the geometry kernels, allocated on the main stream before any fork
         off = L - nfp                              # FP level j interpolates level j + off + 1's features onto level j + off's points
-        if geo is not None:                        # everything that depends on coordinates only was computed ahead (compute_geometry): read in place
-            cidx, nxyz, nbr, d2, w3, idx3 = (list(geo[k]) for k in ("cidx", "nxyz", "nbr", "d2", "w3", "idx3"))
+        searched = geo is not None and "nbr" in geo      # geo may hold the samplings of every level only (compute_geometry(samplings_only=True)): the searches then run here
+        if geo is not None:                        # computed ahead (compute_geometry): read in place
+            cidx, nxyz = list(geo["cidx"]), list(geo["nxyz"])
         else:
             cidx = [torch.empty((B, npts[i + 1]), dtype=torch.int32, device=dev) for i in range(L)]
             nxyz = [torch.empty((B, npts[i + 1], 3), dtype=torch.float32, device=dev) for i in range(L)]
+        if searched:
+            nbr, d2, w3, idx3 = (list(geo[k]) for k in ("nbr", "d2", "w3", "idx3"))
+        else:
             nbr = [torch.empty((B, npts[i + 1], self.knn[i]), dtype=torch.int32, device=dev) for i in range(L)]
             d2 = [torch.empty((B, npts[i + 1], self.knn[i]), dtype=torch.float32, device=dev) for i in range(L)]
             w3 = [torch.empty((B, npts[j + off], 3), dtype=torch.float32, device=dev) for j in range(nfp)]
@@ -734,12 +741,12 @@ class PatchAugNetEngine:
         # first level: the input cloud's cell sort does not depend on the centres, so it is issued BEFORE the sampling chain (one workgroup per
         # cloud, ~15 us, next to nothing in CU-time); the neighbour search then copies the record instead of sorting in each of its workgroups
         cells = None
-        if geo is None and self._presort_ok(npts[0], npts[1], self.knn[0]):
+        if not searched and self._presort_ok(npts[0], npts[1], self.knn[0]):
             cells = torch.empty(_lib.lib().pa_cloud_cellsort_floats(B, npts[0]), dtype=torch.float32, device=dev)
             call("pa_cloud_cellsort", B, npts[0], ptr(xyz), ptr(cells))
 
         def knn(i):
-            if geo is not None:
+            if searched:
                 return
             if i == 0 and cells is not None:
                 call("pa_knnquery_presorted", B, npts[0], npts[1], self.knn[0], ptr(xyz), ptr(nxyz[0]), ptr(cells), ptr(nbr[0]), ptr(d2[0]))
@@ -747,7 +754,7 @@ class PatchAugNetEngine:
             call("pa_knnquery", B, npts[i], npts[i + 1], self.knn[i], ptr(l_xyz[i]), ptr(nxyz[i]), ptr(nbr[i]), ptr(d2[i]))
 
         def tnn(j):      # patch_aug_net.py:350-353
-            if geo is not None:
+            if searched:
                 return
             call("pa_three_nn_weights", B, npts[j + off], npts[j + off + 1], ptr(l_xyz[j + off]), ptr(l_xyz[j + off + 1]), ptr(w3[j]), ptr(idx3[j]))
 

@@ -165,8 +165,8 @@ class SampledAheadExtractor:
     """Descriptor extraction over a KNOWN list of batches (the reference's ``SceneDataSet.make_descs`` loop, datasets/scene_dataset.py:510-523, walks a
     dataset whose submaps are all there before the first forward) with the first-level sampling taken out of the per-batch graphs:
 
-      * the farthest-point sampling of a whole GROUP of batches (``group`` x B clouds: one workgroup per CU at 8 x 32) is ONE launch on a sampling
-        stream, a group ahead of the batches that consume it -- ~1000 serial rounds per cloud that depend on coordinates only;
+      * the farthest-point sampling of a whole GROUP of batches (``group`` x B clouds: one workgroup per CU at 8 x 32) is ONE launch per level on a
+        sampling stream, a group ahead of the batches that consume it -- ~1000 serial rounds per cloud that depend on coordinates only;
       * the rest of a batch's step is a captured hipGraph per (buffer set, position in the group) on ``n_streams`` feature streams, reading the
         group's coordinates and samples IN PLACE (``PatchAugNetEngine.forward(s0=...)``; graphs of one stream share a memory pool).
 
@@ -193,12 +193,13 @@ class SampledAheadExtractor:
             x0 = torch.zeros(batch_shape, dtype=torch.float32, device=self.device)
             model(x0, return_feat=False)                                  # builds the engine
             eng = self._engine = model._engine
-            # what runs a group ahead: "sampling" (default) = the first level's sampling alone; "geometry" = every launch that depends on coordinates only
-            # (sampling, centre gathers and neighbour search of all levels, the decoder's 3-NN weights).  Measured (profiles/r06_ab_log.txt): 20 steps
-            # 41.0-41.3 k (sampling) vs 39.0-39.8 k (geometry) vs 39.2-40.1 k (plain graphs); 100 steps 41.0 vs 40.4 vs 41.4 k -- the group's
-            # chip-filling search launches on the side stream take from the dense kernels what they save the graphs.
+            # what runs a group ahead: "samplings" (default) = the farthest-point sampling of EVERY level (level i + 1 samples level i's centres: coordinates
+            # only); "sampling" = the first level's alone; "geometry" = every launch that depends on coordinates only (+ centre gathers, neighbour search of all
+            # levels, the decoder's 3-NN weights).  Measured (profiles/r06_ab_log.txt), 20 steps: 41.3-41.6 k (samplings) / 41.1-41.4 k (sampling) / 39.0-39.8 k
+            # (geometry) / 39.2-40.1 k (plain graphs); PPT-Net fp16 62.3 / 61.6 k.  The group's chip-filling SEARCH launches on the side stream take from the dense
+            # kernels what they save the graphs; the small sampling launches of the coarser levels do not.
             import os
-            self.mode = ahead or os.environ.get("PA_AHEAD", "sampling")
+            self.mode = ahead or os.environ.get("PA_AHEAD", "samplings")
             self.sets = []
             pools = [None] * len(streams)
             for q in range(2):
@@ -210,7 +211,7 @@ class SampledAheadExtractor:
                     k = p % len(streams)
                     st = streams[k]
                     gs = eng.geometry_slice(geo, p * B, (p + 1) * B)
-                    kw = {"geo": gs} if self.mode == "geometry" else {"s0": (gs["cidx"][0], gs["nxyz"][0])}
+                    kw = {"geo": gs} if self.mode == "geometry" else {"geo": {"cidx": gs["cidx"], "nxyz": gs["nxyz"]}} if self.mode == "samplings" else {"s0": (gs["cidx"][0], gs["nxyz"][0])}
                     st.wait_stream(cur)
                     with torch.cuda.stream(st):
                         for _ in range(warmup if pools[k] is None else 0):
@@ -257,7 +258,7 @@ class SampledAheadExtractor:
                 else:
                     for j in range(n):
                         xbig[j].copy_(batches[gi * G + j], non_blocking=True)
-                self._engine.compute_geometry(xbig.view(G * B, N, 3)[:n * B], self._engine.geometry_slice(geo, 0, n * B), first_level_only=self.mode != "geometry")
+                self._engine.compute_geometry(xbig.view(G * B, N, 3)[:n * B], self._engine.geometry_slice(geo, 0, n * B), first_level_only=self.mode == "sampling", samplings_only=self.mode == "samplings")
                 ev_s[gi] = torch.cuda.Event()
                 ev_s[gi].record(samp)
         sample(0)

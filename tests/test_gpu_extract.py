@@ -316,7 +316,7 @@ def test_graphed_extractor_distinct_batches_with_eager_work_between_replays(name
 
 
 @pytest.mark.parametrize("name,dtype,ahead", [("patch_aug_net", "f32", "sampling"), ("pptnet", "f32", "sampling"), ("pptnet", "f16", "sampling"), ("patch_aug_net", "f16", "sampling"),
-                                              ("patch_aug_net", "f32", "geometry"), ("pptnet", "f16", "geometry")])
+                                              ("patch_aug_net", "f32", "geometry"), ("pptnet", "f16", "geometry"), ("patch_aug_net", "f32", "samplings"), ("pptnet", "f16", "samplings")])
 def test_sampled_ahead_extractor_is_bit_identical_to_the_plain_forward(name, dtype, ahead):
     """extract.SampledAheadExtractor (round 6): the first-level sampling of groups of batches as one launch a group ahead on a sampling stream, the rest of
     every step as a captured graph reading the group's coordinates and samples in place.  21 distinct batches (two full groups of 8 and a ragged one,

@@ -1,11 +1,9 @@
 cd /root/repo; export TMPDIR=/tmp; mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_extract.py -x -q -m gpu -k "sampled_ahead or latency" 2>&1 | tail -3
 B="python bench.py --gpus 1 --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-pmc --no-kernel-pass --no-trace"
-for i in 1 2 3; do $B 2>/dev/null | tail -1 | python -c "
+for i in 1 2 3; do for E in "PA_AHEAD=samplings" "PA_AHEAD=sampling"; do env $E $B 2>/dev/null | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('driver protocol', round(d['value']), d['repetitions']['submaps_per_s'], 'plain', round(d.get('plain_graph_pipeline',{}).get('value',0)))"; done
-python bench.py --no-extras --no-cpu-baseline --no-pmc --no-kernel-pass --no-trace 2>/dev/null | tail -1 | python -c "
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('driver protocol $E', round(d['value']), d['repetitions']['submaps_per_s'])"; done; done
+for E in "PA_AHEAD=samplings" "PA_AHEAD=sampling"; do for M in "--model pptnet --mlp-dtype f16" "--mlp-dtype f16"; do env $E $B $M 2>/dev/null | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('100 steps', round(d['value']), d['repetitions']['submaps_per_s'], 'plain', round(d.get('plain_graph_pipeline',{}).get('value',0)))"
-for G in 4 16; do $B --group $G 2>/dev/null | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('group $G', round(d['value']), d['repetitions']['submaps_per_s'])"; done
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$E $M', round(d['value']), d['repetitions']['submaps_per_s'])"; done; done
