@@ -1092,7 +1092,7 @@ def main():
                    "batch_per_gpu": a.batch, "points": a.points,
                    "path": "fused HIP engine" if model.fused_eval else "HIP point ops + torch dense ops (module path)",
                    "weights": "key-seeded random init", "parallelism": f"dp{world}", "streams": a.streams,
-                   "launch": ((f"look-ahead pipeline: the first-level sampling of {a.group} consecutive batches ({a.group * a.batch} clouds) is one launch on a sampling stream, a group ahead; "
+                   "launch": ((f"look-ahead pipeline: the farthest-point sampling (every level) of {a.group} consecutive batches ({a.group * a.batch} clouds) is one launch per level on a sampling stream, a group ahead; "
                                f"the rest of every step is one hipGraph replay on {a.streams} feature streams reading the group's coordinates and samples in place "
                                "(extract.SampledAheadExtractor); K distinct HBM-resident batches, descriptors copied to the result buffer") if ahead is not None else
                               "hipGraph replay of the whole step per stream (the HBM-resident batch is read in place; descriptors copied to the result buffer)") if use_graphs else "python launches"},

@@ -1,9 +1,3 @@
 cd /root/repo; export TMPDIR=/tmp; mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_extract.py -x -q -m gpu -k "sampled_ahead or latency" 2>&1 | tail -3
-B="python bench.py --gpus 1 --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-pmc --no-kernel-pass --no-trace"
-for i in 1 2 3; do for E in "PA_AHEAD=samplings" "PA_AHEAD=sampling"; do env $E $B 2>/dev/null | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('driver protocol $E', round(d['value']), d['repetitions']['submaps_per_s'])"; done; done
-for E in "PA_AHEAD=samplings" "PA_AHEAD=sampling"; do for M in "--model pptnet --mlp-dtype f16" "--mlp-dtype f16"; do env $E $B $M 2>/dev/null | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$E $M', round(d['value']), d['repetitions']['submaps_per_s'])"; done; done
+timeout 2600 python tests/fuzz_gpu.py 40 2>&1 | grep -v amdgpu.ids | tail -30 > gpurun_out/r06f_fuzz.log; cat gpurun_out/r06f_fuzz.log
+timeout 600 python tools/probes/stream_determinism_soak.py 10 2>&1 | grep -v amdgpu.ids | tail -6 >> gpurun_out/r06f_fuzz.log; tail -5 gpurun_out/r06f_fuzz.log
