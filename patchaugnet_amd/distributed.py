@@ -79,7 +79,8 @@ def extract_dataset(model, load_batch, n_total, batch_size=32, n_streams=4, dim=
         pipe.begin()
     # full batches: the look-ahead pipeline (extract.SampledAheadExtractor: the first-level sampling of 8 batches as one launch a group ahead, the rest of
     # every batch as a captured graph); the ragged tail (and everything, without graphs) goes through the eager stream pipeline
-    nfull = (hi - lo) // batch_size if (graphs and pipe is not None and hi - lo >= 2 * n_streams * batch_size) else 0
+    fused = hasattr(model, "_engine") and getattr(model, "fused_eval", True)      # the look-ahead extractor drives the fused engine; any other model takes the eager pipeline
+    nfull = (hi - lo) // batch_size if (graphs and fused and pipe is not None and hi - lo >= 2 * n_streams * batch_size) else 0
     if nfull:
         first = load_batch(lo, lo + batch_size)
         ex = _graphed_extractor(model, tuple(first.shape), n_streams, device)

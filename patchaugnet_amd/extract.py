@@ -234,6 +234,8 @@ class SampledAheadExtractor:
         if eng is not self._engine or self._model.training or (eng is not None and eng.stale(self._model)):
             raise RuntimeError("SampledAheadExtractor: the model's weights or mode changed after capture (load_state_dict / train()); build a new one")
         nb = len(batches)
+        if nb == 0:
+            return out
         G, B = self.group, self.shape[0]
         N = self.shape[2]
         cur = torch.cuda.current_stream(self.device)
