@@ -41,7 +41,7 @@ def parse():
     p.add_argument("--no-trace", action="store_true", help="skip the two rocprofv3 --kernel-trace passes behind stage_rooflines / roofline.frac (the roofline then carries the HIP-event figure only)")
     p.add_argument("--no-lookahead", action="store_true", help="the plain pipeline: one captured graph of the WHOLE step per stream (extract.GraphedExtractor) instead of the "
                                                                 "first-level sampling of groups of batches one group ahead (extract.SampledAheadExtractor)")
-    p.add_argument("--group", type=int, default=8, help="batches per sampling launch of the look-ahead pipeline (8 x 32 clouds = one workgroup per CU)")
+    p.add_argument("--group", type=int, default=16, help="batches per sampling launch of the look-ahead pipeline (16 x 32 clouds = two sampling workgroups per CU)")
     p.add_argument("--only-steps", action="store_true", help="the timed steps and nothing else (the child run of the kernel-trace passes)")
     p.add_argument("--cpu-batch", type=int, default=8)
     p.add_argument("--model", choices=["patch_aug_net", "pptnet"], default="patch_aug_net", help="pptnet = BASELINE.json configs[4]")
@@ -784,7 +784,7 @@ def extras(a):
         x = synthetic_submaps(a.batch, a.points, seed=1234).cuda()
         steps = 40
         with torch.no_grad():
-            # the headline's pipeline (extract.SampledAheadExtractor: first-level sampling of 8 batches a group ahead) on 40 distinct resident batches
+            # the headline's pipeline (extract.SampledAheadExtractor: sampling of 16 batches a group ahead) on 40 distinct resident batches
             from patchaugnet_amd.extract import SampledAheadExtractor
             xs = torch.stack([synthetic_submaps(a.batch, a.points, seed=4321 + i) for i in range(steps)]).cuda()
             out = torch.empty(steps, a.batch, 256, device="cuda")

@@ -313,6 +313,12 @@ int launch_reg(int b, int n, int m, FpsOrder ord, const float *xyz, float *temp,
     // workgroups (<= 32 KB) off the sampling CUs: + 1.0 / + 1.8 / + 0.6 % of the pipeline's rate at 104 / 128 / 156 KB (profiles/r06_ab_log.txt).  Only
     // for chains of >= 512 rounds over clouds that fill a workgroup's registers (the first level of both models); PA_FPS_LDS_RESERVE overrides (bytes, 0 = off).
     static const long reserve = getenv("PA_FPS_LDS_RESERVE") ? atol(getenv("PA_FPS_LDS_RESERVE")) : 128 * 1024;
+    // ... and only for launches of at most one workgroup per CU (b <= 256: a batch's own sampling, the look-ahead pipeline's groups of <= 8 batches).  A
+    // launch over MORE clouds than CUs (the look-ahead pipeline's default group: 16 batches = 512 clouds) keeps the 64 KB of the copy: two sampling
+    // workgroups share a CU and the group is ONE round of workgroups instead of two -- half the CU-time per cloud, and the chain's length is hidden a
+    // group ahead: 42.9 k against 42.0-42.4 k submaps/s with the reserve (profiles/r06_ab_log.txt).  PA_FPS_LDS_RESERVE_ALWAYS = A/B knob.
+    static const bool always = getenv("PA_FPS_LDS_RESERVE_ALWAYS") != nullptr;
+    if (b <= 256 || always)
     if (m >= 512 && n >= 2048 && lds < (size_t)reserve && reserve <= 160 * 1024 - 2048) lds = (size_t)reserve;
     if (lds > 48 * 1024)  // opt in to the large-LDS carve-out (gfx950: 160 KiB per CU)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_reg_kernel<NT, PPT, true>),

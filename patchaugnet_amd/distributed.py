@@ -63,7 +63,7 @@ def extract_dataset(model, load_batch, n_total, batch_size=32, n_streams=4, dim=
     load_batch(lo, hi) -> (hi - lo, 1, N, 3) fp32 tensor on the compute device (the caller owns file I/O / H2D);
     model(x, return_feat=False) -> (B, dim).  Batches of this rank's shard are issued round-robin on `n_streams` HIP streams
     (patchaugnet_amd/extract.py); n_streams = 0 runs them inline on the current stream (CPU stand-ins in tests).  graphs=True runs the
-    full-size batches through extract.SampledAheadExtractor (first-level sampling of 8 batches a group ahead, one captured hipGraph per
+    full-size batches through extract.SampledAheadExtractor (sampling of 16 batches a group ahead, one captured hipGraph per
     batch); load_batch may then return pinned host tensors, which are copied into the group's coordinate buffer on the sampling stream."""
     _, rank, world = dist_info()
     lo, hi = shard_bounds(n_total, rank, world)
@@ -77,7 +77,7 @@ def extract_dataset(model, load_batch, n_total, batch_size=32, n_streams=4, dim=
         _prepare(model, device)         # engine built on the caller's stream before the pipeline streams fork from it
         pipe = StreamPipeline(n_streams, device)
         pipe.begin()
-    # full batches: the look-ahead pipeline (extract.SampledAheadExtractor: the first-level sampling of 8 batches as one launch a group ahead, the rest of
+    # full batches: the look-ahead pipeline (extract.SampledAheadExtractor: the sampling of 16 batches as one launch per level a group ahead, the rest of
     # every batch as a captured graph); the ragged tail (and everything, without graphs) goes through the eager stream pipeline
     fused = hasattr(model, "_engine") and getattr(model, "fused_eval", True)      # the look-ahead extractor drives the fused engine; any other model takes the eager pipeline
     nfull = (hi - lo) // batch_size if (graphs and fused and pipe is not None and hi - lo >= 2 * n_streams * batch_size) else 0

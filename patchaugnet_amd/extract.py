@@ -165,19 +165,20 @@ class SampledAheadExtractor:
     """Descriptor extraction over a KNOWN list of batches (the reference's ``SceneDataSet.make_descs`` loop, datasets/scene_dataset.py:510-523, walks a
     dataset whose submaps are all there before the first forward) with the first-level sampling taken out of the per-batch graphs:
 
-      * the farthest-point sampling of a whole GROUP of batches (``group`` x B clouds: one workgroup per CU at 8 x 32) is ONE launch per level on a
+      * the farthest-point sampling of a whole GROUP of batches (``group`` x B clouds; the default 16 x 32 = 512 clouds is two sampling workgroups
+        per CU, one round of workgroups: half the CU-time per cloud of a 256-cloud launch, csrc/fps.hip launch_reg) is ONE launch per level on a
         sampling stream, a group ahead of the batches that consume it -- ~1000 serial rounds per cloud that depend on coordinates only;
       * the rest of a batch's step is a captured hipGraph per (buffer set, position in the group) on ``n_streams`` feature streams, reading the
         group's coordinates and samples IN PLACE (``PatchAugNetEngine.forward(s0=...)``; graphs of one stream share a memory pool).
 
     Why: after a synchronisation the four plain graphs of ``GraphedExtractor`` run in lock-step -- four samplings at once
     on 128 of 256 CUs with nothing else to do, then four dense phases sharing the chip -- and need ~16 steps to drift apart; a 20-step region
-    (the driver's protocol) runs at 39.3 k submaps/s that way and at 41.5-42.0 k with the sampling a group ahead.  Long regions converge (41 k both):
-    the dense phases' co-run is the bound there.  Descriptors are bit-identical to the plain forward (tests/test_gpu_extract.py).
+    (the driver's protocol) runs at 39.3 k submaps/s that way, at 41.5 k with the sampling of 8 batches a group ahead and at 42.1 k with 16; long regions
+    41.5 k (plain graphs, groups of 8) against 42.9 k (groups of 16): the sampling launches' CU-time is what the dense phases get back.  Descriptors are bit-identical to the plain forward (tests/test_gpu_extract.py).
 
     Only for a fixed batch shape and the fused engine; ``GraphedExtractor`` stays the tool for one batch at a time."""
 
-    def __init__(self, model, batch_shape, n_streams=4, group=8, device=None, warmup=1, ahead=None):
+    def __init__(self, model, batch_shape, n_streams=4, group=16, device=None, warmup=1, ahead=None):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         assert not model.training, "hipGraph capture is for evaluation (fused engine, no autograd)"
         B, _, N, _ = batch_shape

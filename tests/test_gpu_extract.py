@@ -346,3 +346,21 @@ def test_sampled_ahead_extractor_is_bit_identical_to_the_plain_forward(name, dty
     m.train()
     with pytest.raises(RuntimeError):
         ex.extract(xd, out)
+
+
+def test_sampled_ahead_extractor_with_two_sampling_workgroups_per_cu():
+    """The shipped look-ahead configuration: groups of 16 batches of 32 = 512 clouds per sampling launch, more clouds than CUs, so the first-level
+    launch runs without its LDS reserve and two sampling workgroups share a CU (csrc/fps.hip launch_reg).  35 batches (two full groups and a ragged
+    one): bit-identical to the plain forward."""
+    from patchaugnet_amd.extract import SampledAheadExtractor
+    m = _model("patch_aug_net")
+    nb = 35
+    xd = torch.stack([synthetic_submaps(32, 4096, 700 + i, "street" if i % 5 == 0 else "uniform") for i in range(nb)]).cuda()
+    with torch.no_grad():
+        ref = torch.stack([m(xd[i], return_feat=False) for i in range(nb)])
+        ex = SampledAheadExtractor(m, (32, 1, 4096, 3))
+        assert ex.group == 16
+        out = torch.full((nb, 32, 256), float("nan"), device="cuda")
+        ex.extract(xd, out)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)

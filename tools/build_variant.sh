@@ -11,7 +11,7 @@ OBJS=""
 for f in *.hip; do
   [[ "$EXP_ONLY" == *" $f "* ]] && continue
   if [[ " $SRCS " == *" $f "* ]]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -Wno-unused-function $FLAGS -c $f -o ab/$NAME/${f%.hip}.o
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -fno-vectorize -fvisibility=hidden -Wno-unused-function $FLAGS -c $f -o ab/$NAME/${f%.hip}.o
     OBJS="$OBJS ab/$NAME/${f%.hip}.o"
   else
     OBJS="$OBJS ${f%.hip}.o"
