@@ -88,8 +88,14 @@ __global__ __launch_bounds__(W * 64, MINW) void fpx32_kernel(PaChain a)
     int *nb = reinterpret_cast<int *>(buf + R * FX_STR);
     float *wt = reinterpret_cast<float *>(nb + 3 * R), *sk = wt + 3 * R;
     const long row0 = tile * R;
-#define FX_STAMP(i) do { if (a.dbg && tile < 512 && lane == 0) a.dbg[tile * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#ifndef FX_STAMP_TILES
+#define FX_STAMP_TILES 512
+#endif
+#define FX_STAMP(i) do { if (a.dbg && tile < FX_STAMP_TILES && lane == 0) a.dbg[tile * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
     FX_STAMP(0);
+#ifdef FX_STAMP_CLOCK
+    if (a.dbg && tile < FX_STAMP_TILES && lane == 0) a.dbg[tile * 8 + 5] = (long long)__builtin_amdgcn_s_memrealtime();      // constant 100 MHz beside the shader-clock stamps
+#endif
     // ---- the tile's neighbour rows, weights and skip channels (pa_chain.h chain_prologue, MODE_FPX)
     for (int q = lane; q < 3 * R; q += 64) {
         const int r = q / 3;
@@ -231,6 +237,9 @@ __global__ __launch_bounds__(W * 64, MINW) void fpx32_kernel(PaChain a)
         }
         FX_STAMP(3 + nh);
     }
+#ifdef FX_STAMP_CLOCK
+    if (a.dbg && tile < FX_STAMP_TILES && lane == 0) a.dbg[tile * 8 + 6] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
 #undef FX_STAMP
 }
 
@@ -253,7 +262,11 @@ int pa_fpx32_try(const PaChain &a, hipStream_t st)
     // Four-wave workgroups of 16-row wave tiles, three per CU (36 KB of LDS each: they start and finish at different times, so their gather / store
     // phases interleave by themselves, and another stream's workgroup fits beside two of them).  Measured and dropped:
     // one twelve-wave workgroup per CU 0.347 ms and two six-wave ones 0.43 ms against 0.305 ms (lock-step phases, the CU drains between workgroups);
-    // 32-row wave tiles at two waves per SIMD (half the weight stream) 0.311-0.317 ms; eight-wave workgroups at 128 registers spill.
+    // 32-row wave tiles at two waves per SIMD (half the weight stream) 0.311-0.317 ms; eight-wave workgroups at 128 registers spill; TWO of these
+    // workgroups per CU (an exact four rounds at batch 32 instead of 2.67): 0.311 vs 0.296 ms, pipeline 42.5 vs 42.8 k.
+    // Where the launch's 0.76-0.78 of the nominal peak goes (tools/probes/fx_phases.py on a stamp build, profiles/r06_fp0_clock.txt): the shader clock under
+    // this kernel is 2.16 GHz, not 2.4 (s_memtime against s_memrealtime over every tile: 0.90); a tile takes 211.6 k cycles against 196.6 k of pure MFMA
+    // issue for its three co-resident waves (0.93); and 8192 tiles on 3072 wave slots are 2.67 rounds plus the ramp (0.91).
     const long ntiles = (a.rows + 15) / 16;
     const size_t lds = (size_t)4 * fx_wave_floats(1) * 4;
     auto kern = fpx32_kernel<1, 4, 3, 2>;
