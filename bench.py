@@ -142,6 +142,43 @@ def profiling_fp0_launch_ms(model, x):
         return None
 
 
+def dominant_kernel_clock(model, x):
+    """Shader clock under the dominant kernel: the kernel's debug stamps (csrc/fpx_f32.hip FX_STAMP: s_memtime at a tile's start and end, the constant
+    100 MHz s_memrealtime beside them; written only when pa_chain_debug_buffer hands the launch a buffer) over the first 512 wave tiles of one launch
+    inside a real forward.  The nominal fp32 MFMA peak is 2.4 GHz; what the chip holds under this kernel is what the kernel can be measured against."""
+    import ctypes
+    import numpy as np
+    from patchaugnet_amd import _lib
+    lib = _lib.lib()
+    lib.pa_chain_debug_buffer.argtypes, lib.pa_chain_debug_buffer.restype = [ctypes.c_void_p], None
+    chain = model._engine.fp[0]
+    buf = torch.zeros(512 * 8, dtype=torch.int64, device=x.device)
+    origs = {}
+    for nm in ("fp_premul", "fp"):
+        def wrapped(*a, _o=getattr(chain, nm), **k):
+            lib.pa_chain_debug_buffer(ctypes.c_void_p(buf.data_ptr()))
+            try:
+                return _o(*a, **k)
+            finally:
+                lib.pa_chain_debug_buffer(None)
+        origs[nm] = getattr(chain, nm)
+        setattr(chain, nm, wrapped)
+    try:
+        with torch.no_grad():
+            model(x, return_feat=False)
+        torch.cuda.synchronize()
+    finally:
+        for nm, o in origs.items():
+            setattr(chain, nm, o)
+    t = buf.view(512, 8).cpu().numpy()
+    t = t[(t[:, 0] > 0) & (t[:, 6] > t[:, 5])]
+    if len(t) < 64:
+        return None
+    mhz = (t[:, 4] - t[:, 0]) / ((t[:, 6] - t[:, 5]) / 100.0)
+    return {"mhz": float(np.median(mhz)), "p10": float(np.percentile(mhz, 10)), "p90": float(np.percentile(mhz, 90)), "tiles": int(len(t)),
+            "tile_cycles": float(np.median(t[:, 4] - t[:, 0])), "tile_us": float(np.median((t[:, 6] - t[:, 5]) / 100.0))}
+
+
 def dominant_kernel_roofline(st, cfg, batch, points, grouping, pmc=None, pmc_note=None):
     """Roofline of the kernel that owns the most CU-time in a step.
 
@@ -1147,6 +1184,14 @@ def main():
                 line.update(dominant_kernel_roofline(st, cfg, a.batch, a.points, g, pmc, note))
                 if "roofline" in line and b2b:
                     line["roofline"]["timing"] = "HIP events on the launch stream around 9 back-to-back launches of the kernel (average); one bracketed launch: kernels.fp0_chain_single_bracketed_ms"
+                try:      # the clock the chip holds under the dominant kernel (the nominal peak is 2.4 GHz)
+                    ck = dominant_kernel_clock(model, x) if "roofline" in line and line["roofline"].get("bound") == "mfma" else None
+                    if ck:
+                        line["roofline"]["shader_clock_mhz"] = ck
+                        line["roofline"]["shader_clock_note"] = ("s_memtime ticks per s_memrealtime microsecond over the first 512 wave tiles of one launch inside a forward "
+                                                                 "(the kernel's own debug stamps); peak = 256 CUs x 4 SIMDs x 64 flop/cycle x 2.4 GHz assumes the nominal clock")
+                except Exception as ex:
+                    line["roofline"]["shader_clock_mhz"] = {"error": repr(ex)}
                 try:
                     line["roofline_latency"] = fps_latency_roofline(a.batch, a.points, cfg["SAMPLING"][0])
                 except Exception as ex:
@@ -1163,6 +1208,8 @@ def main():
                             r["frac_hip_events_back_to_back"], r["ms_per_launch_hip_events_back_to_back"] = r["frac"], r["ms_per_launch"]
                             r["ms_per_launch"], r["achieved"], r["frac"] = dom["us_per_launch"] / 1e3, dom["achieved"], dom["frac"]
                             r["frac_in_pipeline"], r["ms_per_launch_in_pipeline"] = dom["frac_in_pipeline"], (dom["us_per_launch_in_pipeline"] or 0) / 1e3
+                            if isinstance(r.get("shader_clock_mhz"), dict) and r["shader_clock_mhz"].get("mhz"):
+                                r["frac_of_peak_at_measured_clock"] = r["frac"] * 2400.0 / r["shader_clock_mhz"]["mhz"]
                             r["timing"] = ("rocprofv3 --kernel-trace average of the kernel inside the real step, one stream (frac) and the headline's "
                                            f"{a.streams}-stream pipeline (frac_in_pipeline), measured in this run; HIP events around 9 back-to-back launches: frac_hip_events_back_to_back")
                     except Exception as ex:

@@ -93,9 +93,7 @@ __global__ __launch_bounds__(W * 64, MINW) void fpx32_kernel(PaChain a)
 #endif
 #define FX_STAMP(i) do { if (a.dbg && tile < FX_STAMP_TILES && lane == 0) a.dbg[tile * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
     FX_STAMP(0);
-#ifdef FX_STAMP_CLOCK
     if (a.dbg && tile < FX_STAMP_TILES && lane == 0) a.dbg[tile * 8 + 5] = (long long)__builtin_amdgcn_s_memrealtime();      // constant 100 MHz beside the shader-clock stamps
-#endif
     // ---- the tile's neighbour rows, weights and skip channels (pa_chain.h chain_prologue, MODE_FPX)
     for (int q = lane; q < 3 * R; q += 64) {
         const int r = q / 3;
@@ -237,9 +235,7 @@ __global__ __launch_bounds__(W * 64, MINW) void fpx32_kernel(PaChain a)
         }
         FX_STAMP(3 + nh);
     }
-#ifdef FX_STAMP_CLOCK
     if (a.dbg && tile < FX_STAMP_TILES && lane == 0) a.dbg[tile * 8 + 6] = (long long)__builtin_amdgcn_s_memrealtime();
-#endif
 #undef FX_STAMP
 }
 

@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """Phase stamps of the finest FP level's half-K kernel (fpx32_kernel, csrc/fpx_f32.hip FX_STAMP): index loads + first half prologue | layer A (two passes,
 the second half prologue between them, bias) | layer B first output half (staging, two passes, store) | second output half.  Cycles per 16-row wave tile.
-The shipped library stamps the first 512 tiles; every tile and the shader clock (s_memtime ticks per s_memrealtime microsecond) need a stamp build:
-    tools/build_variant.sh stampall "-DFX_STAMP_TILES=8192 -DFX_STAMP_CLOCK" fpx_f32.hip
+The shipped library stamps the first 512 tiles (phases and the shader clock: s_memtime ticks per s_memrealtime microsecond; bench.py reports that clock as
+roofline.shader_clock_mhz); every tile needs a stamp build:
+    tools/build_variant.sh stampall "-DFX_STAMP_TILES=8192" fpx_f32.hip
     FX_STAMP_TILES=8192 PA_LIB_PATH=patchaugnet_amd/csrc/ab/libpa_stampall.so python tools/probes/fx_phases.py"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
