@@ -49,6 +49,19 @@ def test_fps_bit_exact(P, b, n, m, kind):
     assert got.dtype == np.int32 and np.array_equal(got, ref), f"first mismatch col {np.argmax((got != ref).any(0))}"
 
 
+def test_fps_over_more_clouds_than_cus_is_the_per_cloud_result(P):
+    """A first-level launch over more clouds than CUs (the look-ahead pipeline's groups: 16 x 32 = 512 clouds) drops its LDS reserve so that two sampling
+    workgroups share a CU (csrc/fps.hip launch_reg): same kernel, same samples.  300 clouds of 4096 points against the oracle on a slice and against the
+    32-cloud launches (which keep the reserve) on all of them."""
+    x = cloud(300, 4096, "uniform")
+    xd = dev(x)
+    got = P.furthestsampling(xd, 1024)
+    ref = o.furthestsampling(x[:6], 1024)
+    assert np.array_equal(got[:6].cpu().numpy(), ref)
+    parts = torch.cat([P.furthestsampling(xd[i:i + 32].contiguous(), 1024) for i in range(0, 300, 32)])
+    assert torch.equal(got, parts)
+
+
 def test_fps_leaves_temp_like_reference():
     """temp holds the final running minima after the call (sampling_cuda_kernel.cu:94-95 writes it back every round)."""
     from patchaugnet_amd import _lib
